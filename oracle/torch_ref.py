@@ -1,0 +1,416 @@
+"""CPU oracle: plain-PyTorch fp32 restatement of the ViLMedic hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``vilmedic_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` do, and there only as the checker / the reported CPU
+baseline -- never as the product path.
+
+Parity status: PINNED.  Every function below is checked by
+``tests/test_oracle_golden.py`` against fixtures under ``tests/golden/`` that
+``tools/make_golden.py`` produced in the build container by importing the
+reference's own block files (``/root/reference/vilmedic/blocks/**``) on top of
+HuggingFace ``transformers`` (the third-party dependency that holds the
+arithmetic; the reference pins ``transformers==4.55.3`` in ``setup.py:29``, the
+container carries 5.15.0 whose BERT/ViT block arithmetic is identical).
+
+All functions are *functional*: they take a flat ``state`` dict of tensors using
+the parameter names of the reference's pinned HF version (what a reference
+checkpoint holds) and plain python config dicts.
+
+Reference anchors (``ref:`` = /root/reference, ``hf:`` = site-packages/transformers):
+  ViT            hf:models/vit/modeling_vit.py:42-70,129-160,192-290,336-400
+                 reached from ref:vilmedic/blocks/vision/visual_encoder.py:56-58,180-186
+  decoder        hf:models/bert_generation/modeling_bert_generation.py:45-85,89-231,264-358,394-426,590-703
+                 reached from ref:vilmedic/blocks/huggingface/decoder/decoder_model.py:39-49
+  causal-LM loss hf:loss/loss_utils.py:32-72
+  RRG            ref:vilmedic/models/rrg/RRG.py:25-45
+  losses         ref:vilmedic/blocks/losses/selfsup/{ConVIRTLoss.py:12-31,InfoNCELoss.py:11-19,GLoRIALoss.py:5-170}
+                 ref:vilmedic/blocks/losses/mvqa/LabelSmoothingCrossEntropyLoss.py:38-48
+  SCST loss      ref:vilmedic/blocks/rl/SCST.py:14-45
+  decode         ref:vilmedic/blocks/huggingface/decoder/evaluation.py:36-83 +
+                 hf:generation/utils.py (_sample, _beam_search)
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------- helpers
+def linear(x, state, prefix):
+    return F.linear(x, state[prefix + ".weight"], state.get(prefix + ".bias"))
+
+
+def layer_norm(x, state, prefix, eps):
+    return F.layer_norm(x, (x.shape[-1],), state[prefix + ".weight"], state[prefix + ".bias"], eps)
+
+
+def split_heads(x, n_heads):
+    b, s, d = x.shape
+    return x.view(b, s, n_heads, d // n_heads).transpose(1, 2)
+
+
+def attention_core(q, k, v, additive_mask):
+    """softmax(q k^T / sqrt(dh) + mask) v   (hf:...bert_generation.py:60-85)."""
+    dh = q.shape[-1]
+    scores = torch.matmul(q, k.transpose(2, 3)) * (dh ** -0.5)
+    if additive_mask is not None:
+        scores = scores + additive_mask
+    probs = torch.softmax(scores, dim=-1)
+    ctx = torch.matmul(probs, v)
+    b, h, s, _ = ctx.shape
+    return ctx.transpose(1, 2).reshape(b, s, h * dh)
+
+
+NEG_INF = torch.finfo(torch.float32).min
+
+
+# --------------------------------------------------------------------------- ViT
+def vit_patch_embed(images, state, prefix, patch):
+    """Conv2d(k=patch, stride=patch) as a GEMM over flattened patches
+    (hf:models/vit/modeling_vit.py:60,69)."""
+    w = state[prefix + "embeddings.patch_embeddings.projection.weight"]  # [D, C, p, p]
+    b = state[prefix + "embeddings.patch_embeddings.projection.bias"]
+    B, C, H, W = images.shape
+    gh, gw = H // patch, W // patch
+    x = images.view(B, C, gh, patch, gw, patch).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * patch * patch)
+    return x @ w.view(w.shape[0], -1).t() + b
+
+
+def vit_forward(images, state, cfg, prefix=""):
+    """HF ViTModel(add_pooling_layer=False).last_hidden_state, pre-LN blocks.
+
+    cfg keys: hidden_size, num_hidden_layers, num_attention_heads, patch_size,
+    layer_norm_eps.  Parameter names are those of transformers 4.55.3
+    (``encoder.layer.{i}.attention.attention.query`` ...).
+    """
+    nh = cfg["num_attention_heads"]
+    eps = cfg.get("layer_norm_eps", 1e-12)
+    x = vit_patch_embed(images, state, prefix, cfg["patch_size"])
+    cls = state[prefix + "embeddings.cls_token"].expand(x.shape[0], -1, -1)
+    x = torch.cat([cls, x], dim=1) + state[prefix + "embeddings.position_embeddings"]
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"{prefix}encoder.layer.{i}."
+        h = layer_norm(x, state, p + "layernorm_before", eps)
+        q = split_heads(linear(h, state, p + "attention.attention.query"), nh)
+        k = split_heads(linear(h, state, p + "attention.attention.key"), nh)
+        v = split_heads(linear(h, state, p + "attention.attention.value"), nh)
+        ctx = attention_core(q, k, v, None)
+        x = linear(ctx, state, p + "attention.output.dense") + x
+        h = layer_norm(x, state, p + "layernorm_after", eps)
+        h = F.gelu(linear(h, state, p + "intermediate.dense"))
+        x = linear(h, state, p + "output.dense") + x
+    return layer_norm(x, state, prefix + "layernorm", eps)
+
+
+def visual_encode(features, state, prefix="visual_projection"):
+    """VisualEncoder.encode tail: mask from feature magnitude, then optional
+    projection (ref:vilmedic/blocks/vision/visual_encoder.py:137-139)."""
+    mask = features.abs().sum(-1) != 0
+    if prefix + ".weight" in state:
+        features = linear(features, state, prefix)
+    return features, mask
+
+
+# --------------------------------------------------------------------------- BERT blocks
+def bert_self_output(ctx, residual, state, p, eps):
+    """LN(dense(ctx) + residual)  (hf:...bert_generation.py:45-56)."""
+    return layer_norm(linear(ctx, state, p + ".dense") + residual, state, p + ".LayerNorm", eps)
+
+
+def bert_layer(x, state, p, cfg, self_mask, enc=None, enc_mask=None):
+    """One post-LN BERT layer; decoder variant when ``enc`` is given
+    (hf:...bert_generation.py:294-358)."""
+    nh, eps = cfg["num_attention_heads"], cfg["layer_norm_eps"]
+    q = split_heads(linear(x, state, p + "attention.self.query"), nh)
+    k = split_heads(linear(x, state, p + "attention.self.key"), nh)
+    v = split_heads(linear(x, state, p + "attention.self.value"), nh)
+    x = bert_self_output(attention_core(q, k, v, self_mask), x, state, p + "attention.output", eps)
+    if enc is not None:
+        q = split_heads(linear(x, state, p + "crossattention.self.query"), nh)
+        k = split_heads(linear(enc, state, p + "crossattention.self.key"), nh)
+        v = split_heads(linear(enc, state, p + "crossattention.self.value"), nh)
+        x = bert_self_output(attention_core(q, k, v, enc_mask), x, state, p + "crossattention.output", eps)
+    h = F.gelu(linear(x, state, p + "intermediate.dense"))
+    return layer_norm(linear(h, state, p + "output.dense") + x, state, p + "output.LayerNorm", eps)
+
+
+def key_padding_mask(mask, dtype=torch.float32):
+    """[B,S] {0,1}/bool -> additive [B,1,1,S] (HF create_bidirectional_mask semantics)."""
+    if mask is None:
+        return None
+    keep = mask.to(torch.bool)
+    return torch.zeros(keep.shape, dtype=dtype).masked_fill(~keep, NEG_INF)[:, None, None, :]
+
+
+def causal_padding_mask(attention_mask, L):
+    """causal AND key-padding additive mask [B,1,L,L] (HF create_causal_mask).
+
+    Rows that end up fully masked cannot occur here: position i always sees
+    itself unless attention_mask[i]==0 and everything before it is also 0,
+    which the [CLS]-first batches of the reference never produce
+    (ref:vilmedic/datasets/base/TextDataset.py:94-100)."""
+    causal = torch.tril(torch.ones(L, L, dtype=torch.bool))
+    keep = causal[None, None]
+    if attention_mask is not None:
+        keep = keep & attention_mask.to(torch.bool)[:, None, None, :]
+    return torch.zeros(keep.shape, dtype=torch.float32).masked_fill(~keep, NEG_INF)
+
+
+def bert_embeddings(input_ids, state, prefix, eps, past_len=0, pad_token_id=None):
+    """LN(word[ids] + pos[arange])  (hf:...bert_generation.py:394-426).
+    ``nn.Embedding(padding_idx=pad_token_id)`` (:399): the lookup sends NO gradient to the
+    pad row (the tied LM head still does)."""
+    L = input_ids.shape[1]
+    pos = torch.arange(past_len, past_len + L)
+    x = F.embedding(input_ids, state[prefix + "word_embeddings.weight"], padding_idx=pad_token_id) \
+        + state[prefix + "position_embeddings.weight"][pos]
+    return layer_norm(x, state, prefix + "LayerNorm", eps)
+
+
+def decoder_hidden(input_ids, attention_mask, enc, enc_mask, state, cfg, prefix="bert."):
+    L = input_ids.shape[1]
+    x = bert_embeddings(input_ids, state, prefix + "embeddings.", cfg["layer_norm_eps"],
+                        pad_token_id=cfg.get("pad_token_id"))
+    self_mask = causal_padding_mask(attention_mask, L)
+    cross_mask = key_padding_mask(enc_mask)
+    for i in range(cfg["num_hidden_layers"]):
+        x = bert_layer(x, state, f"{prefix}encoder.layer.{i}.", cfg, self_mask, enc, cross_mask)
+    return x
+
+
+def lm_logits(hidden, state):
+    """Tied LM head (hf:...bert_generation.py:590-610): word-embedding weight + lm_head.bias."""
+    return F.linear(hidden, state["bert.embeddings.word_embeddings.weight"], state["lm_head.bias"])
+
+
+def causal_lm_loss(logits, labels):
+    """mean CE of logits[:, :-1] vs labels[:, 1:], pads INCLUDED because the
+    reference passes labels=input_ids (ref:...decoder_model.py:46; hf:loss/loss_utils.py:49-72)."""
+    V = logits.shape[-1]
+    return F.cross_entropy(logits[:, :-1].reshape(-1, V).float(), labels[:, 1:].reshape(-1))
+
+
+def decoder_forward(input_ids, attention_mask, enc, enc_mask, state, cfg):
+    """DecoderModel.forward -> (loss, logits)  (ref:...decoder_model.py:39-49)."""
+    h = decoder_hidden(input_ids, attention_mask, enc, enc_mask, state, cfg)
+    logits = lm_logits(h, state)
+    return causal_lm_loss(logits, input_ids), logits
+
+
+def bert_encoder_forward(x, state, cfg, prefix, attention_mask=None):
+    """Bidirectional BERT stack on already-embedded inputs
+    (MVQA: ref:vilmedic/models/mvqa/MVQA.py:43; text tower of ConVIRT)."""
+    m = key_padding_mask(attention_mask)
+    for i in range(cfg["num_hidden_layers"]):
+        x = bert_layer(x, state, f"{prefix}layer.{i}.", cfg, m)
+    return x
+
+
+def bert_pooler(x, state, prefix):
+    """tanh(W h[:,0] + b)  (BertPooler)."""
+    return torch.tanh(linear(x[:, 0], state, prefix + ".dense"))
+
+
+def text_encoder_forward(input_ids, attention_mask, state, cfg, prefix=""):
+    """EncoderModel(proto=None) = BertGenerationEncoder (+BertPooler)
+    (ref:vilmedic/blocks/huggingface/encoder/encoder_model.py:44-62)."""
+    x = bert_embeddings(input_ids, state, prefix + "embeddings.", cfg["layer_norm_eps"],
+                        pad_token_id=cfg.get("pad_token_id"))
+    x = bert_encoder_forward(x, state, cfg, prefix + "encoder.", attention_mask)
+    return x
+
+
+# --------------------------------------------------------------------------- RRG
+def rrg_vit_forward(images, input_ids, attention_mask, state, vit_cfg, dec_cfg):
+    """RRG.forward with a ViT VisualEncoder (ref:vilmedic/models/rrg/RRG.py:25-41).
+    state keys: ``enc.model.*``, optional ``enc.visual_projection.*``, ``dec.decoder.*``."""
+    feats = vit_forward(images, state, vit_cfg, prefix="enc.model.")
+    feats, mask = visual_encode(feats, state, "enc.visual_projection")
+    dec_state = {k[len("dec.decoder."):]: v for k, v in state.items() if k.startswith("dec.decoder.")}
+    return decoder_forward(input_ids, attention_mask, feats, mask, dec_state, dec_cfg)
+
+
+# --------------------------------------------------------------------------- losses
+def pairwise_cosine(a, b, eps=1e-8):
+    a_n = a / a.norm(dim=1, keepdim=True).clamp(min=eps)
+    b_n = b / b.norm(dim=1, keepdim=True).clamp(min=eps)
+    return a_n @ b_n.t()
+
+
+def convirt_loss(linguistic, visual, tau, lambda_):
+    """ref:vilmedic/blocks/losses/selfsup/ConVIRTLoss.py:12-31 -> (loss, loss_l, loss_v)."""
+    nominator = torch.exp(F.cosine_similarity(linguistic, visual) / tau)
+    den_l = torch.exp(pairwise_cosine(linguistic, visual) / tau).sum(1)
+    loss_l = -torch.log(nominator / den_l)
+    den_v = torch.exp(pairwise_cosine(visual, linguistic) / tau).sum(1)
+    loss_v = -torch.log(nominator / den_v)
+    return torch.mean(lambda_ * loss_v + (1 - lambda_) * loss_l), loss_l, loss_v
+
+
+def infonce_loss(linguistic, visual):
+    """ref:vilmedic/blocks/losses/selfsup/InfoNCELoss.py:11-19 (tau unused, no norm)."""
+    n = linguistic.shape[0]
+    logits = linguistic @ visual.t()
+    labels = torch.arange(n)
+    loss_t = F.cross_entropy(logits, labels, reduction="none")
+    loss_i = F.cross_entropy(logits.t(), labels, reduction="none")
+    return ((loss_i + loss_t) / 2).mean(), loss_t, loss_i
+
+
+def label_smoothing_ce(output, target, smoothing=0.1):
+    """ref:vilmedic/blocks/losses/mvqa/LabelSmoothingCrossEntropyLoss.py:38-48 (reduction='mean')."""
+    c = output.shape[-1]
+    logp = F.log_softmax(output, dim=-1)
+    return (-logp.sum(-1)).mean() * smoothing / c + (1 - smoothing) * F.nll_loss(logp, target)
+
+
+def gloria_attention(query, context, temp1):
+    """ref:vilmedic/blocks/losses/selfsup/GLoRIALoss.py:13-51.
+    query [B,D,T], context [B,D,ih,iw] -> weighted context [B,D,T], attn [B,T,ih,iw]."""
+    B, T = query.shape[0], query.shape[2]
+    ih, iw = context.shape[2], context.shape[3]
+    S = ih * iw
+    ctx = context.view(B, -1, S)
+    attn = torch.bmm(ctx.transpose(1, 2), query)              # [B,S,T]
+    attn = torch.softmax(attn.view(B * S, T), dim=-1).view(B, S, T)
+    attn = attn.transpose(1, 2).contiguous().view(B * T, S) * temp1
+    attn = torch.softmax(attn, dim=-1).view(B, T, S)
+    wctx = torch.bmm(ctx, attn.transpose(1, 2))               # [B,D,T]
+    return wctx, attn.view(B, T, ih, iw)
+
+
+def gloria_cosine(x1, x2, eps=1e-8):
+    """ref:...GLoRIALoss.py:5-10 (clamps the PRODUCT of norms, unlike F.cosine_similarity)."""
+    return (x1 * x2).sum(1) / (x1.norm(dim=1) * x2.norm(dim=1)).clamp(min=eps)
+
+
+def gloria_global_loss(cnn_code, rnn_code, temp3, eps=1e-8):
+    """ref:...GLoRIALoss.py:54-75."""
+    B = cnn_code.shape[0]
+    labels = torch.arange(B)
+    cnn_norm = cnn_code.norm(dim=-1, keepdim=True)
+    rnn_norm = rnn_code.norm(dim=-1, keepdim=True)
+    s0 = (cnn_code @ rnn_code.t()) / (cnn_norm @ rnn_norm.t()).clamp(min=eps) * temp3
+    return F.cross_entropy(s0, labels), F.cross_entropy(s0.t(), labels)
+
+
+def gloria_local_loss(img_features, words_emb, cap_lens, temp1, temp2, temp3):
+    """ref:...GLoRIALoss.py:78-129 (agg='sum')."""
+    B = img_features.shape[0]
+    sims = []
+    for i in range(B):
+        T = cap_lens[i]
+        word = words_emb[i, :, :T].unsqueeze(0).repeat(B, 1, 1)        # [B,D,T]  (:91, [CLS] kept)
+        wctx, _ = gloria_attention(word, img_features, temp1)
+        word = word.transpose(1, 2).reshape(B * T, -1)
+        wctx = wctx.transpose(1, 2).reshape(B * T, -1)
+        row = gloria_cosine(word, wctx).view(B, T)
+        row = torch.log(torch.exp(row * temp2).sum(dim=1, keepdim=True))
+        sims.append(row)
+    sims = torch.cat(sims, 1) * temp3                                   # [B(img), B(cap)]
+    labels = torch.arange(B)
+    return F.cross_entropy(sims, labels), F.cross_entropy(sims.t(), labels)
+
+
+def scst_loss(logp, seq, reward_sampling, reward_greedy, scores_weights, pad_token_id):
+    """ref:vilmedic/blocks/rl/SCST.py:14-45 -> loss (scalar)."""
+    logp = logp.clone()
+    logp[logp == -float("inf")] = 0.0
+    mask = (seq > pad_token_id).float()
+    x = logp.squeeze(-1) * mask
+    x = x / mask.sum()
+    loss = 0.0
+    for w, rs, rg in zip(scores_weights, reward_sampling, reward_greedy):
+        r = torch.as_tensor(rs, dtype=x.dtype) - torch.as_tensor(rg, dtype=x.dtype)
+        loss = loss + torch.sum(w * (-x * r.unsqueeze(-1)))
+    return loss
+
+
+# --------------------------------------------------------------------------- decode
+def decoder_step_logits(ids, enc, enc_mask, state, cfg):
+    """Full-prefix recompute of next-token fp32 log-softmax scores (no KV cache;
+    the cache is an optimisation, not part of the arithmetic)."""
+    h = decoder_hidden(ids, None, enc, enc_mask, state, cfg)
+    return torch.log_softmax(lm_logits(h[:, -1], state).float(), dim=-1)
+
+
+def greedy_decode(enc, enc_mask, state, cfg, bos, eos, pad, max_length):
+    """HF GenerationMixin._sample with do_sample=False, as driven by
+    ref:...decoder/evaluation.py:73-78 (num_beams unset).  Finished rows are
+    padded with ``pad``; stops when every row has emitted ``eos`` or at max_length."""
+    B = enc.shape[0]
+    ids = torch.full((B, 1), bos, dtype=torch.long)
+    unfinished = torch.ones(B, dtype=torch.bool)
+    while ids.shape[1] < max_length:
+        nxt = decoder_step_logits(ids, enc, enc_mask, state, cfg).argmax(-1)
+        nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
+        ids = torch.cat([ids, nxt[:, None]], 1)
+        unfinished = unfinished & (nxt != eos)
+        if not unfinished.any():
+            break
+    return ids
+
+
+def beam_decode(enc, enc_mask, state, cfg, bos, eos, pad, max_length, num_beams, length_penalty=1.0):
+    """HF GenerationMixin._beam_search (hf:generation/utils.py:3008-3207 helpers,
+    :3208-3520 loop) with early_stopping=False, do_sample=False,
+    num_return_sequences=1, one eos id, stopping criteria = {max_length, eos}.
+
+    Returns (sequences [B, T] padded with ``pad``, sequences_scores [B])."""
+    B, V = enc.shape[0], state["lm_head.bias"].shape[0]
+    nb, keep, prompt = num_beams, 2 * num_beams, 1
+    enc_b = enc.repeat_interleave(nb, 0)
+    mask_b = enc_mask.repeat_interleave(nb, 0) if enc_mask is not None else None
+
+    def gather(t, idx):                       # _gather_beams
+        while idx.dim() < t.dim():
+            idx = idx.unsqueeze(-1)
+        return torch.gather(t, 1, idx.expand(-1, -1, *t.shape[2:]))
+
+    running = torch.full((B, nb, max_length), pad, dtype=torch.long)
+    running[:, :, 0] = bos
+    seqs = running.clone()
+    running_len = torch.zeros(B, nb, dtype=torch.long)      # generated tokens (stands in for beam_indices)
+    seq_len = torch.zeros(B, nb, dtype=torch.long)
+    running_scores = torch.zeros(B, nb)
+    running_scores[:, 1:] = -1e9
+    beam_scores = torch.full((B, nb), -1e9)
+    finished = torch.zeros(B, nb, dtype=torch.bool)
+    unsat = torch.ones(B, 1, dtype=torch.bool)              # is_early_stop_heuristic_unsatisfied
+    top_mask = torch.cat([torch.ones(nb, dtype=torch.bool), torch.zeros(keep - nb, dtype=torch.bool)])
+    cur = prompt
+    while True:
+        flat = running[:, :, :cur].reshape(B * nb, cur)
+        logp = decoder_step_logits(flat, enc_b, mask_b, state, cfg).view(B, nb, V)
+        logp = (logp + running_scores[:, :, None]).view(B, nb * V)
+        topk_lp, topk_idx = torch.topk(logp, keep)
+        src_beam = topk_idx // V
+        tok = topk_idx % V
+        cand = gather(running, src_beam).clone()
+        cand[:, :, cur] = tok
+        cand_len = gather(running_len, src_beam) + 1
+        hits = (tok == eos) | (cur + 1 >= max_length)
+        # running beams for the next iteration
+        run_lp = topk_lp + hits.float() * -1e9
+        nxt = torch.topk(run_lp, nb)[1]
+        running, running_scores, running_len = gather(cand, nxt), gather(run_lp, nxt), gather(cand_len, nxt)
+        # finished pool
+        just = hits & top_mask[None, :]
+        fin_lp = topk_lp / ((cur + 1 - prompt) ** length_penalty)
+        fin_lp = fin_lp + (~unsat).float() * -1e9
+        fin_lp = fin_lp + (~just).float() * -1e9
+        m_seq = torch.cat([seqs, cand], 1)
+        m_sc = torch.cat([beam_scores, fin_lp], 1)
+        m_len = torch.cat([seq_len, cand_len], 1)
+        m_fin = torch.cat([finished, just], 1)
+        top = torch.topk(m_sc, nb)[1]
+        seqs, beam_scores, seq_len, finished = gather(m_seq, top), gather(m_sc, top), gather(m_len, top), gather(m_fin, top)
+        cur += 1
+        best_possible = running_scores[:, :1] / ((cur - prompt) ** length_penalty)
+        worst_fin = torch.where(finished, beam_scores.min(1, keepdim=True)[0], torch.tensor(-1e9))
+        unsat = unsat & (best_possible > worst_fin).any(-1, keepdim=True)
+        if not (bool(unsat.any()) and not bool(hits.all())):
+            break
+    out_len = prompt + int(seq_len[:, 0].max())
+    return seqs[:, 0, :out_len], beam_scores[:, 0]

@@ -1,0 +1,159 @@
+"""Deterministic weight / input recipes shared by ``tools/make_golden.py`` (which
+feeds them to the *reference* blocks to produce ``tests/golden/*.pt``) and by
+the tests (which feed the same tensors to the oracle and to the HIP path).
+
+Storing the recipe (seed + shapes) instead of the tensors keeps fixtures small;
+every fixture also stores a checksum of the generated state so RNG drift
+between torch builds is detected instead of silently mis-compared.
+
+Parameter names are the ones a reference checkpoint holds (HF transformers
+4.55.3, the reference's pin in ``setup.py:29``).
+"""
+import torch
+
+
+# ----------------------------------------------------------------------------- shapes
+def vit_shapes(cfg, prefix=""):
+    d, ff, p, c = cfg["hidden_size"], cfg["intermediate_size"], cfg["patch_size"], cfg.get("num_channels", 3)
+    n = (cfg["image_size"] // p) ** 2
+    s = {
+        "embeddings.cls_token": (1, 1, d),
+        "embeddings.position_embeddings": (1, n + 1, d),
+        "embeddings.patch_embeddings.projection.weight": (d, c, p, p),
+        "embeddings.patch_embeddings.projection.bias": (d,),
+        "layernorm.weight": (d,), "layernorm.bias": (d,),
+    }
+    for i in range(cfg["num_hidden_layers"]):
+        L = f"encoder.layer.{i}."
+        for nm in ("query", "key", "value"):
+            s[L + f"attention.attention.{nm}.weight"] = (d, d)
+            s[L + f"attention.attention.{nm}.bias"] = (d,)
+        s[L + "attention.output.dense.weight"] = (d, d)
+        s[L + "attention.output.dense.bias"] = (d,)
+        s[L + "intermediate.dense.weight"] = (ff, d)
+        s[L + "intermediate.dense.bias"] = (ff,)
+        s[L + "output.dense.weight"] = (d, ff)
+        s[L + "output.dense.bias"] = (d,)
+        for nm in ("layernorm_before", "layernorm_after"):
+            s[L + nm + ".weight"] = (d,)
+            s[L + nm + ".bias"] = (d,)
+    return {prefix + k: v for k, v in s.items()}
+
+
+def bert_layer_shapes(cfg, prefix, cross, enc_dim=None):
+    d, ff = cfg["hidden_size"], cfg["intermediate_size"]
+    enc_dim = enc_dim or d
+    s = {}
+    blocks = [("attention", d)] + ([("crossattention", enc_dim)] if cross else [])
+    for blk, kv_in in blocks:
+        s[f"{blk}.self.query.weight"] = (d, d)
+        s[f"{blk}.self.query.bias"] = (d,)
+        for nm in ("key", "value"):
+            s[f"{blk}.self.{nm}.weight"] = (d, kv_in)
+            s[f"{blk}.self.{nm}.bias"] = (d,)
+        s[f"{blk}.output.dense.weight"] = (d, d)
+        s[f"{blk}.output.dense.bias"] = (d,)
+        s[f"{blk}.output.LayerNorm.weight"] = (d,)
+        s[f"{blk}.output.LayerNorm.bias"] = (d,)
+    s["intermediate.dense.weight"] = (ff, d)
+    s["intermediate.dense.bias"] = (ff,)
+    s["output.dense.weight"] = (d, ff)
+    s["output.dense.bias"] = (d,)
+    s["output.LayerNorm.weight"] = (d,)
+    s["output.LayerNorm.bias"] = (d,)
+    return {prefix + k: v for k, v in s.items()}
+
+
+def bert_embedding_shapes(cfg, prefix):
+    d = cfg["hidden_size"]
+    return {
+        prefix + "word_embeddings.weight": (cfg["vocab_size"], d),
+        prefix + "position_embeddings.weight": (cfg["max_position_embeddings"], d),
+        prefix + "LayerNorm.weight": (d,), prefix + "LayerNorm.bias": (d,),
+    }
+
+
+def decoder_shapes(cfg, prefix=""):
+    """BertGenerationDecoder with cross-attention; LM head tied to word embeddings
+    (``lm_head.decoder.weight`` is an alias and is not generated)."""
+    s = bert_embedding_shapes(cfg, "bert.embeddings.")
+    for i in range(cfg["num_hidden_layers"]):
+        s.update(bert_layer_shapes(cfg, f"bert.encoder.layer.{i}.", cross=True))
+    s["lm_head.bias"] = (cfg["vocab_size"],)
+    return {prefix + k: v for k, v in s.items()}
+
+
+def text_encoder_shapes(cfg, prefix=""):
+    s = bert_embedding_shapes(cfg, "embeddings.")
+    for i in range(cfg["num_hidden_layers"]):
+        s.update(bert_layer_shapes(cfg, f"encoder.layer.{i}.", cross=False))
+    return {prefix + k: v for k, v in s.items()}
+
+
+def bert_stack_shapes(cfg, prefix=""):
+    s = {}
+    for i in range(cfg["num_hidden_layers"]):
+        s.update(bert_layer_shapes(cfg, f"layer.{i}.", cross=False))
+    return {prefix + k: v for k, v in s.items()}
+
+
+# ----------------------------------------------------------------------------- tensors
+def rand_state(shapes, seed, std=0.05, emb_std=None):
+    """LayerNorm weights ~ 1+0.1N, biases ~ 0.02N, everything else ~ std*N
+    (embedding tables ~ emb_std*N when given)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for name in sorted(shapes):
+        shape = shapes[name]
+        x = torch.randn(*shape, generator=g)
+        low = name.lower()
+        if ("layernorm" in low) and name.endswith(".weight"):
+            x = 1.0 + 0.1 * x
+        elif name.endswith(".bias"):
+            x = 0.02 * x
+        elif emb_std is not None and "embeddings" in low:
+            x = emb_std * x
+        else:
+            x = std * x
+        out[name] = x
+    return out
+
+
+def state_checksum(state):
+    return float(sum(v.double().abs().sum() for v in state.values()))
+
+
+def make_images(B, size, seed=0, channels=3):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(B, channels, size, size, generator=g)
+
+
+def make_reports(B, L, V, seed=0, cls=0, pad=1, sep=2):
+    """[CLS]=0, body U{3..V-1} of length U{L/2..L-2}, [SEP]=2, [PAD]=1."""
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.full((B, L), pad, dtype=torch.long)
+    mask = torch.zeros(B, L, dtype=torch.long)
+    for b in range(B):
+        n = int(torch.randint(L // 2, L - 1, (1,), generator=g))
+        ids[b, 0] = cls
+        ids[b, 1:1 + n - 1] = torch.randint(3, V, (n - 1,), generator=g)
+        ids[b, n] = sep
+        mask[b, :n + 1] = 1
+    return ids, mask
+
+
+# ----------------------------------------------------------------------------- configs
+VIT_TINY = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                image_size=32, patch_size=8, num_channels=3, layer_norm_eps=1e-12)
+VIT_B16_1L = dict(hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=3072,
+                  image_size=224, patch_size=16, num_channels=3, layer_norm_eps=1e-12)
+DEC_TINY = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                vocab_size=97, max_position_embeddings=64, layer_norm_eps=1e-5,
+                bos_token_id=0, pad_token_id=1, eos_token_id=2)
+DEC_768_2L = dict(hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=3072,
+                  vocab_size=1000, max_position_embeddings=514, layer_norm_eps=1e-5,
+                  bos_token_id=0, pad_token_id=1, eos_token_id=2)
+MVQA_TINY = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=96,
+                 layer_norm_eps=1e-12)
+TXT_TINY = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                vocab_size=97, max_position_embeddings=64, layer_norm_eps=1e-12, pad_token_id=1)

@@ -1,0 +1,175 @@
+"""Pin the CPU oracle (oracle/torch_ref.py) to the reference: every fixture under
+tests/golden/ was produced by tools/make_golden.py from the reference's own block
+files; the oracle must reproduce them (fp32, tight tolerance; token ids bit-exact)."""
+import pytest
+import torch
+
+import golden_recipes as R
+from oracle import torch_ref as O
+
+
+def close(a, b, rtol=2e-4, atol=2e-5):
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol)
+
+
+def test_g1_vit_tiny(golden):
+    g = golden("g1_vit_tiny")
+    st = R.rand_state(R.vit_shapes(g["cfg"]), g["seed"])
+    assert abs(R.state_checksum(st) - g["checksum"]) < 1e-6 * g["checksum"]
+    images = R.make_images(g["B"], g["cfg"]["image_size"], seed=g["seed"])
+    images[g["blank_image"]] = 0.0
+    feats, mask = O.visual_encode(O.vit_forward(images, st, g["cfg"]), {})
+    close(feats, g["features"])
+    assert torch.equal(mask, g["mask"])
+
+
+def test_g2_vit_b16_layer(golden):
+    g = golden("g2_vit_b16_1layer")
+    st = R.rand_state(R.vit_shapes(g["cfg"]), g["seed"])
+    images = R.make_images(g["B"], 224, seed=g["seed"])
+    feats = O.vit_forward(images, st, g["cfg"])
+    close(feats[:, ::8], g["features"], rtol=1e-3, atol=1e-4)
+    assert abs(float(feats.double().sum()) - g["features_full_sum"]) < 1e-2
+
+
+def _decoder_inputs(g):
+    cfg = g["cfg"]
+    ids, am = R.make_reports(g["B"], g["L"], cfg["vocab_size"], seed=g["seed"])
+    gen = torch.Generator().manual_seed(g["seed"] + 1)
+    enc = torch.randn(g["B"], g["S"], cfg["hidden_size"], generator=gen)
+    enc[~g["enc_mask"]] = 0.0
+    return ids, am, enc
+
+
+def test_g3_decoder_loss_logits_grads(golden):
+    g = golden("g3_decoder_tiny")
+    cfg = g["cfg"]
+    st = R.rand_state(R.decoder_shapes(cfg), g["seed"])
+    assert abs(R.state_checksum(st) - g["checksum"]) < 1e-6 * g["checksum"]
+    st = {k: v.requires_grad_(True) for k, v in st.items()}
+    ids, am, enc = _decoder_inputs(g)
+    enc.requires_grad_(True)
+    loss, logits = O.decoder_forward(ids, am, enc, g["enc_mask"], st, cfg)
+    close(loss, g["loss"])
+    close(logits, g["logits"])
+    loss.backward()
+    for n, ref in g["grads"].items():
+        close(st[n].grad, ref, rtol=1e-3, atol=1e-6)
+    close(enc.grad, g["enc_grad"], rtol=1e-3, atol=1e-7)
+    assert {"loss", "logits", "past_key_values", "hidden_states", "attentions", "cross_attentions"} <= set(g["out_keys"])
+
+
+def test_g5_rrg_adam_trajectory(golden):
+    g = golden("g5_rrg_tiny")
+    vst = {"enc.model." + k: v for k, v in R.rand_state(R.vit_shapes(g["vit_cfg"]), g["seed"]).items()}
+    dst = {"dec.decoder." + k: v for k, v in R.rand_state(R.decoder_shapes(g["dec_cfg"]), g["seed"] + 1).items()}
+    st = {k: v.requires_grad_(True) for k, v in {**vst, **dst}.items()}
+    images = R.make_images(g["B"], g["vit_cfg"]["image_size"], seed=g["seed"])
+    ids, am = R.make_reports(g["B"], g["L"], g["dec_cfg"]["vocab_size"], seed=g["seed"])
+    opt = torch.optim.Adam(list(st.values()), lr=g["lr"])
+    for step in range(3):
+        loss, logits = O.rrg_vit_forward(images, ids, am, st, g["vit_cfg"], g["dec_cfg"])
+        if step == 0:
+            close(logits, g["logits0"])
+        close(loss.detach(), g["losses"][step], rtol=1e-4, atol=1e-5)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+
+@pytest.mark.parametrize("B", [8, 64])
+def test_g6_contrastive_and_ce_losses(golden, B):
+    g = golden("g6_losses")
+    gen = torch.Generator().manual_seed(1234 + B)
+    l = torch.randn(B, 96, generator=gen).requires_grad_(True)
+    v = torch.randn(B, 96, generator=gen).requires_grad_(True)
+    ref = g[f"convirt_{B}"]
+    loss, ll, lv = O.convirt_loss(l, v, 0.1, 0.75)
+    loss.backward()
+    close(loss, ref["loss"]), close(ll, ref["loss_l"]), close(lv, ref["loss_v"])
+    close(l.grad, ref["gl"], atol=1e-6), close(v.grad, ref["gv"], atol=1e-6)
+    l2 = (0.2 * l.detach()).requires_grad_(True)
+    v2 = (0.2 * v.detach()).requires_grad_(True)
+    ref = g[f"infonce_{B}"]
+    loss, lt, li = O.infonce_loss(l2, v2)
+    loss.backward()
+    close(loss, ref["loss"]), close(lt, ref["loss_t"]), close(li, ref["loss_i"])
+    close(l2.grad, ref["gl"], atol=1e-6), close(v2.grad, ref["gv"], atol=1e-6)
+    logits = torch.randn(B, 33, generator=gen).requires_grad_(True)
+    ref = g[f"lsce_{B}"]
+    loss = O.label_smoothing_ce(logits, ref["target"], 0.1)
+    loss.backward()
+    close(loss, ref["loss"]), close(logits.grad, ref["g"], atol=1e-7)
+    # the reference's own statement: equals F.cross_entropy(label_smoothing=eps)
+    close(loss.detach(), torch.nn.functional.cross_entropy(logits.detach(), ref["target"], label_smoothing=0.1))
+
+
+def test_g6_convirt_known_answer(golden):
+    g = golden("g6_losses")
+    torch.manual_seed(1234)
+    a, b = torch.randn(8, 768), torch.randn(8, 768)
+    loss = O.convirt_loss(a, b, 0.1, 0.75)[0]
+    close(loss, g["convirt_known_answer"])
+    assert abs(float(loss) - 1.9949309826) < 1e-5
+
+
+def test_g6_gloria(golden):
+    g = golden("g6_losses")["gloria"]
+    B, D, T, hw = g["B"], g["D"], g["T"], g["hw"]
+    gen = torch.Generator().manual_seed(99)
+    glob = torch.randn(B, D, generator=gen).requires_grad_(True)
+    loc = torch.randn(B, D, hw, hw, generator=gen).requires_grad_(True)
+    words = torch.randn(B, D, T, generator=gen).requires_grad_(True)
+    sent = torch.randn(B, D, generator=gen).requires_grad_(True)
+    l0, l1 = O.gloria_local_loss(loc, words, g["cap_lens"], 4.0, 5.0, 10.0)
+    g0, g1 = O.gloria_global_loss(glob, sent, 10.0)
+    loss = (l0 + l1) * 1.0 + (g0 + g1) * 1.0
+    loss.backward()
+    close(loss, g["loss"])
+    close(glob.grad, g["g_glob"], atol=1e-6), close(loc.grad, g["g_loc"], atol=1e-6)
+    close(words.grad, g["g_words"], atol=1e-6), close(sent.grad, g["g_sent"], atol=1e-6)
+
+
+def test_g7_greedy_and_beam_ids_bit_exact(golden):
+    g = golden("g7_decode")
+    cfg = g["cfg"]
+    rc = g["recipe"]
+    st = R.rand_state(R.decoder_shapes(cfg), g["seed"], std=rc["std"], emb_std=rc["emb_std"])
+    st["lm_head.bias"][cfg["eos_token_id"]] += rc["eos_bias"]
+    assert abs(R.state_checksum(st) - g["checksum"]) < 1e-6 * g["checksum"]
+    gen = torch.Generator().manual_seed(g["seed"] + 1)
+    enc = torch.randn(g["B"], g["S"], cfg["hidden_size"], generator=gen)
+    enc[~g["enc_mask"]] = 0.0
+    ids = O.greedy_decode(enc, g["enc_mask"], st, cfg, 0, 2, 1, g["max_len"])
+    assert torch.equal(ids, g["beams1_lp1.0"]["sequences"])
+    for lp in (1.0, 2.0):
+        ref = g[f"beams4_lp{lp}"]
+        seqs, scores = O.beam_decode(enc, g["enc_mask"], st, cfg, 0, 2, 1, g["max_len"], 4, lp)
+        assert torch.equal(seqs, ref["sequences"]), (lp, seqs, ref["sequences"])
+        close(scores, ref["scores"], rtol=1e-4, atol=1e-4)
+
+
+def test_g8_scst_loss(golden):
+    g = golden("g8_scst")
+    inp = g["logp"].clone().requires_grad_(True)
+    loss = O.scst_loss(inp * 1.0, g["seq"], g["rs"], g["rg"], g["w"], g["pad"])
+    loss.backward()
+    close(loss, g["loss"])
+    close(inp.grad, g["grad"])
+
+
+def test_g9_mvqa_core_and_text_encoder(golden):
+    g = golden("g9_mvqa_text")
+    m = g["mvqa"]
+    st = R.rand_state(R.bert_stack_shapes(m["cfg"]), m["seed"])
+    h = O.bert_encoder_forward(m["x"], st, m["cfg"], "")
+    close(h, m["hidden"])
+    pooled = O.bert_pooler(h, {"p.dense.weight": m["pw"], "p.dense.bias": m["pb"]}, "p")
+    close(pooled, m["pooled"])
+    close(torch.nn.functional.linear(pooled, m["cw"], m["cb"]), m["logits"])
+    t = g["text"]
+    st = R.rand_state(R.text_encoder_shapes(t["cfg"]), t["seed"])
+    ids, am = R.make_reports(t["B"], t["L"], t["cfg"]["vocab_size"], seed=t["seed"])
+    h = O.text_encoder_forward(ids, am, st, t["cfg"])
+    close(h, t["last_hidden_state"])
+    close(O.bert_pooler(h, {"p.dense.weight": t["pw"], "p.dense.bias": t["pb"]}, "p"), t["pooler_output"])

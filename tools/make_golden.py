@@ -1,0 +1,354 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.pt by running the REFERENCE's own block files.
+
+Runs only in the build container (needs /root/reference + HF transformers).
+The reference's python never ships: this script loads its block files *by
+path* (``vilmedic/__init__`` cannot be imported here: omegaconf/torchvision are
+absent), with three shims:
+  1. ``Tensor.cuda``/``Module.cuda`` -> identity (reference hard-calls ``.cuda()``);
+  2. ``AttrDict`` standing in for OmegaConf ``DictConfig``;
+  3. stub ``torchvision`` / ``monai`` modules so ``visual_encoder.py`` imports.
+Fixtures hold inputs' recipes (seed/shape, see tests/golden_recipes.py), a
+checksum of the generated weights, and the reference's outputs.
+
+    python tools/make_golden.py            # writes tests/golden/*.pt
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import golden_recipes as R  # noqa: E402
+
+REF = "/root/reference/vilmedic/"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+import transformers  # noqa: E402  (must precede the stubs)
+import transformers.models.vit.modeling_vit  # noqa: E402,F401
+import transformers.models.resnet.modeling_resnet  # noqa: E402,F401
+import transformers.models.deit.modeling_deit  # noqa: E402,F401
+import transformers.models.poolformer.modeling_poolformer  # noqa: E402,F401
+
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.nn.Module.cuda = lambda self, *a, **k: self
+
+
+class AttrDict(dict):
+    __getattr__ = dict.get
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _stub_modules():
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    tvm.__all__ = []
+    tv.models = tvm
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.models"] = tvm
+    for n in ["monai", "monai.networks", "monai.networks.nets", "monai.networks.nets.densenet"]:
+        sys.modules[n] = types.ModuleType(n)
+    dn = sys.modules["monai.networks.nets.densenet"]
+    for n in ["densenet121", "densenet169", "densenet201", "densenet264"]:
+        setattr(dn, n, None)
+
+
+def load_ref(name, rel):
+    spec = importlib.util.spec_from_file_location(name, REF + rel)
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+_stub_modules()
+ve = load_ref("ref_visual_encoder", "blocks/vision/visual_encoder.py")
+dm = load_ref("ref_decoder_model", "blocks/huggingface/decoder/decoder_model.py")
+em = load_ref("ref_encoder_model", "blocks/huggingface/encoder/encoder_model.py")
+lc = load_ref("ref_convirt", "blocks/losses/selfsup/ConVIRTLoss.py")
+li = load_ref("ref_infonce", "blocks/losses/selfsup/InfoNCELoss.py")
+lg = load_ref("ref_gloria", "blocks/losses/selfsup/GLoRIALoss.py")
+ll = load_ref("ref_lsce", "blocks/losses/mvqa/LabelSmoothingCrossEntropyLoss.py")
+cl = load_ref("ref_classifier", "blocks/classifier/classifier.py")
+
+
+# ------------------------------------------------------------------ name maps (HF 5.x <-> pinned 4.55.3)
+def vit_to_hf5(name):
+    """canonical (4.55.3) ViT name -> transformers 5.x name."""
+    name = name.replace("encoder.layer.", "layers.")
+    name = name.replace("attention.attention.query", "attention.q_proj")
+    name = name.replace("attention.attention.key", "attention.k_proj")
+    name = name.replace("attention.attention.value", "attention.v_proj")
+    name = name.replace("attention.output.dense", "attention.o_proj")
+    name = name.replace("intermediate.dense", "mlp.fc1")
+    name = name.replace("output.dense", "mlp.fc2")
+    return name
+
+
+def load_into(module, state, rename=lambda n: n, extra_alias=None):
+    sd = {rename(k): v.clone() for k, v in state.items()}
+    for dst, src in (extra_alias or {}).items():
+        sd[dst] = sd[src]
+    missing, unexpected = module.load_state_dict(sd, strict=False)
+    missing = [m for m in missing if "position_ids" not in m]
+    assert not missing and not unexpected, (missing, unexpected)
+
+
+def build_ref_vit(cfg, seed, visual_projection=None):
+    enc = ve.VisualEncoder(backbone="vit", permute="no_permute", dropout_out=0.0,
+                           visual_projection=AttrDict(visual_projection) if visual_projection else None,
+                           **{k: v for k, v in cfg.items()}, attn_implementation="eager")
+    st = R.rand_state(R.vit_shapes(cfg), seed)
+    load_into(enc.model, st, vit_to_hf5)
+    full = {"model." + k: v for k, v in st.items()}
+    if visual_projection:
+        g = torch.Generator().manual_seed(seed + 77)
+        w = 0.05 * torch.randn(visual_projection["out_features"], visual_projection["in_features"], generator=g)
+        b = 0.02 * torch.randn(visual_projection["out_features"], generator=g)
+        enc.visual_projection.weight.data.copy_(w)
+        enc.visual_projection.bias.data.copy_(b)
+        full["visual_projection.weight"], full["visual_projection.bias"] = w, b
+    return enc.eval(), full
+
+
+def build_ref_decoder(cfg, seed, std=0.05, emb_std=None, eos_bias=0.0):
+    d = AttrDict(proto=None, add_cross_attention=True, is_decoder=True, hidden_act="gelu",
+                 attention_probs_dropout_prob=0.0, hidden_dropout_prob=0.0,
+                 position_embedding_type="absolute", use_cache=True, **cfg)
+    dec = dm.DecoderModel(d)
+    dec.decoder.config._attn_implementation = "eager"
+    st = R.rand_state(R.decoder_shapes(cfg), seed, std=std, emb_std=emb_std)
+    st["lm_head.bias"][cfg["eos_token_id"]] += eos_bias
+    load_into(dec.decoder, st, extra_alias={"lm_head.decoder.weight": "bert.embeddings.word_embeddings.weight",
+                                            "lm_head.decoder.bias": "lm_head.bias"})
+    return dec.eval(), st
+
+
+def save(name, obj):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".pt")
+    torch.save(obj, path)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# ------------------------------------------------------------------ G1/G2: ViT through VisualEncoder
+def gen_vit():
+    for tag, cfg, B, seed in [("g1_vit_tiny", R.VIT_TINY, 3, 11), ("g2_vit_b16_1layer", R.VIT_B16_1L, 1, 12)]:
+        enc, st = build_ref_vit(cfg, seed)
+        images = R.make_images(B, cfg["image_size"], seed=seed)
+        if tag == "g1_vit_tiny":
+            images[1] = 0.0  # exercises the "mask from magnitude" rule on a blank image (still non-zero features)
+        with torch.no_grad():
+            feats, mask = enc.encode(images)
+        save(tag, dict(cfg=cfg, seed=seed, B=B, blank_image=1 if tag == "g1_vit_tiny" else None,
+                       checksum=R.state_checksum(st), features=feats if tag == "g1_vit_tiny" else feats[:, ::8].clone(),
+                       features_full_sum=float(feats.double().sum()), mask=mask))
+
+
+# ------------------------------------------------------------------ G3/G4: decoder fwd + grads
+def gen_decoder():
+    cfg, seed, B, L, S = R.DEC_TINY, 21, 4, 24, 10
+    dec, st = build_ref_decoder(cfg, seed)
+    ids, am = R.make_reports(B, L, cfg["vocab_size"], seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    enc = torch.randn(B, S, cfg["hidden_size"], generator=g)
+    enc_mask = torch.ones(B, S, dtype=torch.bool)
+    enc_mask[1, 7:] = False
+    enc_mask[3, 3:] = False
+    enc[~enc_mask] = 0.0
+    enc = enc.requires_grad_(True)
+    dec.train()  # dropout probs are 0; exercise the training graph
+    out = dec(input_ids=ids, attention_mask=am, encoder_outputs=enc, encoder_attention_mask=enc_mask)
+    assert set(out.keys()) >= {"loss", "logits"}
+    out["loss"].backward()
+    named = dict(dec.decoder.named_parameters())
+    grad_names = ["bert.embeddings.word_embeddings.weight", "bert.embeddings.position_embeddings.weight",
+                  "bert.embeddings.LayerNorm.weight", "bert.encoder.layer.0.attention.self.query.weight",
+                  "bert.encoder.layer.0.crossattention.self.key.weight", "bert.encoder.layer.0.crossattention.self.value.bias",
+                  "bert.encoder.layer.1.crossattention.output.dense.weight", "bert.encoder.layer.1.intermediate.dense.weight",
+                  "bert.encoder.layer.1.output.LayerNorm.bias", "lm_head.bias"]
+    save("g3_decoder_tiny", dict(cfg=cfg, seed=seed, B=B, L=L, S=S, checksum=R.state_checksum(st),
+                                 enc_mask=enc_mask, loss=out["loss"].detach(), logits=out["logits"].detach(),
+                                 out_keys=sorted(out.keys()),
+                                 grads={n: named[n].grad.clone() for n in grad_names},
+                                 enc_grad=enc.grad.clone()))
+
+
+# ------------------------------------------------------------------ G5/G10: RRG (ViT + decoder) loss and Adam trajectory
+def gen_rrg():
+    vcfg, dcfg, seed, B, L = R.VIT_TINY, R.DEC_TINY, 31, 4, 20
+    enc, est = build_ref_vit(vcfg, seed)
+    dec, dst = build_ref_decoder(dcfg, seed + 1)
+    images = R.make_images(B, vcfg["image_size"], seed=seed)
+    ids, am = R.make_reports(B, L, dcfg["vocab_size"], seed=seed)
+    # RRG.forward == enc.encode -> dec(...)  (ref: vilmedic/models/rrg/RRG.py:25-41)
+    params = list(enc.parameters()) + list(dec.parameters())
+    opt = torch.optim.Adam(params, lr=1e-3)
+    enc.train(), dec.train()
+    losses, logits0 = [], None
+    for step in range(3):
+        feats, fmask = enc.encode(images)
+        out = dec(input_ids=ids, attention_mask=am, encoder_outputs=feats, encoder_attention_mask=fmask)
+        if step == 0:
+            logits0 = out["logits"].detach().clone()
+        losses.append(out["loss"].detach().clone())
+        opt.zero_grad()
+        out["loss"].backward()
+        opt.step()
+    save("g5_rrg_tiny", dict(vit_cfg=vcfg, dec_cfg=dcfg, seed=seed, B=B, L=L,
+                             checksum=R.state_checksum(est) + R.state_checksum(dst),
+                             losses=torch.stack(losses), logits0=logits0, lr=1e-3))
+
+
+# ------------------------------------------------------------------ G6: losses
+def gen_losses():
+    out = {}
+    for B in (8, 64):
+        g = torch.Generator().manual_seed(1234 + B)
+        l = torch.randn(B, 96, generator=g).requires_grad_(True)
+        v = torch.randn(B, 96, generator=g).requires_grad_(True)
+        loss, ll_, lv = lc.ConVIRTLoss(tau=0.1, lambda_=0.75)(l, v)
+        loss.backward()
+        out[f"convirt_{B}"] = dict(loss=loss.detach(), loss_l=ll_.detach(), loss_v=lv.detach(), gl=l.grad.clone(), gv=v.grad.clone())
+        l2 = (0.2 * l.detach()).requires_grad_(True)
+        v2 = (0.2 * v.detach()).requires_grad_(True)
+        loss, lt, li_ = li.InfoNCELoss(tau=0.1)(l2, v2)
+        loss.backward()
+        out[f"infonce_{B}"] = dict(loss=loss.detach(), loss_t=lt.detach(), loss_i=li_.detach(), gl=l2.grad.clone(), gv=v2.grad.clone())
+        logits = torch.randn(B, 33, generator=g).requires_grad_(True)
+        tgt = torch.randint(0, 33, (B,), generator=g)
+        loss = ll.LabelSmoothingCrossEntropy(smoothing=0.1)(logits, tgt)
+        loss.backward()
+        out[f"lsce_{B}"] = dict(loss=loss.detach(), target=tgt, g=logits.grad.clone())
+    # known answer quoted in SURVEY §8(a) a13
+    torch.manual_seed(1234)
+    a, b = torch.randn(8, 768), torch.randn(8, 768)
+    out["convirt_known_answer"] = lc.ConVIRTLoss(tau=0.1, lambda_=0.75)(a, b)[0]
+    # GLoRIA
+    B, D, T, hw = 6, 32, 9, 5
+    g = torch.Generator().manual_seed(99)
+    glob = torch.randn(B, D, generator=g).requires_grad_(True)
+    loc = torch.randn(B, D, hw, hw, generator=g).requires_grad_(True)
+    words = torch.randn(B, D, T, generator=g).requires_grad_(True)
+    sent = torch.randn(B, D, generator=g).requires_grad_(True)
+    cap_lens = [4, 7, 3, 6, 5, 7]
+    sents = [["[CLS]"] + ["w"] * (n - 1) + ["[SEP]"] + ["[PAD]"] * (T - n - 1) for n in cap_lens]
+    gl = lg.GLoRIALoss(local_loss_weight=1.0, global_loss_weight=1.0, temp1=4.0, temp2=5.0, temp3=10.0)
+    loss, attn_maps = gl(glob, loc, words, sent, sents)
+    loss.backward()
+    out["gloria"] = dict(B=B, D=D, T=T, hw=hw, cap_lens=cap_lens, loss=loss.detach(),
+                         g_glob=glob.grad.clone(), g_loc=loc.grad.clone(), g_words=words.grad.clone(), g_sent=sent.grad.clone(),
+                         attn0=attn_maps[0].detach())
+    save("g6_losses", out)
+
+
+# ------------------------------------------------------------------ G7: greedy + beam decode
+def gen_decode():
+    from transformers import GenerationConfig
+    from transformers.cache_utils import DynamicCache, EncoderDecoderCache
+    cfg, seed, B, S, max_len = R.DEC_TINY, 41, 5, 10, 24
+    # random tied-embedding decoders repeat their last token under argmax (SURVEY §7 hard parts):
+    # large layer weights + small embeddings + an eos bias make greedy/beam paths non-degenerate.
+    recipe = dict(std=0.6, emb_std=0.2, eos_bias=3.0)
+    dec, st = build_ref_decoder(cfg, seed, **recipe)
+    hf = dec.decoder
+    g = torch.Generator().manual_seed(seed + 1)
+    enc = torch.randn(B, S, cfg["hidden_size"], generator=g)
+    enc_mask = torch.ones(B, S, dtype=torch.bool)
+    enc_mask[2, 6:] = False
+    enc[~enc_mask] = 0.0
+    res = dict(cfg=cfg, seed=seed, B=B, S=S, max_len=max_len, recipe=recipe, enc_mask=enc_mask, checksum=R.state_checksum(st))
+    for nb in (1, 4):
+        for lp in ((1.0,) if nb == 1 else (1.0, 2.0)):
+            args = dict(bos_token_id=0, eos_token_id=2, pad_token_id=1, num_return_sequences=1, max_length=max_len,
+                        use_cache=True, num_beams=nb, length_penalty=lp, return_dict_in_generate=True, output_scores=True)
+            # evaluation.py:73-78 call; shim 3 of SURVEY §8c: give HF 5.x the cache type cross-attention expects
+            with torch.no_grad():
+                o = hf.generate(input_ids=torch.ones((B, 1), dtype=torch.long) * 0,
+                                generation_config=GenerationConfig(**args),
+                                encoder_hidden_states=enc, encoder_attention_mask=enc_mask,
+                                past_key_values=EncoderDecoderCache(DynamicCache(config=hf.config), DynamicCache(config=hf.config)))
+            key = f"beams{nb}_lp{lp}"
+            res[key] = dict(sequences=o.sequences, scores=getattr(o, "sequences_scores", None))
+            print(key, o.sequences.tolist())
+    save("g7_decode", res)
+
+
+# ------------------------------------------------------------------ G9: MVQA core + text encoder
+def gen_mvqa_text():
+    from transformers.models.bert.modeling_bert import BertEncoder, BertPooler
+    from transformers.models.bert_generation import BertGenerationConfig
+    cfg, seed, B, S, C = R.MVQA_TINY, 51, 4, 9, 13
+    hfcfg = BertGenerationConfig(hidden_act="gelu", attention_probs_dropout_prob=0.0, hidden_dropout_prob=0.0, **cfg)
+    hfcfg._attn_implementation = "eager"
+    enc = BertEncoder(hfcfg).eval()
+    pool = BertPooler(hfcfg).eval()
+    clf = cl.Classifier(input_size=cfg["hidden_size"], num_classes=C, dropout=0.0).eval()
+    st = R.rand_state(R.bert_stack_shapes(cfg), seed)
+    load_into(enc, st)
+    g = torch.Generator().manual_seed(seed + 1)
+    pw, pb = 0.1 * torch.randn(64, 64, generator=g), 0.02 * torch.randn(64, generator=g)
+    cw, cb = 0.1 * torch.randn(C, 64, generator=g), 0.02 * torch.randn(C, generator=g)
+    pool.dense.weight.data.copy_(pw), pool.dense.bias.data.copy_(pb)
+    lin = [m for m in clf.modules() if isinstance(m, torch.nn.Linear)][0]
+    lin.weight.data.copy_(cw), lin.bias.data.copy_(cb)
+    x = torch.randn(B, S, 64, generator=g)
+    with torch.no_grad():
+        h = enc(x).last_hidden_state          # MVQA.py:43
+        pooled = pool(h)                      # MVQA.py:47
+        logits = clf(pooled)                  # MVQA.py:49
+    out = dict(mvqa=dict(cfg=cfg, seed=seed, B=B, S=S, C=C, checksum=R.state_checksum(st), x=x, pw=pw, pb=pb, cw=cw, cb=cb,
+                         hidden=h, pooled=pooled, logits=logits))
+    # EncoderModel(proto=None): random BertGenerationEncoder + BertPooler (encoder_model.py:18-29,44-62)
+    tcfg, seed = R.TXT_TINY, 61
+    e = em.EncoderModel(AttrDict(proto=None, add_pooling_layer=True, hidden_act="gelu", attention_probs_dropout_prob=0.0,
+                                 hidden_dropout_prob=0.0, **tcfg))
+    e.encoder.config._attn_implementation = "eager"
+    st = R.rand_state(R.text_encoder_shapes(tcfg), seed)
+    load_into(e.encoder, st)
+    e.pooler.dense.weight.data.copy_(pw), e.pooler.dense.bias.data.copy_(pb)
+    ids, am = R.make_reports(4, 16, tcfg["vocab_size"], seed=seed)
+    with torch.no_grad():
+        o = e.eval()(input_ids=ids, attention_mask=am)
+    out["text"] = dict(cfg=tcfg, seed=seed, B=4, L=16, checksum=R.state_checksum(st), pw=pw, pb=pb,
+                       last_hidden_state=o.last_hidden_state, pooler_output=o.pooler_output)
+    save("g9_mvqa_text", out)
+
+
+# ------------------------------------------------------------------ G8: scst_loss (pure function, load source by exec of the def only)
+def gen_scst():
+    import ast
+    src = open(REF + "blocks/rl/SCST.py").read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "scst_loss"][0]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "scst_loss", "exec"), ns)
+    g = torch.Generator().manual_seed(71)
+    B, T = 5, 11
+    logp = -torch.rand(B, T, 1, generator=g) * 5
+    logp[1, 4, 0] = -float("inf")
+    logp[3, 9, 0] = -float("inf")
+    seq = torch.randint(3, 50, (B, T), generator=g)
+    seq[0, 7:] = 1
+    seq[2, 3:] = 1
+    seq[4, 10:] = 0
+    rs = [torch.rand(B, generator=g).tolist(), torch.rand(B, generator=g).tolist()]
+    rg = [torch.rand(B, generator=g).tolist(), torch.rand(B, generator=g).tolist()]
+    w = [0.7, 0.3]
+    inp = logp.clone().requires_grad_(True)
+    loss, dr, drm = ns["scst_loss"](inp * 1.0, seq, rs, rg, w, 1)
+    loss.backward()
+    save("g8_scst", dict(logp=logp, seq=seq, rs=rs, rg=rg, w=w, pad=1, loss=loss.detach(), grad=inp.grad.clone(),
+                         delta_reward=dr, delta_reward_per_metric=drm))
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst"]
+    for w in which:
+        globals()["gen_" + w]()
