@@ -1,0 +1,151 @@
+/*
+ * vmhip.h -- C ABI of libvmhip.so, the MI355X (gfx950) hot path of vilmedic_amd.
+ *
+ * The reference (jbdel/vilmedic) has no FFI boundary of its own: its hot path is
+ * reached through Python class lookup (`eval(proto)`, vilmedic/executors/utils.py:110)
+ * and executed by third-party torch/transformers kernels (SURVEY.md §2.2, §8b "B2").
+ * Every entry point below therefore cites the reference *call site* whose
+ * arithmetic it replaces (ref: = /root/reference, hf: = the pinned HF
+ * transformers implementation the reference dispatches to).
+ *
+ * Conventions
+ *   - plain pointers + sizes; all pointers are DEVICE pointers unless noted;
+ *   - activations are bf16 (uint16 storage), statistics/params/grads fp32;
+ *   - every call enqueues on the hipStream_t passed as `stream` (void*), never
+ *     synchronises, never allocates; workspaces are caller-provided;
+ *   - return 0 on success or a negative vm_status; vm_last_error() gives text;
+ *   - row-major, leading dimensions in ELEMENTS and multiples of 8.
+ */
+#ifndef VMHIP_H
+#define VMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { VM_OK = 0, VM_EINVAL = -1, VM_EUNSUPPORTED = -2, VM_EHIP = -3 } vm_status;
+typedef enum { VM_BF16 = 1, VM_F32 = 0 } vm_dtype;
+
+const char* vm_last_error(void);
+int vm_version(void);
+
+/* ---- lightweight per-family profiler (HIP events on the launch stream; bench.py roofline) */
+int vm_prof_enable(int on);
+int vm_prof_reset(void);
+/* family: 0 gemm, 1 attention, 2 layernorm, 3 loss, 4 elementwise, 5 optimizer, 6 decode */
+int vm_prof_read(int family, double* ms_total, double* work_total, int64_t* launches); /* syncs events */
+
+/* ------------------------------------------------------------------ GEMM (MFMA bf16)
+ * C[M,N] = epilogue( sum_k opA(A)[m,k] * opB(B)[n,k] )
+ *   a_layout 0: A is [M,K] (K contiguous)   1: A is [K,M] (M contiguous)
+ *   b_layout 0: B is [N,K] (K contiguous)   1: B is [K,N] (N contiguous)
+ * Replaces nn.Linear fwd/bwd inside HF BERT/ViT blocks:
+ *   hf:models/bert_generation/modeling_bert_generation.py:104-106,172-174 (QKV),
+ *   :45-56 (out-proj), :264-291 (MLP), :590-598 (LM head); hf:models/vit/modeling_vit.py:60 (patch-embed conv as GEMM).
+ */
+typedef struct {
+    const float* bias;        /* [N] fp32 or NULL: added to the accumulator                     */
+    int act;                  /* 0 none, 1 erf-GELU (hf:activations.py "gelu")                   */
+    void* aux_out;            /* bf16 [M,N] (ldc): pre-activation z when act==1, or NULL         */
+    const void* mul_gelu_z;   /* bf16 [M,N] (ldc): multiply result by gelu'(z) (MLP backward)    */
+    float dropout_p;          /* inverted dropout on (acc+bias) before the residual              */
+    uint64_t dropout_seed;    /* counter-based RNG: keep-mask = f(seed, m*N+n)                   */
+    const void* residual;     /* bf16 [M,N] (ldr) added last, or NULL                            */
+    int64_t ldr;
+    float alpha;              /* scale applied to the accumulator first (1.0f default)           */
+    const float* alpha_dev;   /* optional DEVICE scalar multiplied into alpha (upstream dL/dloss)  */
+    int out_dtype;            /* VM_BF16 or VM_F32                                               */
+    int accumulate;           /* fp32 output only: atomically add into C (wgrad / split-K)       */
+    int split_k;              /* >=1; >1 requires out fp32 + accumulate                          */
+} vm_gemm_epilogue;
+
+int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void* B, int64_t ldb, int b_layout,
+                 void* C, int64_t ldc, int M, int N, int K, const vm_gemm_epilogue* epi, void* stream);
+
+/* ------------------------------------------------------------------ LayerNorm
+ * hf:...bert_generation.py:49,55 (post-LN, eps from YAML), hf:models/vit/modeling_vit.py:261-262,348 (pre-LN).
+ * y = (x-mean)*rstd*gamma+beta over the last dim; x,y bf16 [rows,cols]; mean/rstd fp32 [rows]. */
+int vm_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                     int rows, int cols, float eps, void* stream);
+/* dx bf16; dgamma/dbeta fp32 [cols] are ACCUMULATED (+=); ws: fp32 workspace of vm_layernorm_bwd_ws(rows,cols) bytes */
+size_t vm_layernorm_bwd_ws(int rows, int cols);
+int vm_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                     void* dx, float* dgamma, float* dbeta, int rows, int cols, void* ws, void* stream);
+
+/* ------------------------------------------------------------------ attention (self / causal / cross)
+ * softmax(Q K^T * scale + mask) V with optional dropout on the probabilities.
+ * hf:...bert_generation.py:60-85 (eager_attention_forward), :114-154 (self), :181-231 (cross).
+ * q: bf16, row (b*Lq+i) at q + row*ldq + h*dh ; k,v likewise with Lk rows per batch; o: [B*Lq, H*dh] ld=ldo.
+ * key_mask: uint8 [B,Lk] (1 = attend) or NULL; causal: key j visible to query i iff j<=i.
+ * stats: fp32 [B,H,Lq,2] = (row max, row sum) of the scaled+masked scores (saved for backward). dh must be 64. */
+int vm_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                     void* o, int64_t ldo, float* stats, const uint8_t* key_mask,
+                     int B, int H, int Lq, int Lk, int dh, float scale, int causal,
+                     float dropout_p, uint64_t dropout_seed, void* stream);
+int vm_attention_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                     const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* stats,
+                     const uint8_t* key_mask,
+                     void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
+                     int B, int H, int Lq, int Lk, int dh, float scale, int causal,
+                     float dropout_p, uint64_t dropout_seed, float* ws_delta /* fp32 [B,H,Lq] */, void* stream);
+
+/* ------------------------------------------------------------------ embeddings
+ * hf:...bert_generation.py:394-426: out = word[ids] + pos[past_len + t]   (LayerNorm is a separate call) */
+int vm_embedding_fwd(const int64_t* ids, const float* word, const float* pos, void* out /* bf16 [B*L, D] */,
+                     int B, int L, int D, int past_len, void* stream);
+/* scatter-add d_out into fp32 grads; rows with id==padding_idx get no word gradient (nn.Embedding(padding_idx)) */
+int vm_embedding_bwd(const int64_t* ids, const void* d_out, float* d_word, float* d_pos,
+                     int B, int L, int D, int padding_idx, void* stream);
+
+/* ------------------------------------------------------------------ ViT patch assembly
+ * hf:models/vit/modeling_vit.py:60,69 (conv as GEMM), :146-157 (cls + position embeddings). */
+int vm_im2col_patches(const float* images /* [B,C,H,W] fp32 */, void* out /* bf16 [B*gh*gw, C*p*p] */,
+                      int B, int C, int H, int W, int p, void* stream);
+int vm_vit_assemble(const void* patches /* bf16 [B*n, D] */, const float* cls /* [D] */, const float* pos /* [(n+1),D] */,
+                    void* out /* bf16 [B,(n+1),D] */, int B, int n, int D, void* stream);
+int vm_vit_assemble_bwd(const void* d_out /* bf16 [B,(n+1),D] */, void* d_patches /* bf16 [B*n,D] */,
+                        float* d_cls /* += [D] */, float* d_pos /* += [(n+1),D] */, int B, int n, int D, void* stream);
+
+/* ------------------------------------------------------------------ losses
+ * Shifted causal-LM cross-entropy (hf:loss/loss_utils.py:49-72; labels = input_ids, pads included,
+ * ref:vilmedic/blocks/huggingface/decoder/decoder_model.py:46).  logits bf16 [B*L, ldl]; label of row (b,t) is
+ * ids[b,t+1]; rows with t==L-1 are ignored.  loss_sum: fp32[1] += sum of row losses (caller divides by B*(L-1)).
+ * dlogits (bf16, same layout, may alias logits) = (softmax - onehot) * grad_scale, zero on ignored rows / pad cols. */
+int vm_ce_shift_fwd_bwd(const void* logits, int64_t ldl, const int64_t* ids, int B, int L, int V,
+                        float* loss_sum, float* row_lse /* fp32 [B*L] or NULL */, void* dlogits, float grad_scale,
+                        void* stream);
+/* Generic CE with label smoothing on fp32 logits [R,C] (MVQA head; ref:...LabelSmoothingCrossEntropyLoss.py:38-48) */
+int vm_ce_smooth_fwd_bwd(const float* logits, const int64_t* target, int R, int C, float smoothing,
+                         float* loss_sum, float* dlogits, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------ element-wise / reductions */
+int vm_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
+int vm_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
+/* dst[r, 0:cols] (ld_dst) = bf16(src fp32 [rows, cols]); pad columns/rows left untouched */
+int vm_cast_pad_f32_to_bf16(const float* src, void* dst, int rows, int cols, int64_t ld_dst, void* stream);
+int vm_colsum_bf16(const void* x, int64_t ldx, float* out /* += [cols] */, int rows, int cols,
+                   const float* scale_dev /* optional device scalar */, void* stream);
+int vm_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+/* out = keep(seed, idx) ? x/(1-p) : 0 with idx = flat element index (the mask vm_gemm_bf16 uses with idx = m*N+n) */
+int vm_dropout_apply_bf16(const void* x, void* out, int64_t n, float p, uint64_t seed, void* stream);
+int vm_feature_mask(const void* feats /* bf16 [rows, cols] */, uint8_t* mask, int rows, int cols, void* stream);
+
+/* ------------------------------------------------------------------ optimizer
+ * torch.optim.Adam/AdamW semantics (ref:vilmedic/executors/utils.py:65-94 builds any torch.optim by name).
+ * One launch over a flat arena: p,m,v fp32 [n]; g fp32 [n]; optional bf16 shadow refresh. */
+int vm_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16 /* or NULL */, int64_t n,
+                 float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled_wd,
+                 float bias_corr1, float bias_corr2, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------ decode step helpers
+ * hf:generation/utils.py:3384-3389 (fp32 log_softmax), :3113-3119 (top-k over beams*V), :2925 (argmax). */
+int vm_logsoftmax_f32(const float* logits, int64_t ldl, float* out, int rows, int V, void* stream);
+int vm_argmax_f32(const float* x, int64_t ldx, int64_t* idx, float* val, int rows, int cols, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VMHIP_H */

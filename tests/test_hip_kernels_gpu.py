@@ -1,0 +1,239 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against plain-PyTorch fp32 math on the
+same bf16-rounded inputs.  Tolerances are stated per test; integer outputs are bit-exact."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+@pytest.mark.parametrize("la,lb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(200, 136, 192), (128, 128, 64), (333, 97, 104), (1, 8, 8)])
+def test_gemm_layouts(la, lb, M, N, K):
+    from vilmedic_amd import ops
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    ref = A.float() @ B.float().t()
+    pad = lambda n: (n + 7) // 8 * 8
+    Ad = torch.zeros(M, pad(K), dtype=BF) if la == 0 else torch.zeros(K, pad(M), dtype=BF)
+    Bd = torch.zeros(N, pad(K), dtype=BF) if lb == 0 else torch.zeros(K, pad(N), dtype=BF)
+    (Ad[:, :K] if la == 0 else Ad[:, :M]).copy_(A if la == 0 else A.t())
+    (Bd[:, :K] if lb == 0 else Bd[:, :N]).copy_(B if lb == 0 else B.t())
+    Ad, Bd = Ad.to(dev()), Bd.to(dev())
+    C = torch.zeros(M, pad(N), dtype=torch.float32, device=dev())
+    ops.gemm(Ad, la, Bd, lb, C, M, N, K)
+    torch.testing.assert_close(C[:, :N].cpu(), ref, rtol=1e-4, atol=1e-3)     # fp32 accumulate of exact bf16 products
+    Cb = torch.zeros(M, pad(N), dtype=BF, device=dev())
+    ops.gemm(Ad, la, Bd, lb, Cb, M, N, K)
+    torch.testing.assert_close(Cb[:, :N].float().cpu(), ref, rtol=1e-2, atol=2e-2)   # one bf16 rounding of the output
+
+
+def test_gemm_epilogues_and_splitk():
+    from vilmedic_amd import ops
+    M, N, K = 300, 256, 512
+    A, B = rnd(M, K, seed=3).to(dev()), rnd(N, K, scale=0.05, seed=4).to(dev())
+    bias = torch.randn(N, device=dev())
+    res = rnd(M, N, seed=5).to(dev())
+    z = torch.empty(M, N, dtype=BF, device=dev())
+    y = torch.empty(M, N, dtype=BF, device=dev())
+    ops.gemm(A, 0, B, 0, y, M, N, K, bias=bias, act=1, aux_out=z, residual=res)
+    zr = A.float() @ B.float().t() + bias
+    torch.testing.assert_close(z.float(), zr, rtol=1e-2, atol=2e-2)
+    torch.testing.assert_close(y.float(), torch.nn.functional.gelu(zr) + res.float(), rtol=1e-2, atol=3e-2)
+    # gelu' multiply (MLP backward epilogue)
+    dz = torch.empty(M, N, dtype=BF, device=dev())
+    ops.gemm(A, 0, B, 0, dz, M, N, K, mul_gelu_z=z)
+    zf = z.float().requires_grad_(True)
+    torch.nn.functional.gelu(zf).sum().backward()
+    torch.testing.assert_close(dz.float(), (A.float() @ B.float().t()) * zf.grad, rtol=2e-2, atol=3e-2)
+    # split-K fp32 accumulate == single pass, and accumulates on top of existing content
+    C1 = torch.ones(M, N, dtype=torch.float32, device=dev())
+    ops.gemm(A, 0, B, 0, C1, M, N, K, accumulate=True, split_k=4)
+    torch.testing.assert_close(C1, A.float() @ B.float().t() + 1.0, rtol=1e-4, atol=1e-3)
+    # device-scalar alpha
+    sc = torch.tensor([0.25], device=dev())
+    C2 = torch.zeros(M, N, dtype=torch.float32, device=dev())
+    ops.gemm(A, 0, B, 0, C2, M, N, K, alpha_dev=sc)
+    torch.testing.assert_close(C2, 0.25 * (A.float() @ B.float().t()), rtol=1e-4, atol=1e-3)
+
+
+def test_gemm_dropout_mask_is_reproducible_and_unbiased():
+    from vilmedic_amd import ops
+    M, N, K = 512, 512, 64
+    A, B = torch.ones(M, K, dtype=BF, device=dev()), torch.ones(N, K, dtype=BF, device=dev()) / K
+    y = torch.empty(M, N, dtype=BF, device=dev())
+    ops.gemm(A, 0, B, 0, y, M, N, K, dropout_p=0.1, dropout_seed=1234)
+    keep = (y != 0).float().mean().item()
+    assert abs(keep - 0.9) < 0.01
+    assert torch.allclose(y[y != 0].float(), torch.tensor(1 / 0.9, device=dev()), rtol=1e-2)
+    # the stand-alone mask kernel (used in backward) regenerates the same mask
+    ones = torch.ones(M, N, dtype=BF, device=dev())
+    m2 = ops.dropout_apply(ones, 0.1, 1234)
+    assert torch.equal(m2 != 0, y != 0)
+
+
+@pytest.mark.parametrize("rows,cols", [(1000, 768), (37, 64), (50, 1664), (3, 2048)])
+def test_layernorm_fwd_bwd(rows, cols):
+    from vilmedic_amd import ops
+    x = rnd(rows, cols, scale=2.0, seed=6).to(dev()).requires_grad_(True)
+    g = (1 + 0.1 * torch.randn(cols)).to(dev())
+    b = (0.1 * torch.randn(cols)).to(dev())
+    gg, gb = torch.zeros(cols, device=dev()), torch.zeros(cols, device=dev())
+    y = ops.layer_norm(x, g, b, 1e-5, gg, gb)
+    dy = rnd(rows, cols, seed=7).to(dev())
+    y.backward(dy)
+    xf = x.detach().float().requires_grad_(True)
+    gf, bf_ = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xf, (cols,), gf, bf_, 1e-5)
+    yr.backward(dy.float())
+    torch.testing.assert_close(y.float(), yr, rtol=1e-2, atol=2e-2)
+    torch.testing.assert_close(x.grad.float(), xf.grad, rtol=1e-2, atol=2e-2)
+    torch.testing.assert_close(gg, gf.grad, rtol=1e-3, atol=2e-2)
+    torch.testing.assert_close(gb, bf_.grad, rtol=1e-3, atol=2e-2)
+
+
+def _attn_ref(q, k, v, H, key_mask, causal):
+    B, Lq, D = q.shape
+    Lk = k.shape[1]
+    dh = D // H
+    qh = q.view(B, Lq, H, dh).transpose(1, 2)
+    kh = k.view(B, Lk, H, dh).transpose(1, 2)
+    vh = v.view(B, Lk, H, dh).transpose(1, 2)
+    s = qh @ kh.transpose(2, 3) * dh ** -0.5
+    neg = torch.finfo(torch.float32).min
+    if key_mask is not None:
+        s = s.masked_fill(~key_mask.bool()[:, None, None, :], neg)
+    if causal:
+        s = s.masked_fill(~torch.tril(torch.ones(Lq, Lk, dtype=torch.bool, device=q.device)), neg)
+    p = torch.softmax(s, -1)
+    return (p @ vh).transpose(1, 2).reshape(B, Lq, D)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,causal,masked", [
+    (2, 2, 17, 17, False, False),      # ViT-tiny shaped, ragged tile
+    (3, 12, 197, 197, False, False),   # ViT-B/16 sequence
+    (2, 4, 128, 128, True, True),      # decoder self-attention: causal + padding
+    (2, 4, 128, 197, False, True),     # cross-attention with a key-padding mask
+    (1, 1, 1, 300, False, True),       # single query row (decode step), > 4 key tiles
+    (2, 2, 70, 64, False, False),
+])
+def test_attention_fwd_bwd(B, H, Lq, Lk, causal, masked):
+    from vilmedic_amd import ops
+    D = H * 64
+    q = rnd(B, Lq, D, seed=10).to(dev()).requires_grad_(True)
+    k = rnd(B, Lk, D, seed=11).to(dev()).requires_grad_(True)
+    v = rnd(B, Lk, D, seed=12).to(dev()).requires_grad_(True)
+    km = None
+    if masked:
+        km = torch.ones(B, Lk, dtype=torch.uint8, device=dev())
+        km[0, Lk // 2:] = 0
+        if B > 1:
+            km[1, Lk - 3:] = 0
+    o = ops.AttentionFn.apply(q, k, v, km, H, causal, 0.0)
+    do = rnd(B, Lq, D, seed=13).to(dev())
+    o.backward(do)
+    qf, kf, vf = [t.detach().float().requires_grad_(True) for t in (q, k, v)]
+    orf = _attn_ref(qf, kf, vf, H, km, causal)
+    orf.backward(do.float())
+    torch.testing.assert_close(o.float(), orf, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(q.grad.float(), qf.grad, rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(k.grad.float(), kf.grad, rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(v.grad.float(), vf.grad, rtol=3e-2, atol=3e-2)
+
+
+def test_attention_fully_masked_row_is_uniform():
+    """HF adds finfo.min to masked scores: a row whose keys are ALL masked attends uniformly (softmax of equal values)."""
+    from vilmedic_amd import ops
+    B, H, Lq, Lk = 1, 1, 5, 9
+    q, k, v = [rnd(B, L, 64, seed=s).to(dev()) for L, s in ((Lq, 1), (Lk, 2), (Lk, 3))]
+    km = torch.zeros(B, Lk, dtype=torch.uint8, device=dev())
+    o = ops.AttentionFn.apply(q, k, v, km, H, False, 0.0)
+    torch.testing.assert_close(o.float()[0], v.float()[0].mean(0, keepdim=True).expand(Lq, -1), rtol=2e-2, atol=2e-2)
+
+
+def test_attention_dropout_statistics_and_backward_consistency():
+    from vilmedic_amd import ops
+    B, H, L = 2, 2, 64
+    D = H * 64
+    q = rnd(B, L, D, seed=20).to(dev()).requires_grad_(True)
+    k = rnd(B, L, D, seed=21).to(dev()).requires_grad_(True)
+    v = torch.ones(B, L, D, dtype=BF, device=dev()).requires_grad_(True)
+    ops.manual_seed(7)
+    o = ops.AttentionFn.apply(q, k, v, None, H, False, 0.5)
+    # with V == 1 each output equals sum_j dropped P_ij; its mean over many rows is ~1
+    assert abs(o.float().mean().item() - 1.0) < 0.05
+    # finite-difference-free check: dV = P_drop^T dO, so sum(dV) == sum_i dO_i * sum_j P_drop_ij == sum(o * dO)
+    do = torch.ones_like(o)
+    o.backward(do)
+    assert abs(v.grad.float().sum().item() / (o.float() * do.float()).sum().item() - 1) < 2e-2
+
+
+def test_embedding_and_ce():
+    from vilmedic_amd import ops
+    B, L, V, D = 3, 10, 50, 64
+    ids = torch.randint(0, V, (B, L), device=dev())
+    ids[0, 3] = 1
+    word = torch.randn(V, D, device=dev())
+    pos = torch.randn(32, D, device=dev())
+    gw, gp = torch.zeros_like(word), torch.zeros_like(pos)
+    anchor = torch.zeros(1, device=dev(), requires_grad=True)
+    out = ops.embedding(anchor, ids, word, pos, padding_idx=1, g_word=gw, g_pos=gp)
+    torch.testing.assert_close(out.float(), (word[ids] + pos[:L]).to(BF).float())
+    dout = rnd(B, L, D, seed=3).to(dev())
+    out.backward(dout)
+    wr = word.clone().requires_grad_(True)
+    pr = pos.clone().requires_grad_(True)
+    (torch.nn.functional.embedding(ids, wr, padding_idx=1) + pr[:L]).backward(dout.float())
+    torch.testing.assert_close(gw, wr.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gp, pr.grad, rtol=1e-5, atol=1e-5)
+    # shifted CE fused fwd+bwd vs torch (pads included, last position ignored)
+    Vp = 56
+    logits = torch.zeros(B * L, Vp, dtype=BF, device=dev())
+    logits[:, :V] = rnd(B * L, V, scale=2.0, seed=4).to(dev())
+    loss_sum = torch.zeros(1, device=dev())
+    dl = torch.empty_like(logits)
+    from vilmedic_amd._lib import lib, ptr, stream, check
+    check(lib().vm_ce_shift_fwd_bwd(ptr(logits), Vp, ptr(ids), B, L, V, ptr(loss_sum), None, ptr(dl), 1.0 / (B * (L - 1)), stream()))
+    lf = logits[:, :V].float().view(B, L, V).requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lf[:, :-1].reshape(-1, V), ids[:, 1:].reshape(-1))
+    ref.backward()
+    torch.testing.assert_close(loss_sum[0] / (B * (L - 1)), ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dl[:, :V].float().view(B, L, V), lf.grad, rtol=1e-2, atol=1e-4)
+    assert torch.count_nonzero(dl[:, V:]) == 0
+
+
+def test_adam_matches_torch():
+    from vilmedic_amd._lib import lib, ptr, stream, check
+    n = 10007
+    p = torch.randn(n, device=dev()); g = torch.randn(n, device=dev())
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    m = torch.zeros(n, device=dev()); v = torch.zeros(n, device=dev()); sh = torch.empty(n, dtype=BF, device=dev())
+    for step in range(1, 4):
+        pr.grad = g.clone()
+        opt.step()
+        check(lib().vm_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), ptr(sh), n, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1,
+                                 1 - 0.9 ** step, 1 - 0.999 ** step, 1.0, stream()))
+        torch.testing.assert_close(p, pr.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(sh.float(), p.to(BF).float())
+
+
+def test_argmax_logsoftmax():
+    from vilmedic_amd._lib import lib, ptr, stream, check
+    x = torch.randn(7, 1000, device=dev())
+    x[2, 5] = x[2, 900] = 50.0     # tie -> lowest index
+    out = torch.empty_like(x)
+    check(lib().vm_logsoftmax_f32(ptr(x), 1000, ptr(out), 7, 1000, stream()))
+    torch.testing.assert_close(out, torch.log_softmax(x, -1), rtol=1e-5, atol=1e-5)
+    idx = torch.empty(7, dtype=torch.long, device=dev())
+    check(lib().vm_argmax_f32(ptr(x), 1000, ptr(idx), None, 7, 1000, stream()))
+    assert torch.equal(idx, x.argmax(-1)) and idx[2] == 5

@@ -1,0 +1,158 @@
+// gpu_probe.hip -- standalone first-contact test for the GPU box (no Python):
+//   1. prints the lane mapping of ds_read_b64_tr_b16 (gemm layout-1 fragments depend on it);
+//   2. checks vm_gemm_bf16 in all four operand layouts against a CPU reference;
+//   3. checks vm_layernorm_fwd/bwd against a CPU reference.
+// build: hipcc --offload-arch=gfx950 -O2 tools/gpu_probe.hip vilmedic_amd/csrc/{gemm,layernorm,runtime}.o -o tools/gpu_probe.bin
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <vector>
+#include "../include/vmhip.h"
+
+typedef short v4s __attribute__((ext_vector_type(4)));
+__global__ void tr_probe(short* out) {
+    __shared__ short lds[1024];
+    for (int i = threadIdx.x; i < 1024; i += 64) lds[i] = (short)i;
+    __syncthreads();
+    // lane l supplies address of elements [4l, 4l+3]
+    const __attribute__((address_space(3))) v4s* p = (const __attribute__((address_space(3))) v4s*)(lds + threadIdx.x * 4);
+    v4s v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p);
+    for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = v[j];
+}
+
+static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
+static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static float frand() { return (float)rand() / RAND_MAX * 2.f - 1.f; }
+
+static int test_gemm(int M, int N, int K, int la, int lb, int split, bool f32out) {
+    // logical A(m,k), B(n,k)
+    std::vector<float> A((size_t)M * K), B((size_t)N * K);
+    for (auto& x : A) x = bf2f(f2bf(frand()));
+    for (auto& x : B) x = bf2f(f2bf(frand()));
+    int64_t lda = la == 0 ? (K + 7) / 8 * 8 : (M + 7) / 8 * 8;
+    int64_t ldb = lb == 0 ? (K + 7) / 8 * 8 : (N + 7) / 8 * 8;
+    std::vector<uint16_t> hA((size_t)(la == 0 ? M : K) * lda, 0), hB((size_t)(lb == 0 ? N : K) * ldb, 0);
+    for (int m = 0; m < M; ++m) for (int k = 0; k < K; ++k) hA[la == 0 ? (size_t)m * lda + k : (size_t)k * lda + m] = f2bf(A[(size_t)m * K + k]);
+    for (int n = 0; n < N; ++n) for (int k = 0; k < K; ++k) hB[lb == 0 ? (size_t)n * ldb + k : (size_t)k * ldb + n] = f2bf(B[(size_t)n * K + k]);
+    int64_t ldc = (N + 7) / 8 * 8;
+    void *dA, *dB, *dC;
+    hipMalloc(&dA, hA.size() * 2); hipMalloc(&dB, hB.size() * 2); hipMalloc(&dC, (size_t)M * ldc * 4);
+    hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice);
+    hipMemset(dC, 0, (size_t)M * ldc * 4);
+    vm_gemm_epilogue e = {};
+    e.alpha = 1.f; e.out_dtype = f32out ? VM_F32 : VM_BF16; e.split_k = split; e.accumulate = split > 1;
+    int rc = vm_gemm_bf16(dA, lda, la, dB, ldb, lb, dC, ldc, M, N, K, &e, nullptr);
+    if (rc) { printf("gemm rc=%d %s\n", rc, vm_last_error()); return 1; }
+    hipDeviceSynchronize();
+    std::vector<float> C((size_t)M * ldc);
+    if (f32out) hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost);
+    else { std::vector<uint16_t> t(C.size()); hipMemcpy(t.data(), dC, t.size() * 2, hipMemcpyDeviceToHost); for (size_t i = 0; i < t.size(); ++i) C[i] = bf2f(t[i]); }
+    double maxerr = 0; int bad = 0;
+    for (int m = 0; m < M; m += (M > 512 ? 37 : 1)) for (int n = 0; n < N; ++n) {
+        double ref = 0; for (int k = 0; k < K; ++k) ref += (double)A[(size_t)m * K + k] * B[(size_t)n * K + k];
+        double err = fabs(ref - C[(size_t)m * ldc + n]);
+        double tol = f32out ? 1e-3 + 1e-4 * fabs(ref) : 0.02 + 0.01 * fabs(ref);
+        if (err > tol) { if (bad < 5) printf("  mismatch m=%d n=%d ref=%f got=%f\n", m, n, ref, C[(size_t)m * ldc + n]); ++bad; }
+        if (err > maxerr) maxerr = err;
+    }
+    printf("gemm M=%d N=%d K=%d la=%d lb=%d split=%d f32=%d maxerr=%.4g bad=%d %s\n", M, N, K, la, lb, split, (int)f32out, maxerr, bad, bad ? "FAIL" : "ok");
+    hipFree(dA); hipFree(dB); hipFree(dC);
+    return bad != 0;
+}
+
+static void bench_gemm(int M, int N, int K, int la, int lb) {
+    int64_t lda = la == 0 ? K : M, ldb = lb == 0 ? K : N;
+    void *dA, *dB, *dC;
+    size_t na = (size_t)M * K, nb = (size_t)N * K;
+    std::vector<uint16_t> h(std::max(na, nb));
+    for (auto& x : h) x = f2bf(frand());
+    hipMalloc(&dA, na * 2); hipMalloc(&dB, nb * 2); hipMalloc(&dC, (size_t)M * N * 2);
+    hipMemcpy(dA, h.data(), na * 2, hipMemcpyHostToDevice); hipMemcpy(dB, h.data(), nb * 2, hipMemcpyHostToDevice);
+    vm_gemm_epilogue e = {}; e.alpha = 1.f; e.out_dtype = VM_BF16; e.split_k = 1;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 3; ++i) vm_gemm_bf16(dA, lda, la, dB, ldb, lb, dC, N, M, N, K, &e, nullptr);
+    hipEventRecord(a, nullptr);
+    const int it = 20;
+    for (int i = 0; i < it; ++i) vm_gemm_bf16(dA, lda, la, dB, ldb, lb, dC, N, M, N, K, &e, nullptr);
+    hipEventRecord(b, nullptr); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); ms /= it;
+    printf("bench M=%d N=%d K=%d la=%d lb=%d: %.3f ms  %.1f TFLOP/s\n", M, N, K, la, lb, ms, 2.0 * M * N * K / ms * 1e-9);
+    hipFree(dA); hipFree(dB); hipFree(dC);
+}
+
+static int test_ln(int rows, int cols) {
+    std::vector<float> x((size_t)rows * cols), dy(x.size()), g(cols), bta(cols);
+    for (auto& v : x) v = bf2f(f2bf(frand() * 2 + 0.3f));
+    for (auto& v : dy) v = bf2f(f2bf(frand()));
+    for (auto& v : g) v = 1.f + 0.1f * frand();
+    for (auto& v : bta) v = 0.1f * frand();
+    std::vector<uint16_t> hx(x.size()), hdy(x.size());
+    for (size_t i = 0; i < x.size(); ++i) { hx[i] = f2bf(x[i]); hdy[i] = f2bf(dy[i]); }
+    void *dx_, *ddy, *dyo, *ddx, *dg, *db, *dmean, *drstd, *dgam, *dbet, *ws;
+    hipMalloc(&dx_, hx.size() * 2); hipMalloc(&ddy, hx.size() * 2); hipMalloc(&dyo, hx.size() * 2); hipMalloc(&ddx, hx.size() * 2);
+    hipMalloc(&dg, cols * 4); hipMalloc(&db, cols * 4); hipMalloc(&dmean, rows * 4); hipMalloc(&drstd, rows * 4);
+    hipMalloc(&dgam, cols * 4); hipMalloc(&dbet, cols * 4); hipMalloc(&ws, vm_layernorm_bwd_ws(rows, cols));
+    hipMemcpy(dx_, hx.data(), hx.size() * 2, hipMemcpyHostToDevice); hipMemcpy(ddy, hdy.data(), hx.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dgam, g.data(), cols * 4, hipMemcpyHostToDevice); hipMemcpy(dbet, bta.data(), cols * 4, hipMemcpyHostToDevice);
+    hipMemset(dg, 0, cols * 4); hipMemset(db, 0, cols * 4);
+    int rc = vm_layernorm_fwd(dx_, (float*)dgam, (float*)dbet, dyo, (float*)dmean, (float*)drstd, rows, cols, 1e-5f, nullptr);
+    rc |= vm_layernorm_bwd(ddy, dx_, (float*)dgam, (float*)dmean, (float*)drstd, ddx, (float*)dg, (float*)db, rows, cols, ws, nullptr);
+    if (rc) { printf("ln rc=%d %s\n", rc, vm_last_error()); return 1; }
+    hipDeviceSynchronize();
+    std::vector<uint16_t> hy(hx.size()), hdx(hx.size()); std::vector<float> hdg(cols), hdb(cols);
+    hipMemcpy(hy.data(), dyo, hy.size() * 2, hipMemcpyDeviceToHost); hipMemcpy(hdx.data(), ddx, hy.size() * 2, hipMemcpyDeviceToHost);
+    hipMemcpy(hdg.data(), dg, cols * 4, hipMemcpyDeviceToHost); hipMemcpy(hdb.data(), db, cols * 4, hipMemcpyDeviceToHost);
+    int bad = 0; double e1 = 0, e2 = 0, e3 = 0;
+    std::vector<double> rdg(cols, 0), rdb(cols, 0);
+    for (int r = 0; r < rows; ++r) {
+        double mu = 0, var = 0;
+        for (int c = 0; c < cols; ++c) mu += x[(size_t)r * cols + c];
+        mu /= cols;
+        for (int c = 0; c < cols; ++c) { double d = x[(size_t)r * cols + c] - mu; var += d * d; }
+        double rs = 1.0 / sqrt(var / cols + 1e-5);
+        double s1 = 0, s2 = 0;
+        for (int c = 0; c < cols; ++c) { double xh = (x[(size_t)r * cols + c] - mu) * rs, gy = dy[(size_t)r * cols + c] * g[c]; s1 += gy; s2 += gy * xh; rdg[c] += dy[(size_t)r * cols + c] * xh; rdb[c] += dy[(size_t)r * cols + c]; }
+        s1 /= cols; s2 /= cols;
+        for (int c = 0; c < cols; ++c) {
+            double xh = (x[(size_t)r * cols + c] - mu) * rs;
+            double yref = xh * g[c] + bta[c], dxref = rs * (dy[(size_t)r * cols + c] * g[c] - s1 - xh * s2);
+            double ey = fabs(yref - bf2f(hy[(size_t)r * cols + c])), ed = fabs(dxref - bf2f(hdx[(size_t)r * cols + c]));
+            if (ey > 0.02 + 0.01 * fabs(yref) || ed > 0.02 + 0.01 * fabs(dxref)) ++bad;
+            if (ey > e1) e1 = ey; if (ed > e2) e2 = ed;
+        }
+    }
+    for (int c = 0; c < cols; ++c) { double e = fmax(fabs(rdg[c] - hdg[c]), fabs(rdb[c] - hdb[c])); if (e > e3) e3 = e; if (e > 1e-2 + 1e-3 * fabs(rdg[c])) ++bad; }
+    printf("layernorm rows=%d cols=%d  max|dy|=%.3g max|ddx|=%.3g max|dgamma,dbeta|=%.3g bad=%d %s\n", rows, cols, e1, e2, e3, bad, bad ? "FAIL" : "ok");
+    return bad != 0;
+}
+
+int main() {
+    short* d; hipMalloc(&d, 256 * 2);
+    hipLaunchKernelGGL(tr_probe, dim3(1), dim3(64), 0, 0, d);
+    short h[256]; hipMemcpy(h, d, 512, hipMemcpyDeviceToHost);
+    printf("ds_read_b64_tr_b16 with lane l -> &lds[4l] (values are source element indices):\n");
+    for (int l = 0; l < 64; ++l) { printf("  lane %2d: %4d %4d %4d %4d%s", l, h[l * 4], h[l * 4 + 1], h[l * 4 + 2], h[l * 4 + 3], (l & 3) == 3 ? "\n" : ""); }
+    int fails = 0;
+    for (int la = 0; la < 2; ++la) for (int lb = 0; lb < 2; ++lb) {
+        fails += test_gemm(200, 136, 192, la, lb, 1, false);
+        fails += test_gemm(128, 128, 64, la, lb, 1, true);
+        fails += test_gemm(333, 97, 104, la, lb, 1, true);
+    }
+    fails += test_gemm(256, 256, 1024, 1, 1, 4, true);
+    fails += test_gemm(1000, 768, 768, 0, 0, 1, false);
+    fails += test_ln(1000, 768);
+    fails += test_ln(37, 64);
+    fails += test_ln(50, 1664);
+    bench_gemm(12608, 3072, 768, 0, 0);
+    bench_gemm(12608, 768, 3072, 0, 0);
+    bench_gemm(12608, 768, 3072, 0, 1);
+    bench_gemm(3072, 768, 12608, 1, 1);
+    bench_gemm(8192, 30528, 768, 0, 0);
+    bench_gemm(8192, 8192, 8192, 0, 0);
+    printf("fails=%d\n", fails);
+    return fails;
+}

@@ -1,0 +1,98 @@
+"""ctypes binding of libvmhip.so (the C ABI in include/vmhip.h).
+
+The product path has NO fallback: if the library is missing or a call fails,
+an exception is raised.  PyTorch is used only to own device memory and streams.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvmhip.so")
+
+VM_F32, VM_BF16 = 0, 1
+
+
+class GemmEpilogue(C.Structure):
+    _fields_ = [
+        ("bias", C.c_void_p), ("act", C.c_int), ("aux_out", C.c_void_p), ("mul_gelu_z", C.c_void_p),
+        ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64), ("residual", C.c_void_p), ("ldr", C.c_int64),
+        ("alpha", C.c_float), ("alpha_dev", C.c_void_p), ("out_dtype", C.c_int), ("accumulate", C.c_int), ("split_k", C.c_int),
+    ]
+
+
+_lib = None
+
+_P, _I, _L, _F, _U64, _SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
+
+# name -> (restype, argtypes).  Must list every symbol declared in include/vmhip.h (tests check this).
+SIGNATURES = {
+    "vm_last_error": (C.c_char_p, []),
+    "vm_version": (_I, []),
+    "vm_prof_enable": (_I, [_I]),
+    "vm_prof_reset": (_I, []),
+    "vm_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "vm_gemm_bf16": (_I, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, C.POINTER(GemmEpilogue), _P]),
+    "vm_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
+    "vm_layernorm_bwd_ws": (_SZ, [_I, _I]),
+    "vm_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "vm_attention_fwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _U64, _P]),
+    "vm_attention_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _P, _L, _P, _L,
+                              _I, _I, _I, _I, _I, _F, _I, _F, _U64, _P, _P]),
+    "vm_embedding_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vm_embedding_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vm_im2col_patches": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "vm_vit_assemble": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "vm_vit_assemble_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "vm_ce_shift_fwd_bwd": (_I, [_P, _L, _P, _I, _I, _I, _P, _P, _P, _F, _P]),
+    "vm_ce_smooth_fwd_bwd": (_I, [_P, _P, _I, _I, _F, _P, _P, _F, _P]),
+    "vm_cast_f32_to_bf16": (_I, [_P, _P, _L, _P]),
+    "vm_cast_bf16_to_f32": (_I, [_P, _P, _L, _P]),
+    "vm_cast_pad_f32_to_bf16": (_I, [_P, _P, _I, _I, _L, _P]),
+    "vm_colsum_bf16": (_I, [_P, _L, _P, _I, _I, _P, _P]),
+    "vm_add_bf16": (_I, [_P, _P, _P, _L, _P]),
+    "vm_dropout_apply_bf16": (_I, [_P, _P, _L, _F, _U64, _P]),
+    "vm_feature_mask": (_I, [_P, _P, _I, _I, _P]),
+    "vm_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _F, _F, _P]),
+    "vm_logsoftmax_f32": (_I, [_P, _L, _P, _I, _I, _P]),
+    "vm_argmax_f32": (_I, [_P, _L, _P, _P, _I, _I, _P]),
+}
+
+
+class VmHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libvmhip.so (once).  Raises if it has not been built -- there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VmHipError(f"{LIB_PATH} not found: build it with `python -m vilmedic_amd.build` "
+                         "(the HIP hot path has no fallback)")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(status, what=""):
+    if status != 0:
+        raise VmHipError(f"{what} failed ({status}): {lib().vm_last_error().decode()}")
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise VmHipError("vilmedic_amd ops need device tensors: the HIP path has no CPU fallback")
+    return C.c_void_p(t.data_ptr())

@@ -1,0 +1,170 @@
+"""CNN backbones for VisualEncoder.  torchvision is not installed in this image, so the architectures the shipped
+YAMLs name (resnet18/34/50/101, densenet121/169) are declared here with torchvision's module / parameter names
+(``conv1, bn1, layer1.0.conv1 ...``, ``features.denseblock1.denselayer1.norm1 ...``) so reference checkpoints load.
+They run through MIOpen via PyTorch-ROCm (CNN stems are NOT hand-written kernels).
+ref: vilmedic/blocks/vision/visual_encoder.py:71-81 (eval(backbone)(pretrained=...) truncated at output_layer)."""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inp, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inp, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + idt)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inp, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inp, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + idt)
+
+
+class ResNet(nn.Module):
+    def __init__(self, block, layers, num_classes=1000):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = self._make(block, 64, layers[0])
+        self.layer2 = self._make(block, 128, layers[1], 2)
+        self.layer3 = self._make(block, 256, layers[2], 2)
+        self.layer4 = self._make(block, 512, layers[3], 2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512 * block.expansion, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def _make(self, block, planes, n, stride=1):
+        down = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
+                                 nn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, down)]
+        self.inplanes = planes * block.expansion
+        layers += [block(self.inplanes, planes) for _ in range(1, n)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return self.fc(torch.flatten(self.avgpool(x), 1))
+
+
+class _DenseLayer(nn.Module):
+    def __init__(self, inp, growth, bn_size):
+        super().__init__()
+        self.norm1 = nn.BatchNorm2d(inp)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.conv1 = nn.Conv2d(inp, bn_size * growth, 1, bias=False)
+        self.norm2 = nn.BatchNorm2d(bn_size * growth)
+        self.relu2 = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(bn_size * growth, growth, 3, 1, 1, bias=False)
+
+    def forward(self, feats):
+        x = torch.cat(feats, 1) if isinstance(feats, (list, tuple)) else feats
+        x = self.conv1(self.relu1(self.norm1(x)))
+        return self.conv2(self.relu2(self.norm2(x)))
+
+
+class _DenseBlock(nn.ModuleDict):
+    def __init__(self, n, inp, bn_size, growth):
+        super().__init__()
+        for i in range(n):
+            self.add_module(f"denselayer{i + 1}", _DenseLayer(inp + i * growth, growth, bn_size))
+
+    def forward(self, x):
+        feats = [x]
+        for _, layer in self.items():
+            feats.append(layer(feats))
+        return torch.cat(feats, 1)
+
+
+class DenseNet(nn.Module):
+    def __init__(self, growth=32, blocks=(6, 12, 24, 16), init_feat=64, bn_size=4, num_classes=1000):
+        super().__init__()
+        self.features = nn.Sequential(OrderedDict([
+            ("conv0", nn.Conv2d(3, init_feat, 7, 2, 3, bias=False)), ("norm0", nn.BatchNorm2d(init_feat)),
+            ("relu0", nn.ReLU(inplace=True)), ("pool0", nn.MaxPool2d(3, 2, 1))]))
+        nf = init_feat
+        for i, n in enumerate(blocks):
+            self.features.add_module(f"denseblock{i + 1}", _DenseBlock(n, nf, bn_size, growth))
+            nf += n * growth
+            if i != len(blocks) - 1:
+                self.features.add_module(f"transition{i + 1}", nn.Sequential(OrderedDict([
+                    ("norm", nn.BatchNorm2d(nf)), ("relu", nn.ReLU(inplace=True)),
+                    ("conv", nn.Conv2d(nf, nf // 2, 1, bias=False)), ("pool", nn.AvgPool2d(2, 2))])))
+                nf //= 2
+        self.features.add_module("norm5", nn.BatchNorm2d(nf))
+        self.classifier = nn.Linear(nf, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+
+    def forward(self, x):
+        out = F.relu(self.features(x), inplace=True)
+        return self.classifier(torch.flatten(F.adaptive_avg_pool2d(out, (1, 1)), 1))
+
+
+_FACTORY = {
+    "resnet18": lambda: ResNet(BasicBlock, [2, 2, 2, 2]), "resnet34": lambda: ResNet(BasicBlock, [3, 4, 6, 3]),
+    "resnet50": lambda: ResNet(Bottleneck, [3, 4, 6, 3]), "resnet101": lambda: ResNet(Bottleneck, [3, 4, 23, 3]),
+    "densenet121": lambda: DenseNet(32, (6, 12, 24, 16), 64), "densenet169": lambda: DenseNet(32, (6, 12, 32, 32), 64),
+    "densenet201": lambda: DenseNet(32, (6, 12, 48, 32), 64),
+}
+
+
+def build(backbone, output_layer, pretrained, **kwargs):
+    if "densenet" in backbone and output_layer == "avgpool":          # visual_encoder.py:48-53
+        sub = build(backbone, "features", pretrained, **kwargs)
+        sub.add_module("relu", nn.ReLU(inplace=True))
+        sub.add_module("avgpool", nn.AdaptiveAvgPool2d((1, 1)))
+        sub.add_module("flatten", nn.Flatten(1))
+        return sub
+    if backbone not in _FACTORY:
+        raise ValueError(f"unknown backbone {backbone!r}; available: {sorted(_FACTORY)} + 'vit'")
+    network = _FACTORY[backbone]()   # `pretrained` weights would need a download: random init (no network here)
+    if output_layer is not None and output_layer != "classifier":
+        names = [n for n, _ in network.named_children()]
+        assert output_layer in names, "{} not in {}".format(output_layer, names)
+        sub = []
+        for n, c in network.named_children():
+            sub.append(c)
+            if n == output_layer:
+                break
+        network = nn.Sequential(*sub)
+    return network

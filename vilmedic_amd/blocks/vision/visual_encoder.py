@@ -1,0 +1,133 @@
+"""VisualEncoder -- same constructor kwargs, ``forward`` / ``encode`` contract and state-dict prefixes
+(``model.*``, ``visual_projection.*``) as ref:vilmedic/blocks/vision/visual_encoder.py:86-237.
+
+ViT backbones run on the hand-written HIP path (vilmedic_amd.nn.ViTModel).  CNN backbones are torch modules
+executed by MIOpen through PyTorch-ROCm (not in the north-star kernel list)."""
+import json
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ...arena import arena_of
+from ...nn import VIT_DEFAULTS, ViTModel, make_config, Affine
+from . import cnn as _cnn
+
+
+def get_network(backbone, output_layer, pretrained, **kwargs):
+    """ref: visual_encoder.py:43-83."""
+    if "vit" in backbone.lower():
+        kwargs = {k: v for k, v in kwargs.items() if k not in ("attn_implementation", "return_dict")}
+        return ViTModel(make_config(VIT_DEFAULTS, kwargs))
+    if "deit" in backbone.lower() or "hfpoolformer" in backbone.lower() or "3d" in backbone.lower():
+        raise NotImplementedError(f"backbone {backbone!r} is outside the MI355X hot path (SURVEY §8a)")
+    return _cnn.build(backbone, output_layer, pretrained, **kwargs)
+
+
+class VisualEncoder(nn.Module):
+    def __init__(self, backbone, permute, dropout_out=0.0, freeze=False, output_layer=None, pretrained=True,
+                 slice_encode=None, slice_dim=None, visual_projection=None, **kwargs):
+        super().__init__()
+        self.backbone = backbone
+        self.output_layer = output_layer
+        self.permute = permute
+        self.freeze = freeze
+        self.pretrained = pretrained
+        self.model = get_network(self.backbone, self.output_layer, self.pretrained, **kwargs)
+        self.dropout_out = nn.Dropout(p=dropout_out)
+        self.is3D = "3d" in backbone
+        self.slice_encode = slice_encode
+        self.slice_dim = slice_dim
+        if visual_projection:
+            vp = dict(visual_projection)
+            self.visual_projection = Affine(vp["out_features"], vp["in_features"], std=(1.0 / vp["in_features"]) ** 0.5)
+        else:
+            self.visual_projection = nn.Identity()
+        assert permute in ["batch_first", "spatial_first", "no_permute"]
+        if freeze:  # the reference touches a stale attribute here; intended behaviour: freeze the backbone
+            for _, param in self.model.named_parameters():
+                param.requires_grad = False
+
+    # ------------------------------------------------------------------ encode (visual_encoder.py:130-178)
+    def encode(self, images, images_mask=None, **kwargs):
+        images = images.cuda()
+        images_mask = images_mask.cuda() if images_mask is not None else images_mask
+        if images.dim() == 4:
+            features = self(images)
+            return self._mask_and_project(features)
+        assert images.dim() == 5, "wrong images shape"
+        if self.is3D:
+            raise NotImplementedError("3-D backbones are outside the MI355X hot path")
+        B, N = images.shape[:2]
+        features = self(images.reshape(B * N, *images.shape[2:]))
+        if features.dim() <= 2:
+            raise Exception("The input size is too small for this model. The spatial dim has been shrunk to 1.")
+        features = features.view(B, N, features.shape[-2], features.shape[-1])
+        if images_mask is not None:
+            features = features * images_mask.unsqueeze(-1).unsqueeze(-1).to(features.dtype)
+        features = features.reshape(B, N * features.shape[2], features.shape[3])
+        return self._mask_and_project(features)
+
+    def _mask_and_project(self, features):
+        if features.dtype != torch.bfloat16:
+            features = features.to(torch.bfloat16)
+        features = features.contiguous()
+        shape = features.shape
+        mask = ops.feature_mask(features.view(-1, shape[-1])).view(shape[:-1]).bool()
+        if isinstance(self.visual_projection, nn.Identity):
+            return features, mask
+        arena = arena_of(self)
+        arena.refresh()
+        vp = self.visual_projection
+        out = ops.linear(features, arena.shadow(vp.weight), vp.bias, wgrad_buf=arena.grad(vp.weight),
+                         bgrad_buf=arena.grad(vp.bias), anchor=vp.weight)
+        return out, mask
+
+    # ------------------------------------------------------------------ forward (visual_encoder.py:180-208)
+    def forward(self, images, **kwargs):
+        if isinstance(self.model, ViTModel):
+            out = self.model(images)
+            return self._dropout_out(out)
+        out = self.model(images)
+        out = self._dropout_out(out)
+        if self.permute == "no_permute":
+            pass
+        elif self.permute == "batch_first":
+            out = out.view(*out.size()[:2], -1).permute(0, 2, 1)
+            if out.shape[1] == 1:
+                out = out.squeeze(1)
+        elif self.permute == "spatial_first":
+            out = out.view(*out.size()[:2], -1).permute(2, 0, 1)
+        else:
+            raise NotImplementedError()
+        return out
+
+    def _dropout_out(self, x):
+        if self.training and self.dropout_out.p > 0:
+            from ...nn import DropoutFn
+            if x.dtype == torch.bfloat16:
+                return DropoutFn.apply(x, self.dropout_out.p)
+            return self.dropout_out(x)
+        return x
+
+    def train(self, mode: bool = True):
+        if self.freeze:
+            mode = False
+        self.training = mode
+        for module in self.children():
+            module.train(mode)
+        return self
+
+    def __repr__(self):
+        is_vit = isinstance(self.model, ViTModel)
+        repr_dict = {
+            "type": type(self.model).__name__ if is_vit else None,
+            "config": str(dict(self.model.config)) if is_vit else None,
+            "dropout_out": self.dropout_out.p,
+            "freeze": self.freeze,
+            "output_layer": str(self.output_layer) if self.output_layer is not None else None,
+            "pretrained": self.pretrained if not is_vit else None,
+            "visual_projection": str(self.visual_projection),
+        }
+        repr_dict = {k: v for k, v in repr_dict.items() if v is not None}
+        return f"{self.backbone}:\n{json.dumps(repr_dict, indent=2)}"

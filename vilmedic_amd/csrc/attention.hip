@@ -1,0 +1,446 @@
+// attention.hip -- flash-style multi-head attention forward / backward for gfx950 (dh = 64).
+//
+// One workgroup = 4 waves; each wave OWNS a 16-row fragment (16 queries in fwd / dQ, 16 keys in dK/dV)
+// that it keeps in registers as the MFMA B operand, and the other sequence streams through LDS in
+// 64-row tiles shared by the 4 waves (K,V tiles for fwd/dQ; Q,dO tiles for dK/dV).
+//
+// Everything is computed TRANSPOSED ("swapped QK^T"): S^T = K Q^T puts one query per lane column, so
+//   * the softmax row reduction is in-register plus two cross-lane shuffles (xor 16, 32);
+//   * P^T in the MFMA C/D layout is directly the B operand of O^T = V^T P^T -- no LDS round trip
+//     (the k-slot <-> key permutation this implies is applied consistently to the A operand);
+//   * V^T / K^T / Q^T / dO^T A-operands are gathered from row-major LDS tiles with the gfx950
+//     transpose read ds_read_b64_tr_b16.
+// Masks: key_mask (1 = attend) and causal are applied as a -1e30 score (a fully masked row degrades to
+// the uniform distribution exactly like HF's additive finfo.min mask); keys >= Lk get -inf.
+// stats[b,h,i] = (row max m, row sum l) of the scaled+masked scores, saved for the backward pass.
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short v4s __attribute__((ext_vector_type(4)));
+
+#define DH 64
+#define TROWS 64                 // rows per streamed tile
+#define TSTRIDE 144              // bytes per LDS tile row (64 bf16 + 16 B pad)
+#define TILE_BYTES (TROWS * TSTRIDE)
+#define MASKED_SCORE (-1e30f)
+
+struct AttnArgs {
+    const bf16_t *q, *k, *v, *o, *d_o;
+    bf16_t *out, *dq, *dk, *dv;
+    int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+    float* stats;            // [B,H,Lq,2]
+    float* delta;            // [B,H,Lq]
+    const uint8_t* key_mask; // [B,Lk] or null
+    int B, H, Lq, Lk;
+    float scale; int causal;
+    float dropout_p; uint64_t seed; uint32_t thresh; float drop_scale;
+};
+
+__device__ __forceinline__ bf16x8_t ld_frag_global(const bf16_t* p, const bf16_t* safe, bool ok) {
+    uint4 v = *reinterpret_cast<const uint4*>(ok ? p : safe);
+    if (!ok) v = make_uint4(0, 0, 0, 0);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+// A operand from a row-major LDS tile, contraction = the tile's columns (dh): rows rbase+(lane&15)
+__device__ __forceinline__ bf16x8_t lds_frag_rows(const char* tile, int rbase, int kk, int lane) {
+    return *reinterpret_cast<const bf16x8_t*>(tile + (rbase + (lane & 15)) * TSTRIDE + (kk * 32 + (lane >> 4) * 8) * 2);
+}
+// A operand = tile^T: output rows = tile columns cbase+(lane&15); contraction = tile rows.
+// k-slot (g,e) of step s maps to tile row 32 s + 4 g + e (e<4) / 32 s + 16 + 4 g + (e-4) (e>=4),
+// matching a B operand packed from two C/D fragments {frag 2s, frag 2s+1}.
+__device__ __forceinline__ bf16x8_t lds_frag_tr(const char* tile, int cbase, int s, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const int row = 32 * s + 4 * g + (i >> 2);
+    const int col = cbase + (i & 3) * 4;
+    const __attribute__((address_space(3))) v4s* p0 = (const __attribute__((address_space(3))) v4s*)(tile + row * TSTRIDE + col * 2);
+    const __attribute__((address_space(3))) v4s* p1 = (const __attribute__((address_space(3))) v4s*)(tile + (row + 16) * TSTRIDE + col * 2);
+    v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p0);
+    v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p1);
+    short8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ bf16x8_t pack_b_operand(const float4_t& a, const float4_t& b) {
+    uint4 u;
+    u.x = pack_bf16x2(a[0], a[1]); u.y = pack_bf16x2(a[2], a[3]);
+    u.z = pack_bf16x2(b[0], b[1]); u.w = pack_bf16x2(b[2], b[3]);
+    return __builtin_bit_cast(bf16x8_t, u);
+}
+__device__ __forceinline__ float col_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float col_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+
+// stream one 64 x 64 bf16 tile (rows row0.. of a [rows, ld] matrix at column offset already applied)
+struct Stage2 { uint4 a, b; };
+// predicated 16-B load: out-of-range lanes re-read a valid address (``safe``) and zero the result, so the
+// compiler keeps a plain global_load (a select between the pointer and a stack zero becomes a flat load)
+__device__ __forceinline__ uint4 ld16_or_zero(const bf16_t* p, const bf16_t* safe, bool ok) {
+    uint4 v = *reinterpret_cast<const uint4*>(ok ? p : safe);
+    if (!ok) v = make_uint4(0, 0, 0, 0);
+    return v;
+}
+__device__ __forceinline__ Stage2 tile_load(const bf16_t* base, int64_t ld, int row0, int nrows, int tid) {
+    Stage2 r;
+    const int row = tid >> 3, c = tid & 7;
+    r.a = ld16_or_zero(base + (int64_t)(row0 + row) * ld + c * 8, base, row0 + row < nrows);
+    r.b = ld16_or_zero(base + (int64_t)(row0 + row + 32) * ld + c * 8, base, row0 + row + 32 < nrows);
+    return r;
+}
+__device__ __forceinline__ void tile_store(const Stage2& r, char* tile, int tid) {
+    const int row = tid >> 3, c = tid & 7;
+    *reinterpret_cast<uint4*>(tile + row * TSTRIDE + c * 16) = r.a;
+    *reinterpret_cast<uint4*>(tile + (row + 32) * TSTRIDE + c * 16) = r.b;
+}
+// store a transposed 64(dh) x 16(rows) accumulator as rows of a [*, ld] bf16 matrix: lane owns row (lane&15)
+__device__ __forceinline__ void store_t_acc(bf16_t* rowptr, const float4_t (&acc)[4], float mul, int lane) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        uint2 u;
+        u.x = pack_bf16x2(acc[f][0] * mul, acc[f][1] * mul);
+        u.y = pack_bf16x2(acc[f][2] * mul, acc[f][3] * mul);
+        *reinterpret_cast<uint2*>(rowptr + 16 * f + 4 * g) = u;
+    }
+}
+
+// =============================================================================== forward
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES + 64];
+    char* sk = smem; char* sv = smem + TILE_BYTES; uint8_t* smask = reinterpret_cast<uint8_t*>(smem + 2 * TILE_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64 + wave * 16;
+    const int qrow = q0 + c;
+    const bool qok = qrow < p.Lq;
+    const bf16_t* qp = p.q + (int64_t)(b * p.Lq + qrow) * p.ldq + h * DH;
+    bf16x8_t qf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) qf[kk] = ld_frag_global(qp + kk * 32 + g * 8, p.q, qok);
+    const bf16_t* kbase = p.k + (int64_t)b * p.Lk * p.ldk + h * DH;
+    const bf16_t* vbase = p.v + (int64_t)b * p.Lk * p.ldv + h * DH;
+    float4_t o[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) o[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;
+    int ntiles = (p.Lk + TROWS - 1) / TROWS;
+    if (p.causal) ntiles = min(ntiles, min((int)blockIdx.x * 64 + 63, p.Lq - 1) / TROWS + 1);
+    Stage2 rk, rv;
+    rk = tile_load(kbase, p.ldk, 0, p.Lk, tid);
+    rv = tile_load(vbase, p.ldv, 0, p.Lk, tid);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();                       // previous tile fully consumed
+        tile_store(rk, sk, tid);
+        tile_store(rv, sv, tid);
+        if (tid < 64) {
+            const int key = kt * TROWS + tid;
+            smask[tid] = (p.key_mask && key < p.Lk) ? p.key_mask[(int64_t)b * p.Lk + key] : (uint8_t)1;
+        }
+        __syncthreads();
+        if (kt + 1 < ntiles) {
+            rk = tile_load(kbase, p.ldk, (kt + 1) * TROWS, p.Lk, tid);
+            rv = tile_load(vbase, p.ldv, (kt + 1) * TROWS, p.Lk, tid);
+        }
+        float4_t s[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            s[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_rows(sk, 16 * f, kk, lane), qf[kk], s[f], 0, 0, 0);
+        }
+        float mt = -INFINITY;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const uint32_t mk = *reinterpret_cast<const uint32_t*>(smask + 16 * f + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * TROWS + 16 * f + 4 * g + r;
+                float val = s[f][r] * p.scale;
+                const bool keep = ((mk >> (8 * r)) & 0xff) != 0 && !(p.causal && key > qrow);
+                val = keep ? val : MASKED_SCORE;
+                val = key < p.Lk ? val : -INFINITY;
+                s[f][r] = val;
+                mt = fmaxf(mt, val);
+            }
+        }
+        mt = col_max(mt);
+        const float m_new = fmaxf(m, mt);
+        const float alpha = __expf(m - m_new);
+        float ls = 0.f;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = __expf(s[f][r] - m_new); s[f][r] = e; ls += e; }
+        l = l * alpha + col_sum(ls);
+        m = m_new;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[f][r] *= alpha;
+        if (p.dropout_p > 0.f) {
+            const uint64_t base = ((uint64_t)(b * p.H + h) * p.Lq + qrow) * (uint64_t)p.Lk;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * TROWS + 16 * f + 4 * g + r;
+                    s[f][r] = dropout_keep(p.seed, base + key, p.thresh) ? s[f][r] * p.drop_scale : 0.f;
+                }
+        }
+        bf16x8_t pb[2] = {pack_b_operand(s[0], s[1]), pack_b_operand(s[2], s[3])};
+#pragma unroll
+        for (int df = 0; df < 4; ++df)
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+                o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr(sv, 16 * df, st, lane), pb[st], o[df], 0, 0, 0);
+    }
+    if (qok) {
+        store_t_acc(p.out + (int64_t)(b * p.Lq + qrow) * p.ldo + h * DH, o, 1.0f / l, lane);
+        if (g == 0) {
+            float* st = p.stats + ((int64_t)(b * p.H + h) * p.Lq + qrow) * 2;
+            st[0] = m; st[1] = l;
+        }
+    }
+}
+
+// =============================================================================== delta = rowsum(dO * O)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs p) {
+    // one 16-lane group per (b,h,row): 64 dh = 16 lanes x 4 elements
+    const int64_t gid = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int64_t total = (int64_t)p.B * p.H * p.Lq;
+    const int sub = threadIdx.x & 15;
+    float acc = 0.f;
+    if (gid < total) {
+        const int row = (int)(gid % p.Lq); const int bh = (int)(gid / p.Lq); const int h = bh % p.H, b = bh / p.H;
+        const uint2 a = *reinterpret_cast<const uint2*>(p.o + (int64_t)(b * p.Lq + row) * p.ldo + h * DH + sub * 4);
+        const uint2 d = *reinterpret_cast<const uint2*>(p.d_o + (int64_t)(b * p.Lq + row) * p.lddo + h * DH + sub * 4);
+        acc = __uint_as_float(a.x << 16) * __uint_as_float(d.x << 16) + __uint_as_float(a.x & 0xffff0000u) * __uint_as_float(d.x & 0xffff0000u)
+            + __uint_as_float(a.y << 16) * __uint_as_float(d.y << 16) + __uint_as_float(a.y & 0xffff0000u) * __uint_as_float(d.y & 0xffff0000u);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (gid < total && sub == 0) p.delta[gid] = acc;
+}
+
+// =============================================================================== dQ  (owner: 16 queries per wave)
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES + 64];
+    char* sk = smem; char* sv = smem + TILE_BYTES; uint8_t* smask = reinterpret_cast<uint8_t*>(smem + 2 * TILE_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64 + wave * 16;
+    const int qrow = q0 + c;
+    const bool qok = qrow < p.Lq;
+    const bf16_t* qp = p.q + (int64_t)(b * p.Lq + qrow) * p.ldq + h * DH;
+    const bf16_t* dop = p.d_o + (int64_t)(b * p.Lq + qrow) * p.lddo + h * DH;
+    bf16x8_t qf[2], dof[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) { qf[kk] = ld_frag_global(qp + kk * 32 + g * 8, p.q, qok); dof[kk] = ld_frag_global(dop + kk * 32 + g * 8, p.d_o, qok); }
+    float m = 0.f, inv_l = 0.f, delta = 0.f;
+    if (qok) {
+        const int64_t si = (int64_t)(b * p.H + h) * p.Lq + qrow;
+        m = p.stats[si * 2]; inv_l = 1.0f / p.stats[si * 2 + 1]; delta = p.delta[si];
+    }
+    const bf16_t* kbase = p.k + (int64_t)b * p.Lk * p.ldk + h * DH;
+    const bf16_t* vbase = p.v + (int64_t)b * p.Lk * p.ldv + h * DH;
+    float4_t dq[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) dq[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    int ntiles = (p.Lk + TROWS - 1) / TROWS;
+    if (p.causal) ntiles = min(ntiles, min((int)blockIdx.x * 64 + 63, p.Lq - 1) / TROWS + 1);
+    Stage2 rk, rv;
+    rk = tile_load(kbase, p.ldk, 0, p.Lk, tid);
+    rv = tile_load(vbase, p.ldv, 0, p.Lk, tid);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();
+        tile_store(rk, sk, tid);
+        tile_store(rv, sv, tid);
+        if (tid < 64) {
+            const int key = kt * TROWS + tid;
+            smask[tid] = (p.key_mask && key < p.Lk) ? p.key_mask[(int64_t)b * p.Lk + key] : (uint8_t)1;
+        }
+        __syncthreads();
+        if (kt + 1 < ntiles) {
+            rk = tile_load(kbase, p.ldk, (kt + 1) * TROWS, p.Lk, tid);
+            rv = tile_load(vbase, p.ldv, (kt + 1) * TROWS, p.Lk, tid);
+        }
+        float4_t s[4], dp[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            s[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            dp[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_rows(sk, 16 * f, kk, lane), qf[kk], s[f], 0, 0, 0);
+                dp[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_rows(sv, 16 * f, kk, lane), dof[kk], dp[f], 0, 0, 0);
+            }
+        }
+        const uint64_t dbase = ((uint64_t)(b * p.H + h) * p.Lq + qrow) * (uint64_t)p.Lk;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const uint32_t mk = *reinterpret_cast<const uint32_t*>(smask + 16 * f + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * TROWS + 16 * f + 4 * g + r;
+                float val = s[f][r] * p.scale;
+                const bool keep = ((mk >> (8 * r)) & 0xff) != 0 && !(p.causal && key > qrow);
+                val = keep ? val : MASKED_SCORE;
+                const float pr = (key < p.Lk && qok) ? __expf(val - m) * inv_l : 0.f;
+                float dpv = dp[f][r];
+                if (p.dropout_p > 0.f) dpv = dropout_keep(p.seed, dbase + key, p.thresh) ? dpv * p.drop_scale : 0.f;
+                s[f][r] = pr * (dpv - delta);      // dS^T
+            }
+        }
+        bf16x8_t db[2] = {pack_b_operand(s[0], s[1]), pack_b_operand(s[2], s[3])};
+#pragma unroll
+        for (int df = 0; df < 4; ++df)
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+                dq[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr(sk, 16 * df, st, lane), db[st], dq[df], 0, 0, 0);
+    }
+    if (qok) store_t_acc(p.dq + (int64_t)(b * p.Lq + qrow) * p.lddq + h * DH, dq, p.scale, lane);
+}
+
+// =============================================================================== dK, dV  (owner: 16 keys per wave)
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES + 3 * 64 * 4];
+    char* sq = smem; char* sdo = smem + TILE_BYTES;
+    float* sm = reinterpret_cast<float*>(smem + 2 * TILE_BYTES); float* sil = sm + 64; float* sdl = sm + 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64 + wave * 16;
+    const int key = k0 + c;
+    const bool kok = key < p.Lk;
+    const bf16_t* kp = p.k + (int64_t)(b * p.Lk + key) * p.ldk + h * DH;
+    const bf16_t* vp = p.v + (int64_t)(b * p.Lk + key) * p.ldv + h * DH;
+    bf16x8_t kf[2], vf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) { kf[kk] = ld_frag_global(kp + kk * 32 + g * 8, p.k, kok); vf[kk] = ld_frag_global(vp + kk * 32 + g * 8, p.v, kok); }
+    const bool key_keep = kok && (!p.key_mask || p.key_mask[(int64_t)b * p.Lk + key] != 0);
+    const bf16_t* qbase = p.q + (int64_t)b * p.Lq * p.ldq + h * DH;
+    const bf16_t* dobase = p.d_o + (int64_t)b * p.Lq * p.lddo + h * DH;
+    float4_t dk[4], dv[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { dk[f] = (float4_t){0.f, 0.f, 0.f, 0.f}; dv[f] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
+    const int ntiles = (p.Lq + TROWS - 1) / TROWS;
+    const int t_begin = p.causal ? (int)blockIdx.x : 0;   // queries < first key of the block see none of its keys
+    Stage2 rq, rdo;
+    if (t_begin < ntiles) {
+        rq = tile_load(qbase, p.ldq, t_begin * TROWS, p.Lq, tid);
+        rdo = tile_load(dobase, p.lddo, t_begin * TROWS, p.Lq, tid);
+    }
+    for (int qt = t_begin; qt < ntiles; ++qt) {
+        __syncthreads();
+        tile_store(rq, sq, tid);
+        tile_store(rdo, sdo, tid);
+        if (tid < 64) {
+            const int qr = qt * TROWS + tid;
+            float mm = 0.f, il = 0.f, dl = 0.f;
+            if (qr < p.Lq) {
+                const int64_t si = (int64_t)(b * p.H + h) * p.Lq + qr;
+                mm = p.stats[si * 2]; il = 1.0f / p.stats[si * 2 + 1]; dl = p.delta[si];
+            }
+            sm[tid] = mm; sil[tid] = il; sdl[tid] = dl;
+        }
+        __syncthreads();
+        if (qt + 1 < ntiles) {
+            rq = tile_load(qbase, p.ldq, (qt + 1) * TROWS, p.Lq, tid);
+            rdo = tile_load(dobase, p.lddo, (qt + 1) * TROWS, p.Lq, tid);
+        }
+        float4_t s[4], dp[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            s[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            dp[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_rows(sq, 16 * f, kk, lane), kf[kk], s[f], 0, 0, 0);
+                dp[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_rows(sdo, 16 * f, kk, lane), vf[kk], dp[f], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const float4 m4 = *reinterpret_cast<const float4*>(sm + 16 * f + 4 * g);
+            const float4 i4 = *reinterpret_cast<const float4*>(sil + 16 * f + 4 * g);
+            const float4 d4 = *reinterpret_cast<const float4*>(sdl + 16 * f + 4 * g);
+            const float mr[4] = {m4.x, m4.y, m4.z, m4.w}, ir[4] = {i4.x, i4.y, i4.z, i4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qr = qt * TROWS + 16 * f + 4 * g + r;
+                float val = s[f][r] * p.scale;
+                const bool keep = key_keep && !(p.causal && key > qr);
+                val = keep ? val : MASKED_SCORE;
+                const float pr = (qr < p.Lq && kok) ? __expf(val - mr[r]) * ir[r] : 0.f;
+                float dpv = dp[f][r], pd = pr;
+                if (p.dropout_p > 0.f) {
+                    const bool kp_ = dropout_keep(p.seed, ((uint64_t)(b * p.H + h) * p.Lq + qr) * (uint64_t)p.Lk + key, p.thresh);
+                    dpv = kp_ ? dpv * p.drop_scale : 0.f;
+                    pd = kp_ ? pr * p.drop_scale : 0.f;
+                }
+                dp[f][r] = pd;                     // dropped P   -> dV
+                s[f][r] = pr * (dpv - dr[r]);      // dS          -> dK
+            }
+        }
+        bf16x8_t pb[2] = {pack_b_operand(dp[0], dp[1]), pack_b_operand(dp[2], dp[3])};
+        bf16x8_t sb[2] = {pack_b_operand(s[0], s[1]), pack_b_operand(s[2], s[3])};
+#pragma unroll
+        for (int df = 0; df < 4; ++df)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                dv[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr(sdo, 16 * df, st, lane), pb[st], dv[df], 0, 0, 0);
+                dk[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr(sq, 16 * df, st, lane), sb[st], dk[df], 0, 0, 0);
+            }
+    }
+    if (kok) {
+        store_t_acc(p.dk + (int64_t)(b * p.Lk + key) * p.lddk + h * DH, dk, p.scale, lane);
+        store_t_acc(p.dv + (int64_t)(b * p.Lk + key) * p.lddv + h * DH, dv, 1.0f, lane);
+    }
+}
+
+static int check_common(const char* fn, int B, int H, int Lq, int Lk, int dh, int64_t ld0, int64_t ld1, int64_t ld2, int64_t ld3) {
+    VM_REQUIRE(dh == DH, "%s: head dim %d unsupported (only 64)", fn, dh);
+    VM_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "%s: empty problem", fn);
+    VM_REQUIRE((ld0 % 8) == 0 && (ld1 % 8) == 0 && (ld2 % 8) == 0 && (ld3 % 8) == 0, "%s: leading dims must be multiples of 8", fn);
+    return VM_OK;
+}
+
+extern "C" int vm_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                                void* o, int64_t ldo, float* stats, const uint8_t* key_mask,
+                                int B, int H, int Lq, int Lk, int dh, float scale, int causal,
+                                float dropout_p, uint64_t dropout_seed, void* stream) {
+    VM_REQUIRE(q && k && v && o && stats, "vm_attention_fwd: null pointer");
+    int rc = check_common("vm_attention_fwd", B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo);
+    if (rc) return rc;
+    AttnArgs a = {};
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.stats = stats; a.key_mask = key_mask;
+    a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.causal = causal;
+    a.dropout_p = dropout_p; a.seed = dropout_seed; a.thresh = dropout_thresh24(dropout_p);
+    a.drop_scale = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
+    hipStream_t s = (hipStream_t)stream;
+    VmProfScope prof(VM_FAM_ATTN, 4.0 * B * H * (double)Lq * Lk * DH, s);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((Lq + 63) / 64, H, B), dim3(256), 0, s, a);
+    return vm_check_launch("vm_attention_fwd");
+}
+
+extern "C" int vm_attention_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                                const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* stats,
+                                const uint8_t* key_mask,
+                                void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
+                                int B, int H, int Lq, int Lk, int dh, float scale, int causal,
+                                float dropout_p, uint64_t dropout_seed, float* ws_delta, void* stream) {
+    VM_REQUIRE(q && k && v && o && d_o && stats && dq && dk && dv && ws_delta, "vm_attention_bwd: null pointer");
+    int rc = check_common("vm_attention_bwd", B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo);
+    if (rc) return rc;
+    VM_REQUIRE((lddo % 8) == 0 && (lddq % 8) == 0 && (lddk % 8) == 0 && (lddv % 8) == 0, "vm_attention_bwd: leading dims must be multiples of 8");
+    AttnArgs a = {};
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o; a.d_o = (const bf16_t*)d_o;
+    a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+    a.stats = const_cast<float*>(stats); a.delta = ws_delta; a.key_mask = key_mask;
+    a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.causal = causal;
+    a.dropout_p = dropout_p; a.seed = dropout_seed; a.thresh = dropout_thresh24(dropout_p);
+    a.drop_scale = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
+    hipStream_t s = (hipStream_t)stream;
+    VmProfScope prof(VM_FAM_ATTN, 14.0 * B * H * (double)Lq * Lk * DH, s);
+    const int64_t rows = (int64_t)B * H * Lq;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Lq + 63) / 64, H, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Lk + 63) / 64, H, B), dim3(256), 0, s, a);
+    return vm_check_launch("vm_attention_bwd");
+}

@@ -1,0 +1,299 @@
+// gemm.hip -- bf16 MFMA GEMM for gfx950 with fused epilogues.
+//
+//   C[M,N] = epi( sum_k A(m,k) * B(n,k) ),  fp32 accumulate.
+//
+// One 256-thread workgroup (4 waves, 2x2) per 128x128 output tile, BK = 64, v_mfma_f32_16x16x32_bf16,
+// 4x4 fragments per wave.  Operands are staged HBM -> VGPR -> LDS (16-B loads, issue-early /
+// write-late so HBM latency hides under the MFMA phase), double-buffered, one barrier per K-tile.
+// Either operand may be stored with the contraction dim contiguous (layout 0, read with ds_read_b128)
+// or strided (layout 1: the LDS image keeps the global row-major order and the MFMA fragment is
+// gathered with the gfx950 transpose read ds_read_b64_tr_b16), so forward (NT), dgrad (NN) and
+// wgrad (TN) all run on the same kernel without transposed copies of weights or activations.
+// The accumulator tile is staged through LDS as fp32 so the epilogue (bias, erf-GELU, gelu' multiply,
+// dropout, residual add, bf16/fp32 store, fp32 atomic accumulate for split-K) runs on whole 16-B
+// row segments with coalesced HBM traffic.
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define LDS_K_STRIDE 72    // elements per row for layout-0 tiles  [128][72]  (144 B rows, conflict-spreading pad)
+#define LDS_M_STRIDE 136   // elements per row for layout-1 tiles  [64][136]  (272 B rows)
+#define OPER_BYTES 18432   // max(128*72*2, 64*136*2)
+#define STAGE_BYTES (2 * OPER_BYTES)
+#define C_STRIDE 132       // fp32 elements per row of the staged accumulator tile
+#define GEMM_LDS_BYTES (2 * STAGE_BYTES)   // 73728 >= 128*132*4 = 67584
+
+struct GemmArgs {
+    const bf16_t* A; const bf16_t* B; void* C;
+    int64_t lda, ldb, ldc;
+    int M, N, K;
+    int tiles_m, tiles_n, ktiles, ktiles_per_split;
+    vm_gemm_epilogue e;
+    uint32_t drop_thresh; float drop_scale;
+};
+
+// predicated 16-B load: out-of-range lanes re-read the (always valid) matrix base and zero the result,
+// which keeps a plain global_load instead of a pointer-select + flat_load
+__device__ __forceinline__ uint4 ldg16(const bf16_t* p, const bf16_t* safe, bool ok) {
+    uint4 v = *reinterpret_cast<const uint4*>(ok ? p : safe);
+    if (!ok) v = make_uint4(0, 0, 0, 0);
+    return v;
+}
+
+// ---- HBM -> registers for one operand tile (4 x 16 B per thread)
+template <int LAYOUT>
+__device__ __forceinline__ void load_tile(uint4 (&r)[4], const bf16_t* base, int64_t ld, int row0, int nrows, int k0, int K, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = tid + 256 * i;
+        if (LAYOUT == 0) {          // [rows][K]: 8 chunks per 64-wide k-slab
+            const int row = id >> 3, c = id & 7;
+            const int gr = row0 + row, gk = k0 + c * 8;
+            r[i] = ldg16(base + (int64_t)gr * ld + gk, base, gr < nrows && gk < K);
+        } else {                    // [K][rows]: 16 chunks per 128-wide row-slab
+            const int kr = id >> 4, c = id & 15;
+            const int gk = k0 + kr, gr = row0 + c * 8;
+            r[i] = ldg16(base + (int64_t)gk * ld + gr, base, gk < K && gr < nrows);
+        }
+    }
+}
+
+template <int LAYOUT>
+__device__ __forceinline__ void store_tile(const uint4 (&r)[4], char* lds, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = tid + 256 * i;
+        if (LAYOUT == 0) {
+            const int row = id >> 3, c = id & 7;
+            *reinterpret_cast<uint4*>(lds + row * (LDS_K_STRIDE * 2) + c * 16) = r[i];
+        } else {
+            const int kr = id >> 4, c = id & 15;
+            *reinterpret_cast<uint4*>(lds + kr * (LDS_M_STRIDE * 2) + c * 16) = r[i];
+        }
+    }
+}
+
+// ---- LDS -> MFMA fragment: lane l holds 8 consecutive k for row (l&15), k-group (l>>4)
+template <int LAYOUT>
+__device__ __forceinline__ bf16x8_t read_frag(const char* lds, int row_base, int kk, int lane) {
+    if (LAYOUT == 0) {
+        const int row = row_base + (lane & 15);
+        const int kel = kk * 32 + (lane >> 4) * 8;
+        return *reinterpret_cast<const bf16x8_t*>(lds + row * (LDS_K_STRIDE * 2) + kel * 2);
+    } else {
+        // transpose read: within a 16-lane group, lane i supplies the address of 4 contiguous
+        // elements (row-dim) at k = kb + (i>>2); lane c receives the 4 k-values of column c.
+        const int k = kk * 32 + (lane >> 4) * 8 + ((lane & 15) >> 2);
+        const int col = row_base + (lane & 3) * 4;
+        typedef short v4s __attribute__((ext_vector_type(4)));
+        const __attribute__((address_space(3))) v4s* p0 =
+            (const __attribute__((address_space(3))) v4s*)(lds + k * (LDS_M_STRIDE * 2) + col * 2);
+        const __attribute__((address_space(3))) v4s* p1 =
+            (const __attribute__((address_space(3))) v4s*)(lds + (k + 4) * (LDS_M_STRIDE * 2) + col * 2);
+        v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p0);
+        v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p1);
+        short8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8_t, v);
+    }
+}
+
+template <int LA, int LB>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware bijective remap: hardware places block b on XCD b%8; give each XCD a contiguous run of tiles
+    const int nwg = gridDim.x;
+    int bid;
+    {
+        const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int split = bid / tiles;
+    const int t = bid - split * tiles;
+    const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kt_begin = split * p.ktiles_per_split;
+    const int kt_end = min(p.ktiles, kt_begin + p.ktiles_per_split);
+
+    float4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[4], rb[4];
+    if (kt_begin < kt_end) {
+        load_tile<LA>(ra, p.A, p.lda, m0, p.M, kt_begin * BK, p.K, tid);
+        load_tile<LB>(rb, p.B, p.ldb, n0, p.N, kt_begin * BK, p.K, tid);
+        store_tile<LA>(ra, smem, tid);
+        store_tile<LB>(rb, smem + OPER_BYTES, tid);
+    }
+    __syncthreads();
+
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
+        const char* sa = smem + buf * STAGE_BYTES;
+        const char* sb = sa + OPER_BYTES;
+        const bool more = kt + 1 < kt_end;
+        if (more) {   // issue next tile's HBM loads before the MFMA phase
+            load_tile<LA>(ra, p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, tid);
+            load_tile<LB>(rb, p.B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, tid);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = read_frag<LA>(sa, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = read_frag<LB>(sb, wn * 64 + j * 16, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {   // write-late into the other buffer (last read two iterations ago, fenced by the barrier)
+            char* da = smem + (buf ^ 1) * STAGE_BYTES;
+            store_tile<LA>(ra, da, tid);
+            store_tile<LB>(rb, da + OPER_BYTES, tid);
+        }
+        __syncthreads();
+    }
+
+    // ---- stage the fp32 accumulator tile through LDS:  C/D layout col = lane&15, row = (lane>>4)*4 + reg
+    float* cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = wn * 64 + j * 16 + (lane & 15);
+            const int row = wm * 64 + i * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cs[(row + r) * C_STRIDE + col] = acc[i][j][r];
+        }
+    __syncthreads();
+
+    // ---- coalesced epilogue: each thread owns 8 consecutive columns of a row, 8 such segments
+    const vm_gemm_epilogue& e = p.e;
+    const float alpha = e.alpha_dev ? e.alpha * (*e.alpha_dev) : e.alpha;
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+        const int id = tid + 256 * it;
+        const int row = id >> 4, cc = (id & 15) * 8;
+        const int gm = m0 + row, gn = n0 + cc;
+        if (gm >= p.M || gn >= p.N) continue;
+        float v[8];
+        {
+            const float4 lo = *reinterpret_cast<const float4*>(cs + row * C_STRIDE + cc);
+            const float4 hi = *reinterpret_cast<const float4*>(cs + row * C_STRIDE + cc + 4);
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+        }
+        const int nvalid = min(8, p.N - gn);
+        const int64_t off = (int64_t)gm * p.ldc + gn;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= alpha;
+        if (e.bias) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += e.bias[gn + j];
+        }
+        if (e.aux_out) {
+            bf16_t* z = reinterpret_cast<bf16_t*>(e.aux_out) + off;
+            if (nvalid == 8) *reinterpret_cast<uint4*>(z) = pack8(v);
+            else for (int j = 0; j < nvalid; ++j) z[j] = f32_to_bf16(v[j]);
+        }
+        if (e.act == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+        }
+        if (e.mul_gelu_z) {
+            const bf16_t* z = reinterpret_cast<const bf16_t*>(e.mul_gelu_z) + off;
+            float zf[8];
+            if (nvalid == 8) unpack8(*reinterpret_cast<const uint4*>(z), zf);
+            else for (int j = 0; j < 8; ++j) zf[j] = j < nvalid ? bf16_to_f32(z[j]) : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(zf[j]);
+        }
+        if (e.dropout_p > 0.f) {
+            const uint64_t idx = (uint64_t)gm * (uint64_t)p.N + (uint64_t)gn;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = dropout_keep(e.dropout_seed, idx + j, p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
+        }
+        if (e.residual) {
+            const bf16_t* rp = reinterpret_cast<const bf16_t*>(e.residual) + (int64_t)gm * e.ldr + gn;
+            float rf[8];
+            if (nvalid == 8) unpack8(*reinterpret_cast<const uint4*>(rp), rf);
+            else for (int j = 0; j < 8; ++j) rf[j] = j < nvalid ? bf16_to_f32(rp[j]) : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += rf[j];
+        }
+        if (e.out_dtype == VM_BF16) {
+            bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + off;
+            if (nvalid == 8) *reinterpret_cast<uint4*>(c) = pack8(v);
+            else for (int j = 0; j < nvalid; ++j) c[j] = f32_to_bf16(v[j]);
+        } else {
+            float* c = reinterpret_cast<float*>(p.C) + off;
+            if (e.accumulate) {
+                for (int j = 0; j < nvalid; ++j) atomicAdd(c + j, v[j]);
+            } else if (nvalid == 8) {
+                *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+                for (int j = 0; j < nvalid; ++j) c[j] = v[j];
+            }
+        }
+    }
+}
+
+template <int LA, int LB>
+static int launch(const GemmArgs& a, int nblocks, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<LA, LB>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_kernel<LA, LB>), dim3(nblocks), dim3(256), GEMM_LDS_BYTES, s, a);
+    return vm_check_launch("vm_gemm_bf16");
+}
+
+extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void* B, int64_t ldb, int b_layout,
+                            void* C, int64_t ldc, int M, int N, int K, const vm_gemm_epilogue* epi, void* stream) {
+    VM_REQUIRE(A && B && C && epi, "vm_gemm_bf16: null pointer");
+    VM_REQUIRE(M > 0 && N > 0 && K > 0, "vm_gemm_bf16: empty problem M=%d N=%d K=%d", M, N, K);
+    VM_REQUIRE((lda % 8) == 0 && (ldb % 8) == 0, "vm_gemm_bf16: lda/ldb must be multiples of 8 (got %lld, %lld)", (long long)lda, (long long)ldb);
+    VM_REQUIRE(epi->out_dtype == VM_F32 ? (ldc % 4) == 0 : (ldc % 8) == 0, "vm_gemm_bf16: ldc alignment");
+    if (a_layout == 0 || b_layout == 0) VM_REQUIRE((K % 8) == 0, "vm_gemm_bf16: K must be a multiple of 8 for K-contiguous operands (K=%d)", K);
+    VM_REQUIRE(epi->split_k >= 1, "vm_gemm_bf16: split_k must be >= 1");
+    if (epi->split_k > 1) VM_REQUIRE(epi->out_dtype == VM_F32 && epi->accumulate, "vm_gemm_bf16: split_k needs fp32 accumulate output");
+    if (epi->accumulate) VM_REQUIRE(epi->out_dtype == VM_F32, "vm_gemm_bf16: accumulate needs fp32 output");
+    if (epi->residual) VM_REQUIRE((epi->ldr % 8) == 0, "vm_gemm_bf16: ldr alignment");
+    VM_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0, "vm_gemm_bf16: pointers must be 16-byte aligned");
+
+    GemmArgs a;
+    a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+    a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
+    a.ktiles = (K + BK - 1) / BK;
+    int split = epi->split_k;
+    if (split > a.ktiles) split = a.ktiles;
+    a.ktiles_per_split = (a.ktiles + split - 1) / split;
+    split = (a.ktiles + a.ktiles_per_split - 1) / a.ktiles_per_split;
+    a.e = *epi;
+    a.drop_thresh = dropout_thresh24(epi->dropout_p);
+    a.drop_scale = epi->dropout_p > 0.f ? 1.0f / (1.0f - epi->dropout_p) : 1.0f;
+    const int nblocks = a.tiles_m * a.tiles_n * split;
+    hipStream_t s = (hipStream_t)stream;
+    VmProfScope prof(VM_FAM_GEMM, 2.0 * (double)M * (double)N * (double)K, s);
+    if (a_layout == 0 && b_layout == 0) return launch<0, 0>(a, nblocks, s);
+    if (a_layout == 0 && b_layout == 1) return launch<0, 1>(a, nblocks, s);
+    if (a_layout == 1 && b_layout == 0) return launch<1, 0>(a, nblocks, s);
+    if (a_layout == 1 && b_layout == 1) return launch<1, 1>(a, nblocks, s);
+    vm_set_error("vm_gemm_bf16: bad layout flags");
+    return VM_EINVAL;
+}

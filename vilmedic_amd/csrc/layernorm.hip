@@ -1,0 +1,199 @@
+// layernorm.hip -- row LayerNorm forward/backward (HBM-bound; one wave per row, 16-B bf16 vectors,
+// wave64 shuffle reductions, fp32 statistics).
+#include "common.h"
+
+#define LN_MAX_CHUNKS 4   // per-lane 16-B chunks kept in registers: cols <= 64*8*4 = 2048
+
+// rows handled by one wave; 4 waves (256 threads) per block
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                     int rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    const int nchunks = cols >> 3;
+    for (int row = wave_global; row < rows; row += nwaves) {
+        const bf16_t* xr = x + (int64_t)row * cols;
+        float v[NCH][8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nchunks) {
+                unpack8(*reinterpret_cast<const uint4*>(xr + ch * 8), v[c]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[c][j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+            }
+        }
+        const float mu = wave_sum(s) / (float)cols;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nchunks) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = v[c][j] - mu; q += d * d; }
+            }
+        }
+        const float rs = rsqrtf(wave_sum(q) / (float)cols + eps);
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+        bf16_t* yr = y + (int64_t)row * cols;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nchunks) {
+                float o[8];
+                const float4 g0 = *reinterpret_cast<const float4*>(gamma + ch * 8), g1 = *reinterpret_cast<const float4*>(gamma + ch * 8 + 4);
+                const float4 b0 = *reinterpret_cast<const float4*>(beta + ch * 8), b1 = *reinterpret_cast<const float4*>(beta + ch * 8 + 4);
+                const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mu) * rs * g[j] + b[j];
+                *reinterpret_cast<uint4*>(yr + ch * 8) = pack8(o);
+            }
+        }
+    }
+}
+
+// backward: dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  per-wave partial dgamma/dbeta
+// accumulated in registers over the wave's rows, then written to ws[wave][2][cols] and reduced by ln_bwd_reduce.
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, bf16_t* __restrict__ dx,
+                                                     float* __restrict__ ws, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    const int nchunks = cols >> 3;
+    float dg[NCH][8], db[NCH][8], g[NCH][8];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + 64 * c;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dg[c][j] = 0.f; db[c][j] = 0.f; g[c][j] = ch < nchunks ? gamma[ch * 8 + j] : 0.f; }
+    }
+    for (int row = wave_global; row < rows; row += nwaves) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[NCH][8], gy[NCH][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nchunks) {
+                float xv[8], dv[8];
+                unpack8(*reinterpret_cast<const uint4*>(x + (int64_t)row * cols + ch * 8), xv);
+                unpack8(*reinterpret_cast<const uint4*>(dy + (int64_t)row * cols + ch * 8), dv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    xh[c][j] = (xv[j] - mu) * rs;
+                    gy[c][j] = dv[j] * g[c][j];
+                    s1 += gy[c][j];
+                    s2 += gy[c][j] * xh[c][j];
+                    dg[c][j] += dv[j] * xh[c][j];
+                    db[c][j] += dv[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { xh[c][j] = 0.f; gy[c][j] = 0.f; }
+            }
+        }
+        s1 = wave_sum(s1) / (float)cols;
+        s2 = wave_sum(s2) / (float)cols;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nchunks) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = rs * (gy[c][j] - s1 - xh[c][j] * s2);
+                *reinterpret_cast<uint4*>(dx + (int64_t)row * cols + ch * 8) = pack8(o);
+            }
+        }
+    }
+    // block-level reduction of the 4 waves' partials through LDS, then one [2][cols] slab per block
+    extern __shared__ float red[];   // [4][2*cols]
+    float* mine = red + (threadIdx.x >> 6) * 2 * cols;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunks) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { mine[ch * 8 + j] = dg[c][j]; mine[cols + ch * 8 + j] = db[c][j]; }
+        }
+    }
+    __syncthreads();
+    float* wg = ws + (int64_t)blockIdx.x * 2 * cols;
+    for (int i = threadIdx.x; i < 2 * cols; i += 256)
+        wg[i] = red[i] + red[2 * cols + i] + red[4 * cols + i] + red[6 * cols + i];
+}
+
+// grid (ceil(cols/32), 2): blockIdx.y selects dgamma / dbeta; 32 columns x 8 slab-groups per block
+__global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ ws, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int nslabs, int cols) {
+    __shared__ float part[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    float a = 0.f;
+    if (c < cols)
+        for (int w = ty; w < nslabs; w += 8) a += ws[(int64_t)w * 2 * cols + blockIdx.y * cols + c];
+    part[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += part[k][tx];
+        if (blockIdx.y == 0) dgamma[c] += t; else dbeta[c] += t;
+    }
+}
+
+static int ln_grid(int rows) {
+    int blocks = (rows + 3) / 4;
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    return blocks;
+}
+
+extern "C" int vm_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                int rows, int cols, float eps, void* stream) {
+    VM_REQUIRE(x && gamma && beta && y && mean && rstd, "vm_layernorm_fwd: null pointer");
+    VM_REQUIRE(rows > 0 && cols > 0 && (cols % 8) == 0 && cols <= 64 * 8 * LN_MAX_CHUNKS, "vm_layernorm_fwd: cols=%d must be a multiple of 8 and <= 2048", cols);
+    hipStream_t s = (hipStream_t)stream;
+    VmProfScope prof(VM_FAM_LN, 4.0 * rows * (double)cols, s);
+    const int nch = (cols / 8 + 63) / 64;
+    const int grid = ln_grid(rows);
+    const bf16_t* xp = (const bf16_t*)x; bf16_t* yp = (bf16_t*)y;
+    switch (nch) {
+        case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, dim3(grid), dim3(256), 0, s, xp, gamma, beta, yp, mean, rstd, rows, cols, eps); break;
+        case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, dim3(grid), dim3(256), 0, s, xp, gamma, beta, yp, mean, rstd, rows, cols, eps); break;
+        default: hipLaunchKernelGGL(ln_fwd_kernel<4>, dim3(grid), dim3(256), 0, s, xp, gamma, beta, yp, mean, rstd, rows, cols, eps); break;
+    }
+    return vm_check_launch("vm_layernorm_fwd");
+}
+
+extern "C" size_t vm_layernorm_bwd_ws(int rows, int cols) { return (size_t)ln_grid(rows) * 2 * (size_t)cols * sizeof(float); }
+
+extern "C" int vm_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                void* dx, float* dgamma, float* dbeta, int rows, int cols, void* ws, void* stream) {
+    VM_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && ws, "vm_layernorm_bwd: null pointer");
+    VM_REQUIRE(rows > 0 && cols > 0 && (cols % 8) == 0 && cols <= 64 * 8 * LN_MAX_CHUNKS, "vm_layernorm_bwd: cols=%d must be a multiple of 8 and <= 2048", cols);
+    hipStream_t s = (hipStream_t)stream;
+    VmProfScope prof(VM_FAM_LN, 6.0 * rows * (double)cols, s);
+    const int nch = (cols / 8 + 63) / 64;
+    const int grid = ln_grid(rows);
+    const bf16_t* dyp = (const bf16_t*)dy; const bf16_t* xp = (const bf16_t*)x; bf16_t* dxp = (bf16_t*)dx;
+    float* wsp = (float*)ws;
+    const size_t red_bytes = (size_t)4 * 2 * cols * sizeof(float);
+    switch (nch) {
+        case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(grid), dim3(256), red_bytes, s, dyp, xp, gamma, mean, rstd, dxp, wsp, rows, cols); break;
+        case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(grid), dim3(256), red_bytes, s, dyp, xp, gamma, mean, rstd, dxp, wsp, rows, cols); break;
+        default: hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(grid), dim3(256), red_bytes, s, dyp, xp, gamma, mean, rstd, dxp, wsp, rows, cols); break;
+    }
+    hipLaunchKernelGGL(ln_bwd_reduce, dim3((cols + 31) / 32, 2), dim3(256), 0, s, wsp, dgamma, dbeta, grid, cols);
+    return vm_check_launch("vm_layernorm_bwd");
+}

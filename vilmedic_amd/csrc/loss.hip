@@ -1,0 +1,194 @@
+// loss.hip -- fused softmax cross-entropy (forward + gradient in one pass over the logits), label-smoothing CE,
+// and the fp32 log-softmax / argmax helpers of the decode step.  HBM-bound: one workgroup per row.
+#include "common.h"
+
+__device__ __forceinline__ float block_reduce_max(float v, float* sh) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = fmaxf(r, sh[i]);
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float block_reduce_sum(float v, float* sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+    __syncthreads();
+    return r;
+}
+
+// ------------------------------------------------------------------ shifted causal-LM CE on bf16 logits
+// row = (b,t); label = ids[b,t+1]; rows t == L-1 carry no loss.  The row is kept in registers (<= NCH 16-B
+// chunks per thread) so logits are read from HBM once; dlogits may alias logits.
+#define CE_NCH 16   // 256 threads * 16 chunks * 8 = 32768 columns max
+__global__ __launch_bounds__(256) void ce_shift_kernel(const bf16_t* __restrict__ logits, int64_t ldl, const int64_t* __restrict__ ids,
+                                                       int L, int V, float* __restrict__ loss_sum, float* __restrict__ row_lse,
+                                                       bf16_t* __restrict__ dlogits, float grad_scale) {
+    __shared__ float sh[4];
+    const int row = blockIdx.x, t = row % L, b = row / L;
+    const int nch = (int)(ldl >> 3);
+    bf16_t* drow = dlogits ? dlogits + (int64_t)row * ldl : nullptr;
+    if (t == L - 1) {
+        if (drow) for (int ch = threadIdx.x; ch < nch; ch += 256) *reinterpret_cast<uint4*>(drow + ch * 8) = make_uint4(0, 0, 0, 0);
+        if (row_lse && threadIdx.x == 0) row_lse[row] = 0.f;
+        return;
+    }
+    const bf16_t* lrow = logits + (int64_t)row * ldl;
+    const int label = (int)ids[(int64_t)b * L + t + 1];
+    uint4 raw[CE_NCH];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < CE_NCH; ++i) {
+        const int ch = threadIdx.x + 256 * i;
+        raw[i] = make_uint4(0, 0, 0, 0);
+        if (ch < nch) {
+            raw[i] = *reinterpret_cast<const uint4*>(lrow + ch * 8);
+            float f[8];
+            unpack8(raw[i], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (ch * 8 + j < V) mx = fmaxf(mx, f[j]);
+        }
+    }
+    mx = block_reduce_max(mx, sh);
+    float se = 0.f, lab = 0.f;
+#pragma unroll
+    for (int i = 0; i < CE_NCH; ++i) {
+        const int ch = threadIdx.x + 256 * i;
+        if (ch < nch) {
+            float f[8];
+            unpack8(raw[i], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = ch * 8 + j;
+                if (c < V) { se += __expf(f[j] - mx); if (c == label) lab = f[j]; }
+            }
+        }
+    }
+    se = block_reduce_sum(se, sh);
+    lab = block_reduce_sum(lab, sh);
+    const float lse = mx + __logf(se);
+    if (threadIdx.x == 0) {
+        atomicAdd(loss_sum, lse - lab);
+        if (row_lse) row_lse[row] = lse;
+    }
+    if (drow) {
+        const float inv = grad_scale / se;
+#pragma unroll
+        for (int i = 0; i < CE_NCH; ++i) {
+            const int ch = threadIdx.x + 256 * i;
+            if (ch < nch) {
+                float f[8];
+                unpack8(raw[i], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = ch * 8 + j;
+                    float g = c < V ? __expf(f[j] - mx) * inv : 0.f;
+                    if (c == label) g -= grad_scale;
+                    f[j] = g;
+                }
+                *reinterpret_cast<uint4*>(drow + ch * 8) = pack8(f);
+            }
+        }
+    }
+}
+
+extern "C" int vm_ce_shift_fwd_bwd(const void* logits, int64_t ldl, const int64_t* ids, int B, int L, int V,
+                                   float* loss_sum, float* row_lse, void* dlogits, float grad_scale, void* stream) {
+    VM_REQUIRE(logits && ids && loss_sum, "vm_ce_shift_fwd_bwd: null pointer");
+    VM_REQUIRE(B > 0 && L > 1 && V > 0 && ldl >= V && (ldl % 8) == 0, "vm_ce_shift_fwd_bwd: bad shape");
+    VM_REQUIRE(ldl <= 256 * CE_NCH * 8, "vm_ce_shift_fwd_bwd: vocabulary %d too large (max %d)", V, 256 * CE_NCH * 8);
+    hipStream_t s = (hipStream_t)stream;
+    VmProfScope prof(VM_FAM_LOSS, 4.0 * B * L * (double)ldl, s);
+    hipLaunchKernelGGL(ce_shift_kernel, dim3(B * L), dim3(256), 0, s, (const bf16_t*)logits, ldl, ids, L, V, loss_sum, row_lse, (bf16_t*)dlogits, grad_scale);
+    return vm_check_launch("vm_ce_shift_fwd_bwd");
+}
+
+// ------------------------------------------------------------------ label-smoothing CE on small fp32 logits [R,C]
+// loss_row = eps/C * sum_c(-logp_c) + (1-eps) * (-logp_target)       (reduction 'mean' is applied by the caller)
+__global__ __launch_bounds__(64) void ce_smooth_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, int C,
+                                                       float smoothing, float* __restrict__ loss_sum, float* __restrict__ dlogits, float grad_scale) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const float* lr = logits + (int64_t)row * C;
+    float mx = -INFINITY;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, lr[c]);
+    mx = wave_max(mx);
+    float se = 0.f, sl = 0.f;
+    for (int c = lane; c < C; c += 64) { se += __expf(lr[c] - mx); sl += lr[c]; }
+    se = wave_sum(se); sl = wave_sum(sl);
+    const float lse = mx + __logf(se);
+    const int tg = (int)target[row];
+    if (lane == 0) {
+        const float sum_neg_logp = (float)C * lse - sl;
+        atomicAdd(loss_sum, smoothing / (float)C * sum_neg_logp + (1.f - smoothing) * (lse - lr[tg]));
+    }
+    if (dlogits) {
+        for (int c = lane; c < C; c += 64) {
+            const float pr = __expf(lr[c] - lse);
+            float g = pr - smoothing / (float)C - (c == tg ? (1.f - smoothing) : 0.f);
+            dlogits[(int64_t)row * C + c] = g * grad_scale;
+        }
+    }
+}
+extern "C" int vm_ce_smooth_fwd_bwd(const float* logits, const int64_t* target, int R, int C, float smoothing,
+                                    float* loss_sum, float* dlogits, float grad_scale, void* stream) {
+    VM_REQUIRE(logits && target && loss_sum && R > 0 && C > 0, "vm_ce_smooth_fwd_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    VmProfScope prof(VM_FAM_LOSS, 8.0 * R * (double)C, s);
+    hipLaunchKernelGGL(ce_smooth_kernel, dim3(R), dim3(64), 0, s, logits, target, C, smoothing, loss_sum, dlogits, grad_scale);
+    return vm_check_launch("vm_ce_smooth_fwd_bwd");
+}
+
+// ------------------------------------------------------------------ decode helpers (fp32)
+__global__ __launch_bounds__(256) void logsoftmax_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int V) {
+    __shared__ float sh[4];
+    const float* r = x + (int64_t)blockIdx.x * ldx;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < V; c += 256) mx = fmaxf(mx, r[c]);
+    mx = block_reduce_max(mx, sh);
+    float se = 0.f;
+    for (int c = threadIdx.x; c < V; c += 256) se += expf(r[c] - mx);
+    se = block_reduce_sum(se, sh);
+    const float lse = mx + logf(se);
+    float* o = out + (int64_t)blockIdx.x * V;
+    for (int c = threadIdx.x; c < V; c += 256) o[c] = r[c] - lse;
+}
+extern "C" int vm_logsoftmax_f32(const float* logits, int64_t ldl, float* out, int rows, int V, void* stream) {
+    VM_REQUIRE(logits && out && rows > 0 && V > 0 && ldl >= V, "vm_logsoftmax_f32: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    VmProfScope prof(VM_FAM_DECODE, 12.0 * rows * (double)V, s);
+    hipLaunchKernelGGL(logsoftmax_kernel, dim3(rows), dim3(256), 0, s, logits, ldl, out, V);
+    return vm_check_launch("vm_logsoftmax_f32");
+}
+
+// argmax with lowest-index tie-break (torch.argmax returns the first maximal index on CPU)
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ x, int64_t ldx, int64_t* __restrict__ idx, float* __restrict__ val, int cols) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const float* r = x + (int64_t)blockIdx.x * ldx;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float v = r[c];
+        if (v > best || (v == best && c < bi)) { best = v; bi = c; }
+    }
+    sv[threadIdx.x] = best; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const float v = sv[threadIdx.x + o]; const int i = si[threadIdx.x + o];
+            if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && i < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = i; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { idx[blockIdx.x] = si[0]; if (val) val[blockIdx.x] = sv[0]; }
+}
+extern "C" int vm_argmax_f32(const float* x, int64_t ldx, int64_t* idx, float* val, int rows, int cols, void* stream) {
+    VM_REQUIRE(x && idx && rows > 0 && cols > 0 && ldx >= cols, "vm_argmax_f32: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    VmProfScope prof(VM_FAM_DECODE, 4.0 * rows * (double)cols, s);
+    hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, s, x, ldx, idx, val, cols);
+    return vm_check_launch("vm_argmax_f32");
+}

@@ -1,0 +1,74 @@
+// runtime.hip -- error state, version, and the per-family HIP-event profiler of libvmhip.
+#include "common.h"
+#include <cstdarg>
+#include <cstdio>
+#include <mutex>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+void vm_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int vm_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        vm_set_error("%s: %s", what, hipGetErrorString(e));
+        return VM_EHIP;
+    }
+    return VM_OK;
+}
+
+extern "C" const char* vm_last_error(void) { return g_err; }
+extern "C" int vm_version(void) { return 100; }
+
+// ---------------------------------------------------------------- profiler
+struct ProfSlot { hipEvent_t a, b; int fam; double work; };
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfSlot*> g_prof_used, g_prof_free;
+
+VmProfScope::VmProfScope(int family, double work, hipStream_t stream) : fam(family), s(stream), slot(nullptr) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfSlot* p;
+    if (!g_prof_free.empty()) { p = g_prof_free.back(); g_prof_free.pop_back(); }
+    else { p = new ProfSlot(); hipEventCreate(&p->a); hipEventCreate(&p->b); }
+    p->fam = family; p->work = work;
+    hipEventRecord(p->a, stream);
+    slot = p;
+}
+VmProfScope::~VmProfScope() {
+    if (!slot) return;
+    ProfSlot* p = (ProfSlot*)slot;
+    hipEventRecord(p->b, s);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_used.push_back(p);
+}
+
+extern "C" int vm_prof_enable(int on) { g_prof_on = on != 0; return VM_OK; }
+extern "C" int vm_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto* p : g_prof_used) g_prof_free.push_back(p);
+    g_prof_used.clear();
+    return VM_OK;
+}
+extern "C" int vm_prof_read(int family, double* ms_total, double* work_total, int64_t* launches) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double ms = 0, w = 0; int64_t n = 0;
+    for (auto* p : g_prof_used) {
+        if (p->fam != family) continue;
+        hipEventSynchronize(p->b);
+        float t = 0;
+        hipEventElapsedTime(&t, p->a, p->b);
+        ms += t; w += p->work; ++n;
+    }
+    if (ms_total) *ms_total = ms;
+    if (work_total) *work_total = w;
+    if (launches) *launches = n;
+    return VM_OK;
+}

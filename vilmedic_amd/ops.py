@@ -1,0 +1,500 @@
+"""Python host side of the HIP hot path: thin wrappers over the C ABI (include/vmhip.h) and the
+``torch.autograd.Function``s that pair each forward kernel with its backward.
+
+Design notes
+  * activations are bf16 row-major ``[rows, features]``; parameters are fp32 ``nn.Parameter``s (HF names)
+    living in a flat arena (``vilmedic_amd.arena``) with a bf16 *shadow* the GEMMs read;
+  * weight / bias gradients are ACCUMULATED IN PLACE into the fp32 ``.grad`` views of the arena by the
+    wgrad GEMM (fp32 atomics, split-K) and the column-sum kernel -- autograd only routes activation
+    gradients, so no per-step gradient tensors are allocated (sized for 288 GB HBM: everything resident);
+  * dropout masks are regenerated from a counter-based RNG (seed per call site), never stored;
+  * there is NO CPU fallback: every op raises on non-device tensors.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import GemmEpilogue, VM_BF16, VM_F32, check, lib, ptr, stream
+
+BF16 = torch.bfloat16
+
+# ----------------------------------------------------------------------------- RNG seeds for dropout
+_seed_state = {"base": 0x1234ABCD, "counter": 0}
+
+
+def manual_seed(seed):
+    _seed_state["base"] = int(seed) & 0xFFFFFFFF
+    _seed_state["counter"] = 0
+
+
+def next_seed():
+    _seed_state["counter"] += 1
+    return ((_seed_state["base"] << 32) ^ (_seed_state["counter"] * 0x9E3779B1)) & 0xFFFFFFFFFFFFFFFF
+
+
+# ----------------------------------------------------------------------------- raw kernel wrappers
+def gemm(A, a_layout, B, b_layout, C_out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, act=0, aux_out=None,
+         mul_gelu_z=None, dropout_p=0.0, dropout_seed=0, residual=None, ldr=None, alpha=1.0, alpha_dev=None, accumulate=False,
+         split_k=1):
+    e = GemmEpilogue()
+    e.bias = ptr(bias).value if bias is not None else None
+    e.act = act
+    e.aux_out = ptr(aux_out).value if aux_out is not None else None
+    e.mul_gelu_z = ptr(mul_gelu_z).value if mul_gelu_z is not None else None
+    e.dropout_p = dropout_p
+    e.dropout_seed = dropout_seed
+    e.residual = ptr(residual).value if residual is not None else None
+    e.ldr = ldr if ldr is not None else (residual.stride(0) if residual is not None else 0)
+    e.alpha = alpha
+    e.alpha_dev = ptr(alpha_dev).value if alpha_dev is not None else None
+    e.out_dtype = VM_F32 if C_out.dtype == torch.float32 else VM_BF16
+    e.accumulate = 1 if accumulate else 0
+    e.split_k = split_k
+    lda = lda if lda is not None else A.stride(0)
+    ldb = ldb if ldb is not None else B.stride(0)
+    ldc = ldc if ldc is not None else C_out.stride(0)
+    check(lib().vm_gemm_bf16(ptr(A), lda, a_layout, ptr(B), ldb, b_layout, ptr(C_out), ldc, M, N, K, C.byref(e), stream()),
+          "vm_gemm_bf16")
+    return C_out
+
+
+def _split_k_for(out_tiles, k_tiles):
+    """enough blocks to fill 256 CUs x 2; keep >= 4 k-tiles per split"""
+    want = max(1, 768 // max(1, out_tiles))
+    return max(1, min(want, k_tiles // 4 if k_tiles >= 8 else 1))
+
+
+def wgrad(dY, X, dW, *, ld_dy=None, ld_x=None, alpha_dev=None):
+    """dW[N,K] += dY[M,N]^T @ X[M,K]   (fp32 accumulate, split-K over M)."""
+    M, N = dY.shape
+    K = X.shape[1]
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    gemm(dY, 1, X, 1, dW, N, K, M, lda=ld_dy or dY.stride(0), ldb=ld_x or X.stride(0), ldc=dW.stride(0),
+         accumulate=True, split_k=_split_k_for(tiles, (M + 63) // 64), alpha_dev=alpha_dev)
+
+
+def colsum(x, out, rows=None, cols=None, scale_dev=None):
+    rows = rows if rows is not None else x.shape[0]
+    cols = cols if cols is not None else x.shape[1]
+    check(lib().vm_colsum_bf16(ptr(x), x.stride(0), ptr(out), rows, cols, ptr(scale_dev) if scale_dev is not None else None,
+                               stream()), "vm_colsum_bf16")
+
+
+def cast_to_bf16(src, dst=None):
+    dst = dst if dst is not None else torch.empty(src.shape, dtype=BF16, device=src.device)
+    check(lib().vm_cast_f32_to_bf16(ptr(src), ptr(dst), src.numel(), stream()), "vm_cast_f32_to_bf16")
+    return dst
+
+
+def cast_to_f32(src, dst=None):
+    dst = dst if dst is not None else torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    check(lib().vm_cast_bf16_to_f32(ptr(src), ptr(dst), src.numel(), stream()), "vm_cast_bf16_to_f32")
+    return dst
+
+
+def dropout_apply(x, p, seed):
+    out = torch.empty_like(x)
+    check(lib().vm_dropout_apply_bf16(ptr(x), ptr(out), x.numel(), p, seed, stream()), "vm_dropout_apply_bf16")
+    return out
+
+
+def add_bf16(a, b):
+    out = torch.empty_like(a)
+    check(lib().vm_add_bf16(ptr(a), ptr(b), ptr(out), a.numel(), stream()), "vm_add_bf16")
+    return out
+
+
+def feature_mask(feats2d):
+    rows, cols = feats2d.shape
+    m = torch.empty(rows, dtype=torch.uint8, device=feats2d.device)
+    check(lib().vm_feature_mask(ptr(feats2d), ptr(m), rows, cols, stream()), "vm_feature_mask")
+    return m
+
+
+def _grad_buf(p):
+    """fp32 accumulation buffer of a parameter (its arena ``.grad`` view; re-created if a caller set it to None)."""
+    if p.grad is None:
+        view = getattr(p, "_vm_grad_view", None)
+        if view is not None:
+            view.zero_()
+            p.grad = view
+        else:
+            p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+def _2d(x):
+    return x.reshape(-1, x.shape[-1])
+
+
+# ----------------------------------------------------------------------------- Linear (+bias, +dropout, +residual)
+class LinearFn(torch.autograd.Function):
+    """y = dropout(x W^T + b) + residual.   ``w_sh`` is the bf16 shadow [N,K] of the fp32 parameter(s);
+    ``w_params`` / ``b_params`` are lists of the fp32 parameters whose contiguous arena grads receive dW / db
+    (several when Q,K,V projections are fused into one GEMM)."""
+
+    @staticmethod
+    def forward(ctx, x, w_sh, bias_f32, residual, dropout_p, wgrad_buf, bgrad_buf, anchor):
+        x2 = _2d(x)
+        M, K = x2.shape
+        N = w_sh.shape[0]
+        y = torch.empty(M, N, dtype=BF16, device=x.device)
+        seed = next_seed() if dropout_p > 0 else 0
+        gemm(x2, 0, w_sh, 0, y, M, N, K, bias=bias_f32, dropout_p=dropout_p, dropout_seed=seed,
+             residual=_2d(residual) if residual is not None else None)
+        ctx.save_for_backward(x2, w_sh)
+        ctx.meta = (dropout_p, seed, wgrad_buf, bgrad_buf, residual is not None, x.shape)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w_sh = ctx.saved_tensors
+        dropout_p, seed, wgrad_buf, bgrad_buf, has_res, xshape = ctx.meta
+        dy2 = _2d(dy.contiguous())
+        M, N = dy2.shape
+        K = x2.shape[1]
+        dpre = dropout_apply(dy2, dropout_p, seed) if dropout_p > 0 else dy2
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=BF16, device=dy.device)
+            gemm(dpre, 0, w_sh, 1, dx, M, K, N)
+            dx = dx.view(xshape)
+        if wgrad_buf is not None:
+            wgrad(dpre, x2, wgrad_buf)
+        if bgrad_buf is not None:
+            colsum(dpre, bgrad_buf)
+        return dx, None, None, (dy if has_res else None), None, None, None, None
+
+
+def linear(x, w_sh, bias, *, residual=None, dropout_p=0.0, wgrad_buf=None, bgrad_buf=None, anchor=None):
+    return LinearFn.apply(x, w_sh, bias, residual, dropout_p, wgrad_buf, bgrad_buf, anchor)
+
+
+# ----------------------------------------------------------------------------- MLP: FC1 + erf-GELU + FC2 (+dropout) + residual
+class MlpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual, dropout_p, g_w1, g_b1, g_w2, g_b2, anchor):
+        x2 = _2d(x)
+        M, K = x2.shape
+        F = w1.shape[0]
+        z = torch.empty(M, F, dtype=BF16, device=x.device)
+        a = torch.empty(M, F, dtype=BF16, device=x.device)
+        gemm(x2, 0, w1, 0, a, M, F, K, bias=b1, act=1, aux_out=z)
+        y = torch.empty(M, K, dtype=BF16, device=x.device)
+        seed = next_seed() if dropout_p > 0 else 0
+        gemm(a, 0, w2, 0, y, M, K, F, bias=b2, dropout_p=dropout_p, dropout_seed=seed,
+             residual=_2d(residual) if residual is not None else None)
+        ctx.save_for_backward(x2, z, a, w1, w2)
+        ctx.meta = (dropout_p, seed, g_w1, g_b1, g_w2, g_b2, residual is not None, x.shape)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, z, a, w1, w2 = ctx.saved_tensors
+        dropout_p, seed, g_w1, g_b1, g_w2, g_b2, has_res, xshape = ctx.meta
+        dy2 = _2d(dy.contiguous())
+        M, K = dy2.shape
+        F = w1.shape[0]
+        dpre = dropout_apply(dy2, dropout_p, seed) if dropout_p > 0 else dy2
+        if g_w2 is not None:
+            wgrad(dpre, a, g_w2)
+            colsum(dpre, g_b2)
+        dz = torch.empty(M, F, dtype=BF16, device=dy.device)
+        gemm(dpre, 0, w2, 1, dz, M, F, K, mul_gelu_z=z)          # da * gelu'(z) fused in the dgrad epilogue
+        if g_w1 is not None:
+            wgrad(dz, x2, g_w1)
+            colsum(dz, g_b1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=BF16, device=dy.device)
+            gemm(dz, 0, w1, 1, dx, M, K, F)
+            dx = dx.view(xshape)
+        return dx, None, None, None, None, (dy if has_res else None), None, None, None, None, None, None
+
+
+def mlp(x, w1, b1, w2, b2, *, residual=None, dropout_p=0.0, grads=(None, None, None, None), anchor=None):
+    return MlpFn.apply(x, w1, b1, w2, b2, residual, dropout_p, *grads, anchor)
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, g_gamma, g_beta):
+        x2 = _2d(x)
+        rows, cols = x2.shape
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        check(lib().vm_layernorm_fwd(ptr(x2), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows, cols, eps, stream()),
+              "vm_layernorm_fwd")
+        ctx.save_for_backward(x2, gamma, mean, rstd)
+        ctx.meta = (g_gamma, g_beta, x.shape)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, gamma, mean, rstd = ctx.saved_tensors
+        g_gamma, g_beta, xshape = ctx.meta
+        rows, cols = x2.shape
+        dy2 = _2d(dy.contiguous())
+        dx = torch.empty_like(x2)
+        ws = torch.empty(lib().vm_layernorm_bwd_ws(rows, cols) // 4, dtype=torch.float32, device=dy.device)
+        if g_gamma is None:   # frozen affine: still need dx; send the param grads to scratch
+            g_gamma = torch.zeros(cols, dtype=torch.float32, device=dy.device)
+            g_beta = torch.zeros(cols, dtype=torch.float32, device=dy.device)
+        check(lib().vm_layernorm_bwd(ptr(dy2), ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(g_gamma), ptr(g_beta),
+                                     rows, cols, ptr(ws), stream()), "vm_layernorm_bwd")
+        return dx.view(xshape), None, None, None, None, None
+
+
+def layer_norm(x, gamma, beta, eps, g_gamma=None, g_beta=None):
+    return LayerNormFn.apply(x, gamma, beta, eps, g_gamma, g_beta)
+
+
+# ----------------------------------------------------------------------------- attention
+class AttentionFn(torch.autograd.Function):
+    """q [B,Lq,*] k,v [B,Lk,*] are column slices (views) of projection outputs; heads are contiguous 64-wide blocks."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, key_mask, H, causal, dropout_p):
+        B, Lq = q.shape[0], q.shape[1]
+        Lk = k.shape[1]
+        dh = q.shape[2] // H
+        o = torch.empty(B, Lq, H * dh, dtype=BF16, device=q.device)
+        stats = torch.empty(B, H, Lq, 2, dtype=torch.float32, device=q.device)
+        seed = next_seed() if dropout_p > 0 else 0
+        scale = dh ** -0.5
+        check(lib().vm_attention_fwd(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), o.stride(1), ptr(stats),
+                                     ptr(key_mask) if key_mask is not None else None, B, H, Lq, Lk, dh, scale, int(causal),
+                                     dropout_p, seed, stream()), "vm_attention_fwd")
+        ctx.save_for_backward(q, k, v, o, stats, key_mask)
+        ctx.meta = (H, causal, dropout_p, seed, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        q, k, v, o, stats, key_mask = ctx.saved_tensors
+        H, causal, dropout_p, seed, scale = ctx.meta
+        B, Lq = q.shape[0], q.shape[1]
+        Lk = k.shape[1]
+        dh = q.shape[2] // H
+        d_o = d_o.contiguous()
+        # gradients are written in the same packed layout as the inputs (one buffer when q,k,v share storage rows)
+        dq = torch.empty(B, Lq, H * dh, dtype=BF16, device=q.device)
+        dk = torch.empty(B, Lk, H * dh, dtype=BF16, device=q.device)
+        dv = torch.empty(B, Lk, H * dh, dtype=BF16, device=q.device)
+        delta = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
+        check(lib().vm_attention_bwd(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), o.stride(1),
+                                     ptr(d_o), d_o.stride(1), ptr(stats), ptr(key_mask) if key_mask is not None else None,
+                                     ptr(dq), dq.stride(1), ptr(dk), dk.stride(1), ptr(dv), dv.stride(1),
+                                     B, H, Lq, Lk, dh, scale, int(causal), dropout_p, seed, ptr(delta), stream()), "vm_attention_bwd")
+        return dq, dk, dv, None, None, None, None
+
+
+class PackedSelfAttentionFn(torch.autograd.Function):
+    """Self-attention on the fused QKV projection output [B,L,3*D]; the gradient comes back packed [B,L,3*D]
+    so the QKV dgrad/wgrad run as single GEMMs."""
+
+    @staticmethod
+    def forward(ctx, qkv, key_mask, H, causal, dropout_p):
+        B, L, D3 = qkv.shape
+        D = D3 // 3
+        dh = D // H
+        o = torch.empty(B, L, D, dtype=BF16, device=qkv.device)
+        stats = torch.empty(B, H, L, 2, dtype=torch.float32, device=qkv.device)
+        seed = next_seed() if dropout_p > 0 else 0
+        scale = dh ** -0.5
+        q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        check(lib().vm_attention_fwd(ptr(q), D3, ptr(k), D3, ptr(v), D3, ptr(o), D, ptr(stats),
+                                     ptr(key_mask) if key_mask is not None else None, B, H, L, L, dh, scale, int(causal),
+                                     dropout_p, seed, stream()), "vm_attention_fwd")
+        ctx.save_for_backward(qkv, o, stats, key_mask)
+        ctx.meta = (H, causal, dropout_p, seed, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        qkv, o, stats, key_mask = ctx.saved_tensors
+        H, causal, dropout_p, seed, scale = ctx.meta
+        B, L, D3 = qkv.shape
+        D = D3 // 3
+        dh = D // H
+        d_o = d_o.contiguous()
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty(B, H, L, dtype=torch.float32, device=qkv.device)
+        q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        dq, dk, dv = dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:]
+        check(lib().vm_attention_bwd(ptr(q), D3, ptr(k), D3, ptr(v), D3, ptr(o), D, ptr(d_o), D, ptr(stats),
+                                     ptr(key_mask) if key_mask is not None else None, ptr(dq), D3, ptr(dk), D3, ptr(dv), D3,
+                                     B, H, L, L, dh, scale, int(causal), dropout_p, seed, ptr(delta), stream()), "vm_attention_bwd")
+        return dqkv, None, None, None, None
+
+
+class PackedCrossAttentionFn(torch.autograd.Function):
+    """q [B,Lq,D] from the decoder, kv [B,Lk,2*D] = fused K|V projection of the encoder features."""
+
+    @staticmethod
+    def forward(ctx, q, kv, key_mask, H, dropout_p):
+        B, Lq, D = q.shape
+        Lk = kv.shape[1]
+        dh = D // H
+        o = torch.empty(B, Lq, D, dtype=BF16, device=q.device)
+        stats = torch.empty(B, H, Lq, 2, dtype=torch.float32, device=q.device)
+        seed = next_seed() if dropout_p > 0 else 0
+        scale = dh ** -0.5
+        k, v = kv[..., :D], kv[..., D:]
+        check(lib().vm_attention_fwd(ptr(q), D, ptr(k), 2 * D, ptr(v), 2 * D, ptr(o), D, ptr(stats),
+                                     ptr(key_mask) if key_mask is not None else None, B, H, Lq, Lk, dh, scale, 0,
+                                     dropout_p, seed, stream()), "vm_attention_fwd")
+        ctx.save_for_backward(q, kv, o, stats, key_mask)
+        ctx.meta = (H, dropout_p, seed, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        q, kv, o, stats, key_mask = ctx.saved_tensors
+        H, dropout_p, seed, scale = ctx.meta
+        B, Lq, D = q.shape
+        Lk = kv.shape[1]
+        dh = D // H
+        d_o = d_o.contiguous()
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        delta = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
+        k, v = kv[..., :D], kv[..., D:]
+        dk, dv = dkv[..., :D], dkv[..., D:]
+        check(lib().vm_attention_bwd(ptr(q), D, ptr(k), 2 * D, ptr(v), 2 * D, ptr(o), D, ptr(d_o), D, ptr(stats),
+                                     ptr(key_mask) if key_mask is not None else None, ptr(dq), D, ptr(dk), 2 * D, ptr(dv), 2 * D,
+                                     B, H, Lq, Lk, dh, scale, 0, dropout_p, seed, ptr(delta), stream()), "vm_attention_bwd")
+        return dq, dkv, None, None, None
+
+
+def self_attention(qkv, key_mask, H, causal, dropout_p=0.0):
+    return PackedSelfAttentionFn.apply(qkv, key_mask, H, causal, dropout_p)
+
+
+def cross_attention(q, kv, key_mask, H, dropout_p=0.0):
+    return PackedCrossAttentionFn.apply(q, kv, key_mask, H, dropout_p)
+
+
+# ----------------------------------------------------------------------------- embeddings
+class EmbeddingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, ids, word, pos, past_len, padding_idx, g_word, g_pos):
+        B, L = ids.shape
+        D = word.shape[1]
+        out = torch.empty(B, L, D, dtype=BF16, device=word.device)
+        check(lib().vm_embedding_fwd(ptr(ids), ptr(word), ptr(pos), ptr(out), B, L, D, past_len, stream()), "vm_embedding_fwd")
+        ctx.save_for_backward(ids)
+        ctx.meta = (padding_idx, g_word, g_pos, D, past_len)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (ids,) = ctx.saved_tensors
+        padding_idx, g_word, g_pos, D, past_len = ctx.meta
+        B, L = ids.shape
+        if g_word is not None:
+            d_out = d_out.contiguous()
+            gp = g_pos[past_len:] if past_len else g_pos
+            check(lib().vm_embedding_bwd(ptr(ids), ptr(d_out), ptr(g_word), ptr(gp), B, L, D,
+                                         padding_idx if padding_idx is not None else -1, stream()), "vm_embedding_bwd")
+        return None, None, None, None, None, None, None, None
+
+
+def embedding(anchor, ids, word, pos, *, past_len=0, padding_idx=None, g_word=None, g_pos=None):
+    return EmbeddingFn.apply(anchor, ids, word, pos, past_len, padding_idx, g_word, g_pos)
+
+
+# ----------------------------------------------------------------------------- ViT patch embedding (+cls +pos)
+class PatchEmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, images, w_sh, bias, cls, pos, patch, g_w, g_b, g_cls, g_pos):
+        B, Cc, Hh, Ww = images.shape
+        n = (Hh // patch) * (Ww // patch)
+        D, Kd = w_sh.shape
+        cols = torch.empty(B * n, Kd, dtype=BF16, device=images.device)
+        check(lib().vm_im2col_patches(ptr(images), ptr(cols), B, Cc, Hh, Ww, patch, stream()), "vm_im2col_patches")
+        pe = torch.empty(B * n, D, dtype=BF16, device=images.device)
+        gemm(cols, 0, w_sh, 0, pe, B * n, D, Kd, bias=bias)
+        out = torch.empty(B, n + 1, D, dtype=BF16, device=images.device)
+        check(lib().vm_vit_assemble(ptr(pe), ptr(cls), ptr(pos), ptr(out), B, n, D, stream()), "vm_vit_assemble")
+        ctx.save_for_backward(cols)
+        ctx.meta = (B, n, D, g_w, g_b, g_cls, g_pos)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (cols,) = ctx.saved_tensors
+        B, n, D, g_w, g_b, g_cls, g_pos = ctx.meta
+        if g_w is not None:
+            d_out = d_out.contiguous()
+            dpe = torch.empty(B * n, D, dtype=BF16, device=d_out.device)
+            check(lib().vm_vit_assemble_bwd(ptr(d_out), ptr(dpe), ptr(g_cls), ptr(g_pos), B, n, D, stream()), "vm_vit_assemble_bwd")
+            wgrad(dpe, cols, g_w.view(D, -1))
+            colsum(dpe, g_b)
+        return (None,) * 11
+
+
+def patch_embed(anchor, images, w_sh, bias, cls, pos, patch, grads=(None, None, None, None)):
+    return PatchEmbedFn.apply(anchor, images, w_sh, bias, cls, pos, patch, *grads)
+
+
+# ----------------------------------------------------------------------------- LM head + shifted CE (fused fwd/bwd)
+class LmHeadLossFn(torch.autograd.Function):
+    """logits = h E^T + b (bf16, padded leading dim); loss = mean CE(logits[:, :-1], ids[:, 1:]) with pads INCLUDED
+    (ref: decoder_model.py:46 passes labels=input_ids).  The gradient wrt the logits is produced in the same pass
+    that computes the loss; backward only scales it and runs the dgrad/wgrad GEMMs."""
+
+    @staticmethod
+    def forward(ctx, h, emb_sh, bias, ids, V, g_emb, g_bias, want_logits):
+        B, L, D = h.shape
+        Vp = emb_sh.shape[0]
+        h2 = _2d(h)
+        logits = torch.empty(B * L, Vp, dtype=BF16, device=h.device)
+        gemm(h2, 0, emb_sh, 0, logits, B * L, V, D, bias=bias)
+        loss_sum = torch.zeros(1, dtype=torch.float32, device=h.device)
+        inv = 1.0 / (B * (L - 1))
+        need_grad = h.requires_grad or g_emb is not None
+        dlogits = (torch.empty_like(logits) if want_logits else logits) if need_grad else None
+        check(lib().vm_ce_shift_fwd_bwd(ptr(logits), Vp, ptr(ids), B, L, V, ptr(loss_sum), None,
+                                        ptr(dlogits) if dlogits is not None else None, inv, stream()), "vm_ce_shift_fwd_bwd")
+        ctx.save_for_backward(h2, emb_sh, dlogits)
+        ctx.meta = (B, L, D, V, Vp, g_emb, g_bias)
+        loss = (loss_sum * inv).squeeze(0)
+        out_logits = logits.view(B, L, Vp)[..., :V] if want_logits else None
+        ctx.mark_non_differentiable(*( [out_logits] if out_logits is not None else []))
+        return loss, out_logits
+
+    @staticmethod
+    def backward(ctx, dloss, _dlogits_unused):
+        h2, emb_sh, dlogits = ctx.saved_tensors
+        B, L, D, V, Vp, g_emb, g_bias = ctx.meta
+        # dloss (dL/dloss, a device scalar: 1 for loss.backward(), 1/grad_accu or a loss scale otherwise) is folded
+        # into the GEMM / column-sum epilogues through a device pointer -- no host sync, no extra pass over dlogits.
+        sc = dloss.detach().to(torch.float32).contiguous()
+        M = B * L
+        dh = None
+        if ctx.needs_input_grad[0]:
+            dh = torch.empty(M, D, dtype=BF16, device=h2.device)
+            gemm(dlogits, 0, emb_sh, 1, dh, M, D, Vp, alpha_dev=sc)
+            dh = dh.view(B, L, D)
+        if g_emb is not None:
+            wgrad(dlogits, h2, g_emb, alpha_dev=sc)   # dE[V,D] += dlogits^T h (pad columns of dlogits are zero)
+            colsum(dlogits, g_bias, rows=M, cols=V, scale_dev=sc)
+        return dh, None, None, None, None, None, None, None
+
+
+def lm_head_loss(h, emb_sh, bias, ids, V, g_emb=None, g_bias=None, want_logits=True):
+    return LmHeadLossFn.apply(h, emb_sh, bias, ids, V, g_emb, g_bias, want_logits)
+
+
+def lm_logits_f32(h2, emb_sh, bias, V):
+    """fp32 logits for the decode step (hf:generation/utils.py:3384 upcasts to fp32 before log_softmax)."""
+    M, D = h2.shape
+    out = torch.empty(M, V, dtype=torch.float32, device=h2.device) if V % 4 == 0 else \
+        torch.empty(M, (V + 3) // 4 * 4, dtype=torch.float32, device=h2.device)
+    gemm(h2, 0, emb_sh, 0, out, M, V, D, bias=bias)
+    return out[:, :V]

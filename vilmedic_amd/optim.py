@@ -1,0 +1,47 @@
+"""Fused Adam/AdamW over the parameter arena (one HIP launch per step; also refreshes the bf16 shadows)."""
+import torch
+
+from ._lib import check, lib, ptr, stream
+from .arena import arena_of
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam / AdamW arithmetic (``decoupled_weight_decay`` selects AdamW) executed by ``vm_adam_step`` on
+    the flat arena.  Accepts a model (preferred) -- the arena is rooted there."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled_weight_decay=False):
+        self.arena = arena_of(model)
+        params = [p for p, _ in self.arena._layout]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                      decoupled_weight_decay=decoupled_weight_decay))
+        a = self.arena
+        self.m = torch.zeros_like(a.flat)
+        self.v = torch.zeros_like(a.flat)
+        self.steps = 0
+        self.grad_scale = 1.0
+        # frozen parameters: their gradient slices stay zero and m=v=0 -> update is exactly 0 (no weight decay applied
+        # would still move them, so decay is rejected when something is frozen)
+        if weight_decay and any(not p.requires_grad for p in params):
+            raise ValueError("FusedAdam: weight_decay with frozen parameters is not supported")
+
+    def zero_grad(self, set_to_none=False):
+        self.arena.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        self.steps += 1
+        b1, b2 = g["betas"]
+        a = self.arena
+        check(lib().vm_adam_step(ptr(a.flat), ptr(a.gflat), ptr(self.m), ptr(self.v), ptr(a.shadow_flat), a.numel,
+                                 g["lr"], b1, b2, g["eps"], g["weight_decay"], int(g["decoupled_weight_decay"]),
+                                 1 - b1 ** self.steps, 1 - b2 ** self.steps, self.grad_scale, stream()), "vm_adam_step")
+        a.mark_shadow_fresh()
+
+    def state_dict(self):
+        return {"m": self.m, "v": self.v, "steps": self.steps, "param_groups": self.param_groups}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        self.steps = sd["steps"]
