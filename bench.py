@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- RRG training throughput (image-report pairs/s) on MI355X, BASELINE.json's metric.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1], SURVEY §8d "C2"): ViT-B/16 image encoder + 12-layer d=768 BERT-generation decoder
+with cross-attention, bf16 activations / fp32 master weights, per-GPU batch 64, 224x224 synthetic images, 128-token
+synthetic reports, V=30522, dropout 0.1 as in the shipped YAMLs; a step = forward + backward + (gradient all-reduce over
+RCCL when N>1) + fused Adam.  One process per GPU, weak scaling (fixed per-GPU batch).
+
+The JSON line also carries
+  roofline     -- the bf16 MFMA GEMM family (the dominant kernels): algorithmic FLOPs / HIP-event time of those launches,
+                  measured live on the launch stream by the library's event profiler over extra (untimed) steps;
+  cpu_baseline -- the CPU oracle (oracle/torch_ref.py, a port of the reference's math) timed on this box's host cores
+                  on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+VIT_B16 = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+               image_size=224, patch_size=16, num_channels=3, layer_norm_eps=1e-12)
+DEC_12L = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+               vocab_size=30522, max_position_embeddings=514, layer_norm_eps=1e-5, bos_token_id=0, pad_token_id=1,
+               eos_token_id=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, initializer_range=0.02)
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def flops_per_pair_fwd(S=197, L=128, d=768, V=30522, layers=12):
+    """36.80 GMAC fwd per pair at C2."""
+    vit = 196 * 768 * d + layers * (12 * S * d * d + 2 * S * S * d)
+    dec = layers * (4 * L * d * d + 2 * L * L * d + 2 * L * d * d + 2 * S * d * d + 2 * L * S * d + 8 * L * d * d)
+    head = L * d * V
+    return 2.0 * (vit + dec + head)
+
+
+def build_model(device):
+    from vilmedic_amd.models.rrg.RRG import RRG
+    torch.manual_seed(0)
+    model = RRG(decoder=dict(proto=None, **DEC_12L),
+                cnn=dict(proto="VisualEncoder", backbone="vit", permute="no_permute", dropout_out=0.0, **VIT_B16))
+    return model.to(device)
+
+
+def synthetic_batch(B, L, V, device, seed):
+    import golden_recipes as R
+    images = R.make_images(B, 224, seed=seed).to(device)
+    ids, am = R.make_reports(B, L, V, seed=seed)
+    return images, ids.to(device), am.to(device)
+
+
+def cpu_baseline(budget_s=25.0):
+    """Oracle (CPU port of the reference math) on the same model shape, B=2, fwd + bwd + Adam, fp32."""
+    import golden_recipes as R
+    from oracle import torch_ref as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    vcfg, dcfg = dict(VIT_B16), dict(DEC_12L)
+    st = {"enc.model." + k: v for k, v in R.rand_state(R.vit_shapes(vcfg), 0, std=0.02).items()}
+    st.update({"dec.decoder." + k: v for k, v in R.rand_state(R.decoder_shapes(dcfg), 1, std=0.02).items()})
+    st = {k: v.requires_grad_(True) for k, v in st.items()}
+    B, L = 2, 128
+    images = R.make_images(B, 224, seed=0)
+    ids, am = R.make_reports(B, L, dcfg["vocab_size"], seed=0)
+    opt = torch.optim.Adam(list(st.values()), lr=1e-4)
+    times = []
+    t_start = time.time()
+    for i in range(4):
+        t0 = time.time()
+        loss, _ = O.rrg_vit_forward(images, ids, am, st, vcfg, dcfg)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        times.append(time.time() - t0)
+        if time.time() - t_start > budget_s and i >= 1:
+            break
+    t = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": round(B / t, 3), "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/torch_ref.py rrg_vit_forward + backward + Adam, same model (ViT-B/16 + 12L decoder, V=30522), "
+                      f"B={B}, L={L}, fp32, {len(times)} steps (best after 1 warm-up), {threads} torch threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
+    ap.add_argument("--seq", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("VM_BENCH_GRAPH", "0")))
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from vilmedic_amd import ops
+    from vilmedic_amd._lib import lib
+    from vilmedic_amd.optim import FusedAdam
+    from vilmedic_amd.parallel import ArenaDDP
+
+    model = build_model(device)
+    model.train()
+    ops.manual_seed(1234 + rank)
+    ddp = ArenaDDP(model, dist) if world > 1 else None
+    opt = FusedAdam(model, lr=1e-4)
+    B, L, V = args.batch, args.seq, DEC_12L["vocab_size"]
+    images, ids, am = synthetic_batch(B, L, V, device, seed=rank)
+
+    def step():
+        out = model(input_ids=ids, attention_mask=am, images=images, return_logits=False)
+        opt.zero_grad()
+        out["loss"].backward()
+        if ddp is not None:
+            ddp.finish()
+        opt.step()
+        return out["loss"]
+
+    for _ in range(args.warmup):
+        loss = step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = float(loss)
+
+    roof = None
+    if not args.no_roofline and rank == 0:
+        L_ = lib()
+        L_.vm_prof_reset()
+        L_.vm_prof_enable(1)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        L_.vm_prof_enable(0)
+        ms, work, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        fam = {}
+        for f, name in enumerate(["gemm", "attention", "layernorm", "loss", "elementwise", "optimizer"]):
+            L_.vm_prof_read(f, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(n))
+            fam[name] = (ms.value, work.value, n.value)
+        gms, gwork, gn = fam["gemm"]
+        ach = gwork / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all layouts, fwd+dgrad+wgrad)", "achieved": round(ach, 1),
+                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": gn // 2, "avg_launch_ms": round(gms / max(gn, 1), 4),
+                "family_ms_per_step": {k: round(v[0] / 2, 3) for k, v in fam.items()}}
+        L_.vm_prof_reset()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        pairs = B * world * args.steps
+        value = pairs / elapsed
+        step_flops = 3.0 * flops_per_pair_fwd(L=L) * B
+        line = {
+            "metric": "image-report pairs/sec training (RRG, 224px x 128tok)", "value": round(value, 2), "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "config/RRG: ViT-B/16 + 12-layer BERT-generation decoder (d=768, h=12, ff=3072, V=30522), "
+                                   "bf16, 224x224 images, 128-token reports, dropout 0.1, fwd+bwd+Adam",
+                       "per_gpu_batch": B, "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}"},
+            "model_tflops_per_s": round(step_flops * args.steps / elapsed / 1e12 * world, 1),
+            "final_loss": round(final_loss, 4),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

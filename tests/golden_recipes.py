@@ -143,17 +143,18 @@ def make_reports(B, L, V, seed=0, cls=0, pad=1, sep=2):
 
 
 # ----------------------------------------------------------------------------- configs
-VIT_TINY = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+# (head_dim = 64 everywhere: the MFMA attention kernels contract over 32-wide k-steps of the head dimension)
+VIT_TINY = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                 image_size=32, patch_size=8, num_channels=3, layer_norm_eps=1e-12)
 VIT_B16_1L = dict(hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=3072,
                   image_size=224, patch_size=16, num_channels=3, layer_norm_eps=1e-12)
-DEC_TINY = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+DEC_TINY = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                 vocab_size=97, max_position_embeddings=64, layer_norm_eps=1e-5,
                 bos_token_id=0, pad_token_id=1, eos_token_id=2)
 DEC_768_2L = dict(hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=3072,
                   vocab_size=1000, max_position_embeddings=514, layer_norm_eps=1e-5,
                   bos_token_id=0, pad_token_id=1, eos_token_id=2)
-MVQA_TINY = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=96,
+MVQA_TINY = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=192,
                  layer_norm_eps=1e-12)
-TXT_TINY = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+TXT_TINY = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                 vocab_size=97, max_position_embeddings=64, layer_norm_eps=1e-12, pad_token_id=1)

@@ -4,7 +4,8 @@
 Tolerance (north_star: "outputs equal to reference within 1e-3 bf16"): activations travel in bf16 (8-bit
 mantissa, eps = 3.9e-3) with fp32 accumulation/statistics, so we require
     loss:   |hip - ref| <= 2e-3 * max(1, |ref|)
-    logits / features: max-abs error <= 3e-2 on O(1) values (a few bf16 ulps after 2-12 layers) and mean-abs <= 5e-3
+    logits / features: |err| <= 2e-2 + 2e-2*|ref| elementwise (a few bf16 ulps: the OUTPUT itself is rounded to bf16,
+                       ulp(2.0) = 1.6e-2) and mean-abs error <= 5e-3
     gradients: cosine similarity >= 0.999 and relative L2 error <= 3e-2 vs the fp32 oracle.
 """
 import pytest
@@ -22,6 +23,11 @@ def dev():
 
 def rel_l2(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+def close_bf16(got, ref):
+    err = (got - ref).abs()
+    return bool((err <= 2e-2 + 2e-2 * ref.abs()).all()) and err.mean().item() <= 5e-3
 
 
 def cosine(a, b):
@@ -70,13 +76,12 @@ def test_vit_features_vs_golden_and_oracle(golden, name):
         feats, mask = enc.encode(images.to(dev()))
     feats = feats.float().cpu()
     ref = O.vit_forward(images, st, cfg)
-    assert (feats - ref).abs().max() <= 3e-2 and (feats - ref).abs().mean() <= 5e-3
-    gold = g["features"] if name == "g1_vit_tiny" else None
-    if gold is not None:
-        assert (feats - gold).abs().max() <= 3e-2
+    assert close_bf16(feats, ref), ((feats - ref).abs().max(), (feats - ref).abs().mean())
+    if name == "g1_vit_tiny":
+        assert close_bf16(feats, g["features"])
         assert torch.equal(mask.cpu(), g["mask"])
     else:
-        assert (feats[:, ::8] - g["features"]).abs().max() <= 3e-2
+        assert close_bf16(feats[:, ::8], g["features"])
 
 
 def test_decoder_loss_logits_grads_vs_golden(golden):
@@ -96,7 +101,7 @@ def test_decoder_loss_logits_grads_vs_golden(golden):
     assert abs(loss.item() - g["loss"].item()) <= 2e-3 * max(1.0, abs(g["loss"].item()))
     logits = out["logits"].float().cpu()
     assert logits.shape == g["logits"].shape
-    assert (logits - g["logits"]).abs().max() <= 3e-2 and (logits - g["logits"]).abs().mean() <= 5e-3
+    assert close_bf16(logits, g["logits"])
     loss.backward()
     named = dict(dec.decoder.named_parameters())
     for n, ref in g["grads"].items():
@@ -129,7 +134,7 @@ def test_rrg_adam_trajectory_vs_golden(golden):
         out = model(input_ids=ids, attention_mask=am, images=images)
         if step == 0:
             lg = out["logits"].float().cpu()
-            assert (lg - g["logits0"]).abs().max() <= 3e-2
+            assert close_bf16(lg, g["logits0"])
         ref = g["losses"][step].item()
         assert abs(out["loss"].item() - ref) <= 2e-3 * max(1.0, abs(ref)), (step, out["loss"].item(), ref)
         opt.zero_grad()

@@ -1,0 +1,90 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel host logic: chunked flat-gradient averaging equals the
+single-process gradient on the concatenated batch; all-gather-with-grad equals the single-process contrastive loss."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn, world=2):
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, fn, ret), nprocs=world, join=True)
+    return dict(ret)
+
+
+def _grad_avg(rank, world):
+    from vilmedic_amd.parallel import allreduce_mean_, broadcast_
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.GELU(), torch.nn.Linear(32, 4))
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    if rank == 1:
+        flat += 1.0           # replicas start different: broadcast must fix it
+    broadcast_(flat, dist)
+    off = 0
+    for p in model.parameters():
+        p.data.copy_(flat[off:off + p.numel()].view_as(p)); off += p.numel()
+    g = torch.Generator().manual_seed(5)
+    X, Y = torch.randn(8, 16, generator=g), torch.randn(8, 4, generator=g)
+    xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
+    torch.nn.functional.mse_loss(model(xs), ys).backward()
+    gflat = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    out = {}
+    for name, kw in {"fp32": {}, "bf16": dict(wire_dtype=torch.bfloat16, to_wire=lambda s, d: d.copy_(s), from_wire=lambda s, d: d.copy_(s))}.items():
+        gf = gflat.clone()
+        allreduce_mean_(gf, dist, chunks=3, **kw)
+        out[name] = gf
+    # single-process reference on the concatenated batch
+    ref = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.GELU(), torch.nn.Linear(32, 4))
+    ref.load_state_dict(model.state_dict())
+    torch.nn.functional.mse_loss(ref(X), Y).backward()
+    out["ref"] = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    return out
+
+
+def test_flat_gradient_allreduce_equals_single_process_gradient():
+    r = _run(_grad_avg)
+    for rank in (0, 1):
+        torch.testing.assert_close(r[rank]["fp32"], r[rank]["ref"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(r[rank]["bf16"], r[rank]["ref"], rtol=2e-2, atol=2e-3)
+    torch.testing.assert_close(r[0]["fp32"], r[1]["fp32"])
+
+
+def _contrastive(rank, world):
+    from oracle import torch_ref as O
+    from vilmedic_amd.parallel import all_gather_with_grad
+    g = torch.Generator().manual_seed(9)
+    T, V = torch.randn(8, 32, generator=g), torch.randn(8, 32, generator=g)
+    t = T[rank * 4:(rank + 1) * 4].clone().requires_grad_(True)
+    v = V[rank * 4:(rank + 1) * 4].clone().requires_grad_(True)
+    tg, vg = all_gather_with_grad(t, dist), all_gather_with_grad(v, dist)
+    # each rank evaluates the global loss; DDP-style averaging of identical losses keeps the scale
+    loss = O.convirt_loss(tg, vg, 0.1, 0.75)[0]
+    (loss / world).backward()
+    Tr, Vr = T.clone().requires_grad_(True), V.clone().requires_grad_(True)
+    lref = O.convirt_loss(Tr, Vr, 0.1, 0.75)[0]
+    lref.backward()
+    return dict(loss=loss.detach(), lref=lref.detach(), gt=t.grad, gv=v.grad,
+                rt=Tr.grad[rank * 4:(rank + 1) * 4], rv=Vr.grad[rank * 4:(rank + 1) * 4])
+
+
+def test_allgather_negatives_equals_single_process_contrastive_loss():
+    r = _run(_contrastive)
+    for rank in (0, 1):
+        torch.testing.assert_close(r[rank]["loss"], r[rank]["lref"])
+        torch.testing.assert_close(r[rank]["gt"], r[rank]["rt"], rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(r[rank]["gv"], r[rank]["rv"], rtol=1e-4, atol=1e-6)

@@ -292,12 +292,13 @@ def gen_mvqa_text():
     st = R.rand_state(R.bert_stack_shapes(cfg), seed)
     load_into(enc, st)
     g = torch.Generator().manual_seed(seed + 1)
-    pw, pb = 0.1 * torch.randn(64, 64, generator=g), 0.02 * torch.randn(64, generator=g)
-    cw, cb = 0.1 * torch.randn(C, 64, generator=g), 0.02 * torch.randn(C, generator=g)
+    H = cfg["hidden_size"]
+    pw, pb = 0.1 * torch.randn(H, H, generator=g), 0.02 * torch.randn(H, generator=g)
+    cw, cb = 0.1 * torch.randn(C, H, generator=g), 0.02 * torch.randn(C, generator=g)
     pool.dense.weight.data.copy_(pw), pool.dense.bias.data.copy_(pb)
     lin = [m for m in clf.modules() if isinstance(m, torch.nn.Linear)][0]
     lin.weight.data.copy_(cw), lin.bias.data.copy_(cb)
-    x = torch.randn(B, S, 64, generator=g)
+    x = torch.randn(B, S, H, generator=g)
     with torch.no_grad():
         h = enc(x).last_hidden_state          # MVQA.py:43
         pooled = pool(h)                      # MVQA.py:47

@@ -75,9 +75,10 @@ class BertGenerationDecoder(nn.Module):
 
     def forward(self, input_ids=None, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None,
                 labels=None, return_logits=True, **kw):
+        arena = arena_of(self)   # root the arena HERE (before the sub-module forward) so it covers lm_head.bias too
+        arena.refresh()
         out = self.bert(input_ids, attention_mask=attention_mask, encoder_hidden_states=encoder_hidden_states,
                         encoder_attention_mask=encoder_attention_mask)
-        arena = arena_of(self)
         h = out.last_hidden_state
         emb = self.bert.embeddings.word_embeddings.weight
         V = self.config.vocab_size

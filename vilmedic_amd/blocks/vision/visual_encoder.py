@@ -85,6 +85,7 @@ class VisualEncoder(nn.Module):
 
     # ------------------------------------------------------------------ forward (visual_encoder.py:180-208)
     def forward(self, images, **kwargs):
+        arena_of(self)   # root the arena here so it also covers visual_projection (sub-module forwards reuse it)
         if isinstance(self.model, ViTModel):
             out = self.model(images)
             return self._dropout_out(out)
