@@ -59,7 +59,9 @@ typedef struct {
     const float* alpha_dev;   /* optional DEVICE scalar multiplied into alpha (upstream dL/dloss)  */
     int out_dtype;            /* VM_BF16 or VM_F32                                               */
     int accumulate;           /* fp32 output only: atomically add into C (wgrad / split-K)       */
-    int split_k;              /* >=1; >1 requires out fp32 + accumulate                          */
+    int split_k;              /* >=1; >1 requires fp32 output and a plain epilogue (alpha only)  */
+    void* workspace;          /* split_k>1: fp32 scratch of >= split_k*M*ldc*4 bytes (partial slabs, */
+    size_t workspace_bytes;   /*   reduced deterministically by a second kernel; no atomics)        */
 } vm_gemm_epilogue;
 
 int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void* B, int64_t ldb, int b_layout,

@@ -45,6 +45,8 @@ static int test_gemm(int M, int N, int K, int la, int lb, int split, bool f32out
     hipMemset(dC, 0, (size_t)M * ldc * 4);
     vm_gemm_epilogue e = {};
     e.alpha = 1.f; e.out_dtype = f32out ? VM_F32 : VM_BF16; e.split_k = split; e.accumulate = split > 1;
+    void* ws = nullptr;
+    if (split > 1) { e.workspace_bytes = (size_t)split * M * ldc * 4; hipMalloc(&ws, e.workspace_bytes); e.workspace = ws; }
     int rc = vm_gemm_bf16(dA, lda, la, dB, ldb, lb, dC, ldc, M, N, K, &e, nullptr);
     if (rc) { printf("gemm rc=%d %s\n", rc, vm_last_error()); return 1; }
     hipDeviceSynchronize();
@@ -64,7 +66,7 @@ static int test_gemm(int M, int N, int K, int la, int lb, int split, bool f32out
     return bad != 0;
 }
 
-static void bench_gemm(int M, int N, int K, int la, int lb) {
+static void bench_gemm(int M, int N, int K, int la, int lb, int split = 1) {
     int64_t lda = la == 0 ? K : M, ldb = lb == 0 ? K : N;
     void *dA, *dB, *dC;
     size_t na = (size_t)M * K, nb = (size_t)N * K;
@@ -72,7 +74,9 @@ static void bench_gemm(int M, int N, int K, int la, int lb) {
     for (auto& x : h) x = f2bf(frand());
     hipMalloc(&dA, na * 2); hipMalloc(&dB, nb * 2); hipMalloc(&dC, (size_t)M * N * 2);
     hipMemcpy(dA, h.data(), na * 2, hipMemcpyHostToDevice); hipMemcpy(dB, h.data(), nb * 2, hipMemcpyHostToDevice);
-    vm_gemm_epilogue e = {}; e.alpha = 1.f; e.out_dtype = VM_BF16; e.split_k = 1;
+    vm_gemm_epilogue e = {}; e.alpha = 1.f; e.out_dtype = split > 1 ? VM_F32 : VM_BF16; e.split_k = split; e.accumulate = split > 1;
+    void* ws = nullptr;
+    if (split > 1) { hipFree(dC); hipMalloc(&dC, (size_t)M * N * 4); hipMemset(dC, 0, (size_t)M * N * 4); e.workspace_bytes = (size_t)split * M * N * 4; hipMalloc(&ws, e.workspace_bytes); e.workspace = ws; }
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int i = 0; i < 3; ++i) vm_gemm_bf16(dA, lda, la, dB, ldb, lb, dC, N, M, N, K, &e, nullptr);
     hipEventRecord(a, nullptr);
@@ -80,7 +84,7 @@ static void bench_gemm(int M, int N, int K, int la, int lb) {
     for (int i = 0; i < it; ++i) vm_gemm_bf16(dA, lda, la, dB, ldb, lb, dC, N, M, N, K, &e, nullptr);
     hipEventRecord(b, nullptr); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b); ms /= it;
-    printf("bench M=%d N=%d K=%d la=%d lb=%d: %.3f ms  %.1f TFLOP/s\n", M, N, K, la, lb, ms, 2.0 * M * N * K / ms * 1e-9);
+    printf("bench M=%d N=%d K=%d la=%d lb=%d split=%d: %.3f ms  %.1f TFLOP/s\n", M, N, K, la, lb, split, ms, 2.0 * M * N * K / ms * 1e-9);
     hipFree(dA); hipFree(dB); hipFree(dC);
 }
 
@@ -153,6 +157,15 @@ int main() {
     bench_gemm(3072, 768, 12608, 1, 1);
     bench_gemm(8192, 30528, 768, 0, 0);
     bench_gemm(8192, 8192, 8192, 0, 0);
+    bench_gemm(8192, 8192, 8192, 0, 1);
+    bench_gemm(8192, 8192, 8192, 1, 1);
+    bench_gemm(768, 768, 12608, 1, 1, 8);
+    bench_gemm(768, 768, 12608, 1, 1, 14);
+    bench_gemm(3072, 768, 12608, 1, 1, 4);
+    bench_gemm(2304, 768, 8192, 1, 1, 4);
+    bench_gemm(8192, 768, 768, 0, 0);
+    bench_gemm(8192, 768, 768, 0, 1);
+    bench_gemm(12608, 2304, 768, 0, 0);
     printf("fails=%d\n", fails);
     return fails;
 }

@@ -19,6 +19,7 @@ class GemmEpilogue(C.Structure):
         ("bias", C.c_void_p), ("act", C.c_int), ("aux_out", C.c_void_p), ("mul_gelu_z", C.c_void_p),
         ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64), ("residual", C.c_void_p), ("ldr", C.c_int64),
         ("alpha", C.c_float), ("alpha_dev", C.c_void_p), ("out_dtype", C.c_int), ("accumulate", C.c_int), ("split_k", C.c_int),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 
 

@@ -13,6 +13,8 @@
 // dropout, residual add, bf16/fp32 store, fp32 atomic accumulate for split-K) runs on whole 16-B
 // row segments with coalesced HBM traffic.
 #include "common.h"
+#include "gemm_args.h"
+#include <cstdlib>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
@@ -26,14 +28,6 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 #define C_STRIDE 132       // fp32 elements per row of the staged accumulator tile
 #define GEMM_LDS_BYTES (2 * STAGE_BYTES)   // 73728 >= 128*132*4 = 67584
 
-struct GemmArgs {
-    const bf16_t* A; const bf16_t* B; void* C;
-    int64_t lda, ldb, ldc;
-    int M, N, K;
-    int tiles_m, tiles_n, ktiles, ktiles_per_split;
-    vm_gemm_epilogue e;
-    uint32_t drop_thresh; float drop_scale;
-};
 
 // predicated 16-B load: out-of-range lanes re-read the (always valid) matrix base and zero the result,
 // which keeps a plain global_load instead of a pointer-select + flat_load
@@ -270,7 +264,8 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
     VM_REQUIRE(epi->out_dtype == VM_F32 ? (ldc % 4) == 0 : (ldc % 8) == 0, "vm_gemm_bf16: ldc alignment");
     if (a_layout == 0 || b_layout == 0) VM_REQUIRE((K % 8) == 0, "vm_gemm_bf16: K must be a multiple of 8 for K-contiguous operands (K=%d)", K);
     VM_REQUIRE(epi->split_k >= 1, "vm_gemm_bf16: split_k must be >= 1");
-    if (epi->split_k > 1) VM_REQUIRE(epi->out_dtype == VM_F32 && epi->accumulate, "vm_gemm_bf16: split_k needs fp32 accumulate output");
+    if (epi->split_k > 1) VM_REQUIRE(epi->out_dtype == VM_F32 && !epi->bias && !epi->act && !epi->aux_out && !epi->mul_gelu_z && !epi->residual && epi->dropout_p == 0.f,
+                                     "vm_gemm_bf16: split_k needs fp32 output and a plain (alpha-only) epilogue");
     if (epi->accumulate) VM_REQUIRE(epi->out_dtype == VM_F32, "vm_gemm_bf16: accumulate needs fp32 output");
     if (epi->residual) VM_REQUIRE((epi->ldr % 8) == 0, "vm_gemm_bf16: ldr alignment");
     VM_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0, "vm_gemm_bf16: pointers must be 16-byte aligned");
@@ -290,6 +285,20 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
     const int nblocks = a.tiles_m * a.tiles_n * split;
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_GEMM, 2.0 * (double)M * (double)N * (double)K, s);
+    const bool fast_ok = (K % 64) == 0 && (ldc % 4) == 0 && (!epi->bias || ((uintptr_t)epi->bias % 16) == 0) &&
+                         (!epi->residual || (epi->ldr % 4) == 0) && !getenv("VM_GEMM_GENERIC");
+    a.slabs = nullptr;
+    if (fast_ok) {
+        if (split > 1) {
+            const size_t need = (size_t)split * (size_t)M * (size_t)ldc * sizeof(float);
+            VM_REQUIRE(epi->workspace && epi->workspace_bytes >= need, "vm_gemm_bf16: split_k=%d needs a %zu-byte workspace", split, need);
+            a.slabs = (float*)epi->workspace;
+        }
+        int rc = vm_gemm_fast_dispatch(a, a_layout, b_layout, nblocks, s);
+        if (rc == VM_OK && split > 1) rc = vm_gemm_splitk_reduce(a, split, s);
+        return rc;
+    }
+    if (split > 1) VM_REQUIRE(epi->accumulate, "vm_gemm_bf16: generic-path split_k accumulates atomically and needs accumulate=1");
     if (a_layout == 0 && b_layout == 0) return launch<0, 0>(a, nblocks, s);
     if (a_layout == 0 && b_layout == 1) return launch<0, 1>(a, nblocks, s);
     if (a_layout == 1 && b_layout == 0) return launch<1, 0>(a, nblocks, s);

@@ -1,0 +1,17 @@
+// gemm_args.h -- kernel argument block shared by the generic (gemm.hip) and tuned (gemm_fast.hip) GEMM kernels.
+#pragma once
+#include "common.h"
+
+struct GemmArgs {
+    const bf16_t* A; const bf16_t* B; void* C;
+    int64_t lda, ldb, ldc;
+    int M, N, K;
+    int tiles_m, tiles_n, ktiles, ktiles_per_split;
+    vm_gemm_epilogue e;
+    uint32_t drop_thresh; float drop_scale;
+    float* slabs;            // split-K partial slabs [split][M][ldc] fp32 (fast path), or null
+};
+
+// tuned path (gemm_fast.hip): requires K % 64 == 0
+int vm_gemm_splitk_reduce(const GemmArgs& a, int nsplit, hipStream_t s);
+int vm_gemm_fast_dispatch(const GemmArgs& a, int a_layout, int b_layout, int nblocks, hipStream_t s);

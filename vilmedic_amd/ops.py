@@ -52,6 +52,10 @@ def gemm(A, a_layout, B, b_layout, C_out, M, N, K, *, lda=None, ldb=None, ldc=No
     e.out_dtype = VM_F32 if C_out.dtype == torch.float32 else VM_BF16
     e.accumulate = 1 if accumulate else 0
     e.split_k = split_k
+    if split_k > 1:
+        ws = _workspace(split_k * M * (ldc if ldc is not None else C_out.stride(0)) * 4, C_out.device)
+        e.workspace = ptr(ws).value
+        e.workspace_bytes = ws.numel()
     lda = lda if lda is not None else A.stride(0)
     ldb = ldb if ldb is not None else B.stride(0)
     ldc = ldc if ldc is not None else C_out.stride(0)
@@ -60,10 +64,22 @@ def gemm(A, a_layout, B, b_layout, C_out, M, N, K, *, lda=None, ldb=None, ldc=No
     return C_out
 
 
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    """persistent split-K scratch (caller-provided per the C ABI); grows monotonically, one per device"""
+    ws = _ws_cache.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[device] = ws
+    return ws
+
+
 def _split_k_for(out_tiles, k_tiles):
-    """enough blocks to fill 256 CUs x 2; keep >= 4 k-tiles per split"""
-    want = max(1, 768 // max(1, out_tiles))
-    return max(1, min(want, k_tiles // 4 if k_tiles >= 8 else 1))
+    """~512 workgroups (256 CUs x 2 resident) while keeping >= 8 K-tiles per split"""
+    want = max(1, round(512 / max(1, out_tiles)))
+    return max(1, min(want, max(1, k_tiles // 8)))
 
 
 def wgrad(dY, X, dW, *, ld_dy=None, ld_x=None, alpha_dev=None):
