@@ -82,11 +82,14 @@ int vm_layernorm_bwd(const void* dy, const void* x, const float* gamma, const fl
  * hf:...bert_generation.py:60-85 (eager_attention_forward), :114-154 (self), :181-231 (cross).
  * q: bf16, row (b*Lq+i) at q + row*ldq + h*dh ; k,v likewise with Lk rows per batch; o: [B*Lq, H*dh] ld=ldo.
  * key_mask: uint8 [B,Lk] (1 = attend) or NULL; causal: key j visible to query i iff j<=i.
- * stats: fp32 [B,H,Lq,2] = (row max, row sum) of the scaled+masked scores (saved for backward). dh must be 64. */
+ * stats: fp32 [B,H,Lq,2] = (row max, row sum) of the scaled+masked scores (saved for backward). dh must be 64.
+ * kv_row_index (forward only, may be NULL): int32 [B, kv_index_ld]; key j of batch b is row kv_row_index[b][j] of the
+ * k / v matrices (absolute row, batch offset NOT added) -- the decode-time KV cache with beam indirection, so a beam
+ * reorder (hf:generation/utils.py:3478-3485 copies the cache) is a gather of a small index table instead. */
 int vm_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                      void* o, int64_t ldo, float* stats, const uint8_t* key_mask,
                      int B, int H, int Lq, int Lk, int dh, float scale, int causal,
-                     float dropout_p, uint64_t dropout_seed, void* stream);
+                     float dropout_p, uint64_t dropout_seed, const int32_t* kv_row_index, int64_t kv_index_ld, void* stream);
 int vm_attention_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                      const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* stats,
                      const uint8_t* key_mask,
@@ -115,10 +118,14 @@ int vm_vit_assemble_bwd(const void* d_out /* bf16 [B,(n+1),D] */, void* d_patche
  * Shifted causal-LM cross-entropy (hf:loss/loss_utils.py:49-72; labels = input_ids, pads included,
  * ref:vilmedic/blocks/huggingface/decoder/decoder_model.py:46).  logits bf16 [B*L, ldl]; label of row (b,t) is
  * ids[b,t+1]; rows with t==L-1 are ignored.  loss_sum: fp32[1] += sum of row losses (caller divides by B*(L-1)).
- * dlogits (bf16, same layout, may alias logits) = (softmax - onehot) * grad_scale, zero on ignored rows / pad cols. */
+ * dlogits (bf16, same layout, may alias logits) = (softmax - onehot) * grad_scale, zero on ignored rows / pad cols.
+ * row_weight (NULL = 1): fp32 [B*L]; row (b,t) contributes row_weight*CE and its gradient is scaled likewise (SCST:
+ * -(logp*mask/sum(mask))*(r_sample-r_greedy), ref:vilmedic/blocks/rl/SCST.py:14-45).  banned[0..n_banned) (<=4 columns, a HOST array)
+ * are treated as -inf logits (bad_words_ids=[[pad],[bos]], SCST.py:150-151).  row_logp (NULL or fp32 [B*L]) receives
+ * log p(label) of each row. */
 int vm_ce_shift_fwd_bwd(const void* logits, int64_t ldl, const int64_t* ids, int B, int L, int V,
-                        float* loss_sum, float* row_lse /* fp32 [B*L] or NULL */, void* dlogits, float grad_scale,
-                        void* stream);
+                        float* loss_sum, float* row_logp, void* dlogits, float grad_scale,
+                        const float* row_weight, const int32_t* banned, int n_banned, void* stream);
 /* Generic CE with label smoothing on fp32 logits [R,C] (MVQA head; ref:...LabelSmoothingCrossEntropyLoss.py:38-48) */
 int vm_ce_smooth_fwd_bwd(const float* logits, const int64_t* target, int R, int C, float smoothing,
                          float* loss_sum, float* dlogits, float grad_scale, void* stream);

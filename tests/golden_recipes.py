@@ -98,9 +98,9 @@ def bert_stack_shapes(cfg, prefix=""):
 
 
 # ----------------------------------------------------------------------------- tensors
-def rand_state(shapes, seed, std=0.05, emb_std=None):
+def rand_state(shapes, seed, std=0.05, emb_std=None, qk_std=None, pos_std=None):
     """LayerNorm weights ~ 1+0.1N, biases ~ 0.02N, everything else ~ std*N
-    (embedding tables ~ emb_std*N when given)."""
+    (embedding tables ~ emb_std*N, query/key projections ~ qk_std*N when given)."""
     g = torch.Generator().manual_seed(seed)
     out = {}
     for name in sorted(shapes):
@@ -111,8 +111,12 @@ def rand_state(shapes, seed, std=0.05, emb_std=None):
             x = 1.0 + 0.1 * x
         elif name.endswith(".bias"):
             x = 0.02 * x
+        elif pos_std is not None and "position_embeddings" in low:
+            x = pos_std * x
         elif emb_std is not None and "embeddings" in low:
             x = emb_std * x
+        elif qk_std is not None and (".query.weight" in low or ".key.weight" in low):
+            x = qk_std * x
         else:
             x = std * x
         out[name] = x

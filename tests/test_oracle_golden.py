@@ -134,7 +134,7 @@ def test_g7_greedy_and_beam_ids_bit_exact(golden):
     g = golden("g7_decode")
     cfg = g["cfg"]
     rc = g["recipe"]
-    st = R.rand_state(R.decoder_shapes(cfg), g["seed"], std=rc["std"], emb_std=rc["emb_std"])
+    st = R.rand_state(R.decoder_shapes(cfg), g["seed"], std=rc["std"], emb_std=rc["emb_std"], qk_std=rc.get("qk_std"), pos_std=rc.get("pos_std"))
     st["lm_head.bias"][cfg["eos_token_id"]] += rc["eos_bias"]
     assert abs(R.state_checksum(st) - g["checksum"]) < 1e-6 * g["checksum"]
     gen = torch.Generator().manual_seed(g["seed"] + 1)

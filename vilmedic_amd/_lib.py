@@ -38,7 +38,7 @@ SIGNATURES = {
     "vm_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "vm_layernorm_bwd_ws": (_SZ, [_I, _I]),
     "vm_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
-    "vm_attention_fwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _U64, _P]),
+    "vm_attention_fwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _U64, _P, _L, _P]),
     "vm_attention_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _P, _L, _P, _L,
                               _I, _I, _I, _I, _I, _F, _I, _F, _U64, _P, _P]),
     "vm_embedding_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -46,7 +46,7 @@ SIGNATURES = {
     "vm_im2col_patches": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "vm_vit_assemble": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "vm_vit_assemble_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
-    "vm_ce_shift_fwd_bwd": (_I, [_P, _L, _P, _I, _I, _I, _P, _P, _P, _F, _P]),
+    "vm_ce_shift_fwd_bwd": (_I, [_P, _L, _P, _I, _I, _I, _P, _P, _P, _F, _P, C.POINTER(C.c_int32), _I, _P]),
     "vm_ce_smooth_fwd_bwd": (_I, [_P, _P, _I, _I, _F, _P, _P, _F, _P]),
     "vm_cast_f32_to_bf16": (_I, [_P, _P, _L, _P]),
     "vm_cast_bf16_to_f32": (_I, [_P, _P, _L, _P]),

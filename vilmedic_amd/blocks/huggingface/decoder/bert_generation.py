@@ -69,6 +69,12 @@ class BertGenerationDecoder(nn.Module):
         self.lm_head.decoder.weight = self.bert.embeddings.word_embeddings.weight
         self.lm_head.decoder.bias = self.lm_head.bias
 
+    def generate(self, input_ids=None, **kwargs):
+        """greedy / sampling / beam search with a KV cache (vilmedic_amd.generation); same keyword surface as the HF call
+        the reference makes (ref: blocks/huggingface/decoder/evaluation.py:73-78, blocks/rl/SCST.py:115-126,142-157)."""
+        from ....generation import generate
+        return generate(self, input_ids=input_ids, **kwargs)
+
     @property
     def padded_vocab(self):
         return (self.config.vocab_size + 7) // 8 * 8

@@ -31,6 +31,8 @@ struct AttnArgs {
     float* stats;            // [B,H,Lq,2]
     float* delta;            // [B,H,Lq]
     const uint8_t* key_mask; // [B,Lk] or null
+    const int32_t* kv_index; // fwd only: [B, kv_index_ld] absolute K/V row of key j of batch b (KV-cache indirection), or null
+    int64_t kv_index_ld;
     int B, H, Lq, Lk;
     float scale; int causal;
     float dropout_p; uint64_t seed; uint32_t thresh; float drop_scale;
@@ -84,6 +86,16 @@ __device__ __forceinline__ Stage2 tile_load(const bf16_t* base, int64_t ld, int 
     r.b = ld16_or_zero(base + (int64_t)(row0 + row + 32) * ld + c * 8, base, row0 + row + 32 < nrows);
     return r;
 }
+// same, rows gathered through an index table (absolute row numbers): decode-time KV cache with beam indirection
+__device__ __forceinline__ Stage2 tile_load_indexed(const bf16_t* base0, int64_t ld, const int32_t* idx, int row0, int nrows, int tid) {
+    Stage2 r;
+    const int row = tid >> 3, c = tid & 7;
+    const bool ok0 = row0 + row < nrows, ok1 = row0 + row + 32 < nrows;
+    const int64_t r0 = ok0 ? idx[row0 + row] : 0, r1 = ok1 ? idx[row0 + row + 32] : 0;
+    r.a = ld16_or_zero(base0 + r0 * ld + c * 8, base0, ok0);
+    r.b = ld16_or_zero(base0 + r1 * ld + c * 8, base0, ok1);
+    return r;
+}
 __device__ __forceinline__ void tile_store(const Stage2& r, char* tile, int tid) {
     const int row = tid >> 3, c = tid & 7;
     *reinterpret_cast<uint4*>(tile + row * TSTRIDE + c * 16) = r.a;
@@ -122,8 +134,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     int ntiles = (p.Lk + TROWS - 1) / TROWS;
     if (p.causal) ntiles = min(ntiles, min((int)blockIdx.x * 64 + 63, p.Lq - 1) / TROWS + 1);
     Stage2 rk, rv;
-    rk = tile_load(kbase, p.ldk, 0, p.Lk, tid);
-    rv = tile_load(vbase, p.ldv, 0, p.Lk, tid);
+    const int32_t* kvi = p.kv_index ? p.kv_index + (int64_t)b * p.kv_index_ld : nullptr;
+    const bf16_t* k0p = p.k + h * DH;
+    const bf16_t* v0p = p.v + h * DH;
+    if (kvi) { rk = tile_load_indexed(k0p, p.ldk, kvi, 0, p.Lk, tid); rv = tile_load_indexed(v0p, p.ldv, kvi, 0, p.Lk, tid); }
+    else { rk = tile_load(kbase, p.ldk, 0, p.Lk, tid); rv = tile_load(vbase, p.ldv, 0, p.Lk, tid); }
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();                       // previous tile fully consumed
         tile_store(rk, sk, tid);
@@ -134,8 +149,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         }
         __syncthreads();
         if (kt + 1 < ntiles) {
-            rk = tile_load(kbase, p.ldk, (kt + 1) * TROWS, p.Lk, tid);
-            rv = tile_load(vbase, p.ldv, (kt + 1) * TROWS, p.Lk, tid);
+            if (kvi) { rk = tile_load_indexed(k0p, p.ldk, kvi, (kt + 1) * TROWS, p.Lk, tid); rv = tile_load_indexed(v0p, p.ldv, kvi, (kt + 1) * TROWS, p.Lk, tid); }
+            else { rk = tile_load(kbase, p.ldk, (kt + 1) * TROWS, p.Lk, tid); rv = tile_load(vbase, p.ldv, (kt + 1) * TROWS, p.Lk, tid); }
         }
         float4_t s[4];
 #pragma unroll
@@ -402,7 +417,7 @@ static int check_common(const char* fn, int B, int H, int Lq, int Lk, int dh, in
 extern "C" int vm_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                                 void* o, int64_t ldo, float* stats, const uint8_t* key_mask,
                                 int B, int H, int Lq, int Lk, int dh, float scale, int causal,
-                                float dropout_p, uint64_t dropout_seed, void* stream) {
+                                float dropout_p, uint64_t dropout_seed, const int32_t* kv_row_index, int64_t kv_index_ld, void* stream) {
     VM_REQUIRE(q && k && v && o && stats, "vm_attention_fwd: null pointer");
     int rc = check_common("vm_attention_fwd", B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo);
     if (rc) return rc;
@@ -410,6 +425,7 @@ extern "C" int vm_attention_fwd(const void* q, int64_t ldq, const void* k, int64
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.stats = stats; a.key_mask = key_mask;
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.causal = causal;
+    a.kv_index = kv_row_index; a.kv_index_ld = kv_index_ld;
     a.dropout_p = dropout_p; a.seed = dropout_seed; a.thresh = dropout_thresh24(dropout_p);
     a.drop_scale = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
     hipStream_t s = (hipStream_t)stream;

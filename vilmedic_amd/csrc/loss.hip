@@ -25,22 +25,26 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* sh) {
 // row = (b,t); label = ids[b,t+1]; rows t == L-1 carry no loss.  The row is kept in registers (<= NCH 16-B
 // chunks per thread) so logits are read from HBM once; dlogits may alias logits.
 #define CE_NCH 16   // 256 threads * 16 chunks * 8 = 32768 columns max
+struct CeBanned { int n; int col[4]; };
 __global__ __launch_bounds__(256) void ce_shift_kernel(const bf16_t* __restrict__ logits, int64_t ldl, const int64_t* __restrict__ ids,
-                                                       int L, int V, float* __restrict__ loss_sum, float* __restrict__ row_lse,
-                                                       bf16_t* __restrict__ dlogits, float grad_scale) {
+                                                       int L, int V, float* __restrict__ loss_sum, float* __restrict__ row_logp,
+                                                       bf16_t* __restrict__ dlogits, float grad_scale,
+                                                       const float* __restrict__ row_weight, CeBanned ban) {
     __shared__ float sh[4];
     const int row = blockIdx.x, t = row % L, b = row / L;
     const int nch = (int)(ldl >> 3);
     bf16_t* drow = dlogits ? dlogits + (int64_t)row * ldl : nullptr;
-    if (t == L - 1) {
+    const float w = row_weight ? row_weight[row] : 1.0f;
+    if (t == L - 1 || w == 0.0f) {      // no loss from this row (last position / masked-out token)
         if (drow) for (int ch = threadIdx.x; ch < nch; ch += 256) *reinterpret_cast<uint4*>(drow + ch * 8) = make_uint4(0, 0, 0, 0);
-        if (row_lse && threadIdx.x == 0) row_lse[row] = 0.f;
+        if (row_logp && threadIdx.x == 0) row_logp[row] = 0.f;
         return;
     }
     const bf16_t* lrow = logits + (int64_t)row * ldl;
     const int label = (int)ids[(int64_t)b * L + t + 1];
     uint4 raw[CE_NCH];
     float mx = -INFINITY;
+    auto live = [&](int c) { return c < V && !(ban.n > 0 && (c == ban.col[0] || (ban.n > 1 && c == ban.col[1]) || (ban.n > 2 && c == ban.col[2]) || (ban.n > 3 && c == ban.col[3]))); };
 #pragma unroll
     for (int i = 0; i < CE_NCH; ++i) {
         const int ch = threadIdx.x + 256 * i;
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(256) void ce_shift_kernel(const bf16_t* __restrict_
             float f[8];
             unpack8(raw[i], f);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) if (ch * 8 + j < V) mx = fmaxf(mx, f[j]);
+            for (int j = 0; j < 8; ++j) if (live(ch * 8 + j)) mx = fmaxf(mx, f[j]);
         }
     }
     mx = block_reduce_max(mx, sh);
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(256) void ce_shift_kernel(const bf16_t* __restrict_
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int c = ch * 8 + j;
-                if (c < V) { se += __expf(f[j] - mx); if (c == label) lab = f[j]; }
+                if (live(c)) { se += __expf(f[j] - mx); if (c == label) lab = f[j]; }
             }
         }
     }
@@ -72,11 +76,12 @@ __global__ __launch_bounds__(256) void ce_shift_kernel(const bf16_t* __restrict_
     lab = block_reduce_sum(lab, sh);
     const float lse = mx + __logf(se);
     if (threadIdx.x == 0) {
-        atomicAdd(loss_sum, lse - lab);
-        if (row_lse) row_lse[row] = lse;
+        atomicAdd(loss_sum, w * (lse - lab));
+        if (row_logp) row_logp[row] = lab - lse;
     }
     if (drow) {
-        const float inv = grad_scale / se;
+        const float gs = grad_scale * w;
+        const float inv = gs / se;
 #pragma unroll
         for (int i = 0; i < CE_NCH; ++i) {
             const int ch = threadIdx.x + 256 * i;
@@ -86,8 +91,8 @@ __global__ __launch_bounds__(256) void ce_shift_kernel(const bf16_t* __restrict_
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int c = ch * 8 + j;
-                    float g = c < V ? __expf(f[j] - mx) * inv : 0.f;
-                    if (c == label) g -= grad_scale;
+                    float g = live(c) ? __expf(f[j] - mx) * inv : 0.f;
+                    if (c == label) g -= gs;
                     f[j] = g;
                 }
                 *reinterpret_cast<uint4*>(drow + ch * 8) = pack8(f);
@@ -97,13 +102,18 @@ __global__ __launch_bounds__(256) void ce_shift_kernel(const bf16_t* __restrict_
 }
 
 extern "C" int vm_ce_shift_fwd_bwd(const void* logits, int64_t ldl, const int64_t* ids, int B, int L, int V,
-                                   float* loss_sum, float* row_lse, void* dlogits, float grad_scale, void* stream) {
+                                   float* loss_sum, float* row_logp, void* dlogits, float grad_scale,
+                                   const float* row_weight, const int32_t* banned, int n_banned, void* stream) {
     VM_REQUIRE(logits && ids && loss_sum, "vm_ce_shift_fwd_bwd: null pointer");
     VM_REQUIRE(B > 0 && L > 1 && V > 0 && ldl >= V && (ldl % 8) == 0, "vm_ce_shift_fwd_bwd: bad shape");
     VM_REQUIRE(ldl <= 256 * CE_NCH * 8, "vm_ce_shift_fwd_bwd: vocabulary %d too large (max %d)", V, 256 * CE_NCH * 8);
+    VM_REQUIRE(n_banned >= 0 && n_banned <= 4 && (n_banned == 0 || banned), "vm_ce_shift_fwd_bwd: at most 4 banned columns (HOST array)");
+    CeBanned ban = {n_banned, {0, 0, 0, 0}};
+    for (int i = 0; i < n_banned; ++i) ban.col[i] = banned[i];
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_LOSS, 4.0 * B * L * (double)ldl, s);
-    hipLaunchKernelGGL(ce_shift_kernel, dim3(B * L), dim3(256), 0, s, (const bf16_t*)logits, ldl, ids, L, V, loss_sum, row_lse, (bf16_t*)dlogits, grad_scale);
+    hipLaunchKernelGGL(ce_shift_kernel, dim3(B * L), dim3(256), 0, s, (const bf16_t*)logits, ldl, ids, L, V, loss_sum, row_logp, (bf16_t*)dlogits,
+                       grad_scale, row_weight, ban);
     return vm_check_launch("vm_ce_shift_fwd_bwd");
 }
 

@@ -1,0 +1,281 @@
+"""Decode step with KV cache + greedy / sampling / beam-search drivers on the HIP path.
+
+Replaces HF ``GenerationMixin.generate`` as driven by the reference
+(ref: vilmedic/blocks/huggingface/decoder/evaluation.py:73-78 -- greedy/beam for validation;
+ vilmedic/blocks/rl/SCST.py:115-126,142-157 -- greedy and multinomial rollouts).
+Token-selection semantics restate hf:generation/utils.py ``_sample`` (:2783-2975) and ``_beam_search`` (:3208-3520,
+helpers :3008-3207): fp32 log-softmax, top-``2*beams`` over ``beams*V``, beam = idx // V, token = idx % V, the
+early-stop heuristic of ``early_stopping=False``, pad-filling of finished rows.
+
+MI355X-first differences (same results, different data flow):
+  * cross-attention K|V of the image features are projected ONCE per layer and shared by all beams of a sample
+    (HF repeats the encoder states per beam): the beams of a sample are simply extra query rows of one attention call;
+  * a beam reorder never copies the self-attention KV cache (HF: hf:generation/utils.py:3478-3485): the attention
+    kernel gathers keys through a small int32 row-index table, and reordering gathers that table;
+  * K|V of the new token are written straight into the cache by the projection GEMM (strided output).
+"""
+import ctypes as C
+
+import torch
+
+from . import ops
+from ._lib import check, lib, ptr, stream
+from .arena import arena_of
+from .nn import to_key_mask
+
+BF16 = torch.bfloat16
+
+
+def _ln(x, aff, eps):
+    rows, cols = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib().vm_layernorm_fwd(ptr(x), ptr(aff.weight), ptr(aff.bias), ptr(y), ptr(mean), ptr(rstd), rows, cols, eps, stream()),
+          "vm_layernorm_fwd")
+    return y
+
+
+def _attn(q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, key_mask=None, kv_index=None, kv_index_ld=0):
+    dh = 64
+    o = torch.empty(B * Lq, H * dh, dtype=BF16, device=q.device)
+    stats = torch.empty(B * H * Lq * 2, dtype=torch.float32, device=q.device)
+    check(lib().vm_attention_fwd(ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(o), H * dh, ptr(stats),
+                                 ptr(key_mask) if key_mask is not None else None, B, H, Lq, Lk, dh, dh ** -0.5, 0, 0.0, 0,
+                                 ptr(kv_index) if kv_index is not None else None, kv_index_ld, stream()), "vm_attention_fwd")
+    return o
+
+
+class DecodeState:
+    """Per-generate() state: cross K|V per layer, self K|V cache [rows*T, 2D] per layer, row-index table [rows, T]."""
+
+    def __init__(self, decoder, enc, enc_mask, beams, max_length):
+        self.dec = decoder
+        cfg = decoder.config
+        self.cfg = cfg
+        self.arena = arena_of(decoder)
+        self.arena.refresh()
+        self.B = enc.shape[0]
+        self.nb = beams
+        self.M = self.B * beams
+        self.T = max_length
+        self.D = cfg.hidden_size
+        self.H = cfg.num_attention_heads
+        dev = enc.device
+        enc = enc.to(BF16).contiguous()
+        self.S = enc.shape[1]
+        self.enc_mask = to_key_mask(enc_mask)
+        a = self.arena
+        self.layers = decoder.bert.encoder.layer
+        self.cross_kv = []
+        enc2 = enc.view(self.B * self.S, enc.shape[2])
+        for layer in self.layers:
+            ca = layer.crossattention.self
+            kv = torch.empty(self.B * self.S, 2 * self.D, dtype=BF16, device=dev)
+            ops.gemm(enc2, 0, a.shadow_group([ca.key.weight, ca.value.weight]), 0, kv, self.B * self.S, 2 * self.D, enc2.shape[1],
+                     bias=a.f32_group([ca.key.bias, ca.value.bias]))
+            self.cross_kv.append(kv)
+        self.self_kv = [torch.empty(self.M * self.T, 2 * self.D, dtype=BF16, device=dev) for _ in self.layers]
+        self.index = (torch.arange(self.M, device=dev, dtype=torch.int32)[:, None] * self.T
+                      + torch.arange(self.T, device=dev, dtype=torch.int32)[None, :]).contiguous()
+        self.V = cfg.vocab_size
+        self.emb_sh = a.shadow_rows(decoder.bert.embeddings.word_embeddings.weight, decoder.padded_vocab)
+
+    def reorder(self, parent_rows, upto):
+        """beam j continues old beam parent_rows[j]: its history 0..upto-1 is the parent's (index-table gather, no cache copy)"""
+        self.index[:, :upto] = self.index[parent_rows.long(), :upto]
+
+    @torch.no_grad()
+    def step(self, tokens, t):
+        """tokens int64 [M] at position t  ->  fp32 logits [M, V] for position t+1."""
+        a, cfg, D, H, M, T = self.arena, self.cfg, self.D, self.H, self.M, self.T
+        emb = self.dec.bert.embeddings
+        x = torch.empty(M, D, dtype=BF16, device=tokens.device)
+        check(lib().vm_embedding_fwd(ptr(tokens.contiguous()), ptr(emb.word_embeddings.weight), ptr(emb.position_embeddings.weight),
+                                     ptr(x), M, 1, D, t, stream()), "vm_embedding_fwd")
+        x = _ln(x, emb.LayerNorm, cfg.layer_norm_eps)
+        for li, layer in enumerate(self.layers):
+            sa = layer.attention.self
+            q = torch.empty(M, D, dtype=BF16, device=x.device)
+            ops.gemm(x, 0, a.shadow(sa.query.weight), 0, q, M, D, D, bias=sa.query.bias)
+            cache = self.self_kv[li]
+            ops.gemm(x, 0, a.shadow_group([sa.key.weight, sa.value.weight]), 0, cache[t:], M, 2 * D, D, ldc=T * 2 * D,
+                     bias=a.f32_group([sa.key.bias, sa.value.bias]))
+            ctx = _attn(q, D, cache, 2 * D, cache[:, D:], 2 * D, M, H, 1, t + 1, kv_index=self.index, kv_index_ld=T)
+            blk = layer.attention.output
+            s = torch.empty(M, D, dtype=BF16, device=x.device)
+            ops.gemm(ctx, 0, a.shadow(blk.dense.weight), 0, s, M, D, D, bias=blk.dense.bias, residual=x)
+            x = _ln(s, blk.LayerNorm, cfg.layer_norm_eps)
+            ca = layer.crossattention.self
+            ops.gemm(x, 0, a.shadow(ca.query.weight), 0, q, M, D, D, bias=ca.query.bias)
+            kv = self.cross_kv[li]
+            ctx = _attn(q, D, kv, 2 * D, kv[:, D:], 2 * D, self.B, H, self.nb, self.S, key_mask=self.enc_mask)
+            blk = layer.crossattention.output
+            ops.gemm(ctx, 0, a.shadow(blk.dense.weight), 0, s, M, D, D, bias=blk.dense.bias, residual=x)
+            x = _ln(s, blk.LayerNorm, cfg.layer_norm_eps)
+            i, o = layer.intermediate.dense, layer.output.dense
+            F = i.weight.shape[0]
+            h = torch.empty(M, F, dtype=BF16, device=x.device)
+            ops.gemm(x, 0, a.shadow(i.weight), 0, h, M, F, D, bias=i.bias, act=1)
+            ops.gemm(h, 0, a.shadow(o.weight), 0, s, M, D, F, bias=o.bias, residual=x)
+            x = _ln(s, layer.output.LayerNorm, cfg.layer_norm_eps)
+        return ops.lm_logits_f32(x, self.emb_sh, self.dec.lm_head.bias, self.V)
+
+
+def log_softmax_f32(logits):
+    rows, V = logits.shape
+    out = torch.empty(rows, V, dtype=torch.float32, device=logits.device)
+    check(lib().vm_logsoftmax_f32(ptr(logits), logits.stride(0), ptr(out), rows, V, stream()), "vm_logsoftmax_f32")
+    return out
+
+
+def argmax_f32(x):
+    rows, V = x.shape
+    idx = torch.empty(rows, dtype=torch.long, device=x.device)
+    check(lib().vm_argmax_f32(ptr(x), x.stride(0), ptr(idx), None, rows, V, stream()), "vm_argmax_f32")
+    return idx
+
+
+class GenerateOutput:
+    def __init__(self, sequences, sequences_scores=None, scores=None):
+        self.sequences, self.sequences_scores, self.scores = sequences, sequences_scores, scores
+
+
+def _process(logits, bad_ids, top_k):
+    """HF NoBadWordsLogitsProcessor (single-token bad words) then TopKLogitsWarper."""
+    if bad_ids:
+        logits[:, bad_ids] = -float("inf")
+    if top_k:
+        kth = torch.topk(logits, min(top_k, logits.shape[-1]))[0][:, -1:]
+        logits = logits.masked_fill(logits < kth, -float("inf"))
+    return logits
+
+
+@torch.no_grad()
+def sample(decoder, input_ids, enc, enc_mask, *, max_length, eos_token_id, pad_token_id, do_sample=False, top_k=None,
+           bad_words_ids=None, output_scores=False, generator=None):
+    """HF ``_sample``: greedy (argmax) or multinomial sampling, 1 sequence per batch row."""
+    B = input_ids.shape[0]
+    dev = enc.device
+    st = DecodeState(decoder, enc, enc_mask, 1, max_length)
+    seq = torch.full((B, max_length), pad_token_id, dtype=torch.long, device=dev)
+    seq[:, 0] = input_ids[:, 0]
+    unfinished = torch.ones(B, dtype=torch.bool, device=dev)
+    bad = [w[0] for w in (bad_words_ids or [])]
+    scores = []
+    cur = 1
+    while cur < max_length:
+        logits = st.step(seq[:, cur - 1], cur - 1)
+        if do_sample or bad or output_scores:
+            logits = _process(logits.clone(), bad, top_k)
+        if do_sample:
+            probs = torch.softmax(logits, dim=-1)
+            nxt = torch.multinomial(probs, 1, generator=generator).squeeze(1)
+        else:
+            nxt = argmax_f32(logits.contiguous())
+        if output_scores:
+            scores.append(logits)
+        nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad_token_id))
+        seq[:, cur] = nxt
+        unfinished = unfinished & (nxt != eos_token_id)
+        cur += 1
+        if cur % 8 == 0 and not bool(unfinished.any()):      # host sync only every 8 steps; trimmed exactly below
+            break
+    # exact HF stopping point: generation ends right after the step at which the last row finished
+    seq = seq[:, :cur]
+    is_eos = seq[:, 1:] == eos_token_id
+    if bool(is_eos.any(dim=1).all()):
+        last = int((is_eos.float().argmax(dim=1) + 1).max()) + 1
+        seq = seq[:, :last]
+        scores = scores[:last - 1]
+    return GenerateOutput(seq, None, tuple(scores) if output_scores else None)
+
+
+def _gather(t, idx):
+    while idx.dim() < t.dim():
+        idx = idx.unsqueeze(-1)
+    return torch.gather(t, 1, idx.expand(-1, -1, *t.shape[2:]))
+
+
+@torch.no_grad()
+def beam_search(decoder, input_ids, enc, enc_mask, *, max_length, eos_token_id, pad_token_id, num_beams, length_penalty=1.0):
+    """HF ``_beam_search`` (early_stopping=False, do_sample=False, num_return_sequences=1)."""
+    B, nb, keep, prompt = input_ids.shape[0], num_beams, 2 * num_beams, 1
+    dev = enc.device
+    V = decoder.config.vocab_size
+    st = DecodeState(decoder, enc, enc_mask, nb, max_length)
+    running = torch.full((B, nb, max_length), pad_token_id, dtype=torch.long, device=dev)
+    running[:, :, 0] = input_ids[:, :1]
+    seqs = running.clone()
+    running_len = torch.zeros(B, nb, dtype=torch.long, device=dev)
+    seq_len = torch.zeros(B, nb, dtype=torch.long, device=dev)
+    running_scores = torch.zeros(B, nb, device=dev)
+    running_scores[:, 1:] = -1e9
+    beam_scores = torch.full((B, nb), -1e9, device=dev)
+    finished = torch.zeros(B, nb, dtype=torch.bool, device=dev)
+    unsat = torch.ones(B, 1, dtype=torch.bool, device=dev)
+    top_mask = torch.cat([torch.ones(nb, dtype=torch.bool), torch.zeros(keep - nb, dtype=torch.bool)]).to(dev)
+    row_base = (torch.arange(B, device=dev) * nb)[:, None]
+    cur = prompt
+    while True:
+        logits = st.step(running[:, :, cur - 1].reshape(-1), cur - 1)
+        logp = log_softmax_f32(logits.contiguous()).view(B, nb, V)
+        logp = (logp + running_scores[:, :, None]).view(B, nb * V)
+        topk_lp, topk_idx = torch.topk(logp, keep)
+        src_beam = topk_idx // V
+        tok = topk_idx % V
+        cand = _gather(running, src_beam).clone()
+        cand[:, :, cur] = tok
+        cand_len = _gather(running_len, src_beam) + 1
+        hits = (tok == eos_token_id) | (cur + 1 >= max_length)
+        run_lp = topk_lp + hits.float() * -1e9
+        nxt = torch.topk(run_lp, nb)[1]
+        running, running_scores, running_len = _gather(cand, nxt), _gather(run_lp, nxt), _gather(cand_len, nxt)
+        st.reorder((row_base + _gather(src_beam, nxt)).reshape(-1), cur)
+        just = hits & top_mask[None, :]
+        fin_lp = topk_lp / ((cur + 1 - prompt) ** length_penalty)
+        fin_lp = fin_lp + (~unsat).float() * -1e9
+        fin_lp = fin_lp + (~just).float() * -1e9
+        m_seq, m_sc = torch.cat([seqs, cand], 1), torch.cat([beam_scores, fin_lp], 1)
+        m_len, m_fin = torch.cat([seq_len, cand_len], 1), torch.cat([finished, just], 1)
+        top = torch.topk(m_sc, nb)[1]
+        seqs, beam_scores, seq_len, finished = _gather(m_seq, top), _gather(m_sc, top), _gather(m_len, top), _gather(m_fin, top)
+        cur += 1
+        best_possible = running_scores[:, :1] / ((cur - prompt) ** length_penalty)
+        worst_fin = torch.where(finished, beam_scores.min(1, keepdim=True)[0], torch.full_like(beam_scores, -1e9))
+        unsat = unsat & (best_possible > worst_fin).any(-1, keepdim=True)
+        if not (bool(unsat.any()) and not bool(hits.all())):
+            break
+    out_len = prompt + int(seq_len[:, 0].max())
+    return GenerateOutput(seqs[:, 0, :out_len], beam_scores[:, 0])
+
+
+def generate(decoder, input_ids=None, encoder_hidden_states=None, encoder_attention_mask=None, generation_config=None, **kw):
+    """Front door with the keyword surface the reference uses (GenerationConfig kwargs or an object with those attributes)."""
+    args = {}
+    if generation_config is not None:
+        src = generation_config if isinstance(generation_config, dict) else vars(generation_config)
+        args.update({k: v for k, v in src.items() if not k.startswith("_")})
+    args.update(kw)
+    cfg = decoder.config
+    max_length = args.get("max_length") or 20
+    eos = args.get("eos_token_id", cfg.eos_token_id)
+    pad = args.get("pad_token_id", cfg.pad_token_id)
+    nb = args.get("num_beams") or 1
+    ret_dict = args.get("return_dict_in_generate", False)
+    if input_ids is None:
+        bos = args.get("bos_token_id", cfg.bos_token_id)
+        input_ids = torch.full((encoder_hidden_states.shape[0], 1), bos, dtype=torch.long, device=encoder_hidden_states.device)
+    if input_ids.shape[1] != 1:
+        raise NotImplementedError("generate() starts from a single [bos] token (ref: evaluation.py:74)")
+    if nb > 1:
+        if args.get("do_sample"):
+            raise NotImplementedError("beam sampling is outside the reference's call sites")
+        out = beam_search(decoder, input_ids, encoder_hidden_states, encoder_attention_mask, max_length=max_length,
+                          eos_token_id=eos, pad_token_id=pad, num_beams=nb, length_penalty=args.get("length_penalty", 1.0) or 1.0)
+    else:
+        out = sample(decoder, input_ids, encoder_hidden_states, encoder_attention_mask, max_length=max_length, eos_token_id=eos,
+                     pad_token_id=pad, do_sample=bool(args.get("do_sample")), top_k=args.get("top_k"),
+                     bad_words_ids=args.get("bad_words_ids"), output_scores=bool(args.get("output_scores")),
+                     generator=args.get("generator"))
+    return out if ret_dict else out.sequences

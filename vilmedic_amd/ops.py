@@ -284,7 +284,7 @@ class AttentionFn(torch.autograd.Function):
         scale = dh ** -0.5
         check(lib().vm_attention_fwd(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), o.stride(1), ptr(stats),
                                      ptr(key_mask) if key_mask is not None else None, B, H, Lq, Lk, dh, scale, int(causal),
-                                     dropout_p, seed, stream()), "vm_attention_fwd")
+                                     dropout_p, seed, None, 0, stream()), "vm_attention_fwd")
         ctx.save_for_backward(q, k, v, o, stats, key_mask)
         ctx.meta = (H, causal, dropout_p, seed, scale)
         return o
@@ -325,7 +325,7 @@ class PackedSelfAttentionFn(torch.autograd.Function):
         q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
         check(lib().vm_attention_fwd(ptr(q), D3, ptr(k), D3, ptr(v), D3, ptr(o), D, ptr(stats),
                                      ptr(key_mask) if key_mask is not None else None, B, H, L, L, dh, scale, int(causal),
-                                     dropout_p, seed, stream()), "vm_attention_fwd")
+                                     dropout_p, seed, None, 0, stream()), "vm_attention_fwd")
         ctx.save_for_backward(qkv, o, stats, key_mask)
         ctx.meta = (H, causal, dropout_p, seed, scale)
         return o
@@ -363,7 +363,7 @@ class PackedCrossAttentionFn(torch.autograd.Function):
         k, v = kv[..., :D], kv[..., D:]
         check(lib().vm_attention_fwd(ptr(q), D, ptr(k), 2 * D, ptr(v), 2 * D, ptr(o), D, ptr(stats),
                                      ptr(key_mask) if key_mask is not None else None, B, H, Lq, Lk, dh, scale, 0,
-                                     dropout_p, seed, stream()), "vm_attention_fwd")
+                                     dropout_p, seed, None, 0, stream()), "vm_attention_fwd")
         ctx.save_for_backward(q, kv, o, stats, key_mask)
         ctx.meta = (H, dropout_p, seed, scale)
         return o
@@ -476,7 +476,8 @@ class LmHeadLossFn(torch.autograd.Function):
         need_grad = h.requires_grad or g_emb is not None
         dlogits = (torch.empty_like(logits) if want_logits else logits) if need_grad else None
         check(lib().vm_ce_shift_fwd_bwd(ptr(logits), Vp, ptr(ids), B, L, V, ptr(loss_sum), None,
-                                        ptr(dlogits) if dlogits is not None else None, inv, stream()), "vm_ce_shift_fwd_bwd")
+                                        ptr(dlogits) if dlogits is not None else None, inv, None, None, 0, stream()),
+              "vm_ce_shift_fwd_bwd")
         ctx.save_for_backward(h2, emb_sh, dlogits)
         ctx.meta = (B, L, D, V, Vp, g_emb, g_bias)
         loss = (loss_sum * inv).squeeze(0)
