@@ -130,6 +130,18 @@ int vm_ce_shift_fwd_bwd(const void* logits, int64_t ldl, const int64_t* ids, int
 int vm_ce_smooth_fwd_bwd(const float* logits, const int64_t* target, int R, int C, float smoothing,
                          float* loss_sum, float* dlogits, float grad_scale, void* stream);
 
+/* Image-text contrastive similarity (ref:vilmedic/blocks/losses/selfsup/ConVIRTLoss.py:12-31, InfoNCELoss.py:11-19,
+ * GLoRIALoss.py:54-75).  S[R,C] = a_hat b_hat^T / tau is one vm_gemm_bf16 call (fp32 out, alpha = 1/tau); these are
+ * the pieces around it.  Row i pairs with column i + diag_offset (local rows of a rank vs all gathered columns). */
+int vm_rownorm_cast(const float* x /* [rows,D] */, void* out_bf16, float* norms /* [rows] or NULL */, int rows, int D,
+                    int normalize /* 1: x/max(|x|,eps) (ConVIRT cosine)  0: plain cast (InfoNCE) */, float eps, void* stream);
+int vm_lse_rows_f32(const float* S, int64_t ld, float* lse /* [rows] */, float* diag /* [rows] or NULL */, int rows, int cols,
+                    int diag_offset, void* stream);
+int vm_lse_cols_f32(const float* S, int64_t ld, float* lse /* [cols] */, int rows, int cols, void* stream);
+/* G[i,j] = g_rows[i] softmax_row(S)[i,j] + g_cols[j] softmax_col(S)[i,j] - [j == i+diag_offset] (g_rows[i] + g_cols[j])  (bf16) */
+int vm_contrastive_grad(const float* S, int64_t ld, const float* lse_rows, const float* lse_cols, const float* g_rows,
+                        const float* g_cols, void* G_bf16, int64_t ldg, int rows, int cols, int diag_offset, void* stream);
+
 /* ------------------------------------------------------------------ element-wise / reductions */
 int vm_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 int vm_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);

@@ -118,17 +118,22 @@ def _attn_ref(q, k, v, H, key_mask, causal):
     return (p @ vh).transpose(1, 2).reshape(B, Lq, D)
 
 
-@pytest.mark.parametrize("B,H,Lq,Lk,causal,masked", [
+@pytest.mark.parametrize("case", [
     (2, 2, 17, 17, False, False),      # ViT-tiny shaped, ragged tile
+    (2, 8, 49, 49, False, False, 96),  # MVQA transformer: d=768, 8 heads -> head_dim 96 (config/MVQA/vqa.yml:39-42)
+    (2, 3, 70, 90, False, True, 32),
+    (1, 2, 130, 130, True, True, 128),
     (3, 12, 197, 197, False, False),   # ViT-B/16 sequence
     (2, 4, 128, 128, True, True),      # decoder self-attention: causal + padding
     (2, 4, 128, 197, False, True),     # cross-attention with a key-padding mask
     (1, 1, 1, 300, False, True),       # single query row (decode step), > 4 key tiles
     (2, 2, 70, 64, False, False),
 ])
-def test_attention_fwd_bwd(B, H, Lq, Lk, causal, masked):
+def test_attention_fwd_bwd(case):
     from vilmedic_amd import ops
-    D = H * 64
+    B, H, Lq, Lk, causal, masked = case[:6]
+    dh = case[6] if len(case) > 6 else 64
+    D = H * dh
     q = rnd(B, Lq, D, seed=10).to(dev()).requires_grad_(True)
     k = rnd(B, Lk, D, seed=11).to(dev()).requires_grad_(True)
     v = rnd(B, Lk, D, seed=12).to(dev()).requires_grad_(True)

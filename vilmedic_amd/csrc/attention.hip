@@ -18,10 +18,12 @@
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef short v4s __attribute__((ext_vector_type(4)));
 
-#define DH 64
 #define TROWS 64                 // rows per streamed tile
-#define TSTRIDE 144              // bytes per LDS tile row (64 bf16 + 16 B pad)
+#define TSTRIDE (DH * 2 + 16)    // bytes per LDS tile row (DH bf16 + 16 B pad); DH is a template parameter (32/64/96/128)
 #define TILE_BYTES (TROWS * TSTRIDE)
+#define NLD (DH / 32)            // 16-B chunks each thread stages per tile (64 rows x DH/8 chunks / 256 threads)
+#define NDF (DH / 16)            // 16-wide output fragments along the head dimension
+#define NKK (DH / 32)            // 32-deep MFMA k-steps along the head dimension
 #define MASKED_SCORE (-1e30f)
 
 struct AttnArgs {
@@ -44,12 +46,14 @@ __device__ __forceinline__ bf16x8_t ld_frag_global(const bf16_t* p, const bf16_t
     return __builtin_bit_cast(bf16x8_t, v);
 }
 // A operand from a row-major LDS tile, contraction = the tile's columns (dh): rows rbase+(lane&15)
+template <int DH>
 __device__ __forceinline__ bf16x8_t lds_frag_rows(const char* tile, int rbase, int kk, int lane) {
     return *reinterpret_cast<const bf16x8_t*>(tile + (rbase + (lane & 15)) * TSTRIDE + (kk * 32 + (lane >> 4) * 8) * 2);
 }
 // A operand = tile^T: output rows = tile columns cbase+(lane&15); contraction = tile rows.
 // k-slot (g,e) of step s maps to tile row 32 s + 4 g + e (e<4) / 32 s + 16 + 4 g + (e-4) (e>=4),
 // matching a B operand packed from two C/D fragments {frag 2s, frag 2s+1}.
+template <int DH>
 __device__ __forceinline__ bf16x8_t lds_frag_tr(const char* tile, int cbase, int s, int lane) {
     const int g = lane >> 4, i = lane & 15;
     const int row = 32 * s + 4 * g + (i >> 2);
@@ -70,8 +74,8 @@ __device__ __forceinline__ bf16x8_t pack_b_operand(const float4_t& a, const floa
 __device__ __forceinline__ float col_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ __forceinline__ float col_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
 
-// stream one 64 x 64 bf16 tile (rows row0.. of a [rows, ld] matrix at column offset already applied)
-struct Stage2 { uint4 a, b; };
+// stream one 64 x DH bf16 tile (rows row0.. of a [rows, ld] matrix at column offset already applied)
+template <int DH> struct Stage { uint4 r[NLD]; };
 // predicated 16-B load: out-of-range lanes re-read a valid address (``safe``) and zero the result, so the
 // compiler keeps a plain global_load (a select between the pointer and a stack zero becomes a flat load)
 __device__ __forceinline__ uint4 ld16_or_zero(const bf16_t* p, const bf16_t* safe, bool ok) {
@@ -79,33 +83,43 @@ __device__ __forceinline__ uint4 ld16_or_zero(const bf16_t* p, const bf16_t* saf
     if (!ok) v = make_uint4(0, 0, 0, 0);
     return v;
 }
-__device__ __forceinline__ Stage2 tile_load(const bf16_t* base, int64_t ld, int row0, int nrows, int tid) {
-    Stage2 r;
-    const int row = tid >> 3, c = tid & 7;
-    r.a = ld16_or_zero(base + (int64_t)(row0 + row) * ld + c * 8, base, row0 + row < nrows);
-    r.b = ld16_or_zero(base + (int64_t)(row0 + row + 32) * ld + c * 8, base, row0 + row + 32 < nrows);
-    return r;
+template <int DH>
+__device__ __forceinline__ Stage<DH> tile_load(const bf16_t* base, int64_t ld, int row0, int nrows, int tid) {
+    Stage<DH> st;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int id = tid + 256 * i, row = id / (DH / 8), c = id % (DH / 8);
+        st.r[i] = ld16_or_zero(base + (int64_t)(row0 + row) * ld + c * 8, base, row0 + row < nrows);
+    }
+    return st;
 }
 // same, rows gathered through an index table (absolute row numbers): decode-time KV cache with beam indirection
-__device__ __forceinline__ Stage2 tile_load_indexed(const bf16_t* base0, int64_t ld, const int32_t* idx, int row0, int nrows, int tid) {
-    Stage2 r;
-    const int row = tid >> 3, c = tid & 7;
-    const bool ok0 = row0 + row < nrows, ok1 = row0 + row + 32 < nrows;
-    const int64_t r0 = ok0 ? idx[row0 + row] : 0, r1 = ok1 ? idx[row0 + row + 32] : 0;
-    r.a = ld16_or_zero(base0 + r0 * ld + c * 8, base0, ok0);
-    r.b = ld16_or_zero(base0 + r1 * ld + c * 8, base0, ok1);
-    return r;
+template <int DH>
+__device__ __forceinline__ Stage<DH> tile_load_indexed(const bf16_t* base0, int64_t ld, const int32_t* idx, int row0, int nrows, int tid) {
+    Stage<DH> st;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int id = tid + 256 * i, row = id / (DH / 8), c = id % (DH / 8);
+        const bool ok = row0 + row < nrows;
+        const int64_t r = ok ? idx[row0 + row] : 0;
+        st.r[i] = ld16_or_zero(base0 + r * ld + c * 8, base0, ok);
+    }
+    return st;
 }
-__device__ __forceinline__ void tile_store(const Stage2& r, char* tile, int tid) {
-    const int row = tid >> 3, c = tid & 7;
-    *reinterpret_cast<uint4*>(tile + row * TSTRIDE + c * 16) = r.a;
-    *reinterpret_cast<uint4*>(tile + (row + 32) * TSTRIDE + c * 16) = r.b;
+template <int DH>
+__device__ __forceinline__ void tile_store(const Stage<DH>& st, char* tile, int tid) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int id = tid + 256 * i, row = id / (DH / 8), c = id % (DH / 8);
+        *reinterpret_cast<uint4*>(tile + row * TSTRIDE + c * 16) = st.r[i];
+    }
 }
 // store a transposed 64(dh) x 16(rows) accumulator as rows of a [*, ld] bf16 matrix: lane owns row (lane&15)
-__device__ __forceinline__ void store_t_acc(bf16_t* rowptr, const float4_t (&acc)[4], float mul, int lane) {
+template <int DH>
+__device__ __forceinline__ void store_t_acc(bf16_t* rowptr, const float4_t (&acc)[NDF], float mul, int lane) {
     const int g = lane >> 4;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
+    for (int f = 0; f < NDF; ++f) {
         uint2 u;
         u.x = pack_bf16x2(acc[f][0] * mul, acc[f][1] * mul);
         u.y = pack_bf16x2(acc[f][2] * mul, acc[f][3] * mul);
@@ -114,6 +128,7 @@ __device__ __forceinline__ void store_t_acc(bf16_t* rowptr, const float4_t (&acc
 }
 
 // =============================================================================== forward
+template <int DH>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES + 64];
     char* sk = smem; char* sv = smem + TILE_BYTES; uint8_t* smask = reinterpret_cast<uint8_t*>(smem + 2 * TILE_BYTES);
@@ -122,43 +137,43 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     const int qrow = q0 + c;
     const bool qok = qrow < p.Lq;
     const bf16_t* qp = p.q + (int64_t)(b * p.Lq + qrow) * p.ldq + h * DH;
-    bf16x8_t qf[2];
+    bf16x8_t qf[NKK];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) qf[kk] = ld_frag_global(qp + kk * 32 + g * 8, p.q, qok);
+    for (int kk = 0; kk < NKK; ++kk) qf[kk] = ld_frag_global(qp + kk * 32 + g * 8, p.q, qok);
     const bf16_t* kbase = p.k + (int64_t)b * p.Lk * p.ldk + h * DH;
     const bf16_t* vbase = p.v + (int64_t)b * p.Lk * p.ldv + h * DH;
-    float4_t o[4];
+    float4_t o[NDF];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) o[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < NDF; ++f) o[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;
     int ntiles = (p.Lk + TROWS - 1) / TROWS;
     if (p.causal) ntiles = min(ntiles, min((int)blockIdx.x * 64 + 63, p.Lq - 1) / TROWS + 1);
-    Stage2 rk, rv;
+    Stage<DH> rk, rv;
     const int32_t* kvi = p.kv_index ? p.kv_index + (int64_t)b * p.kv_index_ld : nullptr;
     const bf16_t* k0p = p.k + h * DH;
     const bf16_t* v0p = p.v + h * DH;
-    if (kvi) { rk = tile_load_indexed(k0p, p.ldk, kvi, 0, p.Lk, tid); rv = tile_load_indexed(v0p, p.ldv, kvi, 0, p.Lk, tid); }
-    else { rk = tile_load(kbase, p.ldk, 0, p.Lk, tid); rv = tile_load(vbase, p.ldv, 0, p.Lk, tid); }
+    if (kvi) { rk = tile_load_indexed<DH>(k0p, p.ldk, kvi, 0, p.Lk, tid); rv = tile_load_indexed<DH>(v0p, p.ldv, kvi, 0, p.Lk, tid); }
+    else { rk = tile_load<DH>(kbase, p.ldk, 0, p.Lk, tid); rv = tile_load<DH>(vbase, p.ldv, 0, p.Lk, tid); }
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();                       // previous tile fully consumed
-        tile_store(rk, sk, tid);
-        tile_store(rv, sv, tid);
+        tile_store<DH>(rk, sk, tid);
+        tile_store<DH>(rv, sv, tid);
         if (tid < 64) {
             const int key = kt * TROWS + tid;
             smask[tid] = (p.key_mask && key < p.Lk) ? p.key_mask[(int64_t)b * p.Lk + key] : (uint8_t)1;
         }
         __syncthreads();
         if (kt + 1 < ntiles) {
-            if (kvi) { rk = tile_load_indexed(k0p, p.ldk, kvi, (kt + 1) * TROWS, p.Lk, tid); rv = tile_load_indexed(v0p, p.ldv, kvi, (kt + 1) * TROWS, p.Lk, tid); }
-            else { rk = tile_load(kbase, p.ldk, (kt + 1) * TROWS, p.Lk, tid); rv = tile_load(vbase, p.ldv, (kt + 1) * TROWS, p.Lk, tid); }
+            if (kvi) { rk = tile_load_indexed<DH>(k0p, p.ldk, kvi, (kt + 1) * TROWS, p.Lk, tid); rv = tile_load_indexed<DH>(v0p, p.ldv, kvi, (kt + 1) * TROWS, p.Lk, tid); }
+            else { rk = tile_load<DH>(kbase, p.ldk, (kt + 1) * TROWS, p.Lk, tid); rv = tile_load<DH>(vbase, p.ldv, (kt + 1) * TROWS, p.Lk, tid); }
         }
         float4_t s[4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             s[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-                s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_rows(sk, 16 * f, kk, lane), qf[kk], s[f], 0, 0, 0);
+            for (int kk = 0; kk < NKK; ++kk)
+                s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_rows<DH>(sk, 16 * f, kk, lane), qf[kk], s[f], 0, 0, 0);
         }
         float mt = -INFINITY;
 #pragma unroll
@@ -186,7 +201,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         l = l * alpha + col_sum(ls);
         m = m_new;
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+        for (int f = 0; f < NDF; ++f)
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[f][r] *= alpha;
         if (p.dropout_p > 0.f) {
@@ -201,13 +216,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         }
         bf16x8_t pb[2] = {pack_b_operand(s[0], s[1]), pack_b_operand(s[2], s[3])};
 #pragma unroll
-        for (int df = 0; df < 4; ++df)
+        for (int df = 0; df < NDF; ++df)
 #pragma unroll
             for (int st = 0; st < 2; ++st)
-                o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr(sv, 16 * df, st, lane), pb[st], o[df], 0, 0, 0);
+                o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr<DH>(sv, 16 * df, st, lane), pb[st], o[df], 0, 0, 0);
     }
     if (qok) {
-        store_t_acc(p.out + (int64_t)(b * p.Lq + qrow) * p.ldo + h * DH, o, 1.0f / l, lane);
+        store_t_acc<DH>(p.out + (int64_t)(b * p.Lq + qrow) * p.ldo + h * DH, o, 1.0f / l, lane);
         if (g == 0) {
             float* st = p.stats + ((int64_t)(b * p.H + h) * p.Lq + qrow) * 2;
             st[0] = m; st[1] = l;
@@ -216,18 +231,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 }
 
 // =============================================================================== delta = rowsum(dO * O)
-__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs p) {
-    // one 16-lane group per (b,h,row): 64 dh = 16 lanes x 4 elements
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs p, int DH) {
+    // one 16-lane group per (b,h,row)
     const int64_t gid = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int64_t total = (int64_t)p.B * p.H * p.Lq;
     const int sub = threadIdx.x & 15;
     float acc = 0.f;
     if (gid < total) {
         const int row = (int)(gid % p.Lq); const int bh = (int)(gid / p.Lq); const int h = bh % p.H, b = bh / p.H;
-        const uint2 a = *reinterpret_cast<const uint2*>(p.o + (int64_t)(b * p.Lq + row) * p.ldo + h * DH + sub * 4);
-        const uint2 d = *reinterpret_cast<const uint2*>(p.d_o + (int64_t)(b * p.Lq + row) * p.lddo + h * DH + sub * 4);
-        acc = __uint_as_float(a.x << 16) * __uint_as_float(d.x << 16) + __uint_as_float(a.x & 0xffff0000u) * __uint_as_float(d.x & 0xffff0000u)
-            + __uint_as_float(a.y << 16) * __uint_as_float(d.y << 16) + __uint_as_float(a.y & 0xffff0000u) * __uint_as_float(d.y & 0xffff0000u);
+        const bf16_t* op = p.o + (int64_t)(b * p.Lq + row) * p.ldo + h * DH;
+        const bf16_t* dp = p.d_o + (int64_t)(b * p.Lq + row) * p.lddo + h * DH;
+        for (int e = sub * 4; e < DH; e += 64) {
+            const uint2 a = *reinterpret_cast<const uint2*>(op + e);
+            const uint2 d = *reinterpret_cast<const uint2*>(dp + e);
+            acc += __uint_as_float(a.x << 16) * __uint_as_float(d.x << 16) + __uint_as_float(a.x & 0xffff0000u) * __uint_as_float(d.x & 0xffff0000u)
+                 + __uint_as_float(a.y << 16) * __uint_as_float(d.y << 16) + __uint_as_float(a.y & 0xffff0000u) * __uint_as_float(d.y & 0xffff0000u);
+        }
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
@@ -235,6 +254,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs p) {
 }
 
 // =============================================================================== dQ  (owner: 16 queries per wave)
+template <int DH>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES + 64];
     char* sk = smem; char* sv = smem + TILE_BYTES; uint8_t* smask = reinterpret_cast<uint8_t*>(smem + 2 * TILE_BYTES);
@@ -244,9 +264,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
     const bool qok = qrow < p.Lq;
     const bf16_t* qp = p.q + (int64_t)(b * p.Lq + qrow) * p.ldq + h * DH;
     const bf16_t* dop = p.d_o + (int64_t)(b * p.Lq + qrow) * p.lddo + h * DH;
-    bf16x8_t qf[2], dof[2];
+    bf16x8_t qf[NKK], dof[NKK];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) { qf[kk] = ld_frag_global(qp + kk * 32 + g * 8, p.q, qok); dof[kk] = ld_frag_global(dop + kk * 32 + g * 8, p.d_o, qok); }
+    for (int kk = 0; kk < NKK; ++kk) { qf[kk] = ld_frag_global(qp + kk * 32 + g * 8, p.q, qok); dof[kk] = ld_frag_global(dop + kk * 32 + g * 8, p.d_o, qok); }
     float m = 0.f, inv_l = 0.f, delta = 0.f;
     if (qok) {
         const int64_t si = (int64_t)(b * p.H + h) * p.Lq + qrow;
@@ -254,26 +274,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
     }
     const bf16_t* kbase = p.k + (int64_t)b * p.Lk * p.ldk + h * DH;
     const bf16_t* vbase = p.v + (int64_t)b * p.Lk * p.ldv + h * DH;
-    float4_t dq[4];
+    float4_t dq[NDF];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) dq[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < NDF; ++f) dq[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
     int ntiles = (p.Lk + TROWS - 1) / TROWS;
     if (p.causal) ntiles = min(ntiles, min((int)blockIdx.x * 64 + 63, p.Lq - 1) / TROWS + 1);
-    Stage2 rk, rv;
-    rk = tile_load(kbase, p.ldk, 0, p.Lk, tid);
-    rv = tile_load(vbase, p.ldv, 0, p.Lk, tid);
+    Stage<DH> rk, rv;
+    rk = tile_load<DH>(kbase, p.ldk, 0, p.Lk, tid);
+    rv = tile_load<DH>(vbase, p.ldv, 0, p.Lk, tid);
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();
-        tile_store(rk, sk, tid);
-        tile_store(rv, sv, tid);
+        tile_store<DH>(rk, sk, tid);
+        tile_store<DH>(rv, sv, tid);
         if (tid < 64) {
             const int key = kt * TROWS + tid;
             smask[tid] = (p.key_mask && key < p.Lk) ? p.key_mask[(int64_t)b * p.Lk + key] : (uint8_t)1;
         }
         __syncthreads();
         if (kt + 1 < ntiles) {
-            rk = tile_load(kbase, p.ldk, (kt + 1) * TROWS, p.Lk, tid);
-            rv = tile_load(vbase, p.ldv, (kt + 1) * TROWS, p.Lk, tid);
+            rk = tile_load<DH>(kbase, p.ldk, (kt + 1) * TROWS, p.Lk, tid);
+            rv = tile_load<DH>(vbase, p.ldv, (kt + 1) * TROWS, p.Lk, tid);
         }
         float4_t s[4], dp[4];
 #pragma unroll
@@ -281,9 +301,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
             s[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
             dp[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_rows(sk, 16 * f, kk, lane), qf[kk], s[f], 0, 0, 0);
-                dp[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_rows(sv, 16 * f, kk, lane), dof[kk], dp[f], 0, 0, 0);
+            for (int kk = 0; kk < NKK; ++kk) {
+                s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_rows<DH>(sk, 16 * f, kk, lane), qf[kk], s[f], 0, 0, 0);
+                dp[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_rows<DH>(sv, 16 * f, kk, lane), dof[kk], dp[f], 0, 0, 0);
             }
         }
         const uint64_t dbase = ((uint64_t)(b * p.H + h) * p.Lq + qrow) * (uint64_t)p.Lk;
@@ -304,15 +324,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
         }
         bf16x8_t db[2] = {pack_b_operand(s[0], s[1]), pack_b_operand(s[2], s[3])};
 #pragma unroll
-        for (int df = 0; df < 4; ++df)
+        for (int df = 0; df < NDF; ++df)
 #pragma unroll
             for (int st = 0; st < 2; ++st)
-                dq[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr(sk, 16 * df, st, lane), db[st], dq[df], 0, 0, 0);
+                dq[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr<DH>(sk, 16 * df, st, lane), db[st], dq[df], 0, 0, 0);
     }
-    if (qok) store_t_acc(p.dq + (int64_t)(b * p.Lq + qrow) * p.lddq + h * DH, dq, p.scale, lane);
+    if (qok) store_t_acc<DH>(p.dq + (int64_t)(b * p.Lq + qrow) * p.lddq + h * DH, dq, p.scale, lane);
 }
 
 // =============================================================================== dK, dV  (owner: 16 keys per wave)
+template <int DH>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES + 3 * 64 * 4];
     char* sq = smem; char* sdo = smem + TILE_BYTES;
@@ -323,26 +344,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     const bool kok = key < p.Lk;
     const bf16_t* kp = p.k + (int64_t)(b * p.Lk + key) * p.ldk + h * DH;
     const bf16_t* vp = p.v + (int64_t)(b * p.Lk + key) * p.ldv + h * DH;
-    bf16x8_t kf[2], vf[2];
+    bf16x8_t kf[NKK], vf[NKK];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) { kf[kk] = ld_frag_global(kp + kk * 32 + g * 8, p.k, kok); vf[kk] = ld_frag_global(vp + kk * 32 + g * 8, p.v, kok); }
+    for (int kk = 0; kk < NKK; ++kk) { kf[kk] = ld_frag_global(kp + kk * 32 + g * 8, p.k, kok); vf[kk] = ld_frag_global(vp + kk * 32 + g * 8, p.v, kok); }
     const bool key_keep = kok && (!p.key_mask || p.key_mask[(int64_t)b * p.Lk + key] != 0);
     const bf16_t* qbase = p.q + (int64_t)b * p.Lq * p.ldq + h * DH;
     const bf16_t* dobase = p.d_o + (int64_t)b * p.Lq * p.lddo + h * DH;
-    float4_t dk[4], dv[4];
+    float4_t dk[NDF], dv[NDF];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) { dk[f] = (float4_t){0.f, 0.f, 0.f, 0.f}; dv[f] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
+    for (int f = 0; f < NDF; ++f) { dk[f] = (float4_t){0.f, 0.f, 0.f, 0.f}; dv[f] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
     const int ntiles = (p.Lq + TROWS - 1) / TROWS;
     const int t_begin = p.causal ? (int)blockIdx.x : 0;   // queries < first key of the block see none of its keys
-    Stage2 rq, rdo;
+    Stage<DH> rq, rdo;
     if (t_begin < ntiles) {
-        rq = tile_load(qbase, p.ldq, t_begin * TROWS, p.Lq, tid);
-        rdo = tile_load(dobase, p.lddo, t_begin * TROWS, p.Lq, tid);
+        rq = tile_load<DH>(qbase, p.ldq, t_begin * TROWS, p.Lq, tid);
+        rdo = tile_load<DH>(dobase, p.lddo, t_begin * TROWS, p.Lq, tid);
     }
     for (int qt = t_begin; qt < ntiles; ++qt) {
         __syncthreads();
-        tile_store(rq, sq, tid);
-        tile_store(rdo, sdo, tid);
+        tile_store<DH>(rq, sq, tid);
+        tile_store<DH>(rdo, sdo, tid);
         if (tid < 64) {
             const int qr = qt * TROWS + tid;
             float mm = 0.f, il = 0.f, dl = 0.f;
@@ -354,8 +375,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         }
         __syncthreads();
         if (qt + 1 < ntiles) {
-            rq = tile_load(qbase, p.ldq, (qt + 1) * TROWS, p.Lq, tid);
-            rdo = tile_load(dobase, p.lddo, (qt + 1) * TROWS, p.Lq, tid);
+            rq = tile_load<DH>(qbase, p.ldq, (qt + 1) * TROWS, p.Lq, tid);
+            rdo = tile_load<DH>(dobase, p.lddo, (qt + 1) * TROWS, p.Lq, tid);
         }
         float4_t s[4], dp[4];
 #pragma unroll
@@ -363,9 +384,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
             s[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
             dp[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_rows(sq, 16 * f, kk, lane), kf[kk], s[f], 0, 0, 0);
-                dp[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_rows(sdo, 16 * f, kk, lane), vf[kk], dp[f], 0, 0, 0);
+            for (int kk = 0; kk < NKK; ++kk) {
+                s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_rows<DH>(sq, 16 * f, kk, lane), kf[kk], s[f], 0, 0, 0);
+                dp[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_rows<DH>(sdo, 16 * f, kk, lane), vf[kk], dp[f], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -394,21 +415,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         bf16x8_t pb[2] = {pack_b_operand(dp[0], dp[1]), pack_b_operand(dp[2], dp[3])};
         bf16x8_t sb[2] = {pack_b_operand(s[0], s[1]), pack_b_operand(s[2], s[3])};
 #pragma unroll
-        for (int df = 0; df < 4; ++df)
+        for (int df = 0; df < NDF; ++df)
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                dv[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr(sdo, 16 * df, st, lane), pb[st], dv[df], 0, 0, 0);
-                dk[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr(sq, 16 * df, st, lane), sb[st], dk[df], 0, 0, 0);
+                dv[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr<DH>(sdo, 16 * df, st, lane), pb[st], dv[df], 0, 0, 0);
+                dk[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr<DH>(sq, 16 * df, st, lane), sb[st], dk[df], 0, 0, 0);
             }
     }
     if (kok) {
-        store_t_acc(p.dk + (int64_t)(b * p.Lk + key) * p.lddk + h * DH, dk, p.scale, lane);
-        store_t_acc(p.dv + (int64_t)(b * p.Lk + key) * p.lddv + h * DH, dv, 1.0f, lane);
+        store_t_acc<DH>(p.dk + (int64_t)(b * p.Lk + key) * p.lddk + h * DH, dk, p.scale, lane);
+        store_t_acc<DH>(p.dv + (int64_t)(b * p.Lk + key) * p.lddv + h * DH, dv, 1.0f, lane);
     }
 }
 
 static int check_common(const char* fn, int B, int H, int Lq, int Lk, int dh, int64_t ld0, int64_t ld1, int64_t ld2, int64_t ld3) {
-    VM_REQUIRE(dh == DH, "%s: head dim %d unsupported (only 64)", fn, dh);
+    VM_REQUIRE(dh == 32 || dh == 64 || dh == 96 || dh == 128, "%s: head dim %d unsupported (32, 64, 96 or 128)", fn, dh);
     VM_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "%s: empty problem", fn);
     VM_REQUIRE((ld0 % 8) == 0 && (ld1 % 8) == 0 && (ld2 % 8) == 0 && (ld3 % 8) == 0, "%s: leading dims must be multiples of 8", fn);
     return VM_OK;
@@ -429,8 +450,14 @@ extern "C" int vm_attention_fwd(const void* q, int64_t ldq, const void* k, int64
     a.dropout_p = dropout_p; a.seed = dropout_seed; a.thresh = dropout_thresh24(dropout_p);
     a.drop_scale = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
     hipStream_t s = (hipStream_t)stream;
-    VmProfScope prof(VM_FAM_ATTN, 4.0 * B * H * (double)Lq * Lk * DH, s);
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((Lq + 63) / 64, H, B), dim3(256), 0, s, a);
+    VmProfScope prof(VM_FAM_ATTN, 4.0 * B * H * (double)Lq * Lk * dh, s);
+    const dim3 grid((Lq + 63) / 64, H, B);
+    switch (dh) {
+        case 32: hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, s, a); break;
+        case 64: hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, s, a); break;
+        case 96: hipLaunchKernelGGL(attn_fwd_kernel<96>, grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), 0, s, a); break;
+    }
     return vm_check_launch("vm_attention_fwd");
 }
 
@@ -453,10 +480,15 @@ extern "C" int vm_attention_bwd(const void* q, int64_t ldq, const void* k, int64
     a.dropout_p = dropout_p; a.seed = dropout_seed; a.thresh = dropout_thresh24(dropout_p);
     a.drop_scale = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
     hipStream_t s = (hipStream_t)stream;
-    VmProfScope prof(VM_FAM_ATTN, 14.0 * B * H * (double)Lq * Lk * DH, s);
+    VmProfScope prof(VM_FAM_ATTN, 14.0 * B * H * (double)Lq * Lk * dh, s);
     const int64_t rows = (int64_t)B * H * Lq;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Lq + 63) / 64, H, B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Lk + 63) / 64, H, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, a, dh);
+    const dim3 gq((Lq + 63) / 64, H, B), gk((Lk + 63) / 64, H, B);
+    switch (dh) {
+        case 32: hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, gq, dim3(256), 0, s, a); hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, gk, dim3(256), 0, s, a); break;
+        case 64: hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), 0, s, a); hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(256), 0, s, a); break;
+        case 96: hipLaunchKernelGGL(attn_bwd_dq_kernel<96>, gq, dim3(256), 0, s, a); hipLaunchKernelGGL(attn_bwd_dkv_kernel<96>, gk, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, dim3(256), 0, s, a); hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, gk, dim3(256), 0, s, a); break;
+    }
     return vm_check_launch("vm_attention_bwd");
 }

@@ -36,8 +36,7 @@ def _ln(x, aff, eps):
     return y
 
 
-def _attn(q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, key_mask=None, kv_index=None, kv_index_ld=0):
-    dh = 64
+def _attn(q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, dh, key_mask=None, kv_index=None, kv_index_ld=0):
     o = torch.empty(B * Lq, H * dh, dtype=BF16, device=q.device)
     stats = torch.empty(B * H * Lq * 2, dtype=torch.float32, device=q.device)
     check(lib().vm_attention_fwd(ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(o), H * dh, ptr(stats),
@@ -101,7 +100,7 @@ class DecodeState:
             cache = self.self_kv[li]
             ops.gemm(x, 0, a.shadow_group([sa.key.weight, sa.value.weight]), 0, cache[t:], M, 2 * D, D, ldc=T * 2 * D,
                      bias=a.f32_group([sa.key.bias, sa.value.bias]))
-            ctx = _attn(q, D, cache, 2 * D, cache[:, D:], 2 * D, M, H, 1, t + 1, kv_index=self.index, kv_index_ld=T)
+            ctx = _attn(q, D, cache, 2 * D, cache[:, D:], 2 * D, M, H, 1, t + 1, D // H, kv_index=self.index, kv_index_ld=T)
             blk = layer.attention.output
             s = torch.empty(M, D, dtype=BF16, device=x.device)
             ops.gemm(ctx, 0, a.shadow(blk.dense.weight), 0, s, M, D, D, bias=blk.dense.bias, residual=x)
@@ -109,7 +108,7 @@ class DecodeState:
             ca = layer.crossattention.self
             ops.gemm(x, 0, a.shadow(ca.query.weight), 0, q, M, D, D, bias=ca.query.bias)
             kv = self.cross_kv[li]
-            ctx = _attn(q, D, kv, 2 * D, kv[:, D:], 2 * D, self.B, H, self.nb, self.S, key_mask=self.enc_mask)
+            ctx = _attn(q, D, kv, 2 * D, kv[:, D:], 2 * D, self.B, H, self.nb, self.S, D // H, key_mask=self.enc_mask)
             blk = layer.crossattention.output
             ops.gemm(ctx, 0, a.shadow(blk.dense.weight), 0, s, M, D, D, bias=blk.dense.bias, residual=x)
             x = _ln(s, blk.LayerNorm, cfg.layer_norm_eps)

@@ -44,8 +44,8 @@ def make_config(defaults, kwargs):
     cfg.update({k: v for k, v in dict(kwargs).items()})
     if cfg.hidden_act not in ("gelu",):
         raise ValueError(f"hidden_act={cfg.hidden_act!r} unsupported by the HIP path (erf-GELU only)")
-    if cfg.hidden_size % cfg.num_attention_heads or cfg.hidden_size // cfg.num_attention_heads != 64:
-        raise ValueError("the HIP attention kernels need head_dim == 64 "
+    if cfg.hidden_size % cfg.num_attention_heads or cfg.hidden_size // cfg.num_attention_heads not in (32, 64, 96, 128):
+        raise ValueError("the HIP attention kernels need head_dim in {32, 64, 96, 128} "
                          f"(hidden_size={cfg.hidden_size}, heads={cfg.num_attention_heads})")
     return cfg
 
