@@ -64,6 +64,7 @@ typedef struct {
     size_t workspace_bytes;   /*   reduced deterministically by a second kernel; no atomics)        */
 } vm_gemm_epilogue;
 
+int vm_sizeof_gemm_epilogue(void);   /* lets a foreign binding verify its struct layout */
 int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void* B, int64_t ldb, int b_layout,
                  void* C, int64_t ldc, int M, int N, int K, const vm_gemm_epilogue* epi, void* stream);
 
@@ -122,10 +123,12 @@ int vm_vit_assemble_bwd(const void* d_out /* bf16 [B,(n+1),D] */, void* d_patche
  * row_weight (NULL = 1): fp32 [B*L]; row (b,t) contributes row_weight*CE and its gradient is scaled likewise (SCST:
  * -(logp*mask/sum(mask))*(r_sample-r_greedy), ref:vilmedic/blocks/rl/SCST.py:14-45).  banned[0..n_banned) (<=4 columns, a HOST array)
  * are treated as -inf logits (bad_words_ids=[[pad],[bos]], SCST.py:150-151).  row_logp (NULL or fp32 [B*L]) receives
- * log p(label) of each row. */
+ * log p(label) of each row.  row_min_logit (NULL or fp32 [B*L]): logits below it are -inf (TopKLogitsWarper:
+ * the k-th largest logit of the row). */
 int vm_ce_shift_fwd_bwd(const void* logits, int64_t ldl, const int64_t* ids, int B, int L, int V,
                         float* loss_sum, float* row_logp, void* dlogits, float grad_scale,
-                        const float* row_weight, const int32_t* banned, int n_banned, void* stream);
+                        const float* row_weight, const int32_t* banned, int n_banned, const float* row_min_logit,
+                        void* stream);
 /* Generic CE with label smoothing on fp32 logits [R,C] (MVQA head; ref:...LabelSmoothingCrossEntropyLoss.py:38-48) */
 int vm_ce_smooth_fwd_bwd(const float* logits, const int64_t* target, int R, int C, float smoothing,
                          float* loss_sum, float* dlogits, float grad_scale, void* stream);

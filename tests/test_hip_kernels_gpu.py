@@ -207,7 +207,7 @@ def test_embedding_and_ce():
     loss_sum = torch.zeros(1, device=dev())
     dl = torch.empty_like(logits)
     from vilmedic_amd._lib import lib, ptr, stream, check
-    check(lib().vm_ce_shift_fwd_bwd(ptr(logits), Vp, ptr(ids), B, L, V, ptr(loss_sum), None, ptr(dl), 1.0 / (B * (L - 1)), None, None, 0, stream()))
+    check(lib().vm_ce_shift_fwd_bwd(ptr(logits), Vp, ptr(ids), B, L, V, ptr(loss_sum), None, ptr(dl), 1.0 / (B * (L - 1)), None, None, 0, None, stream()))
     lf = logits[:, :V].float().view(B, L, V).requires_grad_(True)
     ref = torch.nn.functional.cross_entropy(lf[:, :-1].reshape(-1, V), ids[:, 1:].reshape(-1))
     ref.backward()

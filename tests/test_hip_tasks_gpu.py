@@ -1,0 +1,190 @@
+"""GPU parity of the task-level pieces: contrastive / CE losses, MVQA core, text encoder, SCST loss, Trainor loop."""
+import pytest
+import torch
+
+import golden_recipes as R
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+@pytest.mark.parametrize("B", [8, 64])
+def test_convirt_infonce_lsce_vs_golden(golden, B):
+    """loss within 2e-3 abs (bf16 similarity GEMM, fp32 log-sum-exp); gradients within 3e-2 relative L2."""
+    from vilmedic_amd.blocks.losses import ConVIRTLoss, InfoNCELoss, LabelSmoothingCrossEntropy
+    g = golden("g6_losses")
+    gen = torch.Generator().manual_seed(1234 + B)
+    l = torch.randn(B, 96, generator=gen)
+    v = torch.randn(B, 96, generator=gen)
+    ld, vd = l.to(dev()).requires_grad_(True), v.to(dev()).requires_grad_(True)
+    ref = g[f"convirt_{B}"]
+    loss, ll, lv = ConVIRTLoss(tau=0.1, lambda_=0.75)(ld, vd)
+    loss.backward()
+    assert abs(loss.item() - ref["loss"].item()) <= 2e-3
+    torch.testing.assert_close(ll.cpu(), ref["loss_l"], rtol=0, atol=2e-2)
+    torch.testing.assert_close(lv.cpu(), ref["loss_v"], rtol=0, atol=2e-2)
+    assert rel(ld.grad.cpu(), ref["gl"]) <= 3e-2 and rel(vd.grad.cpu(), ref["gv"]) <= 3e-2
+    l2, v2 = (0.2 * l).to(dev()).requires_grad_(True), (0.2 * v).to(dev()).requires_grad_(True)
+    ref = g[f"infonce_{B}"]
+    loss, lt, li = InfoNCELoss(tau=0.1)(l2, v2)
+    loss.backward()
+    assert abs(loss.item() - ref["loss"].item()) <= 3e-3
+    torch.testing.assert_close(lt.cpu(), ref["loss_t"], rtol=0, atol=3e-2)
+    assert rel(l2.grad.cpu(), ref["gl"]) <= 3e-2 and rel(v2.grad.cpu(), ref["gv"]) <= 3e-2
+    logits = torch.randn(B, 33, generator=gen)
+    ref = g[f"lsce_{B}"]
+    x = logits.to(dev()).requires_grad_(True)
+    loss = LabelSmoothingCrossEntropy(smoothing=0.1)(x, ref["target"].to(dev()))
+    loss.backward()
+    torch.testing.assert_close(loss.cpu(), ref["loss"], rtol=1e-5, atol=1e-5)      # fp32 kernel
+    torch.testing.assert_close(x.grad.cpu(), ref["g"], rtol=1e-4, atol=1e-6)
+
+
+def test_gloria_loss_vs_golden(golden):
+    from vilmedic_amd.blocks.losses import GLoRIALoss
+    g = golden("g6_losses")["gloria"]
+    B, D, T, hw = g["B"], g["D"], g["T"], g["hw"]
+    gen = torch.Generator().manual_seed(99)
+    glob = torch.randn(B, D, generator=gen).to(dev()).requires_grad_(True)
+    loc = torch.randn(B, D, hw, hw, generator=gen).to(dev()).requires_grad_(True)
+    words = torch.randn(B, D, T, generator=gen).to(dev()).requires_grad_(True)
+    sent = torch.randn(B, D, generator=gen).to(dev()).requires_grad_(True)
+    sents = [["[CLS]"] + ["w"] * (n - 1) + ["[SEP]"] + ["[PAD]"] * (T - n - 1) for n in g["cap_lens"]]
+    loss, attn = GLoRIALoss(1.0, 1.0, 4.0, 5.0, 10.0)(glob, loc, words, sent, sents)
+    loss.backward()
+    assert abs(loss.item() - g["loss"].item()) <= 2e-2
+    assert rel(loc.grad.cpu(), g["g_loc"]) <= 1e-3 and rel(words.grad.cpu(), g["g_words"]) <= 1e-3     # local part: fp32 torch ops
+    assert rel(glob.grad.cpu(), g["g_glob"]) <= 3e-2 and rel(sent.grad.cpu(), g["g_sent"]) <= 3e-2     # global part: bf16 GEMM
+    torch.testing.assert_close(attn[0].cpu(), g["attn0"], rtol=1e-4, atol=1e-5)
+
+
+def test_mvqa_core_and_text_encoder_vs_golden(golden):
+    from vilmedic_amd.arena import arena_of
+    from vilmedic_amd.blocks.huggingface.encoder.encoder_model import EncoderModel
+    from vilmedic_amd.nn import BERT_GEN_DEFAULTS, BertPooler, BertStack, make_config
+    g = golden("g9_mvqa_text")
+    m = g["mvqa"]
+    cfg = make_config(BERT_GEN_DEFAULTS, dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **m["cfg"]))
+
+    class Core(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.transformer, self.pooler = BertStack(cfg), BertPooler(cfg)
+    core = Core().to(dev())
+    st = {"transformer." + k: v for k, v in R.rand_state(R.bert_stack_shapes(m["cfg"]), m["seed"]).items()}
+    st["pooler.dense.weight"], st["pooler.dense.bias"] = m["pw"], m["pb"]
+    core.load_state_dict(st, strict=True)
+    core.eval()
+    arena = arena_of(core)
+    with torch.no_grad():
+        h = core.transformer(m["x"].to(dev()).to(BF), arena)
+        pooled = core.pooler(h, arena)
+    err = (h.float().cpu() - m["hidden"]).abs()
+    assert bool((err <= 3e-2 + 3e-2 * m["hidden"].abs()).all())
+    torch.testing.assert_close(pooled.cpu(), m["pooled"], rtol=0, atol=2e-2)
+    t = g["text"]
+    enc = EncoderModel(dict(proto=None, add_pooling_layer=True, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **t["cfg"])).to(dev())
+    sd = R.rand_state(R.text_encoder_shapes(t["cfg"]), t["seed"])
+    enc.encoder.load_state_dict(sd, strict=True)
+    enc.pooler.load_state_dict({"dense.weight": t["pw"], "dense.bias": t["pb"]})
+    enc.eval()
+    ids, am = R.make_reports(t["B"], t["L"], t["cfg"]["vocab_size"], seed=t["seed"])
+    with torch.no_grad():
+        out = enc(input_ids=ids.to(dev()), attention_mask=am.to(dev()))
+    err = (out.last_hidden_state.float().cpu() - t["last_hidden_state"]).abs()
+    assert bool((err <= 3e-2 + 3e-2 * t["last_hidden_state"].abs()).all())
+    torch.testing.assert_close(out["pooler_output"].cpu(), t["pooler_output"], rtol=0, atol=2e-2)
+
+
+def test_scst_weighted_lm_head_loss_matches_scst_loss_oracle():
+    """The fused policy-gradient loss (row weights + banned columns inside the LM-head CE kernel) equals the reference's
+    scst_loss applied to log-softmax of the bad-word-masked logits (ref: SCST.py:14-45,150-170)."""
+    from oracle import torch_ref as O
+    from test_hip_models_gpu import build_decoder
+    cfg = R.DEC_TINY
+    dec, st = build_decoder(cfg, 5)
+    dec.train()
+    B, T, S = 4, 12, 7
+    gen = torch.Generator().manual_seed(3)
+    seq = torch.randint(3, cfg["vocab_size"], (B, T), generator=gen)
+    seq[:, 0] = 0
+    seq[1, 6], seq[1, 7:] = 2, 1
+    seq[3, 3], seq[3, 4:] = 2, 1
+    enc = torch.randn(B, S, cfg["hidden_size"], generator=gen)
+    rs = [torch.rand(B, generator=gen).tolist()]
+    rg = [torch.rand(B, generator=gen).tolist()]
+    sampled = seq[:, 1:]
+    mask = (sampled > 1).float()
+    coef = torch.tensor(rs[0]) - torch.tensor(rg[0])
+    row_w = torch.zeros(B, T)
+    row_w[:, :-1] = mask * coef[:, None] / mask.sum()
+    enc_d = enc.to(dev()).to(BF).requires_grad_(True)
+    out = dec.decoder(input_ids=seq.to(dev()), attention_mask=None, encoder_hidden_states=enc_d, encoder_attention_mask=None,
+                      labels=seq.to(dev()), return_logits=False, row_weight=row_w.to(dev()), banned=[1, 0])
+    out["loss"].backward()
+    # oracle
+    sto = {k: v.clone().requires_grad_(True) for k, v in st.items()}
+    enc_o = enc.clone().requires_grad_(True)
+    h = O.decoder_hidden(seq, None, enc_o, None, sto, cfg)
+    logits = O.lm_logits(h, sto).float()[:, :-1]
+    logits[:, :, [1, 0]] = -float("inf")
+    logp = torch.log_softmax(logits, -1).gather(2, sampled.unsqueeze(-1))
+    ref = O.scst_loss(logp, sampled, rs, rg, [1.0], 1)
+    ref.backward()
+    assert abs(out["loss"].item() - ref.item()) <= 2e-3 * max(1.0, abs(ref.item())), (out["loss"].item(), ref.item())
+    lp_hip = out["row_logp"][:, :-1].cpu()
+    assert (lp_hip - logp.squeeze(-1).detach()).abs()[mask.bool()].max() <= 5e-2
+    assert rel(enc_d.grad.float().cpu(), enc_o.grad) <= 5e-2
+    gname = "bert.encoder.layer.1.output.dense.weight"
+    assert rel(dict(dec.decoder.named_parameters())[gname].grad.cpu(), sto[gname].grad) <= 5e-2
+
+
+def test_rrg_scst_step_and_validator_decode_run():
+    """RRG_SCST forward (greedy baseline + sampling rollout + fused policy-gradient loss) and the decode driver run end to
+    end on synthetic data; the loss is finite and gradients reach the encoder."""
+    from vilmedic_amd.blocks.huggingface.decoder.evaluation import evaluation
+    from vilmedic_amd.config import Cfg
+    from vilmedic_amd.datasets import SyntheticImSeq
+    from vilmedic_amd.models import RRG_SCST
+    ds = SyntheticImSeq(num_samples=8, image_size=32, vocab_size=97, tokenizer_max_len=16)
+    dl = torch.utils.data.DataLoader(ds, batch_size=4, collate_fn=ds.get_collate_fn())
+    model = RRG_SCST(decoder=dict(proto=None, **R.DEC_TINY), cnn=dict(proto="VisualEncoder", backbone="vit", permute="no_permute",
+                                                                       **R.VIT_TINY), dl=dl, scores="ROUGEL", top_k=20).to(dev())
+    batch = next(iter(dl))
+    out = model(**batch)
+    assert torch.isfinite(out["loss"])
+    out["loss"].backward()
+    p = model.model.enc.model.encoder.layer[0].intermediate.dense.weight
+    assert p.grad.abs().sum() > 0
+    res = evaluation([model.model.eval()], Cfg(beam_width=2, length_penalty=None), dl)
+    assert len(res["hyps"]) == 8 and len(res["refs"]) == 8
+
+
+def test_trainor_runs_and_checkpoints(tmp_path):
+    from vilmedic_amd.config import executor_view, get_config
+    from vilmedic_amd.executors import Trainor
+    import os
+    cfg = get_config(os.path.join(os.path.dirname(__file__), "..", "config", "RRG", "rrg-vit-synthetic.yml"),
+                     ["dataset.num_samples=16", "dataset.image_size=32", "dataset.vocab_size=97", "dataset.tokenizer_max_len=16",
+                      "model.decoder.hidden_size=128", "model.decoder.num_attention_heads=2", "model.decoder.intermediate_size=256",
+                      "model.decoder.num_hidden_layers=2", "model.decoder.max_position_embeddings=64",
+                      "model.cnn.image_size=32", "model.cnn.patch_size=8", "model.cnn.hidden_size=128", "model.cnn.num_attention_heads=2",
+                      "model.cnn.intermediate_size=256", "model.cnn.num_hidden_layers=2",
+                      "trainor.batch_size=4", "trainor.epochs=2", "trainor.eval_start=0", "validator.batch_size=4",
+                      "validator.beam_width=2", f"ckpt_dir={tmp_path}", "trainor.optim_params.lr=0.003"])
+    t = executor_view(cfg, "trainor")
+    t["validator_view"] = executor_view(cfg, "validator")
+    tr = Trainor(t, seed=0)
+    tr.start()
+    ckpts = [f for f in os.listdir(tmp_path) if f.endswith(".pth")]
+    assert len(ckpts) == 1
+    sd = torch.load(os.path.join(tmp_path, ckpts[0]), map_location="cpu")
+    assert {"model", "training_scheduler", "optimizer", "config", "__version__"} <= set(sd)

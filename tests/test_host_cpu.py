@@ -1,0 +1,93 @@
+"""CPU tests (no GPU needed): C-ABI library loads and exports every symbol include/vmhip.h declares, module trees carry
+the reference's parameter names, config loader semantics, scorers, fail-loud behaviour without a device."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import golden_recipes as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vilmedic_amd import _lib, build
+    path = build.build(verbose=False)
+    lib = ctypes.CDLL(path)
+    hdr = open(os.path.join(ROOT, "include", "vmhip.h")).read()
+    declared = set(re.findall(r"\b(vm_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/vmhip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    lib.vm_sizeof_gemm_epilogue.restype = ctypes.c_int
+    assert lib.vm_sizeof_gemm_epilogue() == ctypes.sizeof(_lib.GemmEpilogue)      # struct layout agreed with the C side
+
+
+def test_ops_fail_loudly_on_cpu_tensors():
+    from vilmedic_amd import ops
+    from vilmedic_amd._lib import VmHipError
+    a = torch.zeros(8, 8, dtype=torch.bfloat16)
+    with pytest.raises(VmHipError):
+        ops.gemm(a, 0, a, 0, torch.zeros(8, 8, dtype=torch.bfloat16), 8, 8, 8)
+
+
+def test_module_parameter_names_match_reference_checkpoints():
+    from vilmedic_amd.blocks.huggingface.decoder.decoder_model import DecoderModel
+    from vilmedic_amd.blocks.vision import VisualEncoder
+    enc = VisualEncoder(backbone="vit", permute="no_permute", visual_projection=dict(in_features=128, out_features=64), **R.VIT_TINY)
+    assert set(enc.state_dict()) == {"model." + k for k in R.vit_shapes(R.VIT_TINY)} | {"visual_projection.weight", "visual_projection.bias"}
+    dec = DecoderModel(dict(proto=None, **R.DEC_TINY))
+    names = set(dec.decoder.state_dict())
+    assert names == set(R.decoder_shapes(R.DEC_TINY)) | {"lm_head.decoder.weight", "lm_head.decoder.bias"}
+    # 12-layer decoder: 317 distinct tensors
+    big = DecoderModel(dict(proto=None, hidden_size=64, num_attention_heads=1, intermediate_size=64, num_hidden_layers=12,
+                            vocab_size=50, max_position_embeddings=16))
+    assert len(list(big.parameters())) == 317
+    assert dec.decoder.lm_head.decoder.weight is dec.decoder.bert.embeddings.word_embeddings.weight      # tied head
+    for k, shape in R.decoder_shapes(R.DEC_TINY).items():
+        assert tuple(dec.decoder.state_dict()[k].shape) == tuple(shape), k
+
+
+def test_cnn_backbones_have_torchvision_names_and_shapes():
+    from vilmedic_amd.blocks.vision import VisualEncoder
+    enc = VisualEncoder(backbone="resnet18", permute="batch_first", output_layer="layer4", pretrained=False)
+    keys = set(enc.state_dict())
+    assert "model.0.weight" in keys and "model.4.0.conv1.weight" in keys          # nn.Sequential truncation, as the reference
+    with torch.no_grad():
+        assert enc.model(torch.zeros(1, 3, 64, 64)).shape == (1, 512, 2, 2)
+    dn = VisualEncoder(backbone="densenet169", permute="batch_first", output_layer="features", pretrained=False)
+    with torch.no_grad():
+        assert dn.model(torch.zeros(1, 3, 64, 64)).shape == (1, 1664, 2, 2)
+    rn = VisualEncoder(backbone="resnet50", permute="batch_first", output_layer="avgpool", pretrained=False)
+    with torch.no_grad():
+        assert rn.model(torch.zeros(1, 3, 64, 64)).flatten(1).shape == (1, 2048)
+
+
+def test_config_loader_includes_dotlist_and_coercion(tmp_path):
+    from vilmedic_amd.config import executor_view, get_config
+    (tmp_path / "base.yml").write_text("model:\n  proto: RRG\n  decoder:\n    layer_norm_eps: 1e-05\n    hidden_size: 768\ntrainor:\n  batch_size: 16\n")
+    (tmp_path / "child.yml").write_text("includes:\n  - base.yml\nmodel:\n  decoder:\n    hidden_size: 128\ntrainor:\n  optim_params:\n    lr: '5e-5'\n")
+    c = get_config(str(tmp_path / "child.yml"), ["trainor.batch_size=4", "model.decoder.proto=null"])
+    assert c.model.proto == "RRG" and c.model.decoder.hidden_size == 128 and c.model.decoder.layer_norm_eps == 1e-5
+    assert c.trainor.batch_size == 4 and c.trainor.optim_params.lr == 5e-5 and c.model.decoder.proto is None
+    v = executor_view(c, "trainor")
+    assert v.batch_size == 4 and v.model.proto == "RRG"
+    d = c.model.decoder
+    d2 = dict(d)
+    assert d2.pop("proto") is None and "proto" in d          # sub-trees support ** / pop like a DictConfig
+
+
+def test_rouge_l_and_reward_table():
+    from vilmedic_amd.blocks.scorers import REWARD_COMPLIANT, RougeL
+    mean, per = RougeL()(["the heart is normal", "no pleural effusion"], ["the heart is normal", "effusion pleural no"])
+    assert per[0] == 1.0 and 0 < per[1] < 1 and abs(mean - sum(per) / 2) < 1e-12
+    assert REWARD_COMPLIANT["rougel"][1] == 1
+
+
+def test_out_of_scope_models_raise():
+    import vilmedic_amd.models as M
+    with pytest.raises(NotImplementedError):
+        M.RRS_HF()

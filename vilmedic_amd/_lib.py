@@ -34,6 +34,7 @@ SIGNATURES = {
     "vm_prof_enable": (_I, [_I]),
     "vm_prof_reset": (_I, []),
     "vm_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "vm_sizeof_gemm_epilogue": (_I, []),
     "vm_gemm_bf16": (_I, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, C.POINTER(GemmEpilogue), _P]),
     "vm_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "vm_layernorm_bwd_ws": (_SZ, [_I, _I]),
@@ -46,7 +47,7 @@ SIGNATURES = {
     "vm_im2col_patches": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "vm_vit_assemble": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "vm_vit_assemble_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
-    "vm_ce_shift_fwd_bwd": (_I, [_P, _L, _P, _I, _I, _I, _P, _P, _P, _F, _P, C.POINTER(C.c_int32), _I, _P]),
+    "vm_ce_shift_fwd_bwd": (_I, [_P, _L, _P, _I, _I, _I, _P, _P, _P, _F, _P, C.POINTER(C.c_int32), _I, _P, _P]),
     "vm_ce_smooth_fwd_bwd": (_I, [_P, _P, _I, _I, _F, _P, _P, _F, _P]),
     "vm_rownorm_cast": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
     "vm_lse_rows_f32": (_I, [_P, _L, _P, _P, _I, _I, _I, _P]),
@@ -82,6 +83,8 @@ def lib():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
+    if L.vm_sizeof_gemm_epilogue() != C.sizeof(GemmEpilogue):
+        raise VmHipError("vm_gemm_epilogue layout mismatch between include/vmhip.h and vilmedic_amd/_lib.py")
     _lib = L
     return L
 

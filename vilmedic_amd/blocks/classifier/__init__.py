@@ -1,0 +1,1 @@
+from .classifier import Classifier  # noqa: F401

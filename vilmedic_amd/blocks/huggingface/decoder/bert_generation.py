@@ -80,7 +80,7 @@ class BertGenerationDecoder(nn.Module):
         return (self.config.vocab_size + 7) // 8 * 8
 
     def forward(self, input_ids=None, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None,
-                labels=None, return_logits=True, **kw):
+                labels=None, return_logits=True, row_weight=None, banned=None, top_k=None, **kw):
         arena = arena_of(self)   # root the arena HERE (before the sub-module forward) so it covers lm_head.bias too
         arena.refresh()
         out = self.bert(input_ids, attention_mask=attention_mask, encoder_hidden_states=encoder_hidden_states,
@@ -94,9 +94,11 @@ class BertGenerationDecoder(nn.Module):
             if labels is not input_ids and not torch.equal(labels, input_ids):
                 raise NotImplementedError("the HIP LM-head loss implements the reference's labels=input_ids contract "
                                           "(ref: decoder_model.py:46)")
-            loss, logits = ops.lm_head_loss(h, emb_sh, self.lm_head.bias, input_ids.contiguous(), V,
-                                            g_emb=_rows(arena.grad(emb), V), g_bias=arena.grad(self.lm_head.bias),
-                                            want_logits=return_logits)
+            loss, logits, row_logp = ops.lm_head_loss(h, emb_sh, self.lm_head.bias, input_ids.contiguous(), V,
+                                                      g_emb=_rows(arena.grad(emb), V), g_bias=arena.grad(self.lm_head.bias),
+                                                      want_logits=return_logits, row_weight=row_weight, banned=banned, top_k=top_k)
+            return ModelOutput(loss=loss, logits=logits, past_key_values=None, hidden_states=None, attentions=None,
+                               cross_attentions=None, row_logp=row_logp)
         else:
             B, L, D = h.shape
             logits = ops.lm_logits_f32(h.reshape(B * L, D), emb_sh, self.lm_head.bias, V).view(B, L, V)

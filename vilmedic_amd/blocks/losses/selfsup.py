@@ -1,0 +1,194 @@
+"""ConVIRT / InfoNCE / GLoRIA losses on the HIP path (same constructors and return tuples as the reference).
+
+ref: vilmedic/blocks/losses/selfsup/ConVIRTLoss.py:5-38, InfoNCELoss.py:5-24, GLoRIALoss.py:5-170.
+
+The [B,B] similarity is one bf16 MFMA GEMM with fp32 output (alpha = 1/tau); row / column log-sum-exp, the diagonal
+and the gradient matrix G are produced by the kernels in csrc/contrastive.hip; dA = G B / tau and dB = G^T A / tau are
+two more GEMMs.  When torch.distributed is initialised with world_size > 1 the text / image embeddings are
+all-gathered first (RCCL), so every rank sees the GLOBAL batch of negatives (SURVEY §8e -- a capability the reference
+lacks: under DDP it contrasts within the local shard only, conVIRT.py:97-100).
+"""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ..._lib import check, lib, ptr, stream
+
+BF16 = torch.bfloat16
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+class _SimilarityLossFn(torch.autograd.Function):
+    """(a [R,D], b [C,D]) -> per-row losses  row_i = lse_j S_ij - S_ii,  col_i = lse_j S_ji - S_ii  with
+    S = n(a) n(b)^T * inv_tau  (n = L2 normalisation when ``normalize``)."""
+
+    @staticmethod
+    def forward(ctx, a, b, normalize, inv_tau, eps):
+        R, D = a.shape
+        Cn = b.shape[0]
+        if D % 8:
+            raise ValueError("embedding dim must be a multiple of 8")
+        dev = a.device
+        a32, b32 = a.detach().float().contiguous(), b.detach().float().contiguous()
+        ah = torch.zeros(_pad8(R), D, dtype=BF16, device=dev)
+        bh = torch.zeros(_pad8(Cn), D, dtype=BF16, device=dev)
+        na = torch.empty(R, dtype=torch.float32, device=dev)
+        nb = torch.empty(Cn, dtype=torch.float32, device=dev)
+        L = lib()
+        check(L.vm_rownorm_cast(ptr(a32), ptr(ah), ptr(na), R, D, int(normalize), eps, stream()), "vm_rownorm_cast")
+        check(L.vm_rownorm_cast(ptr(b32), ptr(bh), ptr(nb), Cn, D, int(normalize), eps, stream()), "vm_rownorm_cast")
+        ldS = (Cn + 3) // 4 * 4
+        S = torch.empty(R, ldS, dtype=torch.float32, device=dev)
+        ops.gemm(ah, 0, bh, 0, S, R, Cn, D, alpha=inv_tau)
+        lse_r = torch.empty(R, dtype=torch.float32, device=dev)
+        lse_c = torch.empty(Cn, dtype=torch.float32, device=dev)
+        diag = torch.empty(R, dtype=torch.float32, device=dev)
+        check(L.vm_lse_rows_f32(ptr(S), ldS, ptr(lse_r), ptr(diag), R, Cn, 0, stream()), "vm_lse_rows_f32")
+        check(L.vm_lse_cols_f32(ptr(S), ldS, ptr(lse_c), R, Cn, stream()), "vm_lse_cols_f32")
+        ctx.save_for_backward(a32, b32, ah, bh, na, nb, S, lse_r, lse_c)
+        ctx.meta = (normalize, inv_tau, eps, R, Cn, D, ldS)
+        n = min(R, Cn)
+        return lse_r[:n] - diag[:n], lse_c[:n] - diag[:n]
+
+    @staticmethod
+    def backward(ctx, g_row, g_col):
+        a32, b32, ah, bh, na, nb, S, lse_r, lse_c = ctx.saved_tensors
+        normalize, inv_tau, eps, R, Cn, D, ldS = ctx.meta
+        dev = S.device
+        gr = torch.zeros(R, dtype=torch.float32, device=dev)
+        gc = torch.zeros(Cn, dtype=torch.float32, device=dev)
+        n = min(R, Cn)
+        gr[:n] = g_row.float()
+        gc[:n] = g_col.float()
+        ldg = _pad8(Cn)
+        G = torch.zeros(_pad8(R), ldg, dtype=BF16, device=dev)
+        check(lib().vm_contrastive_grad(ptr(S), ldS, ptr(lse_r), ptr(lse_c), ptr(gr), ptr(gc), ptr(G), ldg, R, Cn, 0, stream()),
+              "vm_contrastive_grad")
+        dah = torch.empty(R, D, dtype=torch.float32, device=dev)
+        dbh = torch.empty(Cn, D, dtype=torch.float32, device=dev)
+        ops.gemm(G, 0, bh, 1, dah, R, D, ldg, alpha=inv_tau)            # dA^ = G B^ / tau      (contraction over columns)
+        ops.gemm(G, 1, ah, 1, dbh, Cn, D, _pad8(R), alpha=inv_tau)      # dB^ = G^T A^ / tau    (contraction over rows)
+        if normalize:
+            da = _normalize_bwd(a32, na, dah, eps)
+            db = _normalize_bwd(b32, nb, dbh, eps)
+        else:
+            da, db = dah, dbh
+        return da, db, None, None, None
+
+
+def _normalize_bwd(x, norms, dxh, eps):
+    """x^ = x / max(|x|, eps):  dx = (dx^ - x^ (x^ . dx^)) / |x|   for |x| > eps, dx^ / eps otherwise."""
+    d = norms.clamp(min=eps)[:, None]
+    xh = x / d
+    proj = (xh * dxh).sum(1, keepdim=True)
+    return torch.where(norms[:, None] > eps, (dxh - xh * proj) / d, dxh / d)
+
+
+def _maybe_gather(*xs):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        from ...parallel import all_gather_with_grad
+        n = xs[0].shape[0]
+        r = dist.get_rank()
+        return [all_gather_with_grad(x.contiguous(), dist) for x in xs], slice(r * n, (r + 1) * n), dist.get_world_size()
+    return list(xs), slice(None), 1
+
+
+class ConVIRTLoss(nn.Module):
+    def __init__(self, tau, lambda_, **kwargs):
+        super().__init__()
+        self.tau = tau
+        self.lambda_ = lambda_
+
+    def forward(self, linguistic, visual):
+        (lg, vg), local, world = _maybe_gather(linguistic, visual)
+        loss_l, loss_v = _SimilarityLossFn.apply(lg, vg, True, 1.0 / self.tau, 1e-8)
+        loss = torch.mean(self.lambda_ * loss_v + (1 - self.lambda_) * loss_l)
+        return loss, loss_l[local], loss_v[local]
+
+    def __repr__(self):
+        return "ConVIRTLoss(\n\t(cos_loss): CosineSimilarity()\n\t(tau): {}\n\t(lambda_): {}\n)".format(self.tau, self.lambda_)
+
+
+class InfoNCELoss(nn.Module):
+    """raw dot-product logits, CE both ways; ``tau`` is stored but NOT applied -- exactly as the reference."""
+
+    def __init__(self, tau, **kwargs):
+        super().__init__()
+        self.tau = tau
+
+    def forward(self, linguistic, visual):
+        (lg, vg), local, world = _maybe_gather(linguistic, visual)
+        loss_t, loss_i = _SimilarityLossFn.apply(lg, vg, False, 1.0, 1e-8)
+        loss = ((loss_i + loss_t) / 2).mean()
+        return loss, loss_t[local], loss_i[local]
+
+    def __repr__(self):
+        return "InfoNCELoss(\n\t(tau): {}\n)".format(self.tau)
+
+
+# ----------------------------------------------------------------------------- GLoRIA (global: HIP similarity; local: batched torch ops)
+def cosine_similarity(x1, x2, dim=1, eps=1e-8):
+    w12 = torch.sum(x1 * x2, dim)
+    w1 = torch.norm(x1, 2, dim)
+    w2 = torch.norm(x2, 2, dim)
+    return (w12 / (w1 * w2).clamp(min=eps)).squeeze()
+
+
+def gloria_attention_fn(query, context, temp1):
+    """ref: GLoRIALoss.py:13-51 (query [B,D,T], context [B,D,ih,iw])."""
+    B, T = query.size(0), query.size(2)
+    ih, iw = context.size(2), context.size(3)
+    S = ih * iw
+    ctx = context.view(B, -1, S)
+    attn = torch.bmm(ctx.transpose(1, 2), query)
+    attn = torch.softmax(attn.view(B * S, T), dim=-1).view(B, S, T)
+    attn = attn.transpose(1, 2).contiguous().view(B * T, S) * temp1
+    attn = torch.softmax(attn, dim=-1).view(B, T, S)
+    return torch.bmm(ctx, attn.transpose(1, 2)), attn.view(B, -1, ih, iw)
+
+
+class GLoRIALoss(nn.Module):
+    def __init__(self, local_loss_weight=1.0, global_loss_weight=1.0, temp1=4.0, temp2=5.0, temp3=10.0):
+        super().__init__()
+        self.local_loss_weight, self.global_loss_weight = local_loss_weight, global_loss_weight
+        self.temp1, self.temp2, self.temp3 = temp1, temp2, temp3
+
+    def forward(self, global_features, local_features, word_embeddings, sent_embeddings, sents):
+        cap_lens = [len([w for w in sent if not w.startswith("[")]) + 1 for sent in sents]
+        l0, l1, attn_maps = self._local(local_features.float(), word_embeddings.float(), cap_lens)
+        # global: cosine-sim [B,B] * temp3 -> CE both ways == the HIP similarity loss with inv_tau = temp3 (mean over rows)
+        row, col = _SimilarityLossFn.apply(global_features.float(), sent_embeddings.float(), True, self.temp3, 1e-8)
+        loss = (l0 + l1) * self.local_loss_weight + (row.mean() + col.mean()) * self.global_loss_weight
+        return loss, attn_maps
+
+    def _local(self, img, words, cap_lens):
+        """ref: GLoRIALoss.py:78-129; the per-caption python loop is batched over equal caption lengths."""
+        B = img.shape[0]
+        sims = torch.empty(B, B, device=img.device, dtype=torch.float32)
+        att_maps = [None] * B
+        by_len = {}
+        for i, T in enumerate(cap_lens):
+            by_len.setdefault(T, []).append(i)
+        ih, iw = img.shape[2], img.shape[3]
+        ctx = img.view(B, -1, ih * iw)
+        for T, idxs in by_len.items():
+            w = words[idxs][:, :, :T]                                      # [n,D,T]
+            n = len(idxs)
+            q = w[:, None].expand(n, B, -1, T).reshape(n * B, -1, T)        # caption-major, image-minor
+            c = img[None].expand(n, B, -1, ih, iw).reshape(n * B, -1, ih, iw)
+            wctx, attn = gloria_attention_fn(q, c, self.temp1)
+            qf = q.transpose(1, 2).reshape(n * B * T, -1)
+            cf = wctx.transpose(1, 2).reshape(n * B * T, -1)
+            row = cosine_similarity(qf, cf).view(n, B, T)
+            row = torch.log(torch.exp(row * self.temp2).sum(-1))           # [n,B]
+            sims[:, idxs] = row.t()
+            attn = attn.view(n, B, T, ih, iw)
+            for k, i in enumerate(idxs):
+                att_maps[i] = attn[k, i].unsqueeze(0).contiguous()
+        sims = sims * self.temp3
+        labels = torch.arange(B, device=img.device)
+        return nn.functional.cross_entropy(sims, labels), nn.functional.cross_entropy(sims.t(), labels), att_maps

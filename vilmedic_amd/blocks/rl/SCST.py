@@ -1,0 +1,123 @@
+"""SCST -- self-critical sequence training on the HIP path.  ref: vilmedic/blocks/rl/SCST.py:14-195.
+
+MI355X-first redesign of ``forward_sampling``: the reference un-wraps HF ``generate`` so autograd records L sequential
+decode steps (SCST.py:142-157).  Here the multinomial rollout runs WITHOUT grad on the KV-cached decode path, and the
+log-probabilities of the sampled tokens are then recomputed WITH grad by ONE teacher-forced batched forward whose
+LM-head kernel applies the same logit filters (bad words, top-k) and the policy-gradient weights
+``mask * (r_sample - r_greedy) / sum(mask)`` -- the same loss and gradient, L-fold fewer launches."""
+import json
+
+import torch
+import torch.nn as nn
+
+from ..scorers import REWARD_COMPLIANT
+
+
+def scst_loss(input, seq, reward_sampling, reward_greedy, scores_weights, pad_token_id):
+    """ref: SCST.py:14-45 (kept for API parity; the training path fuses it into the LM-head loss kernel)."""
+    input = input.clone()
+    input[input == -float("Inf")] = 0.
+    mask = (seq > pad_token_id).float()
+    input = input.squeeze(-1) * mask
+    input = input / torch.sum(mask)
+    dev = input.device
+    delta_rewards = [torch.tensor(rs, device=dev) - torch.tensor(rg, device=dev) for rs, rg in zip(reward_sampling, reward_greedy)]
+    loss = sum(torch.sum(scores_weights[i] * (-input * r.unsqueeze(-1).expand_as(input))) for i, r in enumerate(delta_rewards))
+    delta_reward = torch.mean(torch.stack(delta_rewards))
+    delta_reward_per_metric = torch.mean(torch.stack(delta_rewards), dim=-1)
+    return loss, delta_reward, delta_reward_per_metric
+
+
+class SCST(nn.Module):
+    def __init__(self, decoder, dl, scores, scores_args=None, scores_weights=None, top_k=None, use_nll=False):
+        super().__init__()
+        dataset = dl.dataset
+        if hasattr(dataset, "tokenizer"):
+            self.tokenizer, self.max_length = dataset.tokenizer, dataset.tokenizer_max_len
+        elif hasattr(dataset, "tgt_tokenizer"):
+            self.tokenizer, self.max_length = dataset.tgt_tokenizer, dataset.tgt_tokenizer_max_len
+        else:
+            raise NotImplementedError("Where is tokenizer in dataset?")
+        self.__dict__["decoder"] = decoder            # not registered: the parameters belong to RRG
+        self.top_k, self.use_nll = top_k, use_nll
+        cfg = decoder.config
+        self.bos_token_id, self.eos_token_id, self.pad_token_id = cfg.bos_token_id, cfg.eos_token_id, cfg.pad_token_id
+        assert scores is not None
+        if not isinstance(scores, (list, tuple)):
+            scores = [scores]
+        scores = [s if callable(s) else s.lower() for s in scores]
+        self.scores = scores
+        if len(scores) > 1 or use_nll:
+            assert scores_weights is not None, "You need to mention scores_weights"
+            assert len(scores_weights) == len(scores) + (1 if use_nll else 0)
+            self.scores_weights = list(scores_weights)
+        else:
+            self.scores_weights = [1.0]
+        scores_args = scores_args if scores_args is not None else [None] * len(scores)
+        if not isinstance(scores_args, (list, tuple)):
+            scores_args = [scores_args]
+        self.scores_args = scores_args
+        self.scorers, self.scorers_index = [], []
+        for index, score in enumerate(scores):
+            if callable(score):
+                self.scorers.append(score)
+                self.scorers_index.append(1)
+                continue
+            assert score in REWARD_COMPLIANT, "{} not in {}".format(score, list(REWARD_COMPLIANT))
+            scorer, scorer_index = REWARD_COMPLIANT[score]
+            self.scorers.append(scorer(**scores_args[index]) if scores_args[index] else scorer())
+            self.scorers_index.append(scorer_index)
+
+    def forward_greedy(self, input_ids, encoder_hidden_states, encoder_attention_mask):
+        assert not torch.is_grad_enabled(), "Please add torch.no_grad() decorator"
+        out = self.decoder.generate(input_ids=torch.full((input_ids.shape[0], 1), self.bos_token_id, dtype=torch.long,
+                                                         device=encoder_hidden_states.device),
+                                    max_length=self.max_length, num_beams=1, return_dict_in_generate=True,
+                                    encoder_hidden_states=encoder_hidden_states.detach(),
+                                    encoder_attention_mask=encoder_attention_mask.detach())
+        return self.get_reward(out.sequences.detach(), input_ids)
+
+    def forward_sampling(self, input_ids, attention_mask, encoder_hidden_states, encoder_attention_mask, reward_greedy):
+        assert torch.is_grad_enabled()
+        dev = encoder_hidden_states.device
+        nll_loss = None
+        if self.use_nll:
+            nll_loss = self.decoder(input_ids=input_ids.to(dev), attention_mask=attention_mask.to(dev),
+                                    encoder_hidden_states=encoder_hidden_states, encoder_attention_mask=encoder_attention_mask,
+                                    labels=input_ids.to(dev), return_logits=False)["loss"]
+        banned = [self.pad_token_id, self.bos_token_id]
+        with torch.no_grad():
+            out = self.decoder.generate(input_ids=torch.full((input_ids.shape[0], 1), self.bos_token_id, dtype=torch.long, device=dev),
+                                        max_length=self.max_length, num_beams=1, do_sample=True, top_k=self.top_k,
+                                        bad_words_ids=[[b] for b in banned], return_dict_in_generate=True,
+                                        encoder_hidden_states=encoder_hidden_states.detach(),
+                                        encoder_attention_mask=encoder_attention_mask.detach())
+        seq = out.sequences                       # [B, T] with bos at 0
+        sampled_ids = seq[:, 1:].contiguous()
+        reward_sampling, hyp_list, _ = self.get_reward(sampled_ids, input_ids)
+        weights = self.scores_weights[-len(self.scorers):]
+        delta = [torch.tensor(rs, device=dev, dtype=torch.float32) - torch.tensor(rg, device=dev, dtype=torch.float32)
+                 for rs, rg in zip(reward_sampling, reward_greedy)]
+        coef = sum(w * d for w, d in zip(weights, delta))                                   # [B]
+        mask = (sampled_ids > self.pad_token_id).float()                                    # [B, T-1]
+        row_w = torch.zeros(seq.shape, dtype=torch.float32, device=dev)
+        row_w[:, :-1] = mask * coef[:, None] / mask.sum()                                   # row (b,t) predicts seq[b,t+1]
+        o = self.decoder(input_ids=seq, attention_mask=None, encoder_hidden_states=encoder_hidden_states,
+                         encoder_attention_mask=encoder_attention_mask, labels=seq, return_logits=False,
+                         row_weight=row_w.contiguous(), banned=banned, top_k=self.top_k)
+        loss = o["loss"]
+        if self.use_nll:
+            loss = loss + self.scores_weights[0] * nll_loss
+        delta_reward = torch.mean(torch.stack(delta))
+        delta_reward_per_metric = torch.mean(torch.stack(delta), dim=-1)
+        return loss, delta_reward, delta_reward_per_metric, reward_sampling, hyp_list
+
+    def get_reward(self, rollout_input_ids, input_ids):
+        hyp_list = [self.tokenizer.decode(h, skip_special_tokens=True, clean_up_tokenization_spaces=False) for h in rollout_input_ids]
+        ref_list = [self.tokenizer.decode(r, skip_special_tokens=True, clean_up_tokenization_spaces=False) for r in input_ids]
+        reward = [scorer(ref_list, hyp_list)[idx] for scorer, idx in zip(self.scorers, self.scorers_index)]
+        return reward, hyp_list, ref_list
+
+    def __repr__(self):
+        return "SCST\n" + json.dumps({"Scores": str(self.scores), "scores_args": str(self.scores_args),
+                                      "scores_weights": str(self.scores_weights), "Generate": {"top_k": self.top_k}}, indent=4)

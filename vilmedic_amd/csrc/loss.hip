@@ -29,7 +29,8 @@ struct CeBanned { int n; int col[4]; };
 __global__ __launch_bounds__(256) void ce_shift_kernel(const bf16_t* __restrict__ logits, int64_t ldl, const int64_t* __restrict__ ids,
                                                        int L, int V, float* __restrict__ loss_sum, float* __restrict__ row_logp,
                                                        bf16_t* __restrict__ dlogits, float grad_scale,
-                                                       const float* __restrict__ row_weight, CeBanned ban) {
+                                                       const float* __restrict__ row_weight, CeBanned ban,
+                                                       const float* __restrict__ row_min_logit) {
     __shared__ float sh[4];
     const int row = blockIdx.x, t = row % L, b = row / L;
     const int nch = (int)(ldl >> 3);
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(256) void ce_shift_kernel(const bf16_t* __restrict_
     const int label = (int)ids[(int64_t)b * L + t + 1];
     uint4 raw[CE_NCH];
     float mx = -INFINITY;
+    const float thr = row_min_logit ? row_min_logit[row] : -INFINITY;
     auto live = [&](int c) { return c < V && !(ban.n > 0 && (c == ban.col[0] || (ban.n > 1 && c == ban.col[1]) || (ban.n > 2 && c == ban.col[2]) || (ban.n > 3 && c == ban.col[3]))); };
 #pragma unroll
     for (int i = 0; i < CE_NCH; ++i) {
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void ce_shift_kernel(const bf16_t* __restrict_
             float f[8];
             unpack8(raw[i], f);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) if (live(ch * 8 + j)) mx = fmaxf(mx, f[j]);
+            for (int j = 0; j < 8; ++j) if (live(ch * 8 + j) && f[j] >= thr) mx = fmaxf(mx, f[j]);
         }
     }
     mx = block_reduce_max(mx, sh);
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void ce_shift_kernel(const bf16_t* __restrict_
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int c = ch * 8 + j;
-                if (live(c)) { se += __expf(f[j] - mx); if (c == label) lab = f[j]; }
+                if (live(c) && f[j] >= thr) { se += __expf(f[j] - mx); if (c == label) lab = f[j]; }
             }
         }
     }
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void ce_shift_kernel(const bf16_t* __restrict_
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int c = ch * 8 + j;
-                    float g = live(c) ? __expf(f[j] - mx) * inv : 0.f;
+                    float g = (live(c) && f[j] >= thr) ? __expf(f[j] - mx) * inv : 0.f;
                     if (c == label) g -= gs;
                     f[j] = g;
                 }
@@ -103,7 +105,8 @@ __global__ __launch_bounds__(256) void ce_shift_kernel(const bf16_t* __restrict_
 
 extern "C" int vm_ce_shift_fwd_bwd(const void* logits, int64_t ldl, const int64_t* ids, int B, int L, int V,
                                    float* loss_sum, float* row_logp, void* dlogits, float grad_scale,
-                                   const float* row_weight, const int32_t* banned, int n_banned, void* stream) {
+                                   const float* row_weight, const int32_t* banned, int n_banned, const float* row_min_logit,
+                                   void* stream) {
     VM_REQUIRE(logits && ids && loss_sum, "vm_ce_shift_fwd_bwd: null pointer");
     VM_REQUIRE(B > 0 && L > 1 && V > 0 && ldl >= V && (ldl % 8) == 0, "vm_ce_shift_fwd_bwd: bad shape");
     VM_REQUIRE(ldl <= 256 * CE_NCH * 8, "vm_ce_shift_fwd_bwd: vocabulary %d too large (max %d)", V, 256 * CE_NCH * 8);
@@ -113,7 +116,7 @@ extern "C" int vm_ce_shift_fwd_bwd(const void* logits, int64_t ldl, const int64_
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_LOSS, 4.0 * B * L * (double)ldl, s);
     hipLaunchKernelGGL(ce_shift_kernel, dim3(B * L), dim3(256), 0, s, (const bf16_t*)logits, ldl, ids, L, V, loss_sum, row_logp, (bf16_t*)dlogits,
-                       grad_scale, row_weight, ban);
+                       grad_scale, row_weight, ban, row_min_logit);
     return vm_check_launch("vm_ce_shift_fwd_bwd");
 }
 

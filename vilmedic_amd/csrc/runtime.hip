@@ -25,6 +25,7 @@ int vm_check_launch(const char* what) {
 
 extern "C" const char* vm_last_error(void) { return g_err; }
 extern "C" int vm_version(void) { return 100; }
+extern "C" int vm_sizeof_gemm_epilogue(void) { return (int)sizeof(vm_gemm_epilogue); }
 
 // ---------------------------------------------------------------- profiler
 struct ProfSlot { hipEvent_t a, b; int fam; double work; };

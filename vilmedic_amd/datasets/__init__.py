@@ -1,0 +1,66 @@
+"""Minimal dataset side of the batch-dict contract.  The reference's datasets (PIL / torchvision / HF
+tokenizers; vilmedic/datasets/**) are a CPU input pipeline and OUT OF SCOPE; these two classes produce the same batch
+dicts from synthetic or pre-tokenised tensors so that the executors and models run end to end."""
+import torch
+from torch.utils.data import Dataset
+
+
+class _IdTokenizer:
+    """stand-in tokenizer: decode = space-joined ids (enough for decode drivers / SCST rewards on synthetic data)"""
+
+    def __init__(self, vocab_size, cls=0, pad=1, sep=2):
+        self.vocab_size = vocab_size
+        self.cls_token, self.pad_token, self.sep_token = "[CLS]", "[PAD]", "[SEP]"
+        self.vocab = {"[CLS]": cls, "[PAD]": pad, "[SEP]": sep}
+        self.special = {cls, pad, sep}
+
+    def decode(self, ids, skip_special_tokens=True, clean_up_tokenization_spaces=False):
+        ids = ids.tolist() if hasattr(ids, "tolist") else list(ids)
+        return " ".join(str(i) for i in ids if not (skip_special_tokens and i in self.special))
+
+    def get_vocab(self):
+        return self.vocab
+
+
+class SyntheticImSeq(Dataset):
+    """images ~ N(0,1) [3,S,S]; reports: [CLS] U{3..V-1} x U{L/2..L-2} [SEP] [PAD]*   (SURVEY §8d)."""
+
+    def __init__(self, split="train", num_samples=256, image_size=224, vocab_size=30522, tokenizer_max_len=128, seed=0, **kwargs):
+        g = torch.Generator().manual_seed(seed + {"train": 0, "validate": 1, "test": 2}.get(split, 3))
+        self.images = torch.randn(num_samples, 3, image_size, image_size, generator=g)
+        L, V = tokenizer_max_len, vocab_size
+        self.ids = torch.full((num_samples, L), 1, dtype=torch.long)
+        self.mask = torch.zeros(num_samples, L, dtype=torch.long)
+        for b in range(num_samples):
+            n = int(torch.randint(L // 2, L - 1, (1,), generator=g))
+            self.ids[b, 0] = 0
+            self.ids[b, 1:n] = torch.randint(3, V, (n - 1,), generator=g)
+            self.ids[b, n] = 2
+            self.mask[b, :n + 1] = 1
+        self.tokenizer = _IdTokenizer(V)
+        self.tokenizer_max_len = L
+        self.seq = self           # model code reads dl.dataset.seq.tokenizer.vocab_size (RRG.py:16)
+
+    def __len__(self):
+        return len(self.images)
+
+    def __getitem__(self, i):
+        return {"images": self.images[i], "input_ids": self.ids[i], "attention_mask": self.mask[i]}
+
+    def get_collate_fn(self):
+        def collate(items):
+            return {"images": torch.stack([x["images"] for x in items]), "images_mask": None,
+                    "input_ids": torch.stack([x["input_ids"] for x in items]),
+                    "attention_mask": torch.stack([x["attention_mask"] for x in items])}
+        return collate
+
+
+class TensorImSeq(SyntheticImSeq):
+    """pre-processed tensors on disk: ``{root}/{split}.pt`` = dict(images, input_ids, attention_mask, vocab_size)."""
+
+    def __init__(self, root, split="train", **kwargs):
+        d = torch.load(f"{root}/{split}.pt")
+        self.images, self.ids, self.mask = d["images"], d["input_ids"], d["attention_mask"]
+        self.tokenizer = _IdTokenizer(int(d["vocab_size"]))
+        self.tokenizer_max_len = self.ids.shape[1]
+        self.seq = self

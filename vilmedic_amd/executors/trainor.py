@@ -1,0 +1,120 @@
+"""Trainor -- ref: vilmedic/executors/trainor.py:14-203 and trainor_accelerate.py:24-156 (merged: one process per GPU).
+
+Loop semantics kept: forward -> NaN/Inf guard -> backward (loss / grad_accu) -> every grad_accu iterations optional
+clip_grad_norm_, optimizer step, zero_grad, scheduler iteration step; end of epoch: epoch_step, evaluation, early-stop
+score = mean of ``early_stop_metric`` over splits, eval_step, one-best checkpoint
+{model, training_scheduler, optimizer, config, __version__}.
+Differences (MI355X-first): bf16 activations with fp32 master weights instead of fp16 autocast + GradScaler; data
+parallelism = ArenaDDP over RCCL (flat-gradient all-reduce), the NaN-skip decision is taken COLLECTIVELY (the
+reference's per-rank skip would desynchronise DDP collectives); no stray ``break`` after the first
+iteration (reference defect, trainor_accelerate.py:155)."""
+import os
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..arena import arena_of
+from ..config import to_container
+from .utils import (CheckpointSaver, __version__, create_data_loader, create_model, create_optimizer,
+                    create_training_scheduler, get_logger)
+from .validator import Validator
+
+
+class Trainor(object):
+    def __init__(self, config, seed, logger=None):
+        self.config, self.seed = config, seed
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(self.local_rank)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local_rank))
+            self.dist = dist
+        self.logger = logger or get_logger()
+        if self.rank != 0:
+            self.logger.setLevel("WARNING")
+        torch.manual_seed(seed + self.rank)
+        np.random.seed(seed + self.rank)
+        ops.manual_seed(seed + self.rank)
+        self.state = None
+        if config.get("ckpt") is not None:
+            self.state = torch.load(config.ckpt, map_location="cpu")
+        self.ckpt_dir = config.get("ckpt_dir") or "ckpt"
+        os.makedirs(self.ckpt_dir, exist_ok=True)
+        self.dl = create_data_loader(config, "train", self.logger, rank=self.rank, world=self.world)
+        self.model = create_model(config, self.dl, self.logger, from_training=True, state_dict=self.state)
+        self.ddp = None
+        if self.dist is not None:
+            from ..parallel import ArenaDDP
+            self.ddp = ArenaDDP(self.model, self.dist)
+        self.optimizer = create_optimizer(config, self.logger, self.model, state_dict=self.state)
+        self.training_scheduler = create_training_scheduler(config, self.optimizer, self.logger, state_dict=self.state)
+        self.saver = CheckpointSaver(self.ckpt_dir, self.logger, seed, ckpt=config.get("ckpt"))
+        self.grad_accu = int(config.get("grad_accu") or 1)
+        self.clip = config.get("clip_grad_norm")
+        self.eval_start = int(config.get("eval_start") or 0)
+        self.evaluator = Validator(config.validator_view, [self.model], self.dl, seed, True, self.logger, self.rank, self.world) \
+            if config.get("validator_view") is not None else None
+
+    def _all_finite(self, loss):
+        flag = torch.isfinite(loss.detach()).float().reshape(1)
+        if self.dist is not None:
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    def start(self):
+        cfg = self.config
+        for epoch in range(int(self.training_scheduler.epoch), int(cfg.epochs) + 1):
+            self.model.train()
+            losses = []
+            for iteration, batch in enumerate(self.dl, start=1):
+                out = self.model(**batch, epoch=epoch, iteration=iteration)
+                if "loss" not in out:
+                    continue
+                loss = out["loss"].mean()
+                if not self._all_finite(loss):            # trainor.py:109-112, decided collectively
+                    self.logger.warning("NaN/Inf loss: batch skipped on all ranks")
+                    self.optimizer.zero_grad()
+                    continue
+                (loss / self.grad_accu).backward()
+                if iteration % self.grad_accu == 0:
+                    if self.ddp is not None:
+                        self.ddp.finish()
+                    if self.clip is not None:
+                        torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
+                    self.optimizer.step()
+                    self.optimizer.zero_grad()
+                    self.training_scheduler.iteration_step()
+                losses.append(loss.detach())
+                if iteration % 50 == 0 and self.rank == 0:
+                    self.logger.info("Epoch {}, iter {}, lr {:.2e}, loss {:.4f} {}".format(
+                        epoch, iteration, self.optimizer.param_groups[0]["lr"], float(torch.stack(losses[-50:]).mean()),
+                        out.get("custom_print", "")))
+            training_loss = float(torch.stack(losses).mean()) if losses else float("nan")
+            self.logger.info("Epoch {} done: training_loss {:.4f}".format(epoch, training_loss))
+            self.training_scheduler.epoch_step()
+            early_stop_score = None
+            if self.evaluator is not None and epoch >= self.eval_start:
+                self.evaluator.epoch = epoch
+                scores = self.evaluator.start()
+                metric = cfg.get("early_stop_metric")
+                if metric == "training_loss":
+                    early_stop_score = training_loss
+                else:
+                    vals = [s[metric] for s in scores if metric in s]
+                    early_stop_score = float(np.mean(vals)) if vals else None
+            elif cfg.get("early_stop_metric") == "training_loss":
+                early_stop_score = training_loss
+            ret = self.training_scheduler.eval_step(decay_metric=training_loss if self.training_scheduler.decay_on_training_loss
+                                                    else early_stop_score, early_stop_score=early_stop_score)
+            if ret["save_state"] and self.rank == 0:
+                self.saver.save({"model": self.model.state_dict(), "training_scheduler": self.training_scheduler.state_dict(),
+                                 "optimizer": self.optimizer.state_dict(), "config": to_container(cfg), "__version__": __version__},
+                                tag=early_stop_score, current_epoch=epoch)
+            if ret["done_training"]:
+                self.logger.info("Early stopped reached")
+                break

@@ -1,0 +1,33 @@
+"""Validator -- ref: vilmedic/executors/validator.py:52-114 (eval_func dispatch under no_grad; metrics reduced to the
+loss and the decode outputs -- the reference's text scorers are CPU metrics over absent packages)."""
+import torch
+
+from .utils import create_data_loader, get_eval_func
+
+
+class Validator(object):
+    def __init__(self, config, models, train_dl, seed, from_training, logger, rank=0, world=1):
+        self.config, self.models, self.seed, self.from_training, self.logger = config, models, seed, from_training, logger
+        self.epoch = 0
+        self.splits = [(s, create_data_loader(config, s, logger, called_by_validator=True, rank=rank, world=world))
+                       for s in (config.get("splits") or ["validate"])]
+        self.scores = []
+
+    def start(self):
+        models = [m.eval() for m in self.models]
+        eval_func = get_eval_func(models)
+        self.scores = []
+        with torch.no_grad():
+            for split, dl in self.splits:
+                self.logger.info("Running split: {} by ensembling {} models. Using {}.".format(split, len(models), eval_func.__name__))
+                results = eval_func(models, self.config, dl, from_training=self.from_training)
+                scores = {}
+                if "loss" in results:
+                    scores["validation_loss"] = float(results["loss"])
+                if "refs" in results and "hyps" in results and isinstance(results["hyps"], list):
+                    from ..blocks.scorers import RougeL
+                    scores["ROUGEL"] = RougeL()(results["refs"], results["hyps"])[0]
+                    scores["n_hyps"] = len(results["hyps"])
+                self.scores.append(scores)
+                self.logger.info(str({k: round(v, 4) if isinstance(v, float) else v for k, v in scores.items()}))
+        return self.scores

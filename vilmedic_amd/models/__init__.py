@@ -1,0 +1,22 @@
+"""ref: vilmedic/models/__init__.py:5-17 -- the class names ``eval(proto)`` resolves (executors/utils.py:110)."""
+from .mvqa.MVQA import MVQA  # noqa: F401
+from .rrg.RRG import RRG  # noqa: F401
+from .rrg.RRG_SCST import RRG_SCST  # noqa: F401
+from .selfsup.conVIRT import ConVIRT  # noqa: F401
+
+
+class _OutOfScope:
+    def __init__(self, *a, **k):
+        raise NotImplementedError(f"{type(self).__name__} is outside the MI355X hot path of this build (SURVEY §2 / §8)")
+
+
+class RRS_HF(_OutOfScope):
+    pass
+
+
+class RRG_HF(_OutOfScope):
+    pass
+
+
+class GLoRIA(_OutOfScope):
+    pass

@@ -1,0 +1,56 @@
+"""ConVIRT -- ref: vilmedic/models/selfsup/conVIRT.py:13-109."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ...arena import arena_of
+from ...blocks.huggingface.encoder.encoder_model import EncoderModel
+from ...blocks.losses import ConVIRTLoss, InfoNCELoss  # noqa: F401  (eval(proto) namespace)
+from ...blocks.vision import *  # noqa: F401,F403
+from ..utils import get_n_params
+
+
+def evaluation(models, config, dl, from_training, **kwargs):
+    model = models[0]
+    losses, linguistics, visuals = [], [], []
+    for batch in dl:
+        batch = {k: v.cuda() if isinstance(v, torch.Tensor) else v for k, v in batch.items()}
+        out = model(**batch)
+        losses.append(out["loss"].mean().cpu().data.numpy())
+        if not from_training:
+            linguistics.append(out["linguistic"].cpu().data)
+            visuals.append(out["visual"].cpu().data)
+    if from_training:
+        return {"loss": np.ndarray.mean(np.array(losses))}
+    return {"loss": np.ndarray.mean(np.array(losses)), "linguistic": torch.cat(linguistics), "visual": torch.cat(visuals)}
+
+
+class ConVIRT(nn.Module):
+    def __init__(self, encoder, cnn, projection, loss, forward_batch_size=256, **kwargs):
+        super().__init__()
+        self.linguistic = EncoderModel(encoder)
+        cnn = dict(cnn)
+        self.visual = eval(cnn.pop("proto"))(**cnn)
+        projection = dict(projection)
+        pd = projection["projection_dim"]
+        self.vis_proj = nn.Sequential(nn.Linear(projection["visual_embedding_dim"], pd), nn.ReLU(), nn.Linear(pd, pd))
+        self.lin_proj = nn.Sequential(nn.Linear(projection["textual_embedding_dim"], pd), nn.ReLU(), nn.Linear(pd, pd))
+        loss = dict(loss)
+        self.loss_fn = eval(loss.pop("proto"))(**loss)
+        self.fbs = forward_batch_size          # kept for config compatibility: the towers run on the whole batch at once
+        self.eval_func = evaluation
+
+    def forward(self, input_ids, attention_mask, images, **kwargs):
+        images, input_ids, attention_mask = images.cuda(), input_ids.cuda(), attention_mask.cuda()
+        arena_of(self).refresh()
+        # the reference chunks the towers into forward_batch_size micro-batches inside ONE autograd graph
+        # (conVIRT.py:83-95) -- numerically identical to a single pass, which is what 288 GB of HBM allows.
+        text = self.linguistic(input_ids=input_ids, attention_mask=attention_mask)
+        linguistics = self.lin_proj(text["pooler_output"].float())
+        vis = self.visual(images)
+        visuals = self.vis_proj(vis.float() if vis.dim() == 2 else vis[:, 0].float())
+        loss, loss_l, loss_v = self.loss_fn(linguistics, visuals)
+        return {"loss": loss, "loss_l": loss_l, "loss_v": loss_v, "linguistic": linguistics, "visual": visuals}
+
+    def __repr__(self):
+        return "ConVIRT\n" + str(self.visual) + "\n" + str(self.linguistic) + "\n" + str(self.loss_fn) + "\n{}\n".format(get_n_params(self))

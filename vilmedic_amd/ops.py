@@ -460,33 +460,46 @@ def patch_embed(anchor, images, w_sh, bias, cls, pos, patch, grads=(None, None, 
 
 # ----------------------------------------------------------------------------- LM head + shifted CE (fused fwd/bwd)
 class LmHeadLossFn(torch.autograd.Function):
-    """logits = h E^T + b (bf16, padded leading dim); loss = mean CE(logits[:, :-1], ids[:, 1:]) with pads INCLUDED
-    (ref: decoder_model.py:46 passes labels=input_ids).  The gradient wrt the logits is produced in the same pass
-    that computes the loss; backward only scales it and runs the dgrad/wgrad GEMMs."""
+    """logits = h E^T + b (bf16, padded leading dim); loss = sum_rows w_row CE(logits[b,t], ids[b,t+1]).
+
+    Default (w = 1/(B(L-1))): mean CE of logits[:, :-1] vs ids[:, 1:] with pads INCLUDED (ref: decoder_model.py:46 passes
+    labels=input_ids).  With ``row_weight`` / ``banned`` / ``top_k`` it is the SCST policy-gradient loss
+    (ref: blocks/rl/SCST.py:14-45,142-170).  The gradient wrt the logits is produced in the same pass that computes the
+    loss; backward only runs the dgrad / wgrad GEMMs, with dL/dloss folded in through a device scalar."""
 
     @staticmethod
-    def forward(ctx, h, emb_sh, bias, ids, V, g_emb, g_bias, want_logits):
+    def forward(ctx, h, emb_sh, bias, ids, V, g_emb, g_bias, want_logits, row_weight, banned, top_k):
         B, L, D = h.shape
         Vp = emb_sh.shape[0]
         h2 = _2d(h)
         logits = torch.empty(B * L, Vp, dtype=BF16, device=h.device)
         gemm(h2, 0, emb_sh, 0, logits, B * L, V, D, bias=bias)
         loss_sum = torch.zeros(1, dtype=torch.float32, device=h.device)
-        inv = 1.0 / (B * (L - 1))
+        inv = 1.0 / (B * (L - 1)) if row_weight is None else 1.0
         need_grad = h.requires_grad or g_emb is not None
         dlogits = (torch.empty_like(logits) if want_logits else logits) if need_grad else None
-        check(lib().vm_ce_shift_fwd_bwd(ptr(logits), Vp, ptr(ids), B, L, V, ptr(loss_sum), None,
-                                        ptr(dlogits) if dlogits is not None else None, inv, None, None, 0, stream()),
-              "vm_ce_shift_fwd_bwd")
+        row_logp = torch.empty(B * L, dtype=torch.float32, device=h.device)
+        thr = None
+        if top_k:
+            lv = logits[:, :V].float()
+            if banned:
+                lv[:, list(banned)] = -float("inf")
+            thr = torch.topk(lv, min(top_k, V), dim=-1)[0][:, -1].contiguous()
+        ban = (C.c_int32 * 4)(*(list(banned) + [0] * (4 - len(banned)))) if banned else None
+        check(lib().vm_ce_shift_fwd_bwd(ptr(logits), Vp, ptr(ids), B, L, V, ptr(loss_sum), ptr(row_logp),
+                                        ptr(dlogits) if dlogits is not None else None, inv,
+                                        ptr(row_weight) if row_weight is not None else None, ban, len(banned) if banned else 0,
+                                        ptr(thr) if thr is not None else None, stream()), "vm_ce_shift_fwd_bwd")
         ctx.save_for_backward(h2, emb_sh, dlogits)
         ctx.meta = (B, L, D, V, Vp, g_emb, g_bias)
         loss = (loss_sum * inv).squeeze(0)
         out_logits = logits.view(B, L, Vp)[..., :V] if want_logits else None
-        ctx.mark_non_differentiable(*( [out_logits] if out_logits is not None else []))
-        return loss, out_logits
+        row_logp = row_logp.view(B, L)
+        ctx.mark_non_differentiable(row_logp, *([out_logits] if out_logits is not None else []))
+        return loss, out_logits, row_logp
 
     @staticmethod
-    def backward(ctx, dloss, _dlogits_unused):
+    def backward(ctx, dloss, _dlogits_unused, _dlogp_unused):
         h2, emb_sh, dlogits = ctx.saved_tensors
         B, L, D, V, Vp, g_emb, g_bias = ctx.meta
         # dloss (dL/dloss, a device scalar: 1 for loss.backward(), 1/grad_accu or a loss scale otherwise) is folded
@@ -501,11 +514,12 @@ class LmHeadLossFn(torch.autograd.Function):
         if g_emb is not None:
             wgrad(dlogits, h2, g_emb, alpha_dev=sc)   # dE[V,D] += dlogits^T h (pad columns of dlogits are zero)
             colsum(dlogits, g_bias, rows=M, cols=V, scale_dev=sc)
-        return dh, None, None, None, None, None, None, None
+        return (dh,) + (None,) * 10
 
 
-def lm_head_loss(h, emb_sh, bias, ids, V, g_emb=None, g_bias=None, want_logits=True):
-    return LmHeadLossFn.apply(h, emb_sh, bias, ids, V, g_emb, g_bias, want_logits)
+def lm_head_loss(h, emb_sh, bias, ids, V, g_emb=None, g_bias=None, want_logits=True, row_weight=None, banned=None, top_k=None):
+    """-> (loss, logits or None, row_logp [B,L] = log p(ids[b,t+1] | prefix) under the filtered distribution)"""
+    return LmHeadLossFn.apply(h, emb_sh, bias, ids, V, g_emb, g_bias, want_logits, row_weight, banned, top_k)
 
 
 def lm_logits_f32(h2, emb_sh, bias, V):

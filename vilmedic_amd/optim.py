@@ -39,9 +39,12 @@ class FusedAdam(torch.optim.Optimizer):
         a.mark_shadow_fresh()
 
     def state_dict(self):
-        return {"m": self.m, "v": self.v, "steps": self.steps, "param_groups": self.param_groups}
+        groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
+        return {"m": self.m, "v": self.v, "steps": self.steps, "param_groups": groups}
 
     def load_state_dict(self, sd):
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
         self.steps = sd["steps"]
+        for g, saved in zip(self.param_groups, sd.get("param_groups", [])):
+            g.update({k: v for k, v in saved.items() if k != "params"})
