@@ -111,9 +111,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("VM_FORCE_DDP"):      # VM_FORCE_DDP: exercise the RCCL path on a single GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from vilmedic_amd import ops
@@ -124,7 +125,7 @@ def main():
     model = build_model(device)
     model.train()
     ops.manual_seed(1234 + rank)
-    ddp = ArenaDDP(model, dist) if world > 1 else None
+    ddp = ArenaDDP(model, dist) if dist is not None else None
     opt = FusedAdam(model, lr=1e-4)
     B, L, V = args.batch, args.seq, DEC_12L["vocab_size"]
     images, ids, am = synthetic_batch(B, L, V, device, seed=rank)
@@ -132,9 +133,10 @@ def main():
     def step():
         out = model(input_ids=ids, attention_mask=am, images=images, return_logits=False)
         opt.zero_grad()
-        out["loss"].backward()
         if ddp is not None:
-            ddp.finish()
+            ddp.backward(out["loss"])        # two-phase backward: decoder all-reduce overlaps the ViT backward
+        else:
+            out["loss"].backward()
         opt.step()
         return out["loss"]
 
@@ -156,7 +158,7 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     roof = None
     if not args.no_roofline and rank == 0:
@@ -178,6 +180,8 @@ def main():
                 "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                 "launches_per_step": gn // 2, "avg_launch_ms": round(gms / max(gn, 1), 4),
                 "family_ms_per_step": {k: round(v[0] / 2, 3) for k, v in fam.items()}}
+        if os.environ.get("VM_PROF_DUMP"):
+            L_.vm_prof_dump(os.environ["VM_PROF_DUMP"].encode())
         L_.vm_prof_reset()
 
     cpu = None

@@ -37,6 +37,7 @@ int vm_prof_enable(int on);
 int vm_prof_reset(void);
 /* family: 0 gemm, 1 attention, 2 layernorm, 3 loss, 4 elementwise, 5 optimizer, 6 decode */
 int vm_prof_read(int family, double* ms_total, double* work_total, int64_t* launches); /* syncs events */
+int vm_prof_dump(const char* path);  /* per-shape breakdown: "family tag launches total_ms total_work" per line */
 
 /* ------------------------------------------------------------------ GEMM (MFMA bf16)
  * C[M,N] = epilogue( sum_k opA(A)[m,k] * opB(B)[n,k] )

@@ -134,38 +134,51 @@ static int test_ln(int rows, int cols) {
     return bad != 0;
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc >= 8 && !strcmp(argv[1], "bench")) {   // gpu_probe.bin bench M N K la lb split   (for rocprofv3 --pmc runs)
+        for (int dbg = 0; dbg < 3; ++dbg) {
+            char b[4]; snprintf(b, 4, "%d", dbg); setenv("VM_GEMM_DEBUG", b, 1);
+            printf("dbg=%d ", dbg);
+            bench_gemm(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]));
+        }
+        return 0;
+    }
     short* d; hipMalloc(&d, 256 * 2);
     hipLaunchKernelGGL(tr_probe, dim3(1), dim3(64), 0, 0, d);
     short h[256]; hipMemcpy(h, d, 512, hipMemcpyDeviceToHost);
     printf("ds_read_b64_tr_b16 with lane l -> &lds[4l] (values are source element indices):\n");
     for (int l = 0; l < 64; ++l) { printf("  lane %2d: %4d %4d %4d %4d%s", l, h[l * 4], h[l * 4 + 1], h[l * 4 + 2], h[l * 4 + 3], (l & 3) == 3 ? "\n" : ""); }
     int fails = 0;
-    for (int la = 0; la < 2; ++la) for (int lb = 0; lb < 2; ++lb) {
-        fails += test_gemm(200, 136, 192, la, lb, 1, false);
-        fails += test_gemm(128, 128, 64, la, lb, 1, true);
-        fails += test_gemm(333, 97, 104, la, lb, 1, true);
+    for (int variant = 0; variant < 2; ++variant) {
+        setenv("VM_GEMM_VARIANT", variant ? "1" : "0", 1);
+        printf("---- VM_GEMM_VARIANT=%d correctness\n", variant);
+        for (int la = 0; la < 2; ++la) for (int lb = 0; lb < 2; ++lb) {
+            fails += test_gemm(200, 136, 192, la, lb, 1, false);
+            fails += test_gemm(128, 128, 64, la, lb, 1, true);
+            fails += test_gemm(333, 97, 104, la, lb, 1, true);
+            fails += test_gemm(700, 260, 448, la, lb, 1, true);
+        }
+        fails += test_gemm(256, 256, 1024, 1, 1, 4, true);
+        fails += test_gemm(1000, 768, 768, 0, 0, 1, false);
     }
-    fails += test_gemm(256, 256, 1024, 1, 1, 4, true);
-    fails += test_gemm(1000, 768, 768, 0, 0, 1, false);
+    unsetenv("VM_GEMM_VARIANT");
     fails += test_ln(1000, 768);
     fails += test_ln(37, 64);
     fails += test_ln(50, 1664);
-    bench_gemm(12608, 3072, 768, 0, 0);
-    bench_gemm(12608, 768, 3072, 0, 0);
-    bench_gemm(12608, 768, 3072, 0, 1);
-    bench_gemm(3072, 768, 12608, 1, 1);
-    bench_gemm(8192, 30528, 768, 0, 0);
-    bench_gemm(8192, 8192, 8192, 0, 0);
-    bench_gemm(8192, 8192, 8192, 0, 1);
-    bench_gemm(8192, 8192, 8192, 1, 1);
-    bench_gemm(768, 768, 12608, 1, 1, 8);
-    bench_gemm(768, 768, 12608, 1, 1, 14);
-    bench_gemm(3072, 768, 12608, 1, 1, 4);
-    bench_gemm(2304, 768, 8192, 1, 1, 4);
-    bench_gemm(8192, 768, 768, 0, 0);
-    bench_gemm(8192, 768, 768, 0, 1);
-    bench_gemm(12608, 2304, 768, 0, 0);
+    struct { int M, N, K, la, lb, split; } shapes[] = {
+        {12608, 2304, 768, 0, 0, 1}, {12608, 768, 768, 0, 0, 1}, {12608, 3072, 768, 0, 0, 1}, {12608, 768, 3072, 0, 0, 1},
+        {8192, 2304, 768, 0, 0, 1}, {8192, 768, 768, 0, 0, 1}, {8192, 3072, 768, 0, 0, 1}, {8192, 768, 3072, 0, 0, 1},
+        {12608, 1536, 768, 0, 0, 1}, {8192, 30528, 768, 0, 0, 1},
+        {12608, 768, 2304, 0, 1, 1}, {12608, 768, 768, 0, 1, 1}, {12608, 768, 3072, 0, 1, 1}, {12608, 3072, 768, 0, 1, 1},
+        {8192, 768, 30528, 0, 1, 1},
+        {2304, 768, 12608, 1, 1, 2}, {768, 768, 12608, 1, 1, 8}, {768, 768, 12608, 1, 1, 14}, {3072, 768, 12608, 1, 1, 2}, {3072, 768, 12608, 1, 1, 4},
+        {768, 3072, 12608, 1, 1, 4}, {30528, 768, 8192, 1, 1, 1}, {8192, 8192, 8192, 0, 0, 1}, {8192, 8192, 8192, 1, 1, 1},
+    };
+    for (auto& sh : shapes) for (int variant = 0; variant < 2; ++variant) {
+        setenv("VM_GEMM_VARIANT", variant ? "1" : "0", 1);
+        printf("v%d ", variant);
+        bench_gemm(sh.M, sh.N, sh.K, sh.la, sh.lb, sh.split);
+    }
     printf("fails=%d\n", fails);
     return fails;
 }

@@ -35,6 +35,7 @@ SIGNATURES = {
     "vm_prof_reset": (_I, []),
     "vm_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "vm_sizeof_gemm_epilogue": (_I, []),
+    "vm_prof_dump": (_I, [C.c_char_p]),
     "vm_gemm_bf16": (_I, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, C.POINTER(GemmEpilogue), _P]),
     "vm_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "vm_layernorm_bwd_ws": (_SZ, [_I, _I]),

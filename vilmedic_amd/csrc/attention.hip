@@ -128,10 +128,13 @@ __device__ __forceinline__ void store_t_acc(bf16_t* rowptr, const float4_t (&acc
 }
 
 // =============================================================================== forward
-template <int DH>
+// RES = true: every K/V tile of the (b,h) pair is resident in LDS (Lk <= 256): one barrier for the whole kernel, all
+// HBM loads issued up front; RES = false: tiles stream through one LDS slot with a register prefetch (any Lk).
+template <int DH, bool RES>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES + 64];
-    char* sk = smem; char* sv = smem + TILE_BYTES; uint8_t* smask = reinterpret_cast<uint8_t*>(smem + 2 * TILE_BYTES);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NSLOT = RES ? 4 : 1;
+    uint8_t* smask_all = reinterpret_cast<uint8_t*>(smem + NSLOT * 2 * TILE_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64 + wave * 16;
     const int qrow = q0 + c;
@@ -152,20 +155,38 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     const int32_t* kvi = p.kv_index ? p.kv_index + (int64_t)b * p.kv_index_ld : nullptr;
     const bf16_t* k0p = p.k + h * DH;
     const bf16_t* v0p = p.v + h * DH;
-    if (kvi) { rk = tile_load_indexed<DH>(k0p, p.ldk, kvi, 0, p.Lk, tid); rv = tile_load_indexed<DH>(v0p, p.ldv, kvi, 0, p.Lk, tid); }
-    else { rk = tile_load<DH>(kbase, p.ldk, 0, p.Lk, tid); rv = tile_load<DH>(vbase, p.ldv, 0, p.Lk, tid); }
-    for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();                       // previous tile fully consumed
-        tile_store<DH>(rk, sk, tid);
-        tile_store<DH>(rv, sv, tid);
-        if (tid < 64) {
-            const int key = kt * TROWS + tid;
-            smask[tid] = (p.key_mask && key < p.Lk) ? p.key_mask[(int64_t)b * p.Lk + key] : (uint8_t)1;
+    auto load_kv = [&](int t) {
+        if (kvi) { rk = tile_load_indexed<DH>(k0p, p.ldk, kvi, t * TROWS, p.Lk, tid); rv = tile_load_indexed<DH>(v0p, p.ldv, kvi, t * TROWS, p.Lk, tid); }
+        else { rk = tile_load<DH>(kbase, p.ldk, t * TROWS, p.Lk, tid); rv = tile_load<DH>(vbase, p.ldv, t * TROWS, p.Lk, tid); }
+    };
+    if (RES) {
+        for (int t = 0; t < ntiles; ++t) {
+            load_kv(t);
+            tile_store<DH>(rk, smem + t * 2 * TILE_BYTES, tid);
+            tile_store<DH>(rv, smem + t * 2 * TILE_BYTES + TILE_BYTES, tid);
+        }
+        {
+            const int key = tid;     // 256 threads cover up to 256 keys
+            smask_all[tid] = (p.key_mask && key < p.Lk) ? p.key_mask[(int64_t)b * p.Lk + key] : (uint8_t)1;
         }
         __syncthreads();
-        if (kt + 1 < ntiles) {
-            if (kvi) { rk = tile_load_indexed<DH>(k0p, p.ldk, kvi, (kt + 1) * TROWS, p.Lk, tid); rv = tile_load_indexed<DH>(v0p, p.ldv, kvi, (kt + 1) * TROWS, p.Lk, tid); }
-            else { rk = tile_load<DH>(kbase, p.ldk, (kt + 1) * TROWS, p.Lk, tid); rv = tile_load<DH>(vbase, p.ldv, (kt + 1) * TROWS, p.Lk, tid); }
+    } else {
+        load_kv(0);
+    }
+    for (int kt = 0; kt < ntiles; ++kt) {
+        char* sk = RES ? smem + kt * 2 * TILE_BYTES : smem;
+        char* sv = sk + TILE_BYTES;
+        uint8_t* smask = RES ? smask_all + kt * TROWS : smask_all;
+        if (!RES) {
+            __syncthreads();                   // previous tile fully consumed
+            tile_store<DH>(rk, sk, tid);
+            tile_store<DH>(rv, sv, tid);
+            if (tid < 64) {
+                const int key = kt * TROWS + tid;
+                smask[tid] = (p.key_mask && key < p.Lk) ? p.key_mask[(int64_t)b * p.Lk + key] : (uint8_t)1;
+            }
+            __syncthreads();
+            if (kt + 1 < ntiles) load_kv(kt + 1);
         }
         float4_t s[4];
 #pragma unroll
@@ -254,10 +275,11 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs p, int D
 }
 
 // =============================================================================== dQ  (owner: 16 queries per wave)
-template <int DH>
+template <int DH, bool RES>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES + 64];
-    char* sk = smem; char* sv = smem + TILE_BYTES; uint8_t* smask = reinterpret_cast<uint8_t*>(smem + 2 * TILE_BYTES);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NSLOT = RES ? 4 : 1;
+    uint8_t* smask_all = reinterpret_cast<uint8_t*>(smem + NSLOT * 2 * TILE_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64 + wave * 16;
     const int qrow = q0 + c;
@@ -280,20 +302,35 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
     int ntiles = (p.Lk + TROWS - 1) / TROWS;
     if (p.causal) ntiles = min(ntiles, min((int)blockIdx.x * 64 + 63, p.Lq - 1) / TROWS + 1);
     Stage<DH> rk, rv;
-    rk = tile_load<DH>(kbase, p.ldk, 0, p.Lk, tid);
-    rv = tile_load<DH>(vbase, p.ldv, 0, p.Lk, tid);
-    for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();
-        tile_store<DH>(rk, sk, tid);
-        tile_store<DH>(rv, sv, tid);
-        if (tid < 64) {
-            const int key = kt * TROWS + tid;
-            smask[tid] = (p.key_mask && key < p.Lk) ? p.key_mask[(int64_t)b * p.Lk + key] : (uint8_t)1;
+    auto load_kv = [&](int t) {
+        rk = tile_load<DH>(kbase, p.ldk, t * TROWS, p.Lk, tid);
+        rv = tile_load<DH>(vbase, p.ldv, t * TROWS, p.Lk, tid);
+    };
+    if (RES) {
+        for (int t = 0; t < ntiles; ++t) {
+            load_kv(t);
+            tile_store<DH>(rk, smem + t * 2 * TILE_BYTES, tid);
+            tile_store<DH>(rv, smem + t * 2 * TILE_BYTES + TILE_BYTES, tid);
         }
+        smask_all[tid] = (p.key_mask && tid < p.Lk) ? p.key_mask[(int64_t)b * p.Lk + tid] : (uint8_t)1;
         __syncthreads();
-        if (kt + 1 < ntiles) {
-            rk = tile_load<DH>(kbase, p.ldk, (kt + 1) * TROWS, p.Lk, tid);
-            rv = tile_load<DH>(vbase, p.ldv, (kt + 1) * TROWS, p.Lk, tid);
+    } else {
+        load_kv(0);
+    }
+    for (int kt = 0; kt < ntiles; ++kt) {
+        char* sk = RES ? smem + kt * 2 * TILE_BYTES : smem;
+        char* sv = sk + TILE_BYTES;
+        uint8_t* smask = RES ? smask_all + kt * TROWS : smask_all;
+        if (!RES) {
+            __syncthreads();
+            tile_store<DH>(rk, sk, tid);
+            tile_store<DH>(rv, sv, tid);
+            if (tid < 64) {
+                const int key = kt * TROWS + tid;
+                smask[tid] = (p.key_mask && key < p.Lk) ? p.key_mask[(int64_t)b * p.Lk + key] : (uint8_t)1;
+            }
+            __syncthreads();
+            if (kt + 1 < ntiles) load_kv(kt + 1);
         }
         float4_t s[4], dp[4];
 #pragma unroll
@@ -333,11 +370,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
 }
 
 // =============================================================================== dK, dV  (owner: 16 keys per wave)
-template <int DH>
+template <int DH, bool RES>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES + 3 * 64 * 4];
-    char* sq = smem; char* sdo = smem + TILE_BYTES;
-    float* sm = reinterpret_cast<float*>(smem + 2 * TILE_BYTES); float* sil = sm + 64; float* sdl = sm + 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NSLOT = RES ? 4 : 1;
+    float* stat_all = reinterpret_cast<float*>(smem + NSLOT * 2 * TILE_BYTES);   // [3][NSLOT*64]: m, 1/l, delta
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64 + wave * 16;
     const int key = k0 + c;
@@ -356,27 +393,42 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     const int ntiles = (p.Lq + TROWS - 1) / TROWS;
     const int t_begin = p.causal ? (int)blockIdx.x : 0;   // queries < first key of the block see none of its keys
     Stage<DH> rq, rdo;
-    if (t_begin < ntiles) {
-        rq = tile_load<DH>(qbase, p.ldq, t_begin * TROWS, p.Lq, tid);
-        rdo = tile_load<DH>(dobase, p.lddo, t_begin * TROWS, p.Lq, tid);
+    auto load_q = [&](int t) {
+        rq = tile_load<DH>(qbase, p.ldq, t * TROWS, p.Lq, tid);
+        rdo = tile_load<DH>(dobase, p.lddo, t * TROWS, p.Lq, tid);
+    };
+    auto load_stats = [&](int qr, int slot) {
+        float mm = 0.f, il = 0.f, dl = 0.f;
+        if (qr < p.Lq) {
+            const int64_t si = (int64_t)(b * p.H + h) * p.Lq + qr;
+            mm = p.stats[si * 2]; il = 1.0f / p.stats[si * 2 + 1]; dl = p.delta[si];
+        }
+        stat_all[slot] = mm; stat_all[NSLOT * 64 + slot] = il; stat_all[2 * NSLOT * 64 + slot] = dl;
+    };
+    if (RES) {
+        for (int t = t_begin; t < ntiles; ++t) {
+            load_q(t);
+            tile_store<DH>(rq, smem + t * 2 * TILE_BYTES, tid);
+            tile_store<DH>(rdo, smem + t * 2 * TILE_BYTES + TILE_BYTES, tid);
+        }
+        load_stats(tid, tid);
+        __syncthreads();
+    } else if (t_begin < ntiles) {
+        load_q(t_begin);
     }
     for (int qt = t_begin; qt < ntiles; ++qt) {
-        __syncthreads();
-        tile_store<DH>(rq, sq, tid);
-        tile_store<DH>(rdo, sdo, tid);
-        if (tid < 64) {
-            const int qr = qt * TROWS + tid;
-            float mm = 0.f, il = 0.f, dl = 0.f;
-            if (qr < p.Lq) {
-                const int64_t si = (int64_t)(b * p.H + h) * p.Lq + qr;
-                mm = p.stats[si * 2]; il = 1.0f / p.stats[si * 2 + 1]; dl = p.delta[si];
-            }
-            sm[tid] = mm; sil[tid] = il; sdl[tid] = dl;
-        }
-        __syncthreads();
-        if (qt + 1 < ntiles) {
-            rq = tile_load<DH>(qbase, p.ldq, (qt + 1) * TROWS, p.Lq, tid);
-            rdo = tile_load<DH>(dobase, p.lddo, (qt + 1) * TROWS, p.Lq, tid);
+        char* sq = RES ? smem + qt * 2 * TILE_BYTES : smem;
+        char* sdo = sq + TILE_BYTES;
+        float* sm = stat_all + (RES ? qt * TROWS : 0);
+        float* sil = sm + NSLOT * 64;
+        float* sdl = sm + 2 * NSLOT * 64;
+        if (!RES) {
+            __syncthreads();
+            tile_store<DH>(rq, sq, tid);
+            tile_store<DH>(rdo, sdo, tid);
+            if (tid < 64) load_stats(qt * TROWS + tid, tid);
+            __syncthreads();
+            if (qt + 1 < ntiles) load_q(qt + 1);
         }
         float4_t s[4], dp[4];
 #pragma unroll
@@ -428,6 +480,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     }
 }
 
+static size_t attn_lds(int dh, bool res, int extra) { return (size_t)(res ? 4 : 1) * 2 * 64 * (dh * 2 + 16) + extra; }
+template <typename K>
+static void launch_attn(K kernel, dim3 grid, size_t lds, hipStream_t s, const AttnArgs& a) {
+    if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, a);
+}
+
 static int check_common(const char* fn, int B, int H, int Lq, int Lk, int dh, int64_t ld0, int64_t ld1, int64_t ld2, int64_t ld3) {
     VM_REQUIRE(dh == 32 || dh == 64 || dh == 96 || dh == 128, "%s: head dim %d unsupported (32, 64, 96 or 128)", fn, dh);
     VM_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "%s: empty problem", fn);
@@ -452,12 +511,11 @@ extern "C" int vm_attention_fwd(const void* q, int64_t ldq, const void* k, int64
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_ATTN, 4.0 * B * H * (double)Lq * Lk * dh, s);
     const dim3 grid((Lq + 63) / 64, H, B);
-    switch (dh) {
-        case 32: hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, s, a); break;
-        case 64: hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, s, a); break;
-        case 96: hipLaunchKernelGGL(attn_fwd_kernel<96>, grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), 0, s, a); break;
-    }
+    const bool res = Lk <= 256;
+#define LAUNCH_FWD(D) do { if (res) launch_attn(attn_fwd_kernel<D, true>, grid, attn_lds(D, true, 256), s, a); \
+                           else launch_attn(attn_fwd_kernel<D, false>, grid, attn_lds(D, false, 64), s, a); } while (0)
+    switch (dh) { case 32: LAUNCH_FWD(32); break; case 64: LAUNCH_FWD(64); break; case 96: LAUNCH_FWD(96); break; default: LAUNCH_FWD(128); break; }
+#undef LAUNCH_FWD
     return vm_check_launch("vm_attention_fwd");
 }
 
@@ -484,11 +542,13 @@ extern "C" int vm_attention_bwd(const void* q, int64_t ldq, const void* k, int64
     const int64_t rows = (int64_t)B * H * Lq;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, a, dh);
     const dim3 gq((Lq + 63) / 64, H, B), gk((Lk + 63) / 64, H, B);
-    switch (dh) {
-        case 32: hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, gq, dim3(256), 0, s, a); hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, gk, dim3(256), 0, s, a); break;
-        case 64: hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), 0, s, a); hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(256), 0, s, a); break;
-        case 96: hipLaunchKernelGGL(attn_bwd_dq_kernel<96>, gq, dim3(256), 0, s, a); hipLaunchKernelGGL(attn_bwd_dkv_kernel<96>, gk, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, dim3(256), 0, s, a); hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, gk, dim3(256), 0, s, a); break;
-    }
+    const bool resk = Lk <= 256, resq = Lq <= 256;
+#define LAUNCH_BWD(D) do { \
+        if (resk) launch_attn(attn_bwd_dq_kernel<D, true>, gq, attn_lds(D, true, 256), s, a); \
+        else launch_attn(attn_bwd_dq_kernel<D, false>, gq, attn_lds(D, false, 64), s, a); \
+        if (resq) launch_attn(attn_bwd_dkv_kernel<D, true>, gk, attn_lds(D, true, 3 * 256 * 4), s, a); \
+        else launch_attn(attn_bwd_dkv_kernel<D, false>, gk, attn_lds(D, false, 3 * 64 * 4), s, a); } while (0)
+    switch (dh) { case 32: LAUNCH_BWD(32); break; case 64: LAUNCH_BWD(64); break; case 96: LAUNCH_BWD(96); break; default: LAUNCH_BWD(128); break; }
+#undef LAUNCH_BWD
     return vm_check_launch("vm_attention_bwd");
 }

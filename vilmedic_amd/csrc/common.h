@@ -78,7 +78,7 @@ enum { VM_FAM_GEMM = 0, VM_FAM_ATTN = 1, VM_FAM_LN = 2, VM_FAM_LOSS = 3, VM_FAM_
 // RAII-ish profiler hook: records HIP events on `stream` around a launch when profiling is on.
 struct VmProfScope {
     int fam; hipStream_t s; void* slot;
-    VmProfScope(int family, double work, hipStream_t stream);
+    VmProfScope(int family, double work, hipStream_t stream, const char* tag_fmt = nullptr, ...);
     ~VmProfScope();
 };
 

@@ -284,17 +284,27 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
     a.drop_scale = epi->dropout_p > 0.f ? 1.0f / (1.0f - epi->dropout_p) : 1.0f;
     const int nblocks = a.tiles_m * a.tiles_n * split;
     hipStream_t s = (hipStream_t)stream;
-    VmProfScope prof(VM_FAM_GEMM, 2.0 * (double)M * (double)N * (double)K, s);
-    const bool fast_ok = (K % 64) == 0 && (ldc % 4) == 0 && (!epi->bias || ((uintptr_t)epi->bias % 16) == 0) &&
-                         (!epi->residual || (epi->ldr % 4) == 0) && !getenv("VM_GEMM_GENERIC");
+    VmProfScope prof(VM_FAM_GEMM, 2.0 * (double)M * (double)N * (double)K, s, "M%d_N%d_K%d_l%d%d_sk%d_b%d_a%d_z%d_g%d_d%d_r%d_f%d", M, N, K, a_layout, b_layout,
+                     epi->split_k, epi->bias != nullptr, epi->act, epi->aux_out != nullptr, epi->mul_gelu_z != nullptr, epi->dropout_p > 0.f, epi->residual != nullptr, epi->out_dtype == VM_F32);
+    const bool fast_ok = (K % 64) == 0 && (ldc % 8) == 0 && (!epi->bias || ((uintptr_t)epi->bias % 16) == 0) &&
+                         (!epi->residual || (epi->ldr % 8) == 0) && !getenv("VM_GEMM_GENERIC");
     a.slabs = nullptr;
+    { const char* d = getenv("VM_GEMM_DEBUG"); a.dbg = d ? atoi(d) : 0; }
     if (fast_ok) {
         if (split > 1) {
             const size_t need = (size_t)split * (size_t)M * (size_t)ldc * sizeof(float);
             VM_REQUIRE(epi->workspace && epi->workspace_bytes >= need, "vm_gemm_bf16: split_k=%d needs a %zu-byte workspace", split, need);
             a.slabs = (float*)epi->workspace;
         }
-        int rc = vm_gemm_fast_dispatch(a, a_layout, b_layout, nblocks, s);
+        // tile variant: 256x128 3-stage ring when it still yields enough workgroups (1 per CU), else 128x128 2-stage
+        int variant = 0;
+        const char* force = getenv("VM_GEMM_VARIANT");
+        const int tiles_m256 = (M + 255) / 256;
+        if (force) variant = atoi(force);
+        else if (K >= 4096 && (int64_t)tiles_m256 * a.tiles_n * split >= 1024) variant = 1;   // measured: only huge square-ish problems gain
+        int nb = nblocks;
+        if (variant == 1) { a.tiles_m = tiles_m256; nb = a.tiles_m * a.tiles_n * split; }
+        int rc = vm_gemm_fast_dispatch(a, a_layout, b_layout, nb, variant, s);
         if (rc == VM_OK && split > 1) rc = vm_gemm_splitk_reduce(a, split, s);
         return rc;
     }

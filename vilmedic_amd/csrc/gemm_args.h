@@ -9,9 +9,10 @@ struct GemmArgs {
     int tiles_m, tiles_n, ktiles, ktiles_per_split;
     vm_gemm_epilogue e;
     uint32_t drop_thresh; float drop_scale;
+    int dbg;                 // VM_GEMM_DEBUG experiments (0 in production): 1 skip epilogue, 2 single K-tile
     float* slabs;            // split-K partial slabs [split][M][ldc] fp32 (fast path), or null
 };
 
 // tuned path (gemm_fast.hip): requires K % 64 == 0
 int vm_gemm_splitk_reduce(const GemmArgs& a, int nsplit, hipStream_t s);
-int vm_gemm_fast_dispatch(const GemmArgs& a, int a_layout, int b_layout, int nblocks, hipStream_t s);
+int vm_gemm_fast_dispatch(const GemmArgs& a, int a_layout, int b_layout, int nblocks, int variant, hipStream_t s);

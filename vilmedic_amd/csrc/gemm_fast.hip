@@ -7,7 +7,8 @@
 //     16 lanes x 2 groups of a ds_read_b64_tr_b16 hit 16 distinct 16-B slots);
 //   * the next K-tile's DMA is issued before the MFMA phase of the current one; one vmcnt(0)+barrier per K-tile;
 //   * MFMA operands are swapped (D^T = B_frag x A_frag) so each lane ends up with 4 CONSECUTIVE output columns of one
-//     row: the epilogue runs straight from registers with 8-B bf16 / 16-B fp32 accesses -- no LDS staging of C.
+//     row; the tile is then staged through LDS (fp32, chunk-swizzled, conflict-free 16-B writes) so that the epilogue
+//     touches HBM only in whole 256-B rows.
 // Out-of-range rows/columns are clamped to valid addresses (they only feed outputs that are never stored); the
 // contraction dim has no tail by construction (K % 64 == 0), so no zero-fill is needed.
 #include "common.h"
@@ -16,29 +17,46 @@
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef short v4s __attribute__((ext_vector_type(4)));
 
-#define FBM 128
 #define FBN 128
 #define FBK 64
-#define F_OPER 16384
-#define F_STAGE (2 * F_OPER)
-#define F_LDS (2 * F_STAGE)
+#define F_OPER_B 16384                      // B tile: 128 rows x 64 k x 2 B
+// template parameters: WM = waves along M (2 -> 128-row tile, 256 threads, 2 workgroups/CU;
+//                                          4 -> 256-row tile, 512 threads, 1 workgroup/CU),
+//                      STAGES = LDS ring depth (2: one tile in flight, vmcnt(0)+barrier per K-tile;
+//                                               3: two tiles in flight, COUNTED vmcnt + raw s_barrier so the DMA of
+//                                                  tiles kt+1, kt+2 stays in flight across the barrier)
 
 __device__ __forceinline__ int swz1(int krow) { return ((krow & 3) << 1) | (((krow >> 3) & 1) << 3); }
 
-template <int LAYOUT>
+template <int LAYOUT, int ROWS>   // ROWS = tile extent along the non-contraction dim (128 or 256)
 __device__ __forceinline__ const bf16_t* stage_src(const bf16_t* base, int64_t ld, int row0, int nrows, int q, int lane) {
-    if (LAYOUT == 0) {                       // tile [128 rows][64 k]: one DMA instruction = 8 rows x 128 B
+    if (LAYOUT == 0) {                       // tile [ROWS][64 k]: one DMA instruction = 8 rows x 128 B
         const int row = 8 * q + (lane >> 3);
         const int lc = (lane & 7) ^ (row & 7);
         const int gr = min(row0 + row, nrows - 1);
         return base + (int64_t)gr * ld + lc * 8;
-    } else {                                 // tile [64 k][128 rows]: one DMA instruction = 4 k-rows x 256 B
-        const int krow = 4 * q + (lane >> 4);
-        const int lc = (lane & 15) ^ swz1(krow);
+    } else {                                 // tile [64 k][ROWS]: one DMA instruction = 1 KiB = 1024/(2*ROWS) k-rows
+        constexpr int LPR = ROWS / 8;        // lanes (16-B chunks) per k-row: 16 or 32
+        const int krow = (64 / LPR) * q + lane / LPR;
+        const int lc = (lane % LPR) ^ swz1(krow);     // swizzle the low 4 chunk bits (256-B bank period)
         int col = row0 + lc * 8;
         if (col >= nrows) col = row0;
         return base + (int64_t)krow * ld + col;
     }
+}
+
+// 16-B output store.  VM_C_STORE_SC1: write-through store that does NOT keep the line in this XCD's L2 (outputs are
+// streamed once; keeping them resident evicts the operand panels the co-resident tiles still re-read).
+#ifndef VM_C_STORE_SC1
+#define VM_C_STORE_SC1 0
+#endif
+__device__ __forceinline__ void st16(void* p, uint4 v) {
+#if VM_C_STORE_SC1
+    const uint4_t vv = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(vv) : "memory");
+#else
+    *reinterpret_cast<uint4*>(p) = v;
+#endif
 }
 
 __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_dst) {
@@ -46,8 +64,10 @@ __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int LA, int LB>
-__global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const GemmArgs p) {
+template <int LA, int LB, int WM, int STAGES>
+__global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_fast_kernel(const GemmArgs p) {
+    constexpr int FBM = WM * 64, NW = 2 * WM, F_OPER_A = FBM * 128, F_STAGE = F_OPER_A + F_OPER_B;
+    constexpr int NB_I = 16 / NW;            // B-tile DMA instructions per wave (A-tile: always 4)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -65,25 +85,25 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const GemmArgs p) {
     const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
     const int m0 = tm * FBM, n0 = tn * FBN;
     const int kt_begin = split * p.ktiles_per_split;
-    const int kt_end = min(p.ktiles, kt_begin + p.ktiles_per_split);
+    int kt_end = min(p.ktiles, kt_begin + p.ktiles_per_split);
     if (kt_begin >= kt_end) return;
+    if (p.dbg == 2) kt_end = kt_begin + 1;
 
     // ---- per-thread DMA sources (4 instructions per operand per wave), advanced by one K-tile per iteration
     const bf16_t* srcA[4];
-    const bf16_t* srcB[4];
+    const bf16_t* srcB[NB_I];
     const int64_t stepA = LA == 0 ? FBK : (int64_t)FBK * p.lda;
     const int64_t stepB = LB == 0 ? FBK : (int64_t)FBK * p.ldb;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        srcA[i] = stage_src<LA>(p.A, p.lda, m0, p.M, wave * 4 + i, lane) + kt_begin * stepA;
-        srcB[i] = stage_src<LB>(p.B, p.ldb, n0, p.N, wave * 4 + i, lane) + kt_begin * stepB;
-    }
+    for (int i = 0; i < 4; ++i) srcA[i] = stage_src<LA, FBM>(p.A, p.lda, m0, p.M, wave * 4 + i, lane) + kt_begin * stepA;
+#pragma unroll
+    for (int i = 0; i < NB_I; ++i) srcB[i] = stage_src<LB, FBN>(p.B, p.ldb, n0, p.N, wave * NB_I + i, lane) + kt_begin * stepB;
     auto stage = [&](int buf) {
-        char* da = smem + buf * F_STAGE + (wave * 4) * 1024;
+        char* da = smem + buf * F_STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { glds16(srcA[i], da + i * 1024); srcA[i] += stepA; }
+        for (int i = 0; i < 4; ++i) { glds16(srcA[i], da + (wave * 4 + i) * 1024); srcA[i] += stepA; }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { glds16(srcB[i], da + F_OPER + i * 1024); srcB[i] += stepB; }
+        for (int i = 0; i < NB_I; ++i) { glds16(srcB[i], da + F_OPER_A + (wave * NB_I + i) * 1024); srcB[i] += stepB; }
     };
 
     // ---- per-lane fragment read offsets
@@ -95,12 +115,12 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const GemmArgs p) {
     auto read_frag0 = [&](const char* tile, int rbase, int i, int kk) -> bf16x8_t {
         return *reinterpret_cast<const bf16x8_t*>(tile + (rbase + i * 16 + c) * 128 + (((kk * 4 + g) ^ (c & 7)) << 4));
     };
-    auto read_frag1 = [&](const char* tile, int rbase, int i, int kk) -> bf16x8_t {
+    auto read_frag1 = [&](const char* tile, int rbase, int i, int kk, int row_bytes) -> bf16x8_t {
         const int krow = kk * 32 + 8 * g + j4;
         const int lc = (rbase >> 3) + 2 * i + h1;
         const int off = ((lc ^ s1) << 4) + sub1;
-        const __attribute__((address_space(3))) v4s* p0 = (const __attribute__((address_space(3))) v4s*)(tile + krow * 256 + off);
-        const __attribute__((address_space(3))) v4s* p1 = (const __attribute__((address_space(3))) v4s*)(tile + (krow + 4) * 256 + off);
+        const __attribute__((address_space(3))) v4s* p0 = (const __attribute__((address_space(3))) v4s*)(tile + krow * row_bytes + off);
+        const __attribute__((address_space(3))) v4s* p1 = (const __attribute__((address_space(3))) v4s*)(tile + (krow + 4) * row_bytes + off);
         v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p0);
         v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p1);
         short8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -113,124 +133,160 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
-    stage(0);
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int buf = (kt - kt_begin) & 1;
-        __syncthreads();                       // (compiler adds vmcnt(0)): tile kt landed for every wave; buf^1 is free
-        if (kt + 1 < kt_end) stage(buf ^ 1);
+    auto compute = [&](int buf) {
         const char* sa = smem + buf * F_STAGE;
-        const char* sb = sa + F_OPER;
+        const char* sb = sa + F_OPER_A;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8_t fa[4], fb[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = LA == 0 ? read_frag0(sa, a_rb, i, kk) : read_frag1(sa, a_rb, i, kk);
+            for (int i = 0; i < 4; ++i) fa[i] = LA == 0 ? read_frag0(sa, a_rb, i, kk) : read_frag1(sa, a_rb, i, kk, FBM * 2);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = LB == 0 ? read_frag0(sb, b_rb, j, kk) : read_frag1(sb, b_rb, j, kk);
+            for (int j = 0; j < 4; ++j) fb[j] = LB == 0 ? read_frag0(sb, b_rb, j, kk) : read_frag1(sb, b_rb, j, kk, FBN * 2);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
         }
+    };
+    if (STAGES == 2) {
+        stage(0);
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const int buf = (kt - kt_begin) & 1;
+            __syncthreads();                   // (compiler adds vmcnt(0)): tile kt landed for every wave; buf^1 is free
+            if (kt + 1 < kt_end) stage(buf ^ 1);
+            compute(buf);
+        }
+    } else {
+        // 3-deep ring, two tiles in flight.  Each wave issues NLD = 4 + NB_I DMA instructions per tile, so
+        // "tile kt has landed" == at most NLD * (tiles issued after kt) of this wave's loads are still outstanding.
+        constexpr int NLD = 4 + NB_I;
+        const int nk = kt_end - kt_begin;
+        stage(0);
+        if (nk > 1) stage(1);
+        int buf = 0;
+        for (int it = 0; it < nk; ++it) {
+            const int ahead = min(nk - 1 - it, 1);           // tiles issued after tile `it` at this point (0 or 1)
+            if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();      // every wave's part of tile `it` landed; ring slot (it+2)%3 == (it-1)%3 is drained
+            if (it + 2 < nk) stage(buf == 0 ? 2 : buf - 1);
+            compute(buf);
+            buf = buf == 2 ? 0 : buf + 1;
+        }
     }
 
-    // ---- register epilogue
+    // ---- epilogue.  The accumulators (lane: row m = c, 4 consecutive columns) are staged through LDS as fp32 with a
+    // 16-B-chunk XOR swizzle (conflict-free ds_write_b128), then every thread handles 8 consecutive columns of a row so
+    // that each wave store instruction covers 4 FULL 256-B bf16 rows (512-B fp32 rows): whole-line HBM writes, and the
+    // residual / gelu'(z) operands are read with the same coalesced pattern.  (Storing straight from the MFMA layout
+    // -- 8-B pieces scattered over 16 rows per instruction -- measured 2.4x slower end to end on K = 768 GEMMs.)
+    if (p.dbg == 1 && acc[0][0][0] != 12345.678f) return;
     const vm_gemm_epilogue& e = p.e;
     const float alpha = e.alpha_dev ? e.alpha * (*e.alpha_dev) : e.alpha;
+    float* cs = reinterpret_cast<float*>(smem);     // [FBM][128] fp32, chunk-swizzled
+    constexpr int ITEMS = FBM * 16 / (WM * 128);   // 8-column items per thread
+    {
+        __syncthreads();                            // operand buffers fully consumed by every wave
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gm = m0 + wm * 64 + i * 16 + c;
-        if (gm >= p.M) continue;
+        for (int i = 0; i < 4; ++i) {
+            const int row = wm * 64 + i * 16 + c;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int gn = n0 + wn * 64 + j * 16 + g * 4;
-            if (gn >= p.N) continue;
-            const int nvalid = min(4, p.N - gn);
-            const int64_t off = (int64_t)gm * p.ldc + gn;
-            float v[4] = {acc[j][i][0] * alpha, acc[j][i][1] * alpha, acc[j][i][2] * alpha, acc[j][i][3] * alpha};
-            if (p.slabs) {     // split-K: plain partial-slab store, reduced by splitk_reduce_kernel (deterministic, no atomics)
-                float* sp = p.slabs + (int64_t)split * p.M * p.ldc + off;
-                if (nvalid == 4) *reinterpret_cast<float4*>(sp) = make_float4(v[0], v[1], v[2], v[3]);
-                else for (int r = 0; r < nvalid; ++r) sp[r] = v[r];
-                continue;
-            }
-            if (e.bias) {
-                if (nvalid == 4) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(e.bias + gn);
-                    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-                } else {
-                    for (int r = 0; r < nvalid; ++r) v[r] += e.bias[gn + r];
+            for (int j = 0; j < 4; ++j) {
+                const int gn = n0 + wn * 64 + j * 16 + g * 4;
+                float v[4] = {acc[j][i][0] * alpha, acc[j][i][1] * alpha, acc[j][i][2] * alpha, acc[j][i][3] * alpha};
+                if (e.bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (gn + r < p.N) v[r] += e.bias[gn + r];
                 }
+                const int chunk = (wn * 16 + j * 4 + g) ^ (row & 7);
+                *reinterpret_cast<float4*>(cs + row * 128 + chunk * 4) = make_float4(v[0], v[1], v[2], v[3]);
             }
-            if (e.aux_out) {
-                bf16_t* z = reinterpret_cast<bf16_t*>(e.aux_out) + off;
-                if (nvalid == 4) *reinterpret_cast<uint2*>(z) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                else for (int r = 0; r < nvalid; ++r) z[r] = f32_to_bf16(v[r]);
-            }
-            if (e.act == 1) {
+        }
+        __syncthreads();
+    }
+    auto load8 = [&](int row, int q, float* v) {     // 8 consecutive columns 8q..8q+7 of staged row
+        const float4 lo = *reinterpret_cast<const float4*>(cs + row * 128 + (((2 * q) ^ (row & 7)) << 2));
+        const float4 hi = *reinterpret_cast<const float4*>(cs + row * 128 + (((2 * q + 1) ^ (row & 7)) << 2));
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    };
+#pragma unroll 2
+    for (int it = 0; it < ITEMS; ++it) {
+        const int id = tid + (WM * 128) * it, row = id >> 4, q = id & 15;
+        const int gm = m0 + row, gn = n0 + q * 8;
+        if (gm >= p.M || gn >= p.N) continue;
+        const int nvalid = min(8, p.N - gn);
+        const int64_t off = (int64_t)gm * p.ldc + gn;
+        float v[8];
+        load8(row, q, v);
+        if (p.slabs) {     // split-K: plain partial-slab store, reduced by splitk_reduce_kernel (deterministic, no atomics)
+            float* sp = p.slabs + (int64_t)split * p.M * p.ldc + off;
+            if (nvalid == 8) {
+                *reinterpret_cast<float4*>(sp) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(sp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else for (int r = 0; r < nvalid; ++r) sp[r] = v[r];
+            continue;
+        }
+        if (e.aux_out) {     // pre-activation side output z (bf16), same coalesced pattern
+            bf16_t* z = reinterpret_cast<bf16_t*>(e.aux_out) + off;
+            if (nvalid == 8) st16(z, pack8(v));
+            else for (int r = 0; r < nvalid; ++r) z[r] = f32_to_bf16(v[r]);
+        }
+        if (e.act == 1) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
-            }
-            if (e.mul_gelu_z) {
-                const bf16_t* z = reinterpret_cast<const bf16_t*>(e.mul_gelu_z) + off;
-                float zf[4] = {0.f, 0.f, 0.f, 0.f};
-                if (nvalid == 4) {
-                    const uint2 u = *reinterpret_cast<const uint2*>(z);
-                    zf[0] = __uint_as_float(u.x << 16); zf[1] = __uint_as_float(u.x & 0xffff0000u);
-                    zf[2] = __uint_as_float(u.y << 16); zf[3] = __uint_as_float(u.y & 0xffff0000u);
-                } else {
-                    for (int r = 0; r < nvalid; ++r) zf[r] = bf16_to_f32(z[r]);
-                }
+            for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
+        }
+        if (e.mul_gelu_z) {
+            const bf16_t* z = reinterpret_cast<const bf16_t*>(e.mul_gelu_z) + off;
+            float zf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (nvalid == 8) unpack8(*reinterpret_cast<const uint4*>(z), zf);
+            else for (int r = 0; r < nvalid; ++r) zf[r] = bf16_to_f32(z[r]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f(zf[r]);
-            }
-            if (e.dropout_p > 0.f) {
-                const uint64_t idx = (uint64_t)gm * (uint64_t)p.N + (uint64_t)gn;
+            for (int r = 0; r < 8; ++r) v[r] *= gelu_grad_f(zf[r]);
+        }
+        if (e.dropout_p > 0.f) {
+            const uint64_t idx = (uint64_t)gm * (uint64_t)p.N + (uint64_t)gn;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = dropout_keep(e.dropout_seed, idx + r, p.drop_thresh) ? v[r] * p.drop_scale : 0.f;
-            }
-            if (e.residual) {
-                const bf16_t* rp = reinterpret_cast<const bf16_t*>(e.residual) + (int64_t)gm * e.ldr + gn;
-                if (nvalid == 4) {
-                    const uint2 u = *reinterpret_cast<const uint2*>(rp);
-                    v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
-                    v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
-                } else {
-                    for (int r = 0; r < nvalid; ++r) v[r] += bf16_to_f32(rp[r]);
-                }
-            }
-            if (e.out_dtype == VM_BF16) {
-                bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + off;
-                if (nvalid == 4) *reinterpret_cast<uint2*>(cp) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                else for (int r = 0; r < nvalid; ++r) cp[r] = f32_to_bf16(v[r]);
-            } else {
-                float* cp = reinterpret_cast<float*>(p.C) + off;
-                if (e.accumulate) {     // this thread owns the element (no split): plain read-modify-write
-                    if (nvalid == 4) {
-                        float4 o = *reinterpret_cast<float4*>(cp);
-                        *reinterpret_cast<float4*>(cp) = make_float4(o.x + v[0], o.y + v[1], o.z + v[2], o.w + v[3]);
-                    } else {
-                        for (int r = 0; r < nvalid; ++r) cp[r] += v[r];
-                    }
-                } else if (nvalid == 4) {
-                    *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    for (int r = 0; r < nvalid; ++r) cp[r] = v[r];
-                }
-            }
+            for (int r = 0; r < 8; ++r) v[r] = dropout_keep(e.dropout_seed, idx + r, p.drop_thresh) ? v[r] * p.drop_scale : 0.f;
+        }
+        if (e.residual) {
+            const bf16_t* rp = reinterpret_cast<const bf16_t*>(e.residual) + (int64_t)gm * e.ldr + gn;
+            float rf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (nvalid == 8) unpack8(*reinterpret_cast<const uint4*>(rp), rf);
+            else for (int r = 0; r < nvalid; ++r) rf[r] = bf16_to_f32(rp[r]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += rf[r];
+        }
+        if (e.out_dtype == VM_BF16) {
+            bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + off;
+            if (nvalid == 8) st16(cp, pack8(v));
+            else for (int r = 0; r < nvalid; ++r) cp[r] = f32_to_bf16(v[r]);
+        } else {
+            float* cp = reinterpret_cast<float*>(p.C) + off;
+            if (e.accumulate) {     // this thread owns the elements (no split): plain read-modify-write
+                if (nvalid == 8) {
+                    const float4 o0 = *reinterpret_cast<float4*>(cp), o1 = *reinterpret_cast<float4*>(cp + 4);
+                    *reinterpret_cast<float4*>(cp) = make_float4(o0.x + v[0], o0.y + v[1], o0.z + v[2], o0.w + v[3]);
+                    *reinterpret_cast<float4*>(cp + 4) = make_float4(o1.x + v[4], o1.y + v[5], o1.z + v[6], o1.w + v[7]);
+                } else for (int r = 0; r < nvalid; ++r) cp[r] += v[r];
+            } else if (nvalid == 8) {
+                *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else for (int r = 0; r < nvalid; ++r) cp[r] = v[r];
         }
     }
 }
 
-template <int LA, int LB>
+template <int LA, int LB, int WM, int STAGES>
 static int launch_fast(const GemmArgs& a, int nblocks, hipStream_t s) {
+    constexpr int LDS = STAGES * (WM * 64 * 128 + F_OPER_B);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<LA, LB>), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<LA, LB, WM, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_fast_kernel<LA, LB>), dim3(nblocks), dim3(256), F_LDS, s, a);
+    hipLaunchKernelGGL((gemm_fast_kernel<LA, LB, WM, STAGES>), dim3(nblocks), dim3(WM * 128), LDS, s, a);
     return vm_check_launch("vm_gemm_bf16(fast)");
 }
 
@@ -267,9 +323,16 @@ int vm_gemm_splitk_reduce(const GemmArgs& a, int nsplit, hipStream_t s) {
     return vm_check_launch("vm_gemm_bf16(split-k reduce)");
 }
 
-int vm_gemm_fast_dispatch(const GemmArgs& a, int a_layout, int b_layout, int nblocks, hipStream_t s) {
-    if (a_layout == 0 && b_layout == 0) return launch_fast<0, 0>(a, nblocks, s);
-    if (a_layout == 0 && b_layout == 1) return launch_fast<0, 1>(a, nblocks, s);
-    if (a_layout == 1 && b_layout == 0) return launch_fast<1, 0>(a, nblocks, s);
-    return launch_fast<1, 1>(a, nblocks, s);
+template <int WM, int STAGES>
+static int dispatch_layout(const GemmArgs& a, int a_layout, int b_layout, int nblocks, hipStream_t s) {
+    if (a_layout == 0 && b_layout == 0) return launch_fast<0, 0, WM, STAGES>(a, nblocks, s);
+    if (a_layout == 0 && b_layout == 1) return launch_fast<0, 1, WM, STAGES>(a, nblocks, s);
+    if (a_layout == 1 && b_layout == 0) return launch_fast<1, 0, WM, STAGES>(a, nblocks, s);
+    return launch_fast<1, 1, WM, STAGES>(a, nblocks, s);
+}
+
+// variant 0: 128x128 tile, 2-stage (2 workgroups/CU); variant 1: 256x128 tile, 3-stage ring (1 workgroup/CU)
+int vm_gemm_fast_dispatch(const GemmArgs& a, int a_layout, int b_layout, int nblocks, int variant, hipStream_t s) {
+    if (variant == 1) return dispatch_layout<4, 3>(a, a_layout, b_layout, nblocks, s);
+    return dispatch_layout<2, 2>(a, a_layout, b_layout, nblocks, s);
 }

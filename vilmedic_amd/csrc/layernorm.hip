@@ -133,15 +133,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         wg[i] = red[i] + red[2 * cols + i] + red[4 * cols + i] + red[6 * cols + i];
 }
 
-// grid (ceil(cols/32), 2): blockIdx.y selects dgamma / dbeta; 32 columns x 8 slab-groups per block
+// grid (ceil(cols/32), 2): blockIdx.y selects dgamma / dbeta; 32 columns x 8 slab-groups per block, 8 loads in flight
 __global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ ws, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int nslabs, int cols) {
     __shared__ float part[8][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + tx;
     float a = 0.f;
-    if (c < cols)
-        for (int w = ty; w < nslabs; w += 8) a += ws[(int64_t)w * 2 * cols + blockIdx.y * cols + c];
+    if (c < cols) {
+        const float* base = ws + blockIdx.y * cols + c;
+        const int64_t stride = 2 * (int64_t)cols;
+        int w = ty;
+        for (; w + 56 < nslabs; w += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = base[(int64_t)(w + 8 * u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        for (; w < nslabs; w += 8) a += base[(int64_t)w * stride];
+    }
     part[ty][tx] = a;
     __syncthreads();
     if (ty == 0 && c < cols) {
@@ -152,12 +163,16 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ w
     }
 }
 
-static int ln_grid(int rows) {
+// forward: one row per wave whenever possible (latency-bound per row: maximise rows in flight);
+// backward: bounded so the per-block dgamma/dbeta slabs stay small
+static int ln_grid(int rows, int cap) {
     int blocks = (rows + 3) / 4;
-    if (blocks > 512) blocks = 512;
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return blocks;
 }
+#define LN_FWD_CAP 16384
+#define LN_BWD_CAP 1024
 
 extern "C" int vm_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                 int rows, int cols, float eps, void* stream) {
@@ -166,7 +181,7 @@ extern "C" int vm_layernorm_fwd(const void* x, const float* gamma, const float* 
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_LN, 4.0 * rows * (double)cols, s);
     const int nch = (cols / 8 + 63) / 64;
-    const int grid = ln_grid(rows);
+    const int grid = ln_grid(rows, LN_FWD_CAP);
     const bf16_t* xp = (const bf16_t*)x; bf16_t* yp = (bf16_t*)y;
     switch (nch) {
         case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, dim3(grid), dim3(256), 0, s, xp, gamma, beta, yp, mean, rstd, rows, cols, eps); break;
@@ -176,7 +191,7 @@ extern "C" int vm_layernorm_fwd(const void* x, const float* gamma, const float* 
     return vm_check_launch("vm_layernorm_fwd");
 }
 
-extern "C" size_t vm_layernorm_bwd_ws(int rows, int cols) { return (size_t)ln_grid(rows) * 2 * (size_t)cols * sizeof(float); }
+extern "C" size_t vm_layernorm_bwd_ws(int rows, int cols) { return (size_t)ln_grid(rows, LN_BWD_CAP) * 2 * (size_t)cols * sizeof(float); }
 
 extern "C" int vm_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                 void* dx, float* dgamma, float* dbeta, int rows, int cols, void* ws, void* stream) {
@@ -185,7 +200,7 @@ extern "C" int vm_layernorm_bwd(const void* dy, const void* x, const float* gamm
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_LN, 6.0 * rows * (double)cols, s);
     const int nch = (cols / 8 + 63) / 64;
-    const int grid = ln_grid(rows);
+    const int grid = ln_grid(rows, LN_BWD_CAP);
     const bf16_t* dyp = (const bf16_t*)dy; const bf16_t* xp = (const bf16_t*)x; bf16_t* dxp = (bf16_t*)dx;
     float* wsp = (float*)ws;
     const size_t red_bytes = (size_t)4 * 2 * cols * sizeof(float);

@@ -2,6 +2,9 @@
 #include "common.h"
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
 #include <mutex>
 #include <vector>
 
@@ -28,18 +31,20 @@ extern "C" int vm_version(void) { return 100; }
 extern "C" int vm_sizeof_gemm_epilogue(void) { return (int)sizeof(vm_gemm_epilogue); }
 
 // ---------------------------------------------------------------- profiler
-struct ProfSlot { hipEvent_t a, b; int fam; double work; };
+struct ProfSlot { hipEvent_t a, b; int fam; double work; char tag[96]; };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<ProfSlot*> g_prof_used, g_prof_free;
 
-VmProfScope::VmProfScope(int family, double work, hipStream_t stream) : fam(family), s(stream), slot(nullptr) {
+VmProfScope::VmProfScope(int family, double work, hipStream_t stream, const char* tag_fmt, ...) : fam(family), s(stream), slot(nullptr) {
     if (!g_prof_on) return;
+    char tag[96] = "";
+    if (tag_fmt) { va_list ap; va_start(ap, tag_fmt); vsnprintf(tag, sizeof(tag), tag_fmt, ap); va_end(ap); }
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfSlot* p;
     if (!g_prof_free.empty()) { p = g_prof_free.back(); g_prof_free.pop_back(); }
     else { p = new ProfSlot(); hipEventCreate(&p->a); hipEventCreate(&p->b); }
-    p->fam = family; p->work = work;
+    p->fam = family; p->work = work; memcpy(p->tag, tag, sizeof(tag));
     hipEventRecord(p->a, stream);
     slot = p;
 }
@@ -71,5 +76,25 @@ extern "C" int vm_prof_read(int family, double* ms_total, double* work_total, in
     if (ms_total) *ms_total = ms;
     if (work_total) *work_total = w;
     if (launches) *launches = n;
+    return VM_OK;
+}
+
+// per-tag breakdown of the recorded launches: "family tag launches total_ms total_work" lines (diagnostics for bench.py)
+extern "C" int vm_prof_dump(const char* path) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    struct Acc { double ms = 0, work = 0; long n = 0; };
+    std::map<std::string, Acc> acc;
+    for (auto* p : g_prof_used) {
+        hipEventSynchronize(p->b);
+        float t = 0;
+        hipEventElapsedTime(&t, p->a, p->b);
+        char key[128];
+        snprintf(key, sizeof(key), "%d %s", p->fam, p->tag[0] ? p->tag : "-");
+        Acc& a = acc[key]; a.ms += t; a.work += p->work; a.n += 1;
+    }
+    FILE* f = fopen(path, "w");
+    if (!f) { vm_set_error("vm_prof_dump: cannot open %s", path); return VM_EINVAL; }
+    for (auto& kv : acc) fprintf(f, "%s %ld %.4f %.6g\n", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.work);
+    fclose(f);
     return VM_OK;
 }

@@ -80,10 +80,14 @@ class Trainor(object):
                     self.logger.warning("NaN/Inf loss: batch skipped on all ranks")
                     self.optimizer.zero_grad()
                     continue
-                (loss / self.grad_accu).backward()
-                if iteration % self.grad_accu == 0:
-                    if self.ddp is not None:
+                step_now = iteration % self.grad_accu == 0
+                if self.ddp is not None and step_now and self.grad_accu == 1:
+                    self.ddp.backward(loss)                      # all-reduce overlapped with the encoder backward
+                else:
+                    (loss / self.grad_accu).backward()
+                    if self.ddp is not None and step_now:
                         self.ddp.finish()
+                if step_now:
                     if self.clip is not None:
                         torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
                     self.optimizer.step()

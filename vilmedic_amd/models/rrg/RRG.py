@@ -19,6 +19,8 @@ class RRG(nn.Module):
         cnn = dict(cnn)
         self.enc = eval(cnn.pop("proto"))(**cnn)
         self.eval_func = evaluation
+        self.split_backward = False      # set by ArenaDDP: detach the features so backward can run in two phases
+        self._split = None
 
     def forward(self, input_ids, attention_mask, images, images_mask=None, encoder_outputs=None,
                 encoder_attention_mask=None, epoch=None, iteration=None, **kwargs):
@@ -27,6 +29,10 @@ class RRG(nn.Module):
         arena_of(self).refresh()          # one arena for encoder + decoder parameters
         if encoder_outputs is None:
             encoder_outputs, encoder_attention_mask = self.encode(images, images_mask, **kwargs)
+            if self.split_backward and self.training and torch.is_grad_enabled() and encoder_outputs.requires_grad:
+                leaf = encoder_outputs.detach().requires_grad_(True)
+                self._split = (encoder_outputs, leaf)
+                encoder_outputs = leaf
         return self.dec(input_ids=input_ids, attention_mask=attention_mask, encoder_outputs=encoder_outputs,
                         encoder_attention_mask=encoder_attention_mask, **kwargs)
 

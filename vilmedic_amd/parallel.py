@@ -64,26 +64,72 @@ def broadcast_(flat, dist, src=0):
 
 class ArenaDDP:
     """Wraps a model whose parameters live in a ParamArena: broadcasts rank 0's parameters at construction and averages
-    the flat gradient buffer across ranks in ``finish()`` (call between ``backward()`` and ``optimizer.step()``)."""
+    the flat gradient buffer across ranks.
+
+    ``backward(loss)`` overlaps communication with compute when the model exposes an encoder/decoder split (RRG): the
+    decoder consumes a DETACHED copy of the image features, so ``loss.backward()`` runs exactly the decoder's graph; the
+    decoder's arena range (parameters are laid out [dec | enc]) is then all-reduced asynchronously on RCCL's stream
+    while the encoder's backward (``features.backward(d_features)``) runs on the compute stream; the encoder range
+    follows.  Explicit two-phase backward -- correct by construction, no reliance on autograd's scheduling order.
+    ``finish()`` (no overlap) remains for callers that ran ``loss.backward()`` themselves."""
 
     def __init__(self, model, dist, chunks=4, bf16_wire=True):
         from . import ops
         from .arena import arena_of
         self.dist = dist
+        self.model = model
         self.arena = arena_of(model)
         self.chunks = chunks
         self.bf16_wire = bf16_wire
         self._ops = ops
+        self.world = dist.get_world_size()
         broadcast_(self.arena.flat, dist)
         self.arena.refresh(force=True)
+        self.split_at = None
+        if hasattr(model, "enc") and hasattr(model, "dec") and hasattr(model, "split_backward"):
+            enc_offs = [p._vm_off for p in model.enc.parameters()]
+            dec_offs = [p._vm_off + p.numel() for p in model.dec.parameters()]
+            if enc_offs and dec_offs and min(enc_offs) >= max(dec_offs):
+                self.split_at = min(enc_offs)
+                model.split_backward = True
+        self._wire = torch.empty(self.arena.numel, dtype=torch.bfloat16, device=self.arena.flat.device) if bf16_wire else None
+
+    # ---- asynchronous all-reduce of gflat[s:e] in `chunks` pieces; returns the pending work items
+    def _start(self, s, e, chunks):
+        g, works = self.arena.gflat, []
+        for cs, ce in [(s + a, s + b) for a, b in chunk_ranges(e - s, chunks)]:
+            if self.bf16_wire:
+                self._ops.cast_to_bf16(g[cs:ce], self._wire[cs:ce])
+                works.append((cs, ce, _avg_allreduce(self._wire[cs:ce], self.dist, self.world, async_op=True)))
+            else:
+                works.append((cs, ce, _avg_allreduce(g[cs:ce], self.dist, self.world, async_op=True)))
+        return works
+
+    def _wait(self, works):
+        for cs, ce, w in works:
+            w.wait()
+            if self.bf16_wire:
+                self._ops.cast_to_f32(self._wire[cs:ce], self.arena.gflat[cs:ce])
+
+    def backward(self, loss):
+        """loss.backward() + gradient averaging, communication overlapped with the encoder's backward when possible."""
+        n = self.arena.numel
+        split = getattr(self.model, "_split", None) if self.split_at is not None else None
+        if split is None:
+            loss.backward()
+            self._wait(self._start(0, n, self.chunks))
+            return
+        feats, leaf = split
+        loss.backward()                                  # decoder graph only (features were detached)
+        pending = self._start(0, self.split_at, max(1, self.chunks // 2))
+        if leaf.grad is not None:
+            feats.backward(leaf.grad)                    # encoder graph, overlapping the decoder's all-reduce
+        pending += self._start(self.split_at, n, max(1, self.chunks // 2))
+        self._wait(pending)
+        self.model._split = None
 
     def finish(self):
-        ops = self._ops
-        if self.bf16_wire:
-            allreduce_mean_(self.arena.gflat, self.dist, self.chunks, torch.bfloat16,
-                            to_wire=lambda src, dst: ops.cast_to_bf16(src, dst), from_wire=lambda src, dst: ops.cast_to_f32(src, dst))
-        else:
-            allreduce_mean_(self.arena.gflat, self.dist, self.chunks)
+        self._wait(self._start(0, self.arena.numel, self.chunks))
 
 
 def all_gather_with_grad(x, dist):
