@@ -14,6 +14,7 @@
 // the uniform distribution exactly like HF's additive finfo.min mask); keys >= Lk get -inf.
 // stats[b,h,i] = (row max m, row sum l) of the scaled+masked scores, saved for the backward pass.
 #include "common.h"
+#include <cstdlib>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef short v4s __attribute__((ext_vector_type(4)));
@@ -25,6 +26,9 @@ typedef short v4s __attribute__((ext_vector_type(4)));
 #define NDF (DH / 16)            // 16-wide output fragments along the head dimension
 #define NKK (DH / 32)            // 32-deep MFMA k-steps along the head dimension
 #define MASKED_SCORE (-1e30f)
+#ifndef ATTN_MIN_BLOCKS
+#define ATTN_MIN_BLOCKS 2      // __launch_bounds__ second argument (waves per SIMD) of the streaming variants
+#endif
 
 struct AttnArgs {
     const bf16_t *q, *k, *v, *o, *d_o;
@@ -36,6 +40,7 @@ struct AttnArgs {
     const int32_t* kv_index; // fwd only: [B, kv_index_ld] absolute K/V row of key j of batch b (KV-cache indirection), or null
     int64_t kv_index_ld;
     int B, H, Lq, Lk;
+    int nslot_k, nslot_q;    // resident variants: LDS tile slots actually allocated (ceil(L/64))
     float scale; int causal;
     float dropout_p; uint64_t seed; uint32_t thresh; float drop_scale;
 };
@@ -131,9 +136,9 @@ __device__ __forceinline__ void store_t_acc(bf16_t* rowptr, const float4_t (&acc
 // RES = true: every K/V tile of the (b,h) pair is resident in LDS (Lk <= 256): one barrier for the whole kernel, all
 // HBM loads issued up front; RES = false: tiles stream through one LDS slot with a register prefetch (any Lk).
 template <int DH, bool RES>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, RES ? 4 : ATTN_MIN_BLOCKS) void attn_fwd_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NSLOT = RES ? 4 : 1;
+    const int NSLOT = RES ? p.nslot_k : 1;
     uint8_t* smask_all = reinterpret_cast<uint8_t*>(smem + NSLOT * 2 * TILE_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64 + wave * 16;
@@ -276,9 +281,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs p, int D
 
 // =============================================================================== dQ  (owner: 16 queries per wave)
 template <int DH, bool RES>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, RES ? 4 : ATTN_MIN_BLOCKS) void attn_bwd_dq_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NSLOT = RES ? 4 : 1;
+    const int NSLOT = RES ? p.nslot_k : 1;
     uint8_t* smask_all = reinterpret_cast<uint8_t*>(smem + NSLOT * 2 * TILE_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64 + wave * 16;
@@ -371,9 +376,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
 
 // =============================================================================== dK, dV  (owner: 16 keys per wave)
 template <int DH, bool RES>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, RES ? 2 : ATTN_MIN_BLOCKS) void attn_bwd_dkv_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NSLOT = RES ? 4 : 1;
+    const int NSLOT = RES ? p.nslot_q : 1;
     float* stat_all = reinterpret_cast<float*>(smem + NSLOT * 2 * TILE_BYTES);   // [3][NSLOT*64]: m, 1/l, delta
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64 + wave * 16;
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
             tile_store<DH>(rq, smem + t * 2 * TILE_BYTES, tid);
             tile_store<DH>(rdo, smem + t * 2 * TILE_BYTES + TILE_BYTES, tid);
         }
-        load_stats(tid, tid);
+        if (tid < NSLOT * 64) load_stats(tid, tid);
         __syncthreads();
     } else if (t_begin < ntiles) {
         load_q(t_begin);
@@ -480,7 +485,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     }
 }
 
-static size_t attn_lds(int dh, bool res, int extra) { return (size_t)(res ? 4 : 1) * 2 * 64 * (dh * 2 + 16) + extra; }
+static size_t attn_lds(int dh, int slots, int extra) { return (size_t)slots * 2 * 64 * (dh * 2 + 16) + extra; }
 template <typename K>
 static void launch_attn(K kernel, dim3 grid, size_t lds, hipStream_t s, const AttnArgs& a) {
     if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -511,9 +516,10 @@ extern "C" int vm_attention_fwd(const void* q, int64_t ldq, const void* k, int64
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_ATTN, 4.0 * B * H * (double)Lq * Lk * dh, s);
     const dim3 grid((Lq + 63) / 64, H, B);
-    const bool res = Lk <= 256;
-#define LAUNCH_FWD(D) do { if (res) launch_attn(attn_fwd_kernel<D, true>, grid, attn_lds(D, true, 256), s, a); \
-                           else launch_attn(attn_fwd_kernel<D, false>, grid, attn_lds(D, false, 64), s, a); } while (0)
+    const bool res = Lk <= 256 && !getenv("VM_ATTN_STREAM");
+    a.nslot_k = (Lk + 63) / 64; a.nslot_q = (Lq + 63) / 64;
+#define LAUNCH_FWD(D) do { if (res) launch_attn(attn_fwd_kernel<D, true>, grid, attn_lds(D, a.nslot_k, 256), s, a); \
+                           else launch_attn(attn_fwd_kernel<D, false>, grid, attn_lds(D, 1, 64), s, a); } while (0)
     switch (dh) { case 32: LAUNCH_FWD(32); break; case 64: LAUNCH_FWD(64); break; case 96: LAUNCH_FWD(96); break; default: LAUNCH_FWD(128); break; }
 #undef LAUNCH_FWD
     return vm_check_launch("vm_attention_fwd");
@@ -542,12 +548,13 @@ extern "C" int vm_attention_bwd(const void* q, int64_t ldq, const void* k, int64
     const int64_t rows = (int64_t)B * H * Lq;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, a, dh);
     const dim3 gq((Lq + 63) / 64, H, B), gk((Lk + 63) / 64, H, B);
-    const bool resk = Lk <= 256, resq = Lq <= 256;
+    const bool resk = Lk <= 256 && !getenv("VM_ATTN_STREAM"), resq = Lq <= 256 && !getenv("VM_ATTN_STREAM");
+    a.nslot_k = (Lk + 63) / 64; a.nslot_q = (Lq + 63) / 64;
 #define LAUNCH_BWD(D) do { \
-        if (resk) launch_attn(attn_bwd_dq_kernel<D, true>, gq, attn_lds(D, true, 256), s, a); \
-        else launch_attn(attn_bwd_dq_kernel<D, false>, gq, attn_lds(D, false, 64), s, a); \
-        if (resq) launch_attn(attn_bwd_dkv_kernel<D, true>, gk, attn_lds(D, true, 3 * 256 * 4), s, a); \
-        else launch_attn(attn_bwd_dkv_kernel<D, false>, gk, attn_lds(D, false, 3 * 64 * 4), s, a); } while (0)
+        if (resk) launch_attn(attn_bwd_dq_kernel<D, true>, gq, attn_lds(D, a.nslot_k, 256), s, a); \
+        else launch_attn(attn_bwd_dq_kernel<D, false>, gq, attn_lds(D, 1, 64), s, a); \
+        if (resq) launch_attn(attn_bwd_dkv_kernel<D, true>, gk, attn_lds(D, a.nslot_q, 3 * 256 * 4), s, a); \
+        else launch_attn(attn_bwd_dkv_kernel<D, false>, gk, attn_lds(D, 1, 3 * 64 * 4), s, a); } while (0)
     switch (dh) { case 32: LAUNCH_BWD(32); break; case 64: LAUNCH_BWD(64); break; case 96: LAUNCH_BWD(96); break; default: LAUNCH_BWD(128); break; }
 #undef LAUNCH_BWD
     return vm_check_launch("vm_attention_bwd");

@@ -302,8 +302,11 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
         const int tiles_m256 = (M + 255) / 256;
         if (force) variant = atoi(force);
         else if (K >= 4096 && (int64_t)tiles_m256 * a.tiles_n * split >= 1024) variant = 1;   // measured: only huge square-ish problems gain
-        int nb = nblocks;
-        if (variant == 1) { a.tiles_m = tiles_m256; nb = a.tiles_m * a.tiles_n * split; }
+        int vbm, vbn;
+        vm_gemm_variant_tile(variant, &vbm, &vbn);
+        a.tiles_m = (M + vbm - 1) / vbm;
+        a.tiles_n = (N + vbn - 1) / vbn;
+        const int nb = a.tiles_m * a.tiles_n * split;
         int rc = vm_gemm_fast_dispatch(a, a_layout, b_layout, nb, variant, s);
         if (rc == VM_OK && split > 1) rc = vm_gemm_splitk_reduce(a, split, s);
         return rc;

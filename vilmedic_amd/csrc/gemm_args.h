@@ -15,4 +15,5 @@ struct GemmArgs {
 
 // tuned path (gemm_fast.hip): requires K % 64 == 0
 int vm_gemm_splitk_reduce(const GemmArgs& a, int nsplit, hipStream_t s);
+void vm_gemm_variant_tile(int variant, int* bm, int* bn);
 int vm_gemm_fast_dispatch(const GemmArgs& a, int a_layout, int b_layout, int nblocks, int variant, hipStream_t s);

@@ -17,11 +17,9 @@
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef short v4s __attribute__((ext_vector_type(4)));
 
-#define FBN 128
 #define FBK 64
-#define F_OPER_B 16384                      // B tile: 128 rows x 64 k x 2 B
-// template parameters: WM = waves along M (2 -> 128-row tile, 256 threads, 2 workgroups/CU;
-//                                          4 -> 256-row tile, 512 threads, 1 workgroup/CU),
+// template parameters: WM x WN = waves along M x N, each wave owns a 64x64 sub-tile (tile = 64 WM x 64 WN):
+//                        2x2 -> 128x128, 256 threads, 2 workgroups/CU;  4x2 -> 256x128, 512 threads;  4x4 -> 256x256, 1024 threads
 //                      STAGES = LDS ring depth (2: one tile in flight, vmcnt(0)+barrier per K-tile;
 //                                               3: two tiles in flight, COUNTED vmcnt + raw s_barrier so the DMA of
 //                                                  tiles kt+1, kt+2 stays in flight across the barrier)
@@ -64,14 +62,15 @@ __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int LA, int LB, int WM, int STAGES>
-__global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_fast_kernel(const GemmArgs p) {
-    constexpr int FBM = WM * 64, NW = 2 * WM, F_OPER_A = FBM * 128, F_STAGE = F_OPER_A + F_OPER_B;
-    constexpr int NB_I = 16 / NW;            // B-tile DMA instructions per wave (A-tile: always 4)
+template <int LA, int LB, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fast_kernel(const GemmArgs p) {
+    constexpr int FBM = WM * 64, FBN = WN * 64, NW = WM * WN, NT = NW * 64;
+    constexpr int F_OPER_A = FBM * 128, F_OPER_B = FBN * 128, F_STAGE = F_OPER_A + F_OPER_B;
+    constexpr int NA_I = 8 / WN, NB_I = 8 / WM;   // A- / B-tile DMA instructions (1 KiB each) per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, c = lane & 15;
+    const int wm = wave / WN, wn = wave % WN, g = lane >> 4, c = lane & 15;
 
     const int nwg = gridDim.x;
     int bid;
@@ -90,18 +89,18 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_fast_kernel(co
     if (p.dbg == 2) kt_end = kt_begin + 1;
 
     // ---- per-thread DMA sources (4 instructions per operand per wave), advanced by one K-tile per iteration
-    const bf16_t* srcA[4];
+    const bf16_t* srcA[NA_I];
     const bf16_t* srcB[NB_I];
     const int64_t stepA = LA == 0 ? FBK : (int64_t)FBK * p.lda;
     const int64_t stepB = LB == 0 ? FBK : (int64_t)FBK * p.ldb;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) srcA[i] = stage_src<LA, FBM>(p.A, p.lda, m0, p.M, wave * 4 + i, lane) + kt_begin * stepA;
+    for (int i = 0; i < NA_I; ++i) srcA[i] = stage_src<LA, FBM>(p.A, p.lda, m0, p.M, wave * NA_I + i, lane) + kt_begin * stepA;
 #pragma unroll
     for (int i = 0; i < NB_I; ++i) srcB[i] = stage_src<LB, FBN>(p.B, p.ldb, n0, p.N, wave * NB_I + i, lane) + kt_begin * stepB;
     auto stage = [&](int buf) {
         char* da = smem + buf * F_STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { glds16(srcA[i], da + (wave * 4 + i) * 1024); srcA[i] += stepA; }
+        for (int i = 0; i < NA_I; ++i) { glds16(srcA[i], da + (wave * NA_I + i) * 1024); srcA[i] += stepA; }
 #pragma unroll
         for (int i = 0; i < NB_I; ++i) { glds16(srcB[i], da + F_OPER_A + (wave * NB_I + i) * 1024); srcB[i] += stepB; }
     };
@@ -159,9 +158,9 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_fast_kernel(co
             compute(buf);
         }
     } else {
-        // 3-deep ring, two tiles in flight.  Each wave issues NLD = 4 + NB_I DMA instructions per tile, so
+        // 3-deep ring, two tiles in flight.  Each wave issues NLD = NA_I + NB_I DMA instructions per tile, so
         // "tile kt has landed" == at most NLD * (tiles issued after kt) of this wave's loads are still outstanding.
-        constexpr int NLD = 4 + NB_I;
+        constexpr int NLD = NA_I + NB_I;
         const int nk = kt_end - kt_begin;
         stage(0);
         if (nk > 1) stage(1);
@@ -185,13 +184,25 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_fast_kernel(co
     if (p.dbg == 1 && acc[0][0][0] != 12345.678f) return;
     const vm_gemm_epilogue& e = p.e;
     const float alpha = e.alpha_dev ? e.alpha * (*e.alpha_dev) : e.alpha;
-    float* cs = reinterpret_cast<float*>(smem);     // [FBM][128] fp32, chunk-swizzled
-    constexpr int ITEMS = FBM * 16 / (WM * 128);   // 8-column items per thread
-    {
-        __syncthreads();                            // operand buffers fully consumed by every wave
+    float* cs = reinterpret_cast<float*>(smem);     // [RPP][FBN] fp32, 16-B chunks XOR-swizzled by row
+    constexpr int LDS_BYTES = STAGES * F_STAGE;
+    constexpr int RPP_RAW = LDS_BYTES / (FBN * 4);
+    constexpr int RPP = RPP_RAW >= FBM ? FBM : (RPP_RAW / 64) * 64;   // rows staged per pass (multiple of a wave's 64 rows)
+    constexpr int NPASS = FBM / RPP;
+    constexpr int QPR = FBN / 8;                                     // 8-column items per row
+    constexpr int ITEMS = RPP * QPR / NT;
+    auto load8 = [&](int row, int q, float* v) {     // 8 consecutive columns 8q..8q+7 of staged row
+        const float4 lo = *reinterpret_cast<const float4*>(cs + row * FBN + (((2 * q) ^ (row & 7)) << 2));
+        const float4 hi = *reinterpret_cast<const float4*>(cs + row * FBN + (((2 * q + 1) ^ (row & 7)) << 2));
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    };
+#pragma unroll 1
+    for (int ps = 0; ps < NPASS; ++ps) {
+    __syncthreads();                                // operand buffers / previous pass fully consumed by every wave
+    if (wm * 64 >= ps * RPP && wm * 64 < (ps + 1) * RPP) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = wm * 64 + i * 16 + c;
+            const int row = wm * 64 + i * 16 + c - ps * RPP;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int gn = n0 + wn * 64 + j * 16 + g * 4;
@@ -201,20 +212,15 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_fast_kernel(co
                     for (int r = 0; r < 4; ++r) if (gn + r < p.N) v[r] += e.bias[gn + r];
                 }
                 const int chunk = (wn * 16 + j * 4 + g) ^ (row & 7);
-                *reinterpret_cast<float4*>(cs + row * 128 + chunk * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(cs + row * FBN + chunk * 4) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
-        __syncthreads();
     }
-    auto load8 = [&](int row, int q, float* v) {     // 8 consecutive columns 8q..8q+7 of staged row
-        const float4 lo = *reinterpret_cast<const float4*>(cs + row * 128 + (((2 * q) ^ (row & 7)) << 2));
-        const float4 hi = *reinterpret_cast<const float4*>(cs + row * 128 + (((2 * q + 1) ^ (row & 7)) << 2));
-        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-    };
+    __syncthreads();
 #pragma unroll 2
     for (int it = 0; it < ITEMS; ++it) {
-        const int id = tid + (WM * 128) * it, row = id >> 4, q = id & 15;
-        const int gm = m0 + row, gn = n0 + q * 8;
+        const int id = tid + NT * it, row = id / QPR, q = id % QPR;
+        const int gm = m0 + ps * RPP + row, gn = n0 + q * 8;
         if (gm >= p.M || gn >= p.N) continue;
         const int nvalid = min(8, p.N - gn);
         const int64_t off = (int64_t)gm * p.ldc + gn;
@@ -276,17 +282,18 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_fast_kernel(co
             } else for (int r = 0; r < nvalid; ++r) cp[r] = v[r];
         }
     }
+    }   // passes
 }
 
-template <int LA, int LB, int WM, int STAGES>
+template <int LA, int LB, int WM, int WN, int STAGES>
 static int launch_fast(const GemmArgs& a, int nblocks, hipStream_t s) {
-    constexpr int LDS = STAGES * (WM * 64 * 128 + F_OPER_B);
+    constexpr int LDS = STAGES * (WM + WN) * 64 * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<LA, LB, WM, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<LA, LB, WM, WN, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_fast_kernel<LA, LB, WM, STAGES>), dim3(nblocks), dim3(WM * 128), LDS, s, a);
+    hipLaunchKernelGGL((gemm_fast_kernel<LA, LB, WM, WN, STAGES>), dim3(nblocks), dim3(WM * WN * 64), LDS, s, a);
     return vm_check_launch("vm_gemm_bf16(fast)");
 }
 
@@ -323,16 +330,21 @@ int vm_gemm_splitk_reduce(const GemmArgs& a, int nsplit, hipStream_t s) {
     return vm_check_launch("vm_gemm_bf16(split-k reduce)");
 }
 
-template <int WM, int STAGES>
+template <int WM, int WN, int STAGES>
 static int dispatch_layout(const GemmArgs& a, int a_layout, int b_layout, int nblocks, hipStream_t s) {
-    if (a_layout == 0 && b_layout == 0) return launch_fast<0, 0, WM, STAGES>(a, nblocks, s);
-    if (a_layout == 0 && b_layout == 1) return launch_fast<0, 1, WM, STAGES>(a, nblocks, s);
-    if (a_layout == 1 && b_layout == 0) return launch_fast<1, 0, WM, STAGES>(a, nblocks, s);
-    return launch_fast<1, 1, WM, STAGES>(a, nblocks, s);
+    if (a_layout == 0 && b_layout == 0) return launch_fast<0, 0, WM, WN, STAGES>(a, nblocks, s);
+    if (a_layout == 0 && b_layout == 1) return launch_fast<0, 1, WM, WN, STAGES>(a, nblocks, s);
+    if (a_layout == 1 && b_layout == 0) return launch_fast<1, 0, WM, WN, STAGES>(a, nblocks, s);
+    return launch_fast<1, 1, WM, WN, STAGES>(a, nblocks, s);
 }
 
-// variant 0: 128x128 tile, 2-stage (2 workgroups/CU); variant 1: 256x128 tile, 3-stage ring (1 workgroup/CU)
+// variant 0: 128x128 tile, 2-stage (2 workgroups/CU); 1: 256x128, 3-stage ring; 2: 256x256, 16 waves, 2-stage
 int vm_gemm_fast_dispatch(const GemmArgs& a, int a_layout, int b_layout, int nblocks, int variant, hipStream_t s) {
-    if (variant == 1) return dispatch_layout<4, 3>(a, a_layout, b_layout, nblocks, s);
-    return dispatch_layout<2, 2>(a, a_layout, b_layout, nblocks, s);
+    if (variant == 1) return dispatch_layout<4, 2, 3>(a, a_layout, b_layout, nblocks, s);
+    if (variant == 2) return dispatch_layout<4, 4, 2>(a, a_layout, b_layout, nblocks, s);
+    return dispatch_layout<2, 2, 2>(a, a_layout, b_layout, nblocks, s);
+}
+void vm_gemm_variant_tile(int variant, int* bm, int* bn) {
+    *bm = variant == 0 ? 128 : 256;
+    *bn = variant == 2 ? 256 : 128;
 }
