@@ -88,6 +88,42 @@ static void bench_gemm(int M, int N, int K, int la, int lb, int split = 1) {
     hipFree(dA); hipFree(dB); hipFree(dC);
 }
 
+// epilogue-option benchmark: flags bit0 bias, bit1 gelu act, bit2 z side output, bit3 mul_gelu_z, bit4 dropout, bit5 residual;
+// rot = number of rotating buffer sets (rot > 1: operands/outputs come from HBM, not from a warm L2/MALL)
+static void bench_gemm2(int M, int N, int K, int la, int lb, int flags, int rot) {
+    int64_t lda = la == 0 ? K : M, ldb = lb == 0 ? K : N;
+    size_t na = (size_t)M * K, nb = (size_t)N * K, nc = (size_t)M * N;
+    std::vector<uint16_t> h(std::max(std::max(na, nb), nc));
+    for (auto& x : h) x = f2bf(frand());
+    std::vector<void*> dA(rot), dB(rot), dC(rot), dZ(rot), dR(rot);
+    void* dbias; hipMalloc(&dbias, N * 4); hipMemset(dbias, 0, N * 4);
+    for (int r = 0; r < rot; ++r) {
+        hipMalloc(&dA[r], na * 2); hipMalloc(&dB[r], nb * 2); hipMalloc(&dC[r], nc * 2); hipMalloc(&dZ[r], nc * 2); hipMalloc(&dR[r], nc * 2);
+        hipMemcpy(dA[r], h.data(), na * 2, hipMemcpyHostToDevice); hipMemcpy(dB[r], h.data(), nb * 2, hipMemcpyHostToDevice);
+        hipMemcpy(dZ[r], h.data(), nc * 2, hipMemcpyHostToDevice); hipMemcpy(dR[r], h.data(), nc * 2, hipMemcpyHostToDevice);
+    }
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    const int it = 24;
+    for (int i = -3; i < it; ++i) {
+        if (i == 0) hipEventRecord(a, nullptr);
+        const int r = (i + 3) % rot;
+        vm_gemm_epilogue e = {}; e.alpha = 1.f; e.out_dtype = VM_BF16; e.split_k = 1;
+        if (flags & 1) e.bias = (const float*)dbias;
+        if (flags & 2) e.act = 1;
+        if (flags & 4) e.aux_out = dZ[r];
+        if (flags & 8) e.mul_gelu_z = dZ[r];
+        if (flags & 16) { e.dropout_p = 0.1f; e.dropout_seed = 1234 + i; }
+        if (flags & 32) { e.residual = dR[r]; e.ldr = N; }
+        int rc = vm_gemm_bf16(dA[r], lda, la, dB[r], ldb, lb, dC[r], N, M, N, K, &e, nullptr);
+        if (rc) { printf("rc=%d %s\n", rc, vm_last_error()); return; }
+    }
+    hipEventRecord(b, nullptr); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); ms /= it;
+    printf("epi M=%d N=%d K=%d l%d%d flags=%2d rot=%d: %7.1f us  %6.1f TFLOP/s\n", M, N, K, la, lb, flags, rot, ms * 1e3, 2.0 * M * N * K / ms * 1e-9);
+    for (int r = 0; r < rot; ++r) { hipFree(dA[r]); hipFree(dB[r]); hipFree(dC[r]); hipFree(dZ[r]); hipFree(dR[r]); }
+    hipFree(dbias);
+}
+
 static int test_ln(int rows, int cols) {
     std::vector<float> x((size_t)rows * cols), dy(x.size()), g(cols), bta(cols);
     for (auto& v : x) v = bf2f(f2bf(frand() * 2 + 0.3f));
@@ -143,13 +179,24 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
+    if (argc >= 2 && !strcmp(argv[1], "epi")) {
+        struct { int M, N, K, la, lb, flags; } cs[] = {
+            {12608, 3072, 768, 0, 0, 0}, {12608, 3072, 768, 0, 0, 1}, {12608, 3072, 768, 0, 0, 3}, {12608, 3072, 768, 0, 0, 7}, {12608, 3072, 768, 0, 0, 5},
+            {12608, 3072, 768, 0, 1, 0}, {12608, 3072, 768, 0, 1, 8},
+            {12608, 768, 768, 0, 0, 0}, {12608, 768, 768, 0, 0, 1}, {12608, 768, 768, 0, 0, 33}, {8192, 768, 768, 0, 0, 49},
+            {12608, 768, 3072, 0, 0, 0}, {12608, 768, 3072, 0, 0, 33}, {12608, 2304, 768, 0, 0, 0}, {12608, 2304, 768, 0, 0, 1},
+            {12608, 768, 768, 0, 1, 0}, {8192, 768, 768, 0, 1, 0},
+        };
+        for (auto& c : cs) for (int rot = 1; rot <= 6; rot += 5) bench_gemm2(c.M, c.N, c.K, c.la, c.lb, c.flags, rot);
+        return 0;
+    }
     short* d; hipMalloc(&d, 256 * 2);
     hipLaunchKernelGGL(tr_probe, dim3(1), dim3(64), 0, 0, d);
     short h[256]; hipMemcpy(h, d, 512, hipMemcpyDeviceToHost);
     printf("ds_read_b64_tr_b16 with lane l -> &lds[4l] (values are source element indices):\n");
     for (int l = 0; l < 64; ++l) { printf("  lane %2d: %4d %4d %4d %4d%s", l, h[l * 4], h[l * 4 + 1], h[l * 4 + 2], h[l * 4 + 3], (l & 3) == 3 ? "\n" : ""); }
     int fails = 0;
-    for (int variant = 0; variant < 3; ++variant) {
+    for (int variant = 0; variant < 4; ++variant) {
         { char b[4]; snprintf(b, 4, "%d", variant); setenv("VM_GEMM_VARIANT", b, 1); }
         printf("---- VM_GEMM_VARIANT=%d correctness\n", variant);
         for (int la = 0; la < 2; ++la) for (int lb = 0; lb < 2; ++lb) {
@@ -174,7 +221,7 @@ int main(int argc, char** argv) {
         {2304, 768, 12608, 1, 1, 2}, {768, 768, 12608, 1, 1, 8}, {768, 768, 12608, 1, 1, 14}, {3072, 768, 12608, 1, 1, 2}, {3072, 768, 12608, 1, 1, 4},
         {768, 3072, 12608, 1, 1, 4}, {30528, 768, 8192, 1, 1, 1}, {8192, 8192, 8192, 0, 0, 1}, {8192, 8192, 8192, 1, 1, 1},
     };
-    for (auto& sh : shapes) for (int variant = 0; variant < 3; variant += 2) {
+    for (auto& sh : shapes) for (int variant = 0; variant < 4; variant += 3) {
         { char b[4]; snprintf(b, 4, "%d", variant); setenv("VM_GEMM_VARIANT", b, 1); }
         printf("v%d ", variant);
         bench_gemm(sh.M, sh.N, sh.K, sh.la, sh.lb, sh.split);

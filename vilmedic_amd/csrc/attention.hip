@@ -13,11 +13,8 @@
 // Masks: key_mask (1 = attend) and causal are applied as a -1e30 score (a fully masked row degrades to
 // the uniform distribution exactly like HF's additive finfo.min mask); keys >= Lk get -inf.
 // stats[b,h,i] = (row max m, row sum l) of the scaled+masked scores, saved for the backward pass.
-#include "common.h"
+#include "attention_common.h"
 #include <cstdlib>
-
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef short v4s __attribute__((ext_vector_type(4)));
 
 #define TROWS 64                 // rows per streamed tile
 #define TSTRIDE (DH * 2 + 16)    // bytes per LDS tile row (DH bf16 + 16 B pad); DH is a template parameter (32/64/96/128)
@@ -25,31 +22,10 @@ typedef short v4s __attribute__((ext_vector_type(4)));
 #define NLD (DH / 32)            // 16-B chunks each thread stages per tile (64 rows x DH/8 chunks / 256 threads)
 #define NDF (DH / 16)            // 16-wide output fragments along the head dimension
 #define NKK (DH / 32)            // 32-deep MFMA k-steps along the head dimension
-#define MASKED_SCORE (-1e30f)
 #ifndef ATTN_MIN_BLOCKS
 #define ATTN_MIN_BLOCKS 2      // __launch_bounds__ second argument (waves per SIMD) of the streaming variants
 #endif
 
-struct AttnArgs {
-    const bf16_t *q, *k, *v, *o, *d_o;
-    bf16_t *out, *dq, *dk, *dv;
-    int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
-    float* stats;            // [B,H,Lq,2]
-    float* delta;            // [B,H,Lq]
-    const uint8_t* key_mask; // [B,Lk] or null
-    const int32_t* kv_index; // fwd only: [B, kv_index_ld] absolute K/V row of key j of batch b (KV-cache indirection), or null
-    int64_t kv_index_ld;
-    int B, H, Lq, Lk;
-    int nslot_k, nslot_q;    // resident variants: LDS tile slots actually allocated (ceil(L/64))
-    float scale; int causal;
-    float dropout_p; uint64_t seed; uint32_t thresh; float drop_scale;
-};
-
-__device__ __forceinline__ bf16x8_t ld_frag_global(const bf16_t* p, const bf16_t* safe, bool ok) {
-    uint4 v = *reinterpret_cast<const uint4*>(ok ? p : safe);
-    if (!ok) v = make_uint4(0, 0, 0, 0);
-    return __builtin_bit_cast(bf16x8_t, v);
-}
 // A operand from a row-major LDS tile, contraction = the tile's columns (dh): rows rbase+(lane&15)
 template <int DH>
 __device__ __forceinline__ bf16x8_t lds_frag_rows(const char* tile, int rbase, int kk, int lane) {
@@ -70,24 +46,8 @@ __device__ __forceinline__ bf16x8_t lds_frag_tr(const char* tile, int cbase, int
     short8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);
 }
-__device__ __forceinline__ bf16x8_t pack_b_operand(const float4_t& a, const float4_t& b) {
-    uint4 u;
-    u.x = pack_bf16x2(a[0], a[1]); u.y = pack_bf16x2(a[2], a[3]);
-    u.z = pack_bf16x2(b[0], b[1]); u.w = pack_bf16x2(b[2], b[3]);
-    return __builtin_bit_cast(bf16x8_t, u);
-}
-__device__ __forceinline__ float col_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
-__device__ __forceinline__ float col_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
-
 // stream one 64 x DH bf16 tile (rows row0.. of a [rows, ld] matrix at column offset already applied)
 template <int DH> struct Stage { uint4 r[NLD]; };
-// predicated 16-B load: out-of-range lanes re-read a valid address (``safe``) and zero the result, so the
-// compiler keeps a plain global_load (a select between the pointer and a stack zero becomes a flat load)
-__device__ __forceinline__ uint4 ld16_or_zero(const bf16_t* p, const bf16_t* safe, bool ok) {
-    uint4 v = *reinterpret_cast<const uint4*>(ok ? p : safe);
-    if (!ok) v = make_uint4(0, 0, 0, 0);
-    return v;
-}
 template <int DH>
 __device__ __forceinline__ Stage<DH> tile_load(const bf16_t* base, int64_t ld, int row0, int nrows, int tid) {
     Stage<DH> st;
@@ -231,14 +191,15 @@ __global__ __launch_bounds__(256, RES ? 4 : ATTN_MIN_BLOCKS) void attn_fwd_kerne
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[f][r] *= alpha;
         if (p.dropout_p > 0.f) {
-            const uint64_t base = ((uint64_t)(b * p.H + h) * p.Lq + qrow) * (uint64_t)p.Lk;
+            const uint64_t base = ((uint64_t)(b * p.H + h) * p.Lq + qrow) * (uint64_t)((p.Lk + 1) & ~1);   // even row pitch
+            const DropKey dk_ = drop_key(p.seed);
 #pragma unroll
-            for (int f = 0; f < 4; ++f)
+            for (int f = 0; f < 4; ++f) {
+                bool keep[4];
+                dropout_keep_n<4>(dk_, base + (kt * TROWS + 16 * f + 4 * g), p.thresh, keep);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kt * TROWS + 16 * f + 4 * g + r;
-                    s[f][r] = dropout_keep(p.seed, base + key, p.thresh) ? s[f][r] * p.drop_scale : 0.f;
-                }
+                for (int r = 0; r < 4; ++r) s[f][r] = keep[r] ? s[f][r] * p.drop_scale : 0.f;
+            }
         }
         bf16x8_t pb[2] = {pack_b_operand(s[0], s[1]), pack_b_operand(s[2], s[3])};
 #pragma unroll
@@ -348,7 +309,7 @@ __global__ __launch_bounds__(256, RES ? 4 : ATTN_MIN_BLOCKS) void attn_bwd_dq_ke
                 dp[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_rows<DH>(sv, 16 * f, kk, lane), dof[kk], dp[f], 0, 0, 0);
             }
         }
-        const uint64_t dbase = ((uint64_t)(b * p.H + h) * p.Lq + qrow) * (uint64_t)p.Lk;
+        const uint64_t dbase = ((uint64_t)(b * p.H + h) * p.Lq + qrow) * (uint64_t)((p.Lk + 1) & ~1);
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             const uint32_t mk = *reinterpret_cast<const uint32_t*>(smask + 16 * f + 4 * g);
@@ -360,7 +321,7 @@ __global__ __launch_bounds__(256, RES ? 4 : ATTN_MIN_BLOCKS) void attn_bwd_dq_ke
                 val = keep ? val : MASKED_SCORE;
                 const float pr = (key < p.Lk && qok) ? __expf(val - m) * inv_l : 0.f;
                 float dpv = dp[f][r];
-                if (p.dropout_p > 0.f) dpv = dropout_keep(p.seed, dbase + key, p.thresh) ? dpv * p.drop_scale : 0.f;
+                if (p.dropout_p > 0.f) dpv = dropout_keep(drop_key(p.seed), dbase + key, p.thresh) ? dpv * p.drop_scale : 0.f;
                 s[f][r] = pr * (dpv - delta);      // dS^T
             }
         }
@@ -461,7 +422,7 @@ __global__ __launch_bounds__(256, RES ? 2 : ATTN_MIN_BLOCKS) void attn_bwd_dkv_k
                 const float pr = (qr < p.Lq && kok) ? __expf(val - mr[r]) * ir[r] : 0.f;
                 float dpv = dp[f][r], pd = pr;
                 if (p.dropout_p > 0.f) {
-                    const bool kp_ = dropout_keep(p.seed, ((uint64_t)(b * p.H + h) * p.Lq + qr) * (uint64_t)p.Lk + key, p.thresh);
+                    const bool kp_ = dropout_keep(drop_key(p.seed), ((uint64_t)(b * p.H + h) * p.Lq + qr) * (uint64_t)((p.Lk + 1) & ~1) + key, p.thresh);
                     dpv = kp_ ? dpv * p.drop_scale : 0.f;
                     pd = kp_ ? pr * p.drop_scale : 0.f;
                 }
@@ -511,10 +472,12 @@ extern "C" int vm_attention_fwd(const void* q, int64_t ldq, const void* k, int64
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.stats = stats; a.key_mask = key_mask;
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.causal = causal;
     a.kv_index = kv_row_index; a.kv_index_ld = kv_index_ld;
-    a.dropout_p = dropout_p; a.seed = dropout_seed; a.thresh = dropout_thresh24(dropout_p);
+    a.dropout_p = dropout_p; a.seed = dropout_seed; a.thresh = dropout_thresh16(dropout_p);
     a.drop_scale = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_ATTN, 4.0 * B * H * (double)Lq * Lk * dh, s);
+    // dh = 64 with a short resident sequence (every ViT-B / BERT-base layer): one workgroup per (b, h), K/V loaded once
+    if (dh == 64 && Lk <= 256 && !kv_row_index && !getenv("VM_ATTN_TILE") && !getenv("VM_ATTN_STREAM")) return vm_attn_head_fwd(a, s);
     const dim3 grid((Lq + 63) / 64, H, B);
     const bool res = Lk <= 256 && !getenv("VM_ATTN_STREAM");
     a.nslot_k = (Lk + 63) / 64; a.nslot_q = (Lq + 63) / 64;
@@ -541,12 +504,13 @@ extern "C" int vm_attention_bwd(const void* q, int64_t ldq, const void* k, int64
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
     a.stats = const_cast<float*>(stats); a.delta = ws_delta; a.key_mask = key_mask;
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.causal = causal;
-    a.dropout_p = dropout_p; a.seed = dropout_seed; a.thresh = dropout_thresh24(dropout_p);
+    a.dropout_p = dropout_p; a.seed = dropout_seed; a.thresh = dropout_thresh16(dropout_p);
     a.drop_scale = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_ATTN, 14.0 * B * H * (double)Lq * Lk * dh, s);
     const int64_t rows = (int64_t)B * H * Lq;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, a, dh);
+    if (dh == 64 && Lk <= 256 && Lq <= 256 && !getenv("VM_ATTN_TILE") && !getenv("VM_ATTN_STREAM")) return vm_attn_head_bwd(a, s);
     const dim3 gq((Lq + 63) / 64, H, B), gk((Lk + 63) / 64, H, B);
     const bool resk = Lk <= 256 && !getenv("VM_ATTN_STREAM"), resq = Lq <= 256 && !getenv("VM_ATTN_STREAM");
     a.nslot_k = (Lk + 63) / 64; a.nslot_q = (Lq + 63) / 64;

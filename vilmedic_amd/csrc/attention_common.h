@@ -1,0 +1,50 @@
+// attention_common.h -- argument block and small device helpers shared by attention.hip (tile-streaming kernels, any
+// supported head dim / length) and attention_head.hip (head-resident kernels, dh = 64, L <= 256).
+#pragma once
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short v4s __attribute__((ext_vector_type(4)));
+
+#define MASKED_SCORE (-1e30f)
+
+struct AttnArgs {
+    const bf16_t *q, *k, *v, *o, *d_o;
+    bf16_t *out, *dq, *dk, *dv;
+    int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+    float* stats;            // [B,H,Lq,2]
+    float* delta;            // [B,H,Lq]
+    const uint8_t* key_mask; // [B,Lk] or null
+    const int32_t* kv_index; // fwd only: [B, kv_index_ld] absolute K/V row of key j of batch b (KV-cache indirection), or null
+    int64_t kv_index_ld;
+    int B, H, Lq, Lk;
+    int nslot_k, nslot_q;    // resident variants: LDS tile slots actually allocated (ceil(L/64))
+    int ralloc_k, ralloc_q;  // head-resident variants: LDS rows allocated for K/V resp. Q/dO (L rounded up to 4)
+    float scale; int causal;
+    float dropout_p; uint64_t seed; uint32_t thresh; float drop_scale;
+};
+
+__device__ __forceinline__ bf16x8_t ld_frag_global(const bf16_t* p, const bf16_t* safe, bool ok) {
+    uint4 v = *reinterpret_cast<const uint4*>(ok ? p : safe);
+    if (!ok) v = make_uint4(0, 0, 0, 0);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ bf16x8_t pack_b_operand(const float4_t& a, const float4_t& b) {
+    uint4 u;
+    u.x = pack_bf16x2(a[0], a[1]); u.y = pack_bf16x2(a[2], a[3]);
+    u.z = pack_bf16x2(b[0], b[1]); u.w = pack_bf16x2(b[2], b[3]);
+    return __builtin_bit_cast(bf16x8_t, u);
+}
+__device__ __forceinline__ float col_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float col_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+
+// predicated 16-B load: out-of-range lanes re-read a valid address (``safe``) and zero the result, so the
+// compiler keeps a plain global_load (a select between the pointer and a stack zero becomes a flat load)
+__device__ __forceinline__ uint4 ld16_or_zero(const bf16_t* p, const bf16_t* safe, bool ok) {
+    uint4 v = *reinterpret_cast<const uint4*>(ok ? p : safe);
+    if (!ok) v = make_uint4(0, 0, 0, 0);
+    return v;
+}
+
+int vm_attn_head_fwd(const AttnArgs& a, hipStream_t s);
+int vm_attn_head_bwd(const AttnArgs& a, hipStream_t s);

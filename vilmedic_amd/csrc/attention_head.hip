@@ -1,0 +1,474 @@
+// attention_head.hip -- head-resident attention kernels for gfx950: dh = 64 and the resident sequence <= 256 rows
+// (every ViT-B/16, BERT-base self- and cross-attention of the RRG hot path).
+//
+// One workgroup = one (batch, head) pair (x a chunk of 256 owner rows).  The "other" sequence of the pair (K,V for
+// forward / dQ; Q,dO for dK,dV) is loaded from HBM exactly ONCE per head -- all loads issued before the first LDS
+// store, one barrier per kernel -- into un-padded 128-B LDS rows, and the 4 waves then loop over 16-row owner groups
+// (13 groups for L = 197: waves get 4/3/3/3).  The math of a group is the transposed flash scheme of attention.hip
+// (S^T = K Q^T, P^T feeds the next MFMA as the B operand, transposed A operands via ds_read_b64_tr_b16).
+//
+// LDS layout: row r, 16-B chunk c lives at r*128 + ((c ^ hswz(r)) << 4) with hswz(r) = ((r >> 1) & 3) << 1.
+//   * ds_read_b128 row fragments: one LDS cycle serves 8 rows at chunk x and the 8 other rows of the 16-row fragment
+//     at chunk x+1; row parity picks the 128-B half of the 256-B bank line, (r>>1)&3 the chunk PAIR -> 16 distinct slots;
+//   * ds_read_b64_tr_b16 fragments: one cycle serves 8 consecutive rows x 32 B (a chunk pair each) -> 16 distinct slots.
+// Per-lane fragment offsets are kernel constants (the swizzle of row 16 F + c does not depend on F), control flow is
+// wave-uniform (fragment counts live in SGPRs), and fragments that need no key mask / causal / ragged-tail handling
+// take a one-multiply-per-score path.  Rows are zero-filled past L.  With L = 197 a workgroup needs ~52 KiB, so THREE
+// workgroups (12 waves) share a CU and the 768 (b,h) pairs of a B=64 x 12-head layer are all resident at once.
+#include "attention_common.h"
+
+#define HB 128                                     // bytes per LDS row (64 bf16)
+#define HCHUNK 256                                 // owner rows per workgroup
+__device__ __forceinline__ int hswz(int row) { return ((row >> 1) & 3) << 1; }
+
+// rows [0, nalloc) of two [*, ld] matrices (64 columns at the pointer) -> swizzled LDS; rows >= nvalid are zero.
+__device__ __forceinline__ void head_stage2(const bf16_t* a, int64_t lda, const bf16_t* b, int64_t ldb, int nvalid, int nalloc,
+                                            char* sa, char* sb, int tid) {
+    uint4 ra[8], rb[8];
+    const int r0 = tid >> 3, ch = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = r0 + 32 * i;
+        if (32 * i < nalloc) {
+            ra[i] = ld16_or_zero(a + (int64_t)row * lda + ch * 8, a, row < nvalid);
+            rb[i] = ld16_or_zero(b + (int64_t)row * ldb + ch * 8, b, row < nvalid);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = r0 + 32 * i;
+        if (32 * i < nalloc && row < nalloc) {
+            const int off = row * HB + ((ch ^ hswz(row)) << 4);
+            *reinterpret_cast<uint4*>(sa + off) = ra[i];
+            *reinterpret_cast<uint4*>(sb + off) = rb[i];
+        }
+    }
+}
+// Per-lane LDS byte offsets, constant for the whole kernel (row r = 16 F + (lane&15): (r>>1)&3 does not depend on F):
+//   row[kk]  ds_read_b128 A fragment of 16-row fragment F at k-step kk:     tile + F*2048 + row[kk]
+//   tr[df]   ds_read_b64_tr_b16 of rows 16 F + 4g + e, columns 16 df + ..:   tile + F*2048 + tr[df]  (second half: F+1)
+struct HLane { int row[2]; int tr[4]; };
+__device__ __forceinline__ HLane hlane_offsets(int lane) {
+    const int g = lane >> 4, c = lane & 15;
+    HLane L;
+    const int hs = ((c >> 1) & 3) << 1;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) L.row[kk] = c * HB + (((kk * 4 + g) ^ hs) << 4);
+    const int ri = 4 * g + (c >> 2), hst = ((ri >> 1) & 3) << 1, yi = (c & 3) >> 1, sub = (c & 1) * 8;
+#pragma unroll
+    for (int df = 0; df < 4; ++df) L.tr[df] = ri * HB + (((2 * df + yi) ^ hst) << 4) + sub;
+    return L;
+}
+__device__ __forceinline__ bf16x8_t lds_b128(const char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
+__device__ __forceinline__ v4s lds_tr(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(const __attribute__((address_space(3))) v4s*)p);
+}
+__device__ __forceinline__ bf16x8_t join_tr(v4s lo, v4s hi) {
+    short8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ void hstore_t_acc(bf16_t* rowptr, const float4_t (&acc)[4], float mul, int lane) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        uint2 u;
+        u.x = pack_bf16x2(acc[f][0] * mul, acc[f][1] * mul);
+        u.y = pack_bf16x2(acc[f][2] * mul, acc[f][3] * mul);
+        *reinterpret_cast<uint2*>(rowptr + 16 * f + 4 * g) = u;
+    }
+}
+// scaled + masked score of one 16-key fragment; `plain` (wave-uniform) = no key mask, not on the causal diagonal, no
+// keys past Lk in this fragment: the common case costs one multiply per element.
+__device__ __forceinline__ void mask_scores(float4_t& s, bool plain, const uint8_t* smask, int key0, int qrow, const AttnArgs& p) {
+    if (plain) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] *= p.scale;
+    } else {
+        const uint32_t mk = *reinterpret_cast<const uint32_t*>(smask + key0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = key0 + r;
+            float val = s[r] * p.scale;
+            const bool keep = ((mk >> (8 * r)) & 0xff) != 0 && !(p.causal && key > qrow);
+            val = keep ? val : MASKED_SCORE;
+            s[r] = key < p.Lk ? val : -INFINITY;
+        }
+    }
+}
+
+// =============================================================================== forward
+// K/V rows are allocated up to Lk rounded to 16 (zero-filled past Lk), so every fragment a group attends to is in range.
+__global__ __launch_bounds__(256, 3) void attn_head_fwd_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nalloc = p.ralloc_k;
+    char* sk = smem;
+    char* sv = smem + nalloc * HB;
+    uint8_t* smask = reinterpret_cast<uint8_t*>(sv + nalloc * HB);
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, h = blockIdx.y, qc0 = blockIdx.x * HCHUNK;
+    head_stage2(p.k + (int64_t)b * p.Lk * p.ldk + h * 64, p.ldk, p.v + (int64_t)b * p.Lk * p.ldv + h * 64, p.ldv, p.Lk, nalloc, sk, sv, tid);
+    smask[tid] = (p.key_mask && tid < p.Lk) ? p.key_mask[(int64_t)b * p.Lk + tid] : (uint8_t)1;
+    const int ngroups = (min(HCHUNK, p.Lq - qc0) + 15) / 16;
+    const int kfr_all = (p.Lk + 15) / 16;
+    const bool has_mask = p.key_mask != nullptr;
+    const bool ragged = (p.Lk & 15) != 0;
+    const HLane L = hlane_offsets(lane);
+    const DropKey dkey = drop_key(p.seed);
+    const uint32_t lk_even = (uint32_t)((p.Lk + 1) & ~1);
+    auto load_q = [&](int grp, bf16x8_t (&qf)[2]) {
+        const int qrow = qc0 + grp * 16 + c;
+        const bf16_t* qp = p.q + (int64_t)(b * p.Lq + qrow) * p.ldq + h * 64;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) qf[kk] = ld_frag_global(qp + kk * 32 + g * 8, p.q, qrow < p.Lq && grp < ngroups);
+    };
+    bf16x8_t qn[2];
+    load_q(wave, qn);
+    __syncthreads();
+    for (int grp = wave; grp < ngroups; grp += 4) {
+        const int q0 = qc0 + grp * 16, qrow = q0 + c;
+        const bool qok = qrow < p.Lq;
+        const bf16x8_t qf[2] = {qn[0], qn[1]};
+        load_q(grp + 4, qn);                       // prefetch the next group's queries behind this group's math
+        float4_t o[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) o[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        float m = -INFINITY, l = 0.f;
+        const int diag = q0 >> 4;                                              // fragment holding the causal diagonal
+        const int nfr = p.causal ? min(kfr_all, diag + 1) : kfr_all;           // 16-key fragments this group attends to
+        const uint32_t dbase = (uint32_t)(((uint64_t)(b * p.H + h) * p.Lq + qrow) * lk_even >> 1);   // pair index of key 0
+        for (int kt = 0; kt * 4 < nfr; ++kt) {
+            const int nf = min(4, nfr - 4 * kt);
+            const char* skt = sk + kt * 8192;
+            const char* svt = sv + kt * 8192;
+            float4_t s[4];
+            float mt = -INFINITY;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                if (f < nf) {
+                    const int F = 4 * kt + f;
+                    s[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+                        s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_b128(skt + f * 2048 + L.row[kk]), qf[kk], s[f], 0, 0, 0);
+                    const bool plain = !has_mask && !(p.causal && F == diag) && !(ragged && F == kfr_all - 1);
+                    mask_scores(s[f], plain, smask, 16 * F + 4 * g, qrow, p);
+                    mt = fmaxf(fmaxf(mt, fmaxf(s[f][0], s[f][1])), fmaxf(s[f][2], s[f][3]));
+                } else {
+                    s[f] = (float4_t){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                }
+            }
+            mt = col_max(mt);
+            const float m_new = fmaxf(m, mt);
+            const float alpha = __expf(m - m_new);
+            float ls = 0.f;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float e = __expf(s[f][r] - m_new); s[f][r] = e; ls += e; }
+            l = l * alpha + col_sum(ls);
+            m = m_new;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[f][r] *= alpha;
+            if (p.dropout_p > 0.f) {
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    if (f < nf) {
+                        const uint32_t pr0 = dbase + (uint32_t)(8 * (4 * kt + f) + 2 * g);
+                        const uint32_t h0 = drop_hash(dkey, pr0), h1 = drop_hash(dkey, pr0 + 1);
+                        s[f][0] = (h0 & 0xffffu) >= p.thresh ? s[f][0] * p.drop_scale : 0.f;
+                        s[f][1] = (h0 >> 16) >= p.thresh ? s[f][1] * p.drop_scale : 0.f;
+                        s[f][2] = (h1 & 0xffffu) >= p.thresh ? s[f][2] * p.drop_scale : 0.f;
+                        s[f][3] = (h1 >> 16) >= p.thresh ? s[f][3] * p.drop_scale : 0.f;
+                    }
+                }
+            }
+            const bf16x8_t pb[2] = {pack_b_operand(s[0], s[1]), pack_b_operand(s[2], s[3])};
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                if (2 * st < nf) {
+                    const bool hi_ok = 2 * st + 1 < nf;            // the odd fragment may lie past the allocation
+#pragma unroll
+                    for (int df = 0; df < 4; ++df) {
+                        const v4s lo = lds_tr(svt + (2 * st) * 2048 + L.tr[df]);
+                        v4s hi = (v4s){0, 0, 0, 0};
+                        if (hi_ok) hi = lds_tr(svt + (2 * st + 1) * 2048 + L.tr[df]);
+                        o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_tr(lo, hi), pb[st], o[df], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (qok) {
+            hstore_t_acc(p.out + (int64_t)(b * p.Lq + qrow) * p.ldo + h * 64, o, 1.0f / l, lane);
+            if (g == 0) {
+                float* st = p.stats + ((int64_t)(b * p.H + h) * p.Lq + qrow) * 2;
+                st[0] = m; st[1] = l;
+            }
+        }
+    }
+}
+
+// =============================================================================== dQ  (owner: 16 queries per group)
+__global__ __launch_bounds__(256, 3) void attn_head_dq_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nalloc = p.ralloc_k;
+    char* sk = smem;
+    char* sv = smem + nalloc * HB;
+    uint8_t* smask = reinterpret_cast<uint8_t*>(sv + nalloc * HB);
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, h = blockIdx.y, qc0 = blockIdx.x * HCHUNK;
+    head_stage2(p.k + (int64_t)b * p.Lk * p.ldk + h * 64, p.ldk, p.v + (int64_t)b * p.Lk * p.ldv + h * 64, p.ldv, p.Lk, nalloc, sk, sv, tid);
+    smask[tid] = (p.key_mask && tid < p.Lk) ? p.key_mask[(int64_t)b * p.Lk + tid] : (uint8_t)1;
+    const int ngroups = (min(HCHUNK, p.Lq - qc0) + 15) / 16;
+    const int kfr_all = (p.Lk + 15) / 16;
+    const bool has_mask = p.key_mask != nullptr;
+    const bool ragged = (p.Lk & 15) != 0;
+    const HLane L = hlane_offsets(lane);
+    const DropKey dkey = drop_key(p.seed);
+    const uint32_t lk_even = (uint32_t)((p.Lk + 1) & ~1);
+    struct Own { bf16x8_t qf[2], dof[2]; float m, inv_l, delta; };
+    auto load_own = [&](int grp, Own& w) {
+        const int qrow = qc0 + grp * 16 + c;
+        const bool ok = qrow < p.Lq && grp < ngroups;
+        const bf16_t* qp = p.q + (int64_t)(b * p.Lq + qrow) * p.ldq + h * 64;
+        const bf16_t* dop = p.d_o + (int64_t)(b * p.Lq + qrow) * p.lddo + h * 64;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) { w.qf[kk] = ld_frag_global(qp + kk * 32 + g * 8, p.q, ok); w.dof[kk] = ld_frag_global(dop + kk * 32 + g * 8, p.d_o, ok); }
+        const int64_t si = ok ? (int64_t)(b * p.H + h) * p.Lq + qrow : 0;
+        const float mm = p.stats[si * 2], ll = p.stats[si * 2 + 1], dl = p.delta[si];
+        w.m = ok ? mm : 0.f; w.inv_l = ok ? 1.0f / ll : 0.f; w.delta = ok ? dl : 0.f;
+    };
+    Own nx;
+    load_own(wave, nx);
+    __syncthreads();
+    for (int grp = wave; grp < ngroups; grp += 4) {
+        const int q0 = qc0 + grp * 16, qrow = q0 + c;
+        const bool qok = qrow < p.Lq;
+        const Own w = nx;
+        load_own(grp + 4, nx);
+        float4_t dq[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) dq[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        const int diag = q0 >> 4;
+        const int nfr = p.causal ? min(kfr_all, diag + 1) : kfr_all;
+        const uint32_t dbase = (uint32_t)(((uint64_t)(b * p.H + h) * p.Lq + qrow) * lk_even >> 1);
+        for (int kt = 0; kt * 4 < nfr; ++kt) {
+            const int nf = min(4, nfr - 4 * kt);
+            const char* skt = sk + kt * 8192;
+            const char* svt = sv + kt * 8192;
+            float4_t s[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                s[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                if (f < nf) {
+                    const int F = 4 * kt + f;
+                    float4_t dp = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_b128(skt + f * 2048 + L.row[kk]), w.qf[kk], s[f], 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_b128(svt + f * 2048 + L.row[kk]), w.dof[kk], dp, 0, 0, 0);
+                    }
+                    const bool plain = !has_mask && !(p.causal && F == diag) && !(ragged && F == kfr_all - 1);
+                    mask_scores(s[f], plain, smask, 16 * F + 4 * g, qrow, p);
+                    if (p.dropout_p > 0.f) {
+                        const uint32_t pr0 = dbase + (uint32_t)(8 * F + 2 * g);
+                        const uint32_t h0 = drop_hash(dkey, pr0), h1 = drop_hash(dkey, pr0 + 1);
+                        dp[0] = (h0 & 0xffffu) >= p.thresh ? dp[0] * p.drop_scale : 0.f;
+                        dp[1] = (h0 >> 16) >= p.thresh ? dp[1] * p.drop_scale : 0.f;
+                        dp[2] = (h1 & 0xffffu) >= p.thresh ? dp[2] * p.drop_scale : 0.f;
+                        dp[3] = (h1 >> 16) >= p.thresh ? dp[3] * p.drop_scale : 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pr = __expf(s[f][r] - w.m) * w.inv_l;      // 0 for keys >= Lk (score -inf) and dead queries (inv_l 0)
+                        s[f][r] = pr * (dp[r] - w.delta);                      // dS^T
+                    }
+                }
+            }
+            const bf16x8_t db[2] = {pack_b_operand(s[0], s[1]), pack_b_operand(s[2], s[3])};
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                if (2 * st < nf) {
+                    const bool hi_ok = 2 * st + 1 < nf;
+#pragma unroll
+                    for (int df = 0; df < 4; ++df) {
+                        const v4s lo = lds_tr(skt + (2 * st) * 2048 + L.tr[df]);
+                        v4s hi = (v4s){0, 0, 0, 0};
+                        if (hi_ok) hi = lds_tr(skt + (2 * st + 1) * 2048 + L.tr[df]);
+                        dq[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_tr(lo, hi), db[st], dq[df], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (qok) hstore_t_acc(p.dq + (int64_t)(b * p.Lq + qrow) * p.lddq + h * 64, dq, p.scale, lane);
+    }
+}
+
+// =============================================================================== dK, dV  (owner: 16 keys per group)
+// Q/dO rows are allocated up to Lq rounded to 4 only (with the 3 stats per query this is what still lets three
+// workgroups share a CU at Lq = 197): the last, partial 16-row fragment uses clamped per-lane addresses, and the
+// transposed reads of its missing rows are zeroed in registers (they meet P = dS = 0, and 0 x garbage must stay 0).
+__global__ __launch_bounds__(256, 3) void attn_head_dkv_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nalloc = p.ralloc_q;
+    char* sq = smem;
+    char* sdo = smem + nalloc * HB;
+    float* sm = reinterpret_cast<float*>(sdo + nalloc * HB);      // [3][nalloc]: m, 1/l, delta
+    float* sil = sm + nalloc;
+    float* sdl = sil + nalloc;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, h = blockIdx.y, kc0 = blockIdx.x * HCHUNK;
+    head_stage2(p.q + (int64_t)b * p.Lq * p.ldq + h * 64, p.ldq, p.d_o + (int64_t)b * p.Lq * p.lddo + h * 64, p.lddo, p.Lq, nalloc, sq, sdo, tid);
+    if (tid < nalloc) {
+        float mm = 0.f, il = 0.f, dl = 0.f;
+        if (tid < p.Lq) {
+            const int64_t si = (int64_t)(b * p.H + h) * p.Lq + tid;
+            mm = p.stats[si * 2]; il = 1.0f / p.stats[si * 2 + 1]; dl = p.delta[si];
+        }
+        sm[tid] = mm; sil[tid] = il; sdl[tid] = dl;      // rows >= Lq: 1/l = 0  ->  P = dS = 0
+    }
+    const int ngroups = (min(HCHUNK, p.Lk - kc0) + 15) / 16;
+    const int qfr_all = (p.Lq + 15) / 16;
+    const int F_part = (nalloc & 15) ? (nalloc >> 4) : -1;         // the partial fragment, if any
+    const HLane L = hlane_offsets(lane);
+    HLane LP = L;                                                   // absolute offsets for fragment F_part
+    bool part_dead = false;                                         // this lane's 4 transposed rows lie past the allocation
+    if (F_part >= 0) {
+        const int row = min(16 * F_part + c, nalloc - 1), hs = hswz(row);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) LP.row[kk] = row * HB + (((kk * 4 + g) ^ hs) << 4);
+        const int rt = min(16 * F_part + 4 * g + (c >> 2), nalloc - 1), hst = hswz(rt), yi = (c & 3) >> 1, sub = (c & 1) * 8;
+#pragma unroll
+        for (int df = 0; df < 4; ++df) LP.tr[df] = rt * HB + (((2 * df + yi) ^ hst) << 4) + sub;
+        part_dead = 16 * F_part + 4 * g >= nalloc;
+    }
+    const DropKey dkey = drop_key(p.seed);
+    const uint32_t lk_even = (uint32_t)((p.Lk + 1) & ~1);
+    struct Own { bf16x8_t kf[2], vf[2]; bool keep; };
+    auto load_own = [&](int grp, Own& w) {
+        const int key = kc0 + grp * 16 + c;
+        const bool ok = key < p.Lk && grp < ngroups;
+        const bf16_t* kp = p.k + (int64_t)(b * p.Lk + key) * p.ldk + h * 64;
+        const bf16_t* vp = p.v + (int64_t)(b * p.Lk + key) * p.ldv + h * 64;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) { w.kf[kk] = ld_frag_global(kp + kk * 32 + g * 8, p.k, ok); w.vf[kk] = ld_frag_global(vp + kk * 32 + g * 8, p.v, ok); }
+        const uint8_t mk = (ok && p.key_mask) ? p.key_mask[(int64_t)b * p.Lk + key] : (uint8_t)1;
+        w.keep = mk != 0;
+    };
+    // one half (16 tile rows = fragment F) of a transposed A operand
+    auto tr_half = [&](const char* tile, int F, int df) -> v4s {
+        if (F >= qfr_all) return (v4s){0, 0, 0, 0};
+        if (F == F_part) {
+            v4s v = lds_tr(tile + LP.tr[df]);
+            if (part_dead) v = (v4s){0, 0, 0, 0};
+            return v;
+        }
+        return lds_tr(tile + F * 2048 + L.tr[df]);
+    };
+    Own nx;
+    load_own(wave, nx);
+    __syncthreads();
+    for (int grp = wave; grp < ngroups; grp += 4) {
+        const int k0 = kc0 + grp * 16, key = k0 + c;
+        const bool kok = key < p.Lk;
+        const Own w = nx;
+        load_own(grp + 4, nx);
+        float4_t dk[4], dv[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { dk[f] = (float4_t){0.f, 0.f, 0.f, 0.f}; dv[f] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
+        const int fr_begin = p.causal ? (k0 >> 4) : 0;      // query fragments before the group's first key see none of its keys
+        for (int qt = fr_begin >> 2; qt * 4 < qfr_all; ++qt) {
+            const int f_lo = max(0, fr_begin - 4 * qt), nf = min(4, qfr_all - 4 * qt);
+            float4_t s[4], dp[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                s[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                dp[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                if (f >= f_lo && f < nf) {
+                    const int F = 4 * qt + f;
+                    const bool part = F == F_part;
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const int off = part ? LP.row[kk] : F * 2048 + L.row[kk];
+                        s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_b128(sq + off), w.kf[kk], s[f], 0, 0, 0);
+                        dp[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_b128(sdo + off), w.vf[kk], dp[f], 0, 0, 0);
+                    }
+                    const int si = min(16 * F + 4 * g, nalloc - 4);
+                    const float4 m4 = *reinterpret_cast<const float4*>(sm + si);
+                    const float4 i4 = *reinterpret_cast<const float4*>(sil + si);
+                    const float4 d4 = *reinterpret_cast<const float4*>(sdl + si);
+                    const float mr[4] = {m4.x, m4.y, m4.z, m4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
+                    float ir[4] = {i4.x, i4.y, i4.z, i4.w};
+                    if (part && part_dead) { ir[0] = 0.f; ir[1] = 0.f; ir[2] = 0.f; ir[3] = 0.f; }   // clamped stats index: dead rows
+                    const bool diag = p.causal && F == fr_begin;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int qr = 16 * F + 4 * g + r;
+                        float val = s[f][r] * p.scale;
+                        const bool keep = w.keep && !(diag && key > qr);
+                        val = keep ? val : MASKED_SCORE;
+                        const float pr = kok ? __expf(fminf(val - mr[r], 0.f)) * ir[r] : 0.f;   // live rows have val <= m; dead rows (1/l = 0) must not overflow
+                        float dpv = dp[f][r], pd = pr;
+                        if (p.dropout_p > 0.f) {
+                            const uint32_t pair = (uint32_t)((((uint64_t)(b * p.H + h) * p.Lq + qr) * lk_even + (uint32_t)key) >> 1);
+                            const uint32_t hh = drop_hash(dkey, pair);
+                            const bool kp_ = ((key & 1) ? (hh >> 16) : (hh & 0xffffu)) >= p.thresh;
+                            dpv = kp_ ? dpv * p.drop_scale : 0.f;
+                            pd = kp_ ? pr * p.drop_scale : 0.f;
+                        }
+                        dp[f][r] = pd;                     // dropped P   -> dV
+                        s[f][r] = pr * (dpv - dr[r]);      // dS          -> dK
+                    }
+                }
+            }
+            const bf16x8_t pb[2] = {pack_b_operand(dp[0], dp[1]), pack_b_operand(dp[2], dp[3])};
+            const bf16x8_t sb[2] = {pack_b_operand(s[0], s[1]), pack_b_operand(s[2], s[3])};
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                if (2 * st + 1 >= f_lo && 2 * st < nf) {
+                    const int F0 = 4 * qt + 2 * st;
+#pragma unroll
+                    for (int df = 0; df < 4; ++df) {
+                        dv[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_tr(tr_half(sdo, F0, df), tr_half(sdo, F0 + 1, df)), pb[st], dv[df], 0, 0, 0);
+                        dk[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_tr(tr_half(sq, F0, df), tr_half(sq, F0 + 1, df)), sb[st], dk[df], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (kok) {
+            hstore_t_acc(p.dk + (int64_t)(b * p.Lk + key) * p.lddk + h * 64, dk, p.scale, lane);
+            hstore_t_acc(p.dv + (int64_t)(b * p.Lk + key) * p.lddv + h * 64, dv, 1.0f, lane);
+        }
+    }
+}
+
+// =============================================================================== host
+template <typename K>
+static void launch_head(K kernel, dim3 grid, size_t lds, hipStream_t s, const AttnArgs& a) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * HB + 4096);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, a);
+}
+
+int vm_attn_head_fwd(const AttnArgs& a0, hipStream_t s) {
+    AttnArgs a = a0;
+    a.ralloc_k = (a.Lk + 15) / 16 * 16;
+    launch_head(attn_head_fwd_kernel, dim3((a.Lq + HCHUNK - 1) / HCHUNK, a.H, a.B), (size_t)2 * a.ralloc_k * HB + 256, s, a);
+    return vm_check_launch("vm_attention_fwd(head)");
+}
+
+int vm_attn_head_bwd(const AttnArgs& a0, hipStream_t s) {
+    AttnArgs a = a0;
+    a.ralloc_k = (a.Lk + 15) / 16 * 16;
+    a.ralloc_q = (a.Lq + 3) / 4 * 4;
+    launch_head(attn_head_dq_kernel, dim3((a.Lq + HCHUNK - 1) / HCHUNK, a.H, a.B), (size_t)2 * a.ralloc_k * HB + 256, s, a);
+    launch_head(attn_head_dkv_kernel, dim3((a.Lk + HCHUNK - 1) / HCHUNK, a.H, a.B), (size_t)2 * a.ralloc_q * HB + 12 * a.ralloc_q, s, a);
+    return vm_check_launch("vm_attention_bwd(head)");
+}

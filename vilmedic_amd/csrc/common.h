@@ -14,16 +14,14 @@ typedef __attribute__((ext_vector_type(4))) uint32_t uint4_t;
 #define VM_WAVE 64
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-// round-to-nearest-even, NaN preserved (matches torch .to(bfloat16))
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16, round-to-nearest-even (matches torch .to(bfloat16)): the gfx950 hardware convert v_cvt_pk_bf16_f32
+typedef __bf16 vm_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float vm_f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const vm_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, vm_bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ void unpack8(const uint4 v, float* f) {
     f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
     f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
@@ -67,24 +65,50 @@ __device__ __forceinline__ GeluParts gelu_parts(float z) {
 __device__ __forceinline__ float gelu_f(float x) { return x * gelu_parts(x).cdf; }
 __device__ __forceinline__ float gelu_grad_f(float x) { const GeluParts g = gelu_parts(x); return g.cdf + x * g.pdf; }
 
-// counter-based RNG for dropout: keep iff u24(seed, idx) >= p * 2^24.  Stateless so that the
-// backward pass regenerates the mask instead of storing it.
-// (32-bit murmur3 finaliser over the folded 64-bit counter: ~10 integer ops per element, all 32-bit multiplies)
-__device__ __forceinline__ uint32_t vm_hash_u32(uint64_t seed, uint64_t idx) {
-    uint32_t h = (uint32_t)idx ^ (uint32_t)seed;
-    h += ((uint32_t)(idx >> 32) + (uint32_t)(seed >> 32)) * 0x9E3779B1u;
-    h ^= h >> 16; h *= 0x85EBCA6Bu;
-    h ^= h >> 13; h *= 0xC2B2AE35u;
-    h ^= h >> 16;
-    h += (uint32_t)(seed >> 32);
-    h ^= h >> 15; h *= 0x2C1B3C6Du;
-    h ^= h >> 12;
-    return h;
+// counter-based RNG for dropout.  Stateless, so the backward pass regenerates the mask instead of storing it.
+// One 32-bit hash decides TWO consecutive elements (16 bits each: keep iff u16 >= p * 2^16), which halves the integer
+// multiplies -- v_mul_lo_u32 is a quarter-rate instruction and the mask is generated inside MFMA epilogues and the
+// attention inner loop.  The 64-bit seed is expanded once per kernel (wave-uniform, scalar ALU) into two 32-bit keys;
+// the second key enters between the two multiply rounds so that masks of different seeds are not shifted copies.
+struct DropKey { uint32_t s0, s1; };
+__device__ __forceinline__ DropKey drop_key(uint64_t seed) {          // splitmix64 finaliser
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    DropKey k; k.s0 = (uint32_t)z; k.s1 = (uint32_t)(z >> 32);
+    return k;
 }
-__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh24) {
-    return (vm_hash_u32(seed, idx) >> 8) >= thresh24;
+__device__ __forceinline__ uint32_t drop_hash(const DropKey k, uint32_t pair) {
+    uint32_t x = pair ^ k.s0;
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x += k.s1; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
 }
-static inline uint32_t dropout_thresh24(float p) { return (uint32_t)((double)p * 16777216.0); }
+// element idx of the logical index space (pairs are (2k, 2k+1))
+__device__ __forceinline__ bool dropout_keep(const DropKey k, uint64_t idx, uint32_t thresh16) {
+    const uint32_t h = drop_hash(k, (uint32_t)(idx >> 1));
+    return ((idx & 1) ? (h >> 16) : (h & 0xffffu)) >= thresh16;
+}
+// N consecutive elements starting at idx0: N/2 hashes when idx0 is even (the normal case: even row lengths)
+template <int N>
+__device__ __forceinline__ void dropout_keep_n(const DropKey k, uint64_t idx0, uint32_t thresh16, bool (&keep)[N]) {
+    static_assert(N % 2 == 0, "pairs");
+    if ((idx0 & 1) == 0) {
+        const uint32_t p0 = (uint32_t)(idx0 >> 1);
+#pragma unroll
+        for (int j = 0; j < N / 2; ++j) {
+            const uint32_t h = drop_hash(k, p0 + j);
+            keep[2 * j] = (h & 0xffffu) >= thresh16;
+            keep[2 * j + 1] = (h >> 16) >= thresh16;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) keep[j] = dropout_keep(k, idx0 + j, thresh16);
+    }
+}
+static inline uint32_t dropout_thresh16(float p) { return (uint32_t)((double)p * 65536.0 + 0.5); }
 
 // ---- host-side plumbing
 void vm_set_error(const char* fmt, ...);

@@ -295,8 +295,10 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const bf16_t* __rest
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
         float f[8];
         unpack8(*reinterpret_cast<const uint4*>(x + i * 8), f);
+        bool keep[8];
+        dropout_keep_n<8>(drop_key(seed), (uint64_t)i * 8, thresh, keep);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = dropout_keep(seed, (uint64_t)(i * 8 + j), thresh) ? f[j] * scale : 0.f;
+        for (int j = 0; j < 8; ++j) f[j] = keep[j] ? f[j] * scale : 0.f;
         *reinterpret_cast<uint4*>(out + i * 8) = pack8(f);
     }
 }
@@ -304,6 +306,6 @@ extern "C" int vm_dropout_apply_bf16(const void* x, void* out, int64_t n, float 
     VM_REQUIRE(x && out && n > 0 && (n % 8) == 0 && p >= 0.f && p < 1.f, "vm_dropout_apply_bf16: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_ELT, 4.0 * n, s);
-    hipLaunchKernelGGL(dropout_apply_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, n, seed, dropout_thresh24(p), 1.0f / (1.0f - p));
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, n, seed, dropout_thresh16(p), 1.0f / (1.0f - p));
     return vm_check_launch("vm_dropout_apply_bf16");
 }

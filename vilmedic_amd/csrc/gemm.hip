@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
         if (e.dropout_p > 0.f) {
             const uint64_t idx = (uint64_t)gm * (uint64_t)p.N + (uint64_t)gn;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = dropout_keep(e.dropout_seed, idx + j, p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
+            for (int j = 0; j < 8; ++j) v[j] = dropout_keep(drop_key(e.dropout_seed), idx + j, p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
         }
         if (e.residual) {
             const bf16_t* rp = reinterpret_cast<const bf16_t*>(e.residual) + (int64_t)gm * e.ldr + gn;
@@ -280,7 +280,7 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
     a.ktiles_per_split = (a.ktiles + split - 1) / split;
     split = (a.ktiles + a.ktiles_per_split - 1) / a.ktiles_per_split;
     a.e = *epi;
-    a.drop_thresh = dropout_thresh24(epi->dropout_p);
+    a.drop_thresh = dropout_thresh16(epi->dropout_p);
     a.drop_scale = epi->dropout_p > 0.f ? 1.0f / (1.0f - epi->dropout_p) : 1.0f;
     const int nblocks = a.tiles_m * a.tiles_n * split;
     hipStream_t s = (hipStream_t)stream;

@@ -26,11 +26,16 @@ typedef short v4s __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int swz1(int krow) { return ((krow & 3) << 1) | (((krow >> 3) & 1) << 3); }
 
-template <int LAYOUT, int ROWS>   // ROWS = tile extent along the non-contraction dim (128 or 256)
+template <int LAYOUT, int ROWS, int BKT>   // ROWS = tile extent along the non-contraction dim (128 or 256); BKT = k extent (32 / 64)
 __device__ __forceinline__ const bf16_t* stage_src(const bf16_t* base, int64_t ld, int row0, int nrows, int q, int lane) {
-    if (LAYOUT == 0) {                       // tile [ROWS][64 k]: one DMA instruction = 8 rows x 128 B
+    if (LAYOUT == 0 && BKT == 64) {          // tile [ROWS][64 k]: one DMA instruction = 8 rows x 128 B
         const int row = 8 * q + (lane >> 3);
         const int lc = (lane & 7) ^ (row & 7);
+        const int gr = min(row0 + row, nrows - 1);
+        return base + (int64_t)gr * ld + lc * 8;
+    } else if (LAYOUT == 0) {                // tile [ROWS][32 k]: one DMA instruction = 16 rows x 64 B; 4 rows share a
+        const int row = 16 * q + (lane >> 2);   // 256-B bank period, so the 16-B chunk is XORed with (row>>2)&3
+        const int lc = (lane & 3) ^ ((row >> 2) & 3);
         const int gr = min(row0 + row, nrows - 1);
         return base + (int64_t)gr * ld + lc * 8;
     } else {                                 // tile [64 k][ROWS]: one DMA instruction = 1 KiB = 1024/(2*ROWS) k-rows
@@ -62,11 +67,11 @@ __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int LA, int LB, int WM, int WN, int STAGES>
+template <int LA, int LB, int WM, int WN, int STAGES, int BKT>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fast_kernel(const GemmArgs p) {
     constexpr int FBM = WM * 64, FBN = WN * 64, NW = WM * WN, NT = NW * 64;
-    constexpr int F_OPER_A = FBM * 128, F_OPER_B = FBN * 128, F_STAGE = F_OPER_A + F_OPER_B;
-    constexpr int NA_I = 8 / WN, NB_I = 8 / WM;   // A- / B-tile DMA instructions (1 KiB each) per wave
+    constexpr int F_OPER_A = FBM * BKT * 2, F_OPER_B = FBN * BKT * 2, F_STAGE = F_OPER_A + F_OPER_B;
+    constexpr int NA_I = (BKT / 8) / WN, NB_I = (BKT / 8) / WM;   // A- / B-tile DMA instructions (1 KiB each) per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -91,12 +96,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
     // ---- per-thread DMA sources (4 instructions per operand per wave), advanced by one K-tile per iteration
     const bf16_t* srcA[NA_I];
     const bf16_t* srcB[NB_I];
-    const int64_t stepA = LA == 0 ? FBK : (int64_t)FBK * p.lda;
-    const int64_t stepB = LB == 0 ? FBK : (int64_t)FBK * p.ldb;
+    const int64_t stepA = LA == 0 ? BKT : (int64_t)BKT * p.lda;
+    const int64_t stepB = LB == 0 ? BKT : (int64_t)BKT * p.ldb;
 #pragma unroll
-    for (int i = 0; i < NA_I; ++i) srcA[i] = stage_src<LA, FBM>(p.A, p.lda, m0, p.M, wave * NA_I + i, lane) + kt_begin * stepA;
+    for (int i = 0; i < NA_I; ++i) srcA[i] = stage_src<LA, FBM, BKT>(p.A, p.lda, m0, p.M, wave * NA_I + i, lane) + kt_begin * stepA;
 #pragma unroll
-    for (int i = 0; i < NB_I; ++i) srcB[i] = stage_src<LB, FBN>(p.B, p.ldb, n0, p.N, wave * NB_I + i, lane) + kt_begin * stepB;
+    for (int i = 0; i < NB_I; ++i) srcB[i] = stage_src<LB, FBN, BKT>(p.B, p.ldb, n0, p.N, wave * NB_I + i, lane) + kt_begin * stepB;
     auto stage = [&](int buf) {
         char* da = smem + buf * F_STAGE;
 #pragma unroll
@@ -112,7 +117,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
     const int j4 = c >> 2, s1 = (j4 << 1) | ((g & 1) << 3), sub1 = (c & 1) * 8, h1 = (c & 3) >> 1;
 
     auto read_frag0 = [&](const char* tile, int rbase, int i, int kk) -> bf16x8_t {
-        return *reinterpret_cast<const bf16x8_t*>(tile + (rbase + i * 16 + c) * 128 + (((kk * 4 + g) ^ (c & 7)) << 4));
+        if (BKT == 64) return *reinterpret_cast<const bf16x8_t*>(tile + (rbase + i * 16 + c) * 128 + (((kk * 4 + g) ^ (c & 7)) << 4));
+        return *reinterpret_cast<const bf16x8_t*>(tile + (rbase + i * 16 + c) * 64 + ((g ^ ((c >> 2) & 3)) << 4));
     };
     auto read_frag1 = [&](const char* tile, int rbase, int i, int kk, int row_bytes) -> bf16x8_t {
         const int krow = kk * 32 + 8 * g + j4;
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
         const char* sa = smem + buf * F_STAGE;
         const char* sb = sa + F_OPER_A;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BKT / 32; ++kk) {
             bf16x8_t fa[4], fb[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[i] = LA == 0 ? read_frag0(sa, a_rb, i, kk) : read_frag1(sa, a_rb, i, kk, FBM * 2);
@@ -158,21 +164,23 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
             compute(buf);
         }
     } else {
-        // 3-deep ring, two tiles in flight.  Each wave issues NLD = NA_I + NB_I DMA instructions per tile, so
+        // STAGES-deep ring, STAGES-1 tiles in flight.  Each wave issues NLD = NA_I + NB_I DMA instructions per tile, so
         // "tile kt has landed" == at most NLD * (tiles issued after kt) of this wave's loads are still outstanding.
-        constexpr int NLD = NA_I + NB_I;
+        constexpr int NLD = NA_I + NB_I, D = STAGES - 1;
         const int nk = kt_end - kt_begin;
-        stage(0);
-        if (nk > 1) stage(1);
-        int buf = 0;
+#pragma unroll
+        for (int t = 0; t < D; ++t) if (t < nk) stage(t);
+        int buf = 0, nbuf = D;                                // nbuf = ring slot of the next tile to issue
         for (int it = 0; it < nk; ++it) {
-            const int ahead = min(nk - 1 - it, 1);           // tiles issued after tile `it` at this point (0 or 1)
-            if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+            const int ahead = min(nk - 1 - it, D - 1);       // tiles issued after tile `it` at this point
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();      // every wave's part of tile `it` landed; ring slot (it+2)%3 == (it-1)%3 is drained
-            if (it + 2 < nk) stage(buf == 0 ? 2 : buf - 1);
+            __builtin_amdgcn_s_barrier();      // every wave's part of tile `it` landed; ring slot (it-1)%STAGES is drained
+            if (it + D < nk) stage(nbuf);
             compute(buf);
-            buf = buf == 2 ? 0 : buf + 1;
+            buf = buf == STAGES - 1 ? 0 : buf + 1;
+            nbuf = nbuf == STAGES - 1 ? 0 : nbuf + 1;
         }
     }
 
@@ -196,8 +204,43 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
         const float4 hi = *reinterpret_cast<const float4*>(cs + row * FBN + (((2 * q + 1) ^ (row & 7)) << 2));
         v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
     };
+    // every thread owns a fixed group of 8 columns (q) and rows  tid / QPR + it * (NT / QPR): the per-column operands
+    // (bias) are loaded once, and the per-element operands (residual, z) of ALL of a pass's items are requested before
+    // the LDS staging barriers so their HBM latency is off the critical path.
+    static_assert(NT % QPR == 0, "column group must be thread-invariant");
+    constexpr int RSTEP = NT / QPR;
+    const int q = tid % QPR, row_t = tid / QPR;
+    const int gn = n0 + q * 8;
+    const bool col_ok = gn < p.N;
+    const int nvalid = min(8, p.N - gn);
+    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (e.bias && col_ok) {
+        if (nvalid == 8) {
+            const float4 b0 = *reinterpret_cast<const float4*>(e.bias + gn), b1 = *reinterpret_cast<const float4*>(e.bias + gn + 4);
+            bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+        } else for (int r = 0; r < nvalid; ++r) bias8[r] = e.bias[gn + r];
+    }
+    const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(e.mul_gelu_z);
+    const bf16_t* rsrc = reinterpret_cast<const bf16_t*>(e.residual);
+    const bool vec = nvalid == 8;
+    const DropKey dkey = drop_key(e.dropout_seed);
 #pragma unroll 1
     for (int ps = 0; ps < NPASS; ++ps) {
+    uint4 zq[ITEMS], rq[ITEMS];
+    if (zsrc && vec) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int gm = min(m0 + ps * RPP + row_t + it * RSTEP, p.M - 1);
+            zq[it] = *reinterpret_cast<const uint4*>(zsrc + (int64_t)gm * p.ldc + gn);
+        }
+    }
+    if (rsrc && vec) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int gm = min(m0 + ps * RPP + row_t + it * RSTEP, p.M - 1);
+            rq[it] = *reinterpret_cast<const uint4*>(rsrc + (int64_t)gm * e.ldr + gn);
+        }
+    }
     __syncthreads();                                // operand buffers / previous pass fully consumed by every wave
     if (wm * 64 >= ps * RPP && wm * 64 < (ps + 1) * RPP) {
 #pragma unroll
@@ -205,78 +248,73 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
             const int row = wm * 64 + i * 16 + c - ps * RPP;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int gn = n0 + wn * 64 + j * 16 + g * 4;
-                float v[4] = {acc[j][i][0] * alpha, acc[j][i][1] * alpha, acc[j][i][2] * alpha, acc[j][i][3] * alpha};
-                if (e.bias) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (gn + r < p.N) v[r] += e.bias[gn + r];
-                }
                 const int chunk = (wn * 16 + j * 4 + g) ^ (row & 7);
-                *reinterpret_cast<float4*>(cs + row * FBN + chunk * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(cs + row * FBN + chunk * 4) =
+                    make_float4(acc[j][i][0] * alpha, acc[j][i][1] * alpha, acc[j][i][2] * alpha, acc[j][i][3] * alpha);
             }
         }
     }
     __syncthreads();
-#pragma unroll 2
+#pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
-        const int id = tid + NT * it, row = id / QPR, q = id % QPR;
-        const int gm = m0 + ps * RPP + row, gn = n0 + q * 8;
-        if (gm >= p.M || gn >= p.N) continue;
-        const int nvalid = min(8, p.N - gn);
+        const int row = row_t + it * RSTEP;
+        const int gm = m0 + ps * RPP + row;
+        if (gm >= p.M || !col_ok) continue;
         const int64_t off = (int64_t)gm * p.ldc + gn;
         float v[8];
         load8(row, q, v);
         if (p.slabs) {     // split-K: plain partial-slab store, reduced by splitk_reduce_kernel (deterministic, no atomics)
             float* sp = p.slabs + (int64_t)split * p.M * p.ldc + off;
-            if (nvalid == 8) {
+            if (vec) {
                 *reinterpret_cast<float4*>(sp) = make_float4(v[0], v[1], v[2], v[3]);
                 *reinterpret_cast<float4*>(sp + 4) = make_float4(v[4], v[5], v[6], v[7]);
             } else for (int r = 0; r < nvalid; ++r) sp[r] = v[r];
             continue;
         }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += bias8[r];
         if (e.aux_out) {     // pre-activation side output z (bf16), same coalesced pattern
             bf16_t* z = reinterpret_cast<bf16_t*>(e.aux_out) + off;
-            if (nvalid == 8) st16(z, pack8(v));
+            if (vec) st16(z, pack8(v));
             else for (int r = 0; r < nvalid; ++r) z[r] = f32_to_bf16(v[r]);
         }
         if (e.act == 1) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
         }
-        if (e.mul_gelu_z) {
-            const bf16_t* z = reinterpret_cast<const bf16_t*>(e.mul_gelu_z) + off;
+        if (zsrc) {
             float zf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (nvalid == 8) unpack8(*reinterpret_cast<const uint4*>(z), zf);
-            else for (int r = 0; r < nvalid; ++r) zf[r] = bf16_to_f32(z[r]);
+            if (vec) unpack8(zq[it], zf);
+            else for (int r = 0; r < nvalid; ++r) zf[r] = bf16_to_f32(zsrc[off + r]);
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] *= gelu_grad_f(zf[r]);
         }
         if (e.dropout_p > 0.f) {
-            const uint64_t idx = (uint64_t)gm * (uint64_t)p.N + (uint64_t)gn;
+            bool keep[8];
+            dropout_keep_n<8>(dkey, (uint64_t)gm * (uint64_t)p.N + (uint64_t)gn, p.drop_thresh, keep);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = dropout_keep(e.dropout_seed, idx + r, p.drop_thresh) ? v[r] * p.drop_scale : 0.f;
+            for (int r = 0; r < 8; ++r) v[r] = keep[r] ? v[r] * p.drop_scale : 0.f;
         }
-        if (e.residual) {
-            const bf16_t* rp = reinterpret_cast<const bf16_t*>(e.residual) + (int64_t)gm * e.ldr + gn;
+        if (rsrc) {
             float rf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (nvalid == 8) unpack8(*reinterpret_cast<const uint4*>(rp), rf);
-            else for (int r = 0; r < nvalid; ++r) rf[r] = bf16_to_f32(rp[r]);
+            if (vec) unpack8(rq[it], rf);
+            else for (int r = 0; r < nvalid; ++r) rf[r] = bf16_to_f32(rsrc[(int64_t)gm * e.ldr + gn + r]);
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] += rf[r];
         }
         if (e.out_dtype == VM_BF16) {
             bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + off;
-            if (nvalid == 8) st16(cp, pack8(v));
+            if (vec) st16(cp, pack8(v));
             else for (int r = 0; r < nvalid; ++r) cp[r] = f32_to_bf16(v[r]);
         } else {
             float* cp = reinterpret_cast<float*>(p.C) + off;
             if (e.accumulate) {     // this thread owns the elements (no split): plain read-modify-write
-                if (nvalid == 8) {
+                if (vec) {
                     const float4 o0 = *reinterpret_cast<float4*>(cp), o1 = *reinterpret_cast<float4*>(cp + 4);
                     *reinterpret_cast<float4*>(cp) = make_float4(o0.x + v[0], o0.y + v[1], o0.z + v[2], o0.w + v[3]);
                     *reinterpret_cast<float4*>(cp + 4) = make_float4(o1.x + v[4], o1.y + v[5], o1.z + v[6], o1.w + v[7]);
                 } else for (int r = 0; r < nvalid; ++r) cp[r] += v[r];
-            } else if (nvalid == 8) {
+            } else if (vec) {
                 *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
                 *reinterpret_cast<float4*>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
             } else for (int r = 0; r < nvalid; ++r) cp[r] = v[r];
@@ -285,15 +323,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
     }   // passes
 }
 
-template <int LA, int LB, int WM, int WN, int STAGES>
+template <int LA, int LB, int WM, int WN, int STAGES, int BKT>
 static int launch_fast(const GemmArgs& a, int nblocks, hipStream_t s) {
-    constexpr int LDS = STAGES * (WM + WN) * 64 * 128;
+    constexpr int LDS = STAGES * (WM + WN) * 64 * BKT * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<LA, LB, WM, WN, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<LA, LB, WM, WN, STAGES, BKT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_fast_kernel<LA, LB, WM, WN, STAGES>), dim3(nblocks), dim3(WM * WN * 64), LDS, s, a);
+    hipLaunchKernelGGL((gemm_fast_kernel<LA, LB, WM, WN, STAGES, BKT>), dim3(nblocks), dim3(WM * WN * 64), LDS, s, a);
     return vm_check_launch("vm_gemm_bf16(fast)");
 }
 
@@ -330,21 +368,27 @@ int vm_gemm_splitk_reduce(const GemmArgs& a, int nsplit, hipStream_t s) {
     return vm_check_launch("vm_gemm_bf16(split-k reduce)");
 }
 
-template <int WM, int WN, int STAGES>
+template <int WM, int WN, int STAGES, int BKT>
 static int dispatch_layout(const GemmArgs& a, int a_layout, int b_layout, int nblocks, hipStream_t s) {
-    if (a_layout == 0 && b_layout == 0) return launch_fast<0, 0, WM, WN, STAGES>(a, nblocks, s);
-    if (a_layout == 0 && b_layout == 1) return launch_fast<0, 1, WM, WN, STAGES>(a, nblocks, s);
-    if (a_layout == 1 && b_layout == 0) return launch_fast<1, 0, WM, WN, STAGES>(a, nblocks, s);
-    return launch_fast<1, 1, WM, WN, STAGES>(a, nblocks, s);
+    if (a_layout == 0 && b_layout == 0) return launch_fast<0, 0, WM, WN, STAGES, BKT>(a, nblocks, s);
+    if (a_layout == 0 && b_layout == 1) return launch_fast<0, 1, WM, WN, STAGES, BKT>(a, nblocks, s);
+    if (a_layout == 1 && b_layout == 0) return launch_fast<1, 0, WM, WN, STAGES, BKT>(a, nblocks, s);
+    return launch_fast<1, 1, WM, WN, STAGES, BKT>(a, nblocks, s);
 }
 
 // variant 0: 128x128 tile, 2-stage (2 workgroups/CU); 1: 256x128, 3-stage ring; 2: 256x256, 16 waves, 2-stage
-int vm_gemm_fast_dispatch(const GemmArgs& a, int a_layout, int b_layout, int nblocks, int variant, hipStream_t s) {
-    if (variant == 1) return dispatch_layout<4, 2, 3>(a, a_layout, b_layout, nblocks, s);
-    if (variant == 2) return dispatch_layout<4, 4, 2>(a, a_layout, b_layout, nblocks, s);
-    return dispatch_layout<2, 2, 2>(a, a_layout, b_layout, nblocks, s);
+//         3: 128x128, k-tile 32, 4-stage ring (three half-tiles in flight, still 64 KiB -> 2 workgroups/CU)
+int vm_gemm_fast_dispatch(const GemmArgs& a0, int a_layout, int b_layout, int nblocks, int variant, hipStream_t s) {
+    if (variant == 1) return dispatch_layout<4, 2, 3, 64>(a0, a_layout, b_layout, nblocks, s);
+    if (variant == 2) return dispatch_layout<4, 4, 2, 64>(a0, a_layout, b_layout, nblocks, s);
+    if (variant == 3) {
+        GemmArgs a = a0;                 // k-tiles are counted in units of 32 here
+        a.ktiles *= 2; a.ktiles_per_split *= 2;
+        return dispatch_layout<2, 2, 4, 32>(a, a_layout, b_layout, nblocks, s);
+    }
+    return dispatch_layout<2, 2, 2, 64>(a0, a_layout, b_layout, nblocks, s);
 }
 void vm_gemm_variant_tile(int variant, int* bm, int* bn) {
-    *bm = variant == 0 ? 128 : 256;
+    *bm = (variant == 1 || variant == 2) ? 256 : 128;
     *bn = variant == 2 ? 256 : 128;
 }
