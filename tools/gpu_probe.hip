@@ -185,9 +185,14 @@ int main(int argc, char** argv) {
             {12608, 3072, 768, 0, 1, 0}, {12608, 3072, 768, 0, 1, 8},
             {12608, 768, 768, 0, 0, 0}, {12608, 768, 768, 0, 0, 1}, {12608, 768, 768, 0, 0, 33}, {8192, 768, 768, 0, 0, 49},
             {12608, 768, 3072, 0, 0, 0}, {12608, 768, 3072, 0, 0, 33}, {12608, 2304, 768, 0, 0, 0}, {12608, 2304, 768, 0, 0, 1},
-            {12608, 768, 768, 0, 1, 0}, {8192, 768, 768, 0, 1, 0},
+            {12608, 768, 768, 0, 1, 0}, {8192, 768, 768, 0, 1, 0}, {12608, 768, 3072, 0, 1, 0}, {12608, 768, 2304, 0, 1, 0}, {12608, 1536, 768, 0, 0, 1},
+            {8192, 2304, 768, 0, 0, 1}, {8192, 768, 3072, 0, 0, 49}, {12608, 2304, 768, 0, 1, 0},
         };
-        for (auto& c : cs) for (int rot = 1; rot <= 6; rot += 5) bench_gemm2(c.M, c.N, c.K, c.la, c.lb, c.flags, rot);
+        for (auto& c : cs) for (int variant = 0; variant <= 4; variant += 4) {
+            { char b[4]; snprintf(b, 4, "%d", variant); setenv("VM_GEMM_VARIANT", b, 1); }
+            printf("v%d ", variant);
+            bench_gemm2(c.M, c.N, c.K, c.la, c.lb, c.flags, 6);
+        }
         return 0;
     }
     short* d; hipMalloc(&d, 256 * 2);
@@ -196,16 +201,16 @@ int main(int argc, char** argv) {
     printf("ds_read_b64_tr_b16 with lane l -> &lds[4l] (values are source element indices):\n");
     for (int l = 0; l < 64; ++l) { printf("  lane %2d: %4d %4d %4d %4d%s", l, h[l * 4], h[l * 4 + 1], h[l * 4 + 2], h[l * 4 + 3], (l & 3) == 3 ? "\n" : ""); }
     int fails = 0;
-    for (int variant = 0; variant < 4; ++variant) {
+    for (int variant = 0; variant < 5; ++variant) {
         { char b[4]; snprintf(b, 4, "%d", variant); setenv("VM_GEMM_VARIANT", b, 1); }
         printf("---- VM_GEMM_VARIANT=%d correctness\n", variant);
-        for (int la = 0; la < 2; ++la) for (int lb = 0; lb < 2; ++lb) {
+        for (int la = 0; la < (variant == 4 ? 1 : 2); ++la) for (int lb = 0; lb < 2; ++lb) {
             fails += test_gemm(200, 136, 192, la, lb, 1, false);
             fails += test_gemm(128, 128, 64, la, lb, 1, true);
             fails += test_gemm(333, 97, 104, la, lb, 1, true);
             fails += test_gemm(700, 260, 448, la, lb, 1, true);
         }
-        fails += test_gemm(256, 256, 1024, 1, 1, 4, true);
+        if (variant != 4) fails += test_gemm(256, 256, 1024, 1, 1, 4, true);
         fails += test_gemm(1000, 768, 768, 0, 0, 1, false);
     }
     unsetenv("VM_GEMM_VARIANT");

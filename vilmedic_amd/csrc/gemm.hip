@@ -302,6 +302,14 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
         const int tiles_m256 = (M + 255) / 256;
         if (force) variant = atoi(force);
         else if (K >= 4096 && (int64_t)tiles_m256 * a.tiles_n * split >= 1024) variant = 1;   // measured: only huge square-ish problems gain
+        else if (a_layout == 0) {
+            // 512 workgroup slots (256 CUs x 2 resident workgroups): compare rounds x rows-per-tile of the 128- and the
+            // 160-row tile -- e.g. M = 12608, N = 768: 594 tiles = 2 rounds of 128 rows vs 474 tiles = 1 round of 160 rows
+            const int64_t slots = 512;
+            const int64_t t128 = (int64_t)((M + 127) / 128) * a.tiles_n * split, t160 = (int64_t)((M + 159) / 160) * a.tiles_n * split;
+            const int64_t c128 = (t128 + slots - 1) / slots * 128, c160 = (t160 + slots - 1) / slots * 160;
+            if (c160 <= c128) variant = 4;   // ties: the larger tile re-reads less of B
+        }
         int vbm, vbn;
         vm_gemm_variant_tile(variant, &vbm, &vbn);
         a.tiles_m = (M + vbm - 1) / vbm;

@@ -67,11 +67,13 @@ __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int LA, int LB, int WM, int WN, int STAGES, int BKT>
+template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fast_kernel(const GemmArgs p) {
-    constexpr int FBM = WM * 64, FBN = WN * 64, NW = WM * WN, NT = NW * 64;
+    constexpr int WR = MF * 16;                     // rows per wave (MF 16-row A fragments; 4 or 5)
+    constexpr int FBM = WM * WR, FBN = WN * 64, NW = WM * WN, NT = NW * 64;
     constexpr int F_OPER_A = FBM * BKT * 2, F_OPER_B = FBN * BKT * 2, F_STAGE = F_OPER_A + F_OPER_B;
-    constexpr int NA_I = (BKT / 8) / WN, NB_I = (BKT / 8) / WM;   // A- / B-tile DMA instructions (1 KiB each) per wave
+    constexpr int NA_I = F_OPER_A / 1024 / NW, NB_I = F_OPER_B / 1024 / NW;   // A- / B-tile DMA instructions (1 KiB each) per wave
+    static_assert(NA_I * NW * 1024 == F_OPER_A && NB_I * NW * 1024 == F_OPER_B, "tile must split evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
     // ---- per-lane fragment read offsets
     // layout 0: addr = (rbase + i*16 + c)*128 + (((kk*4+g) ^ (c&7)) * 16)
     // layout 1: addr = krow*256 + ((lc ^ s)*16) + sub,  krow = kk*32 + 8g + (c>>2) (+4), lc = (rbase>>3) + 2i + ((c&3)>>1)
-    const int a_rb = wm * 64, b_rb = wn * 64;
+    const int a_rb = wm * WR, b_rb = wn * 64;
     const int j4 = c >> 2, s1 = (j4 << 1) | ((g & 1) << 3), sub1 = (c & 1) * 8, h1 = (c & 3) >> 1;
 
     auto read_frag0 = [&](const char* tile, int rbase, int i, int kk) -> bf16x8_t {
@@ -132,26 +134,26 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
         return __builtin_bit_cast(bf16x8_t, v);
     };
 
-    float4_t acc[4][4];   // acc[j][i]: n-fragment j, m-fragment i  (D^T layout: lane -> row m = c, 4 consecutive n = 4g..4g+3)
+    float4_t acc[4][MF];   // acc[j][i]: n-fragment j, m-fragment i  (D^T layout: lane -> row m = c, 4 consecutive n = 4g..4g+3)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MF; ++i) acc[j][i] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int buf) {
         const char* sa = smem + buf * F_STAGE;
         const char* sb = sa + F_OPER_A;
 #pragma unroll
         for (int kk = 0; kk < BKT / 32; ++kk) {
-            bf16x8_t fa[4], fb[4];
+            bf16x8_t fa[MF], fb[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = LA == 0 ? read_frag0(sa, a_rb, i, kk) : read_frag1(sa, a_rb, i, kk, FBM * 2);
+            for (int i = 0; i < MF; ++i) fa[i] = LA == 0 ? read_frag0(sa, a_rb, i, kk) : read_frag1(sa, a_rb, i, kk, FBM * 2);
 #pragma unroll
             for (int j = 0; j < 4; ++j) fb[j] = LB == 0 ? read_frag0(sb, b_rb, j, kk) : read_frag1(sb, b_rb, j, kk, FBN * 2);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MF; ++i)
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
         }
     };
@@ -195,7 +197,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
     float* cs = reinterpret_cast<float*>(smem);     // [RPP][FBN] fp32, 16-B chunks XOR-swizzled by row
     constexpr int LDS_BYTES = STAGES * F_STAGE;
     constexpr int RPP_RAW = LDS_BYTES / (FBN * 4);
-    constexpr int RPP = RPP_RAW >= FBM ? FBM : (RPP_RAW / 64) * 64;   // rows staged per pass (multiple of a wave's 64 rows)
+    constexpr int RPP = RPP_RAW >= FBM ? FBM : (RPP_RAW / WR) * WR;   // rows staged per pass (multiple of a wave's WR rows)
+    static_assert(FBM % RPP == 0 && (RPP * (FBN / 8)) % NT == 0, "epilogue pass geometry");
     constexpr int NPASS = FBM / RPP;
     constexpr int QPR = FBN / 8;                                     // 8-column items per row
     constexpr int ITEMS = RPP * QPR / NT;
@@ -242,10 +245,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
         }
     }
     __syncthreads();                                // operand buffers / previous pass fully consumed by every wave
-    if (wm * 64 >= ps * RPP && wm * 64 < (ps + 1) * RPP) {
+    if (wm * WR >= ps * RPP && wm * WR < (ps + 1) * RPP) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wm * 64 + i * 16 + c - ps * RPP;
+        for (int i = 0; i < MF; ++i) {
+            const int row = wm * WR + i * 16 + c - ps * RPP;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int chunk = (wn * 16 + j * 4 + g) ^ (row & 7);
@@ -323,15 +326,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
     }   // passes
 }
 
-template <int LA, int LB, int WM, int WN, int STAGES, int BKT>
+template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF>
 static int launch_fast(const GemmArgs& a, int nblocks, hipStream_t s) {
-    constexpr int LDS = STAGES * (WM + WN) * 64 * BKT * 2;
+    constexpr int LDS = STAGES * (WM * MF * 16 + WN * 64) * BKT * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<LA, LB, WM, WN, STAGES, BKT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<LA, LB, WM, WN, STAGES, BKT, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_fast_kernel<LA, LB, WM, WN, STAGES, BKT>), dim3(nblocks), dim3(WM * WN * 64), LDS, s, a);
+    hipLaunchKernelGGL((gemm_fast_kernel<LA, LB, WM, WN, STAGES, BKT, MF>), dim3(nblocks), dim3(WM * WN * 64), LDS, s, a);
     return vm_check_launch("vm_gemm_bf16(fast)");
 }
 
@@ -368,27 +371,32 @@ int vm_gemm_splitk_reduce(const GemmArgs& a, int nsplit, hipStream_t s) {
     return vm_check_launch("vm_gemm_bf16(split-k reduce)");
 }
 
-template <int WM, int WN, int STAGES, int BKT>
+template <int WM, int WN, int STAGES, int BKT, int MF>
 static int dispatch_layout(const GemmArgs& a, int a_layout, int b_layout, int nblocks, hipStream_t s) {
-    if (a_layout == 0 && b_layout == 0) return launch_fast<0, 0, WM, WN, STAGES, BKT>(a, nblocks, s);
-    if (a_layout == 0 && b_layout == 1) return launch_fast<0, 1, WM, WN, STAGES, BKT>(a, nblocks, s);
-    if (a_layout == 1 && b_layout == 0) return launch_fast<1, 0, WM, WN, STAGES, BKT>(a, nblocks, s);
-    return launch_fast<1, 1, WM, WN, STAGES, BKT>(a, nblocks, s);
+    if (a_layout == 0 && b_layout == 0) return launch_fast<0, 0, WM, WN, STAGES, BKT, MF>(a, nblocks, s);
+    if (a_layout == 0 && b_layout == 1) return launch_fast<0, 1, WM, WN, STAGES, BKT, MF>(a, nblocks, s);
+    if (a_layout == 1 && b_layout == 0) return launch_fast<1, 0, WM, WN, STAGES, BKT, MF>(a, nblocks, s);
+    return launch_fast<1, 1, WM, WN, STAGES, BKT, MF>(a, nblocks, s);
 }
 
 // variant 0: 128x128 tile, 2-stage (2 workgroups/CU); 1: 256x128, 3-stage ring; 2: 256x256, 16 waves, 2-stage
 //         3: 128x128, k-tile 32, 4-stage ring (three half-tiles in flight, still 64 KiB -> 2 workgroups/CU)
 int vm_gemm_fast_dispatch(const GemmArgs& a0, int a_layout, int b_layout, int nblocks, int variant, hipStream_t s) {
-    if (variant == 1) return dispatch_layout<4, 2, 3, 64>(a0, a_layout, b_layout, nblocks, s);
-    if (variant == 2) return dispatch_layout<4, 4, 2, 64>(a0, a_layout, b_layout, nblocks, s);
+    if (variant == 1) return dispatch_layout<4, 2, 3, 64, 4>(a0, a_layout, b_layout, nblocks, s);
+    if (variant == 2) return dispatch_layout<4, 4, 2, 64, 4>(a0, a_layout, b_layout, nblocks, s);
+    if (variant == 4) {                  // 160x128 tile (A row-major only): evens out the tile count when 128-row tiles leave a thin last round
+        if (a_layout != 0) { vm_set_error("vm_gemm_bf16: 160-row tile needs a row-major A"); return VM_EINVAL; }
+        if (b_layout == 0) return launch_fast<0, 0, 2, 2, 2, 64, 5>(a0, nblocks, s);
+        return launch_fast<0, 1, 2, 2, 2, 64, 5>(a0, nblocks, s);
+    }
     if (variant == 3) {
         GemmArgs a = a0;                 // k-tiles are counted in units of 32 here
         a.ktiles *= 2; a.ktiles_per_split *= 2;
-        return dispatch_layout<2, 2, 4, 32>(a, a_layout, b_layout, nblocks, s);
+        return dispatch_layout<2, 2, 4, 32, 4>(a, a_layout, b_layout, nblocks, s);
     }
-    return dispatch_layout<2, 2, 2, 64>(a0, a_layout, b_layout, nblocks, s);
+    return dispatch_layout<2, 2, 2, 64, 4>(a0, a_layout, b_layout, nblocks, s);
 }
 void vm_gemm_variant_tile(int variant, int* bm, int* bn) {
-    *bm = (variant == 1 || variant == 2) ? 256 : 128;
+    *bm = (variant == 1 || variant == 2) ? 256 : variant == 4 ? 160 : 128;
     *bn = variant == 2 ? 256 : 128;
 }
