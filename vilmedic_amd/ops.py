@@ -10,8 +10,10 @@ Design notes
   * dropout masks are regenerated from a counter-based RNG (seed per call site), never stored;
   * there is NO CPU fallback: every op raises on non-device tensors.
 """
+import contextlib
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -68,12 +70,65 @@ _ws_cache = {}
 
 
 def _workspace(nbytes, device):
-    """persistent split-K scratch (caller-provided per the C ABI); grows monotonically, one per device"""
-    ws = _ws_cache.get(device)
+    """persistent split-K scratch (caller-provided per the C ABI); grows monotonically, one per (device, stream):
+    launches that share it are ordered by their stream"""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
-        _ws_cache[device] = ws
+        _ws_cache[key] = ws
     return ws
+
+
+# ----------------------------------------------------------------------------- side stream for parameter gradients
+# In a backward pass only the activation-gradient (dgrad) chain is on the critical path: the weight / bias gradients are
+# consumed by the optimizer alone.  They are therefore launched on a second HIP stream, ordered after the kernel that
+# produced their inputs; the GPU then fills the thin last round of workgroups of a dgrad GEMM with wgrad workgroups
+# (and vice versa) instead of idling CUs.  The main stream re-joins the side stream when the backward pass ends
+# (autograd engine callback) -- or on join_side() for launches made outside a backward pass.
+_side = {"streams": {}, "pending": False, "callback_queued": False}
+SIDE_STREAM = os.environ.get("VM_SIDE_STREAM", "1") != "0"
+
+
+def _side_stream(device):
+    st = _side["streams"].get(device)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side["streams"][device] = st
+    return st
+
+
+def join_side():
+    """main stream waits for everything queued on the side stream so far (no host sync)"""
+    _side["callback_queued"] = False
+    if _side["pending"]:
+        for dev, st in _side["streams"].items():
+            torch.cuda.current_stream(dev).wait_stream(st)
+        _side["pending"] = False
+
+
+@contextlib.contextmanager
+def on_side(*inputs):
+    """launch the enclosed kernels on the side stream, after everything enqueued on the current stream so far.
+    ``inputs`` are the tensors those kernels read: they are recorded on the side stream so the caching allocator does
+    not hand their memory out again before the side stream is done with it."""
+    if not SIDE_STREAM or not inputs:
+        yield
+        return
+    dev = inputs[0].device
+    side = _side_stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    for t in inputs:
+        t.record_stream(side)
+    with torch.cuda.stream(side):
+        yield
+    _side["pending"] = True
+    if not _side["callback_queued"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(join_side)
+            _side["callback_queued"] = True
+        except RuntimeError:            # not inside a backward pass
+            join_side()
 
 
 def _split_k_for(out_tiles, k_tiles):
@@ -174,15 +229,17 @@ class LinearFn(torch.autograd.Function):
         M, N = dy2.shape
         K = x2.shape[1]
         dpre = dropout_apply(dy2, dropout_p, seed) if dropout_p > 0 else dy2
+        if wgrad_buf is not None or bgrad_buf is not None:
+            with on_side(dpre, x2):                   # parameter gradients overlap the dgrad chain
+                if wgrad_buf is not None:
+                    wgrad(dpre, x2, wgrad_buf)
+                if bgrad_buf is not None:
+                    colsum(dpre, bgrad_buf)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=BF16, device=dy.device)
             gemm(dpre, 0, w_sh, 1, dx, M, K, N)
             dx = dx.view(xshape)
-        if wgrad_buf is not None:
-            wgrad(dpre, x2, wgrad_buf)
-        if bgrad_buf is not None:
-            colsum(dpre, bgrad_buf)
         return dx, None, None, (dy if has_res else None), None, None, None, None
 
 
@@ -217,13 +274,15 @@ class MlpFn(torch.autograd.Function):
         F = w1.shape[0]
         dpre = dropout_apply(dy2, dropout_p, seed) if dropout_p > 0 else dy2
         if g_w2 is not None:
-            wgrad(dpre, a, g_w2)
-            colsum(dpre, g_b2)
+            with on_side(dpre, a):
+                wgrad(dpre, a, g_w2)
+                colsum(dpre, g_b2)
         dz = torch.empty(M, F, dtype=BF16, device=dy.device)
         gemm(dpre, 0, w2, 1, dz, M, F, K, mul_gelu_z=z)          # da * gelu'(z) fused in the dgrad epilogue
         if g_w1 is not None:
-            wgrad(dz, x2, g_w1)
-            colsum(dz, g_b1)
+            with on_side(dz, x2):
+                wgrad(dz, x2, g_w1)
+                colsum(dz, g_b1)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=BF16, device=dy.device)
@@ -415,6 +474,7 @@ class EmbeddingFn(torch.autograd.Function):
         padding_idx, g_word, g_pos, D, past_len = ctx.meta
         B, L = ids.shape
         if g_word is not None:
+            join_side()       # the tied LM-head wgrad accumulates into the same g_word on the side stream
             d_out = d_out.contiguous()
             gp = g_pos[past_len:] if past_len else g_pos
             check(lib().vm_embedding_bwd(ptr(ids), ptr(d_out), ptr(g_word), ptr(gp), B, L, D,
@@ -508,14 +568,15 @@ class LmHeadLossFn(torch.autograd.Function):
         # into the GEMM / column-sum epilogues through a device pointer -- no host sync, no extra pass over dlogits.
         sc = dloss.detach().to(torch.float32).contiguous()
         M = B * L
+        if g_emb is not None:
+            with on_side(dlogits, h2, sc):
+                wgrad(dlogits, h2, g_emb, alpha_dev=sc)   # dE[V,D] += dlogits^T h (pad columns of dlogits are zero)
+                colsum(dlogits, g_bias, rows=M, cols=V, scale_dev=sc)
         dh = None
         if ctx.needs_input_grad[0]:
             dh = torch.empty(M, D, dtype=BF16, device=h2.device)
             gemm(dlogits, 0, emb_sh, 1, dh, M, D, Vp, alpha_dev=sc)
             dh = dh.view(B, L, D)
-        if g_emb is not None:
-            wgrad(dlogits, h2, g_emb, alpha_dev=sc)   # dE[V,D] += dlogits^T h (pad columns of dlogits are zero)
-            colsum(dlogits, g_bias, rows=M, cols=V, scale_dev=sc)
         return (dh,) + (None,) * 10
 
 
