@@ -78,6 +78,12 @@ int vm_layernorm_fwd(const void* x, const float* gamma, const float* beta, void*
 size_t vm_layernorm_bwd_ws(int rows, int cols);
 int vm_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                      void* dx, float* dgamma, float* dbeta, int rows, int cols, void* ws, void* stream);
+/* same with the residual-fork gradient sums fused in (either may be NULL): dy2 = second gradient of the LN output y
+   (y feeds a sub-layer and that sub-layer's residual), summed with dy in fp32; dres = gradient added to dx (the LN
+   input x also feeds a residual).  Replaces the separate elementwise adds autograd would launch at the fork. */
+int vm_layernorm_bwd_fused(const void* dy, const void* dy2, const void* dres, const void* x, const float* gamma,
+                           const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                           int rows, int cols, void* ws, void* stream);
 
 /* ------------------------------------------------------------------ attention (self / causal / cross)
  * softmax(Q K^T * scale + mask) V with optional dropout on the probabilities.

@@ -49,8 +49,9 @@ class BertGenerationEncoder(nn.Module):
         enc = encoder_hidden_states
         if enc is not None and enc.dtype != torch.bfloat16:
             enc = enc.to(torch.bfloat16)
+        xr = None          # alias of x for the next residual (see nn.BertLayer: fuses the fork's gradient sum into LN backward)
         for layer in self.encoder.layer:
-            x = layer(x, arena, self_mask, bool(cfg.is_decoder), enc.contiguous() if enc is not None else None, enc_mask)
+            x, xr = layer(x, arena, self_mask, bool(cfg.is_decoder), enc.contiguous() if enc is not None else None, enc_mask, xr=xr)
             if hs is not None:
                 hs.append(x)
         return ModelOutput(last_hidden_state=x, hidden_states=tuple(hs) if hs is not None else None,

@@ -62,8 +62,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 
 // backward: dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  per-wave partial dgamma/dbeta
 // accumulated in registers over the wave's rows, then written to ws[wave][2][cols] and reduced by ln_bwd_reduce.
+// Residual-fork fusion (both optional): dy2 is a second incoming gradient of y (summed in fp32 before use: the LN
+// output feeds a sub-layer AND its residual), dres a gradient added to dx (the LN input also feeds a residual).
 template <int NCH>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dy2,
+                                                     const bf16_t* __restrict__ dres, const bf16_t* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, bf16_t* __restrict__ dx,
                                                      float* __restrict__ ws, int rows, int cols) {
@@ -89,6 +92,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 float xv[8], dv[8];
                 unpack8(*reinterpret_cast<const uint4*>(x + (int64_t)row * cols + ch * 8), xv);
                 unpack8(*reinterpret_cast<const uint4*>(dy + (int64_t)row * cols + ch * 8), dv);
+                if (dy2) {
+                    float d2[8];
+                    unpack8(*reinterpret_cast<const uint4*>(dy2 + (int64_t)row * cols + ch * 8), d2);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dv[j] += d2[j];
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     xh[c][j] = (xv[j] - mu) * rs;
@@ -112,6 +121,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 float o[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = rs * (gy[c][j] - s1 - xh[c][j] * s2);
+                if (dres) {
+                    float r8[8];
+                    unpack8(*reinterpret_cast<const uint4*>(dres + (int64_t)row * cols + ch * 8), r8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] += r8[j];
+                }
                 *reinterpret_cast<uint4*>(dx + (int64_t)row * cols + ch * 8) = pack8(o);
             }
         }
@@ -195,6 +210,12 @@ extern "C" size_t vm_layernorm_bwd_ws(int rows, int cols) { return (size_t)ln_gr
 
 extern "C" int vm_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                 void* dx, float* dgamma, float* dbeta, int rows, int cols, void* ws, void* stream) {
+    return vm_layernorm_bwd_fused(dy, nullptr, nullptr, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, cols, ws, stream);
+}
+
+extern "C" int vm_layernorm_bwd_fused(const void* dy, const void* dy2, const void* dres, const void* x, const float* gamma,
+                                      const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                                      int rows, int cols, void* ws, void* stream) {
     VM_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && ws, "vm_layernorm_bwd: null pointer");
     VM_REQUIRE(rows > 0 && cols > 0 && (cols % 8) == 0 && cols <= 64 * 8 * LN_MAX_CHUNKS, "vm_layernorm_bwd: cols=%d must be a multiple of 8 and <= 2048", cols);
     hipStream_t s = (hipStream_t)stream;
@@ -202,12 +223,13 @@ extern "C" int vm_layernorm_bwd(const void* dy, const void* x, const float* gamm
     const int nch = (cols / 8 + 63) / 64;
     const int grid = ln_grid(rows, LN_BWD_CAP);
     const bf16_t* dyp = (const bf16_t*)dy; const bf16_t* xp = (const bf16_t*)x; bf16_t* dxp = (bf16_t*)dx;
+    const bf16_t* dy2p = (const bf16_t*)dy2; const bf16_t* drp = (const bf16_t*)dres;
     float* wsp = (float*)ws;
     const size_t red_bytes = (size_t)4 * 2 * cols * sizeof(float);
     switch (nch) {
-        case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(grid), dim3(256), red_bytes, s, dyp, xp, gamma, mean, rstd, dxp, wsp, rows, cols); break;
-        case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(grid), dim3(256), red_bytes, s, dyp, xp, gamma, mean, rstd, dxp, wsp, rows, cols); break;
-        default: hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(grid), dim3(256), red_bytes, s, dyp, xp, gamma, mean, rstd, dxp, wsp, rows, cols); break;
+        case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(grid), dim3(256), red_bytes, s, dyp, dy2p, drp, xp, gamma, mean, rstd, dxp, wsp, rows, cols); break;
+        case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(grid), dim3(256), red_bytes, s, dyp, dy2p, drp, xp, gamma, mean, rstd, dxp, wsp, rows, cols); break;
+        default: hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(grid), dim3(256), red_bytes, s, dyp, dy2p, drp, xp, gamma, mean, rstd, dxp, wsp, rows, cols); break;
     }
     hipLaunchKernelGGL(ln_bwd_reduce, dim3((cols + 31) / 32, 2), dim3(256), 0, s, wsp, dgamma, dbeta, grid, cols);
     return vm_check_launch("vm_layernorm_bwd");

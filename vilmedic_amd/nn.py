@@ -9,6 +9,8 @@ Arithmetic is restated in oracle/torch_ref.py (the CPU checker); nothing here fa
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -74,8 +76,14 @@ def _linear(mod, arena, x, aff, **kw):
                       anchor=aff.weight, **kw)
 
 
-def _ln(arena, x, aff, eps):
-    return ops.layer_norm(x, aff.weight, aff.bias, eps, arena.grad(aff.weight), arena.grad(aff.bias))
+_LN_FORK = os.environ.get("VM_LN_FORK", "1") != "0"      # 0: leave the residual-fork gradient sums to autograd (A/B switch)
+
+
+def _ln(arena, x, aff, eps, fork=None):
+    if fork is not None and not _LN_FORK:
+        y = ops.layer_norm(x, aff.weight, aff.bias, eps, arena.grad(aff.weight), arena.grad(aff.bias))
+        return y, (x if fork == "in" else y)
+    return ops.layer_norm(x, aff.weight, aff.bias, eps, arena.grad(aff.weight), arena.grad(aff.bias), fork)
 
 
 # ----------------------------------------------------------------------------- ViT
@@ -113,14 +121,16 @@ class ViTLayer(nn.Module):
         adrop = cfg.attention_probs_dropout_prob if self.training else 0.0
         sa = self.attention.attention
         wl, bl = [sa.query.weight, sa.key.weight, sa.value.weight], [sa.query.bias, sa.key.bias, sa.value.bias]
-        h = _ln(arena, x, self.layernorm_before, cfg.layer_norm_eps)
+        # fork="in": the residual reads an alias of x returned by the LN op, so the two gradients of x meet inside the
+        # LN backward kernel instead of in a separate elementwise add
+        h, xr = _ln(arena, x, self.layernorm_before, cfg.layer_norm_eps, fork="in")
         qkv = ops.linear(h, arena.shadow_group(wl), arena.f32_group(bl), wgrad_buf=arena.grad_group(wl),
                          bgrad_buf=arena.grad_group(bl), anchor=sa.query.weight)
         ctx = ops.self_attention(qkv, None, cfg.num_attention_heads, False, adrop)
-        x = _linear(self, arena, ctx, self.attention.output.dense, residual=x, dropout_p=drop)
-        h = _ln(arena, x, self.layernorm_after, cfg.layer_norm_eps)
+        x = _linear(self, arena, ctx, self.attention.output.dense, residual=xr, dropout_p=drop)
+        h, xr = _ln(arena, x, self.layernorm_after, cfg.layer_norm_eps, fork="in")
         i, o = self.intermediate.dense, self.output.dense
-        return ops.mlp(h, arena.shadow(i.weight), i.bias, arena.shadow(o.weight), o.bias, residual=x, dropout_p=drop,
+        return ops.mlp(h, arena.shadow(i.weight), i.bias, arena.shadow(o.weight), o.bias, residual=xr, dropout_p=drop,
                        grads=(arena.grad(i.weight), arena.grad(i.bias), arena.grad(o.weight), arena.grad(o.bias)), anchor=i.weight)
 
 
@@ -225,28 +235,31 @@ class BertLayer(nn.Module):
         return ops.linear(enc, arena.shadow_group(wl), arena.f32_group(bl), wgrad_buf=arena.grad_group(wl),
                           bgrad_buf=arena.grad_group(bl), anchor=ca.key.weight)
 
+    # Every post-LN output feeds the next sub-layer AND that sub-layer's residual.  The LN op returns the pair
+    # (y, alias of y) -- fork="out" -- so both gradients arrive at its backward and are summed inside the kernel.
     def _attn_out(self, blk, ctx, residual, arena, drop):
         s = _linear(self, arena, ctx, blk.output.dense, residual=residual, dropout_p=drop)
-        return _ln(arena, s, blk.output.LayerNorm, self.cfg.layer_norm_eps)
+        return _ln(arena, s, blk.output.LayerNorm, self.cfg.layer_norm_eps, fork="out")
 
-    def _ffn(self, x, arena, drop):
+    def _ffn(self, x, xr, arena, drop):
         i, o = self.intermediate.dense, self.output.dense
-        s = ops.mlp(x, arena.shadow(i.weight), i.bias, arena.shadow(o.weight), o.bias, residual=x, dropout_p=drop,
+        s = ops.mlp(x, arena.shadow(i.weight), i.bias, arena.shadow(o.weight), o.bias, residual=xr, dropout_p=drop,
                     grads=(arena.grad(i.weight), arena.grad(i.bias), arena.grad(o.weight), arena.grad(o.bias)), anchor=i.weight)
-        return _ln(arena, s, self.output.LayerNorm, self.cfg.layer_norm_eps)
+        return _ln(arena, s, self.output.LayerNorm, self.cfg.layer_norm_eps, fork="out")
 
-    def forward(self, x, arena, self_mask, causal, enc=None, enc_mask=None):
+    def forward(self, x, arena, self_mask, causal, enc=None, enc_mask=None, xr=None):
+        """-> (y, alias of y); ``xr`` is the alias of x a previous layer returned (None: x itself)"""
         cfg = self.cfg
         drop = cfg.hidden_dropout_prob if self.training else 0.0
         adrop = cfg.attention_probs_dropout_prob if self.training else 0.0
         H = cfg.num_attention_heads
         ctx = ops.self_attention(self._self_qkv(x, arena), self_mask, H, causal, adrop)
-        x = self._attn_out(self.attention, ctx, x, arena, drop)
+        x, xr = self._attn_out(self.attention, ctx, x if xr is None else xr, arena, drop)
         if enc is not None:
             q = _linear(self, arena, x, self.crossattention.self.query)
             ctx = ops.cross_attention(q, self.cross_kv(enc, arena), enc_mask, H, adrop)
-            x = self._attn_out(self.crossattention, ctx, x, arena, drop)
-        return self._ffn(x, arena, drop)
+            x, xr = self._attn_out(self.crossattention, ctx, xr, arena, drop)
+        return self._ffn(x, xr, arena, drop)
 
 
 class BertStack(nn.Module):
@@ -258,8 +271,9 @@ class BertStack(nn.Module):
         self.layer = nn.ModuleList([BertLayer(cfg, cross, enc_dim) for _ in range(cfg.num_hidden_layers)])
 
     def forward(self, x, arena, self_mask=None, causal=False, enc=None, enc_mask=None):
+        xr = None
         for layer in self.layer:
-            x = layer(x, arena, self_mask, causal, enc, enc_mask)
+            x, xr = layer(x, arena, self_mask, causal, enc, enc_mask, xr=xr)
         return x
 
 

@@ -297,8 +297,15 @@ def mlp(x, w1, b1, w2, b2, *, residual=None, dropout_p=0.0, grads=(None, None, N
 
 # ----------------------------------------------------------------------------- LayerNorm
 class LayerNormFn(torch.autograd.Function):
+    """y = LN(x).  ``fork`` fuses the gradient sum of a residual fork into the backward kernel instead of leaving it to
+    an autograd elementwise add:
+      fork="in"  (pre-LN block):  returns (y, x_alias); the block feeds x_alias to its residual, so x has ONE consumer
+                 and backward gets (dy, dres):  dx = LN'(dy) + dres;
+      fork="out" (post-LN block): returns (y, y_alias); the next sub-layer reads y, its residual reads y_alias, and
+                 backward gets two gradients of y that are summed in fp32 inside the kernel."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, g_gamma, g_beta):
+    def forward(ctx, x, gamma, beta, eps, g_gamma, g_beta, fork):
         x2 = _2d(x)
         rows, cols = x2.shape
         y = torch.empty_like(x2)
@@ -307,27 +314,42 @@ class LayerNormFn(torch.autograd.Function):
         check(lib().vm_layernorm_fwd(ptr(x2), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows, cols, eps, stream()),
               "vm_layernorm_fwd")
         ctx.save_for_backward(x2, gamma, mean, rstd)
-        ctx.meta = (g_gamma, g_beta, x.shape)
-        return y.view(x.shape)
+        ctx.meta = (g_gamma, g_beta, x.shape, fork)
+        ctx.set_materialize_grads(False)
+        y = y.view(x.shape)
+        if fork == "in":
+            return y, x.view(x.shape)
+        if fork == "out":
+            return y, y.view(x.shape)
+        return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, d2=None):
         x2, gamma, mean, rstd = ctx.saved_tensors
-        g_gamma, g_beta, xshape = ctx.meta
+        g_gamma, g_beta, xshape, fork = ctx.meta
         rows, cols = x2.shape
+        dres = None
+        if fork == "in":
+            dres, d2 = d2, None
+        if dy is None and d2 is not None:
+            dy, d2 = d2, None
+        if dy is None:                      # the normalised output was not used: only the pass-through gradient
+            return dres, None, None, None, None, None, None
         dy2 = _2d(dy.contiguous())
         dx = torch.empty_like(x2)
         ws = torch.empty(lib().vm_layernorm_bwd_ws(rows, cols) // 4, dtype=torch.float32, device=dy.device)
         if g_gamma is None:   # frozen affine: still need dx; send the param grads to scratch
             g_gamma = torch.zeros(cols, dtype=torch.float32, device=dy.device)
             g_beta = torch.zeros(cols, dtype=torch.float32, device=dy.device)
-        check(lib().vm_layernorm_bwd(ptr(dy2), ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(g_gamma), ptr(g_beta),
-                                     rows, cols, ptr(ws), stream()), "vm_layernorm_bwd")
-        return dx.view(xshape), None, None, None, None, None
+        check(lib().vm_layernorm_bwd_fused(ptr(dy2), ptr(_2d(d2.contiguous())) if d2 is not None else None,
+                                           ptr(_2d(dres.contiguous())) if dres is not None else None,
+                                           ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(g_gamma), ptr(g_beta),
+                                           rows, cols, ptr(ws), stream()), "vm_layernorm_bwd")
+        return dx.view(xshape), None, None, None, None, None, None
 
 
-def layer_norm(x, gamma, beta, eps, g_gamma=None, g_beta=None):
-    return LayerNormFn.apply(x, gamma, beta, eps, g_gamma, g_beta)
+def layer_norm(x, gamma, beta, eps, g_gamma=None, g_beta=None, fork=None):
+    return LayerNormFn.apply(x, gamma, beta, eps, g_gamma, g_beta, fork)
 
 
 # ----------------------------------------------------------------------------- attention
