@@ -314,6 +314,10 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
         vm_gemm_variant_tile(variant, &vbm, &vbn);
         a.tiles_m = (M + vbm - 1) / vbm;
         a.tiles_n = (N + vbn - 1) / vbn;
+        // column-group width of the tile order: wide outputs (N >= 3072) run in groups of 8 tile columns so that an XCD's
+        // B working set stays L2-resident (measured +11 % on the N = 30528 LM head, +4 % at N = 3072, neutral below)
+        a.group_w = a.tiles_n >= 24 ? 8 : a.tiles_n;
+        { const char* gw = getenv("VM_GEMM_GROUPW"); if (gw && atoi(gw) > 0) a.group_w = atoi(gw); }
         const int nb = a.tiles_m * a.tiles_n * split;
         int rc = vm_gemm_fast_dispatch(a, a_layout, b_layout, nb, variant, s);
         if (rc == VM_OK && split > 1) rc = vm_gemm_splitk_reduce(a, split, s);

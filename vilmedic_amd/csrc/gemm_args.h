@@ -7,6 +7,7 @@ struct GemmArgs {
     int64_t lda, ldb, ldc;
     int M, N, K;
     int tiles_m, tiles_n, ktiles, ktiles_per_split;
+    int group_w;             // fast path: tile columns per column group of the block-id -> tile map (>= tiles_n: plain row-major)
     vm_gemm_epilogue e;
     uint32_t drop_thresh; float drop_scale;
     int dbg;                 // VM_GEMM_DEBUG experiments (0 in production): 1 skip epilogue, 2 single K-tile

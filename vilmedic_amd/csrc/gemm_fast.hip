@@ -88,7 +88,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
     const int tiles = p.tiles_m * p.tiles_n;
     const int split = bid / tiles;
     const int t = bid - split * tiles;
-    const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+    // tile order: column groups of group_w tile columns, row-major inside a group.  An XCD runs a contiguous range of
+    // ids (remap above), i.e. a (rows x group_w) rectangle: its B working set is group_w column tiles, not all of N.
+    int tm, tn;
+    {
+        const int gw = p.group_w, per_group = p.tiles_m * gw;
+        const int grp = t / per_group, rr = t - grp * per_group;
+        const int w = min(gw, p.tiles_n - grp * gw);
+        tm = rr / w; tn = grp * gw + (rr - tm * w);
+    }
     const int m0 = tm * FBM, n0 = tn * FBN;
     const int kt_begin = split * p.ktiles_per_split;
     int kt_end = min(p.ktiles, kt_begin + p.ktiles_per_split);
@@ -195,7 +203,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
     const vm_gemm_epilogue& e = p.e;
     const float alpha = e.alpha_dev ? e.alpha * (*e.alpha_dev) : e.alpha;
     float* cs = reinterpret_cast<float*>(smem);     // [RPP][FBN] fp32, 16-B chunks XOR-swizzled by row
-    constexpr int LDS_BYTES = STAGES * F_STAGE;
+    constexpr int RING_BYTES = STAGES * F_STAGE;
+    constexpr int LDS_BYTES = RING_BYTES >= WR * FBN * 4 ? RING_BYTES : WR * FBN * 4;   // at least one wave-row of fp32 staging
     constexpr int RPP_RAW = LDS_BYTES / (FBN * 4);
     constexpr int RPP = RPP_RAW >= FBM ? FBM : (RPP_RAW / WR) * WR;   // rows staged per pass (multiple of a wave's WR rows)
     static_assert(FBM % RPP == 0 && (RPP * (FBN / 8)) % NT == 0, "epilogue pass geometry");
@@ -328,7 +337,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
 
 template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF>
 static int launch_fast(const GemmArgs& a, int nblocks, hipStream_t s) {
-    constexpr int LDS = STAGES * (WM * MF * 16 + WN * 64) * BKT * 2;
+    constexpr int RING = STAGES * (WM * MF * 16 + WN * 64) * BKT * 2, STAGE_MIN = MF * 16 * WN * 64 * 4;
+    constexpr int LDS = RING >= STAGE_MIN ? RING : STAGE_MIN;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<LA, LB, WM, WN, STAGES, BKT, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -380,7 +390,8 @@ static int dispatch_layout(const GemmArgs& a, int a_layout, int b_layout, int nb
 }
 
 // variant 0: 128x128 tile, 2-stage (2 workgroups/CU); 1: 256x128, 3-stage ring; 2: 256x256, 16 waves, 2-stage
-//         3: 128x128, k-tile 32, 4-stage ring (three half-tiles in flight, still 64 KiB -> 2 workgroups/CU)
+//         4: 160x128 (5 A fragments per wave), row-major A only
+// (measured and dropped: 128x128 with k-tile 32 x 4-stage ring, 256x128 with 128x64 per wave -- both slower on every hot shape)
 int vm_gemm_fast_dispatch(const GemmArgs& a0, int a_layout, int b_layout, int nblocks, int variant, hipStream_t s) {
     if (variant == 1) return dispatch_layout<4, 2, 3, 64, 4>(a0, a_layout, b_layout, nblocks, s);
     if (variant == 2) return dispatch_layout<4, 4, 2, 64, 4>(a0, a_layout, b_layout, nblocks, s);
@@ -388,11 +399,6 @@ int vm_gemm_fast_dispatch(const GemmArgs& a0, int a_layout, int b_layout, int nb
         if (a_layout != 0) { vm_set_error("vm_gemm_bf16: 160-row tile needs a row-major A"); return VM_EINVAL; }
         if (b_layout == 0) return launch_fast<0, 0, 2, 2, 2, 64, 5>(a0, nblocks, s);
         return launch_fast<0, 1, 2, 2, 2, 64, 5>(a0, nblocks, s);
-    }
-    if (variant == 3) {
-        GemmArgs a = a0;                 // k-tiles are counted in units of 32 here
-        a.ktiles *= 2; a.ktiles_per_split *= 2;
-        return dispatch_layout<2, 2, 4, 32, 4>(a, a_layout, b_layout, nblocks, s);
     }
     return dispatch_layout<2, 2, 2, 64, 4>(a0, a_layout, b_layout, nblocks, s);
 }

@@ -131,11 +131,14 @@ def on_side(*inputs):
             join_side()
 
 
+WGRAD_SLOTS = int(os.environ.get("VM_WGRAD_SLOTS", "512"))
+
+
 def _split_k_for(out_tiles, k_tiles):
     """as many K-splits as fit in ONE resident wave of workgroups (256 CUs x 2): tiles * split <= 512 -- rounding up
     instead would start a nearly empty second round (measured: 576 workgroups run 1.5x longer than 432) -- while
     keeping >= 8 K-tiles per split"""
-    want = max(1, 512 // max(1, out_tiles))
+    want = max(1, WGRAD_SLOTS // max(1, out_tiles))
     return max(1, min(want, max(1, k_tiles // 8)))
 
 
