@@ -59,11 +59,20 @@ def synthetic_batch(B, L, V, device, seed):
     return images, ids.to(device), am.to(device)
 
 
-def cpu_baseline(budget_s=25.0):
-    """Oracle (CPU port of the reference math) on the same model shape, B=2, fwd + bwd + Adam, fp32."""
+def _cpu_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))        # cgroup-limited boxes report hundreds of CPUs; oversubscribing them stalls the oracle
+
+
+def cpu_baseline_child(budget_s=20.0):
+    """Oracle (CPU port of the reference math) on the same model shape, B=2, fwd + bwd + Adam, fp32.  Runs in its own
+    process (no GPU context), prints one JSON object."""
     import golden_recipes as R
     from oracle import torch_ref as O
-    threads = os.cpu_count() or 1
+    threads = _cpu_threads()
     torch.set_num_threads(threads)
     vcfg, dcfg = dict(VIT_B16), dict(DEC_12L)
     st = {"enc.model." + k: v for k, v in R.rand_state(R.vit_shapes(vcfg), 0, std=0.02).items()}
@@ -82,12 +91,27 @@ def cpu_baseline(budget_s=25.0):
         loss.backward()
         opt.step()
         times.append(time.time() - t0)
-        if time.time() - t_start > budget_s and i >= 1:
+        if time.time() - t_start > budget_s:
             break
     t = min(times[1:]) if len(times) > 1 else times[0]
-    return {"value": round(B / t, 3), "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/torch_ref.py rrg_vit_forward + backward + Adam, same model (ViT-B/16 + 12L decoder, V=30522), "
-                      f"B={B}, L={L}, fp32, {len(times)} steps (best after 1 warm-up), {threads} torch threads"}
+    print(json.dumps({"value": round(B / t, 3), "unit": "pairs/s", "cores": threads, "kind": "port",
+                      "sample": f"oracle/torch_ref.py rrg_vit_forward + backward + Adam, same model (ViT-B/16 + 12L decoder, V=30522), "
+                                f"B={B}, L={L}, fp32, {len(times)} steps (best after 1 warm-up), {threads} torch threads"}), flush=True)
+
+
+def cpu_baseline(timeout_s=150.0):
+    """bounded: the oracle runs in a child process that is killed after ``timeout_s``"""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child"], capture_output=True, text=True,
+                           timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "pairs/s", "cores": _cpu_threads(), "kind": "port", "sample": "oracle child failed: " + r.stderr[-200:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "pairs/s", "cores": _cpu_threads(), "kind": "port",
+                "sample": f"oracle (B=2 fwd+bwd+Adam) did not finish one step pair within {timeout_s:.0f} s on this host"}
 
 
 def main():
@@ -98,9 +122,13 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--seq", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("VM_BENCH_GRAPH", "0")))
     args = ap.parse_args()
+    if args.cpu_baseline_child:
+        cpu_baseline_child()
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
