@@ -475,7 +475,7 @@ extern "C" int vm_attention_fwd(const void* q, int64_t ldq, const void* k, int64
     a.dropout_p = dropout_p; a.seed = dropout_seed; a.thresh = dropout_thresh16(dropout_p);
     a.drop_scale = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
     hipStream_t s = (hipStream_t)stream;
-    VmProfScope prof(VM_FAM_ATTN, 4.0 * B * H * (double)Lq * Lk * dh, s);
+    VmProfScope prof(VM_FAM_ATTN, 4.0 * B * H * (double)Lq * Lk * dh, s, "fwd_B%d_H%d_Lq%d_Lk%d_c%d_d%d", B, H, Lq, Lk, causal, dropout_p > 0.f);
     // dh = 64 with a short resident sequence (every ViT-B / BERT-base layer): one workgroup per (b, h), K/V loaded once
     if (dh == 64 && Lk <= 256 && !kv_row_index && !getenv("VM_ATTN_TILE") && !getenv("VM_ATTN_STREAM")) return vm_attn_head_fwd(a, s);
     const dim3 grid((Lq + 63) / 64, H, B);
@@ -507,7 +507,7 @@ extern "C" int vm_attention_bwd(const void* q, int64_t ldq, const void* k, int64
     a.dropout_p = dropout_p; a.seed = dropout_seed; a.thresh = dropout_thresh16(dropout_p);
     a.drop_scale = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
     hipStream_t s = (hipStream_t)stream;
-    VmProfScope prof(VM_FAM_ATTN, 14.0 * B * H * (double)Lq * Lk * dh, s);
+    VmProfScope prof(VM_FAM_ATTN, 14.0 * B * H * (double)Lq * Lk * dh, s, "bwd_B%d_H%d_Lq%d_Lk%d_c%d_d%d", B, H, Lq, Lk, causal, dropout_p > 0.f);
     const int64_t rows = (int64_t)B * H * Lq;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, a, dh);
     if (dh == 64 && Lk <= 256 && Lq <= 256 && !getenv("VM_ATTN_TILE") && !getenv("VM_ATTN_STREAM")) return vm_attn_head_bwd(a, s);

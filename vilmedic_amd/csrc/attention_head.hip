@@ -77,6 +77,13 @@ __device__ __forceinline__ void hstore_t_acc(bf16_t* rowptr, const float4_t (&ac
         *reinterpret_cast<uint2*>(rowptr + 16 * f + 4 * g) = u;
     }
 }
+#define LOG2E_F 1.4426950408889634f
+__device__ __forceinline__ float max4(const float4_t& v) { return fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])); }
+// A operand = (64-row tile)^T for k-step st: rows 32 st + {4g+e, 16+4g+e} of the tile, output rows = columns 16 df + c
+__device__ __forceinline__ bf16x8_t tr_pair(const char* tile, int st, int off) {
+    return join_tr(lds_tr(tile + (2 * st) * 2048 + off), lds_tr(tile + (2 * st + 1) * 2048 + off));
+}
+
 // scaled + masked score of one 16-key fragment; `plain` (wave-uniform) = no key mask, not on the causal diagonal, no
 // keys past Lk in this fragment: the common case costs one multiply per element.
 __device__ __forceinline__ void mask_scores(float4_t& s, bool plain, const uint8_t* smask, int key0, int qrow, const AttnArgs& p) {
@@ -116,6 +123,7 @@ __global__ __launch_bounds__(256, 3) void attn_head_fwd_kernel(const AttnArgs p)
     const HLane L = hlane_offsets(lane);
     const DropKey dkey = drop_key(p.seed);
     const uint32_t lk_even = (uint32_t)((p.Lk + 1) & ~1);
+    const float c2 = p.scale * LOG2E_F;
     auto load_q = [&](int grp, bf16x8_t (&qf)[2]) {
         const int qrow = qc0 + grp * 16 + c;
         const bf16_t* qp = p.q + (int64_t)(b * p.Lq + qrow) * p.ldq + h * 64;
@@ -141,6 +149,51 @@ __global__ __launch_bounds__(256, 3) void attn_head_fwd_kernel(const AttnArgs p)
             const int nf = min(4, nfr - 4 * kt);
             const char* skt = sk + kt * 8192;
             const char* svt = sv + kt * 8192;
+            // "clean" tile (the common case): 4 full fragments, no key mask, not touching the causal diagonal or the ragged
+            // tail.  Scores stay unscaled; exp(s*scale - m) is one fma + one v_exp_f32 (base 2) per element.
+            if (nf == 4 && !has_mask && !(p.causal && 4 * kt + 3 >= diag) && !(ragged && 4 * kt + 3 >= kfr_all - 1)) {
+                float4_t s[4];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    s[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+                        s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_b128(skt + f * 2048 + L.row[kk]), qf[kk], s[f], 0, 0, 0);
+                }
+                const float mt = col_max(fmaxf(fmaxf(max4(s[0]), max4(s[1])), fmaxf(max4(s[2]), max4(s[3])))) * p.scale;
+                const float m_new = fmaxf(m, mt);
+                const float alpha = __expf(m - m_new);
+                const float nm = -m_new * LOG2E_F;
+                float ls = 0.f;
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(s[f][r], c2, nm)); s[f][r] = e; ls += e; }
+                l = l * alpha + col_sum(ls);
+                m = m_new;
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[f][r] *= alpha;
+                if (p.dropout_p > 0.f) {
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        const uint32_t pr0 = dbase + (uint32_t)(8 * (4 * kt + f) + 2 * g);
+                        const uint32_t h0 = drop_hash(dkey, pr0), h1 = drop_hash(dkey, pr0 + 1);
+                        s[f][0] = (h0 & 0xffffu) >= p.thresh ? s[f][0] * p.drop_scale : 0.f;
+                        s[f][1] = (h0 >> 16) >= p.thresh ? s[f][1] * p.drop_scale : 0.f;
+                        s[f][2] = (h1 & 0xffffu) >= p.thresh ? s[f][2] * p.drop_scale : 0.f;
+                        s[f][3] = (h1 >> 16) >= p.thresh ? s[f][3] * p.drop_scale : 0.f;
+                    }
+                }
+                const bf16x8_t pb[2] = {pack_b_operand(s[0], s[1]), pack_b_operand(s[2], s[3])};
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int df = 0; df < 4; ++df)
+                        o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(svt, st, L.tr[df]), pb[st], o[df], 0, 0, 0);
+                continue;
+            }
             float4_t s[4];
             float mt = -INFINITY;
 #pragma unroll
@@ -229,6 +282,7 @@ __global__ __launch_bounds__(256, 3) void attn_head_dq_kernel(const AttnArgs p) 
     const HLane L = hlane_offsets(lane);
     const DropKey dkey = drop_key(p.seed);
     const uint32_t lk_even = (uint32_t)((p.Lk + 1) & ~1);
+    const float c2 = p.scale * LOG2E_F;
     struct Own { bf16x8_t qf[2], dof[2]; float m, inv_l, delta; };
     auto load_own = [&](int grp, Own& w) {
         const int qrow = qc0 + grp * 16 + c;
@@ -249,6 +303,7 @@ __global__ __launch_bounds__(256, 3) void attn_head_dq_kernel(const AttnArgs p) 
         const bool qok = qrow < p.Lq;
         const Own w = nx;
         load_own(grp + 4, nx);
+        const float nm = fmaf(-w.m, LOG2E_F, __builtin_amdgcn_logf(w.inv_l));   // log2 of exp(-m)/l; -inf for dead queries
         float4_t dq[4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) dq[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
@@ -259,6 +314,37 @@ __global__ __launch_bounds__(256, 3) void attn_head_dq_kernel(const AttnArgs p) 
             const int nf = min(4, nfr - 4 * kt);
             const char* skt = sk + kt * 8192;
             const char* svt = sv + kt * 8192;
+            if (nf == 4 && !has_mask && !(p.causal && 4 * kt + 3 >= diag) && !(ragged && 4 * kt + 3 >= kfr_all - 1)) {   // clean tile
+                float4_t s[4];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    s[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                    float4_t dp = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_b128(skt + f * 2048 + L.row[kk]), w.qf[kk], s[f], 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_b128(svt + f * 2048 + L.row[kk]), w.dof[kk], dp, 0, 0, 0);
+                    }
+                    if (p.dropout_p > 0.f) {
+                        const uint32_t pr0 = dbase + (uint32_t)(8 * (4 * kt + f) + 2 * g);
+                        const uint32_t h0 = drop_hash(dkey, pr0), h1 = drop_hash(dkey, pr0 + 1);
+                        dp[0] = (h0 & 0xffffu) >= p.thresh ? dp[0] * p.drop_scale : 0.f;
+                        dp[1] = (h0 >> 16) >= p.thresh ? dp[1] * p.drop_scale : 0.f;
+                        dp[2] = (h1 & 0xffffu) >= p.thresh ? dp[2] * p.drop_scale : 0.f;
+                        dp[3] = (h1 >> 16) >= p.thresh ? dp[3] * p.drop_scale : 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        s[f][r] = __builtin_amdgcn_exp2f(fmaf(s[f][r], c2, nm)) * (dp[r] - w.delta);      // P * (dP - delta)
+                }
+                const bf16x8_t db[2] = {pack_b_operand(s[0], s[1]), pack_b_operand(s[2], s[3])};
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int df = 0; df < 4; ++df)
+                        dq[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(skt, st, L.tr[df]), db[st], dq[df], 0, 0, 0);
+                continue;
+            }
             float4_t s[4];
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
@@ -316,38 +402,40 @@ __global__ __launch_bounds__(256, 3) void attn_head_dkv_kernel(const AttnArgs p)
     const int nalloc = p.ralloc_q;
     char* sq = smem;
     char* sdo = smem + nalloc * HB;
-    float* sm = reinterpret_cast<float*>(sdo + nalloc * HB);      // [3][nalloc]: m, 1/l, delta
-    float* sil = sm + nalloc;
-    float* sdl = sil + nalloc;
+    float* sm = reinterpret_cast<float*>(sdo + nalloc * HB);      // [3][nalloc]: m, nm = log2(exp(-m) / l), delta
+    float* snm = sm + nalloc;
+    float* sdl = snm + nalloc;
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z, h = blockIdx.y, kc0 = blockIdx.x * HCHUNK;
     head_stage2(p.q + (int64_t)b * p.Lq * p.ldq + h * 64, p.ldq, p.d_o + (int64_t)b * p.Lq * p.lddo + h * 64, p.lddo, p.Lq, nalloc, sq, sdo, tid);
     if (tid < nalloc) {
-        float mm = 0.f, il = 0.f, dl = 0.f;
+        float mm = 0.f, nm = -INFINITY, dl = 0.f;
         if (tid < p.Lq) {
             const int64_t si = (int64_t)(b * p.H + h) * p.Lq + tid;
-            mm = p.stats[si * 2]; il = 1.0f / p.stats[si * 2 + 1]; dl = p.delta[si];
+            mm = p.stats[si * 2]; dl = p.delta[si];
+            nm = fmaf(-mm, LOG2E_F, -__builtin_amdgcn_logf(p.stats[si * 2 + 1]));
         }
-        sm[tid] = mm; sil[tid] = il; sdl[tid] = dl;      // rows >= Lq: 1/l = 0  ->  P = dS = 0
+        sm[tid] = mm; snm[tid] = nm; sdl[tid] = dl;      // rows >= Lq: nm = -inf  ->  P = dS = 0
     }
     const int ngroups = (min(HCHUNK, p.Lk - kc0) + 15) / 16;
     const int qfr_all = (p.Lq + 15) / 16;
     const int F_part = (nalloc & 15) ? (nalloc >> 4) : -1;         // the partial fragment, if any
+    const bool has_mask = p.key_mask != nullptr;
     const HLane L = hlane_offsets(lane);
-    HLane LP = L;                                                   // absolute offsets for fragment F_part
-    bool part_dead = false;                                         // this lane's 4 transposed rows lie past the allocation
-    if (F_part >= 0) {
-        const int row = min(16 * F_part + c, nalloc - 1), hs = hswz(row);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) LP.row[kk] = row * HB + (((kk * 4 + g) ^ hs) << 4);
-        const int rt = min(16 * F_part + 4 * g + (c >> 2), nalloc - 1), hst = hswz(rt), yi = (c & 3) >> 1, sub = (c & 1) * 8;
-#pragma unroll
-        for (int df = 0; df < 4; ++df) LP.tr[df] = rt * HB + (((2 * df + yi) ^ hst) << 4) + sub;
-        part_dead = 16 * F_part + 4 * g >= nalloc;
-    }
+    // absolute per-lane offsets for the partial fragment F_part, recomputed where used (rare path; keeps 6 VGPRs free)
+    const bool part_dead = F_part >= 0 && 16 * F_part + 4 * g >= nalloc;       // this lane's 4 transposed rows lie past the allocation
+    auto part_row = [&](int kk) {
+        const int row = min(16 * F_part + c, nalloc - 1);
+        return row * HB + (((kk * 4 + g) ^ hswz(row)) << 4);
+    };
+    auto part_tr = [&](int df) {
+        const int rt = min(16 * F_part + 4 * g + (c >> 2), nalloc - 1);
+        return rt * HB + (((2 * df + ((c & 3) >> 1)) ^ hswz(rt)) << 4) + (c & 1) * 8;
+    };
     const DropKey dkey = drop_key(p.seed);
     const uint32_t lk_even = (uint32_t)((p.Lk + 1) & ~1);
+    const float c2 = p.scale * LOG2E_F;
     struct Own { bf16x8_t kf[2], vf[2]; bool keep; };
     auto load_own = [&](int grp, Own& w) {
         const int key = kc0 + grp * 16 + c;
@@ -363,26 +451,70 @@ __global__ __launch_bounds__(256, 3) void attn_head_dkv_kernel(const AttnArgs p)
     auto tr_half = [&](const char* tile, int F, int df) -> v4s {
         if (F >= qfr_all) return (v4s){0, 0, 0, 0};
         if (F == F_part) {
-            v4s v = lds_tr(tile + LP.tr[df]);
+            v4s v = lds_tr(tile + part_tr(df));
             if (part_dead) v = (v4s){0, 0, 0, 0};
             return v;
         }
         return lds_tr(tile + F * 2048 + L.tr[df]);
     };
-    Own nx;
-    load_own(wave, nx);
     __syncthreads();
     for (int grp = wave; grp < ngroups; grp += 4) {
         const int k0 = kc0 + grp * 16, key = k0 + c;
         const bool kok = key < p.Lk;
-        const Own w = nx;
-        load_own(grp + 4, nx);
+        Own w;                      // (no next-group prefetch here: the kernel is at its VGPR budget for 3 waves/SIMD)
+        load_own(grp, w);
         float4_t dk[4], dv[4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) { dk[f] = (float4_t){0.f, 0.f, 0.f, 0.f}; dv[f] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
         const int fr_begin = p.causal ? (k0 >> 4) : 0;      // query fragments before the group's first key see none of its keys
+        const bool group_full = k0 + 16 <= p.Lk;
         for (int qt = fr_begin >> 2; qt * 4 < qfr_all; ++qt) {
             const int f_lo = max(0, fr_begin - 4 * qt), nf = min(4, qfr_all - 4 * qt);
+            if (f_lo == 0 && nf == 4 && group_full && !has_mask && !(F_part >= 0 && 4 * qt + 3 >= F_part) && !(p.causal && fr_begin >= 4 * qt)) {
+                // clean tile: 4 full query fragments, every key of the group live, no mask / diagonal / partial rows
+                const char* sqt = sq + qt * 8192;
+                const char* sdt = sdo + qt * 8192;
+                float4_t s[4], dp[4];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    s[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                    dp[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_b128(sqt + f * 2048 + L.row[kk]), w.kf[kk], s[f], 0, 0, 0);
+                        dp[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_b128(sdt + f * 2048 + L.row[kk]), w.vf[kk], dp[f], 0, 0, 0);
+                    }
+                    const int si = 64 * qt + 16 * f + 4 * g;
+                    const float4 n4 = *reinterpret_cast<const float4*>(snm + si);
+                    const float4 d4 = *reinterpret_cast<const float4*>(sdl + si);
+                    const float nr[4] = {n4.x, n4.y, n4.z, n4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pr = __builtin_amdgcn_exp2f(fmaf(s[f][r], c2, nr[r]));
+                        float dpv = dp[f][r], pd = pr;
+                        if (p.dropout_p > 0.f) {
+                            const int qr = si + r;
+                            const uint32_t pair = (uint32_t)((((uint64_t)(b * p.H + h) * p.Lq + qr) * lk_even + (uint32_t)key) >> 1);
+                            const uint32_t hh = drop_hash(dkey, pair);
+                            const bool kp_ = ((key & 1) ? (hh >> 16) : (hh & 0xffffu)) >= p.thresh;
+                            dpv = kp_ ? dpv * p.drop_scale : 0.f;
+                            pd = kp_ ? pr * p.drop_scale : 0.f;
+                        }
+                        dp[f][r] = pd;
+                        s[f][r] = pr * (dpv - dr[r]);
+                    }
+                }
+                const bf16x8_t pb[2] = {pack_b_operand(dp[0], dp[1]), pack_b_operand(dp[2], dp[3])};
+                const bf16x8_t sb[2] = {pack_b_operand(s[0], s[1]), pack_b_operand(s[2], s[3])};
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int df = 0; df < 4; ++df) {
+                        dv[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(sdt, st, L.tr[df]), pb[st], dv[df], 0, 0, 0);
+                        dk[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(sqt, st, L.tr[df]), sb[st], dk[df], 0, 0, 0);
+                    }
+                continue;
+            }
             float4_t s[4], dp[4];
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
@@ -393,17 +525,17 @@ __global__ __launch_bounds__(256, 3) void attn_head_dkv_kernel(const AttnArgs p)
                     const bool part = F == F_part;
 #pragma unroll
                     for (int kk = 0; kk < 2; ++kk) {
-                        const int off = part ? LP.row[kk] : F * 2048 + L.row[kk];
+                        const int off = part ? part_row(kk) : F * 2048 + L.row[kk];
                         s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_b128(sq + off), w.kf[kk], s[f], 0, 0, 0);
                         dp[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_b128(sdo + off), w.vf[kk], dp[f], 0, 0, 0);
                     }
                     const int si = min(16 * F + 4 * g, nalloc - 4);
                     const float4 m4 = *reinterpret_cast<const float4*>(sm + si);
-                    const float4 i4 = *reinterpret_cast<const float4*>(sil + si);
+                    const float4 n4 = *reinterpret_cast<const float4*>(snm + si);
                     const float4 d4 = *reinterpret_cast<const float4*>(sdl + si);
                     const float mr[4] = {m4.x, m4.y, m4.z, m4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
-                    float ir[4] = {i4.x, i4.y, i4.z, i4.w};
-                    if (part && part_dead) { ir[0] = 0.f; ir[1] = 0.f; ir[2] = 0.f; ir[3] = 0.f; }   // clamped stats index: dead rows
+                    float nr[4] = {n4.x, n4.y, n4.z, n4.w};
+                    if (part && part_dead) { nr[0] = -INFINITY; nr[1] = -INFINITY; nr[2] = -INFINITY; nr[3] = -INFINITY; }   // clamped stats index: dead rows
                     const bool diag = p.causal && F == fr_begin;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -411,7 +543,8 @@ __global__ __launch_bounds__(256, 3) void attn_head_dkv_kernel(const AttnArgs p)
                         float val = s[f][r] * p.scale;
                         const bool keep = w.keep && !(diag && key > qr);
                         val = keep ? val : MASKED_SCORE;
-                        const float pr = kok ? __expf(fminf(val - mr[r], 0.f)) * ir[r] : 0.f;   // live rows have val <= m; dead rows (1/l = 0) must not overflow
+                        // exp(val - m) / l = 2^((val - m) log2e + (nm + m log2e)); live rows have val <= m, dead rows nm = -inf
+                        const float pr = kok ? __builtin_amdgcn_exp2f(fmaf(fminf(val - mr[r], 0.f), LOG2E_F, fmaf(mr[r], LOG2E_F, nr[r]))) : 0.f;
                         float dpv = dp[f][r], pd = pr;
                         if (p.dropout_p > 0.f) {
                             const uint32_t pair = (uint32_t)((((uint64_t)(b * p.H + h) * p.Lq + qr) * lk_even + (uint32_t)key) >> 1);
