@@ -84,6 +84,11 @@ int vm_layernorm_bwd(const void* dy, const void* x, const float* gamma, const fl
 int vm_layernorm_bwd_fused(const void* dy, const void* dy2, const void* dres, const void* x, const float* gamma,
                            const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                            int rows, int cols, void* ws, void* stream);
+/* the two halves of vm_layernorm_bwd_fused, for callers that run the parameter-gradient reduction on another stream:
+   _partial writes dx and the per-workgroup dgamma/dbeta partials to ws; _reduce accumulates them into dgamma/dbeta */
+int vm_layernorm_bwd_partial(const void* dy, const void* dy2, const void* dres, const void* x, const float* gamma,
+                             const float* mean, const float* rstd, void* dx, int rows, int cols, void* ws, void* stream);
+int vm_layernorm_bwd_reduce(const void* ws, float* dgamma, float* dbeta, int rows, int cols, void* stream);
 
 /* ------------------------------------------------------------------ attention (self / causal / cross)
  * softmax(Q K^T * scale + mask) V with optional dropout on the probabilities.

@@ -508,9 +508,10 @@ extern "C" int vm_attention_bwd(const void* q, int64_t ldq, const void* k, int64
     a.drop_scale = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_ATTN, 14.0 * B * H * (double)Lq * Lk * dh, s, "bwd_B%d_H%d_Lq%d_Lk%d_c%d_d%d", B, H, Lq, Lk, causal, dropout_p > 0.f);
+    // head-resident kernels: delta = rowsum(dO * O) is computed by the dQ kernel (which holds the rows anyway) and saved for dK/dV
+    if (dh == 64 && Lk <= 256 && Lq <= 256 && !getenv("VM_ATTN_TILE") && !getenv("VM_ATTN_STREAM")) return vm_attn_head_bwd(a, s);
     const int64_t rows = (int64_t)B * H * Lq;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, a, dh);
-    if (dh == 64 && Lk <= 256 && Lq <= 256 && !getenv("VM_ATTN_TILE") && !getenv("VM_ATTN_STREAM")) return vm_attn_head_bwd(a, s);
     const dim3 gq((Lq + 63) / 64, H, B), gk((Lk + 63) / 64, H, B);
     const bool resk = Lk <= 256 && !getenv("VM_ATTN_STREAM"), resq = Lq <= 256 && !getenv("VM_ATTN_STREAM");
     a.nslot_k = (Lk + 63) / 64; a.nslot_q = (Lq + 63) / 64;

@@ -283,17 +283,22 @@ __global__ __launch_bounds__(256, 3) void attn_head_dq_kernel(const AttnArgs p) 
     const DropKey dkey = drop_key(p.seed);
     const uint32_t lk_even = (uint32_t)((p.Lk + 1) & ~1);
     const float c2 = p.scale * LOG2E_F;
-    struct Own { bf16x8_t qf[2], dof[2]; float m, inv_l, delta; };
+    struct Own { bf16x8_t qf[2], dof[2], of[2]; float m, inv_l; };      // of: the forward output rows (for delta = rowsum(dO * O))
     auto load_own = [&](int grp, Own& w) {
         const int qrow = qc0 + grp * 16 + c;
         const bool ok = qrow < p.Lq && grp < ngroups;
         const bf16_t* qp = p.q + (int64_t)(b * p.Lq + qrow) * p.ldq + h * 64;
         const bf16_t* dop = p.d_o + (int64_t)(b * p.Lq + qrow) * p.lddo + h * 64;
+        const bf16_t* op = p.o + (int64_t)(b * p.Lq + qrow) * p.ldo + h * 64;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) { w.qf[kk] = ld_frag_global(qp + kk * 32 + g * 8, p.q, ok); w.dof[kk] = ld_frag_global(dop + kk * 32 + g * 8, p.d_o, ok); }
+        for (int kk = 0; kk < 2; ++kk) {
+            w.qf[kk] = ld_frag_global(qp + kk * 32 + g * 8, p.q, ok);
+            w.dof[kk] = ld_frag_global(dop + kk * 32 + g * 8, p.d_o, ok);
+            w.of[kk] = ld_frag_global(op + kk * 32 + g * 8, p.o, ok);
+        }
         const int64_t si = ok ? (int64_t)(b * p.H + h) * p.Lq + qrow : 0;
-        const float mm = p.stats[si * 2], ll = p.stats[si * 2 + 1], dl = p.delta[si];
-        w.m = ok ? mm : 0.f; w.inv_l = ok ? 1.0f / ll : 0.f; w.delta = ok ? dl : 0.f;
+        const float mm = p.stats[si * 2], ll = p.stats[si * 2 + 1];
+        w.m = ok ? mm : 0.f; w.inv_l = ok ? 1.0f / ll : 0.f;
     };
     Own nx;
     load_own(wave, nx);
@@ -304,6 +309,18 @@ __global__ __launch_bounds__(256, 3) void attn_head_dq_kernel(const AttnArgs p) 
         const Own w = nx;
         load_own(grp + 4, nx);
         const float nm = fmaf(-w.m, LOG2E_F, __builtin_amdgcn_logf(w.inv_l));   // log2 of exp(-m)/l; -inf for dead queries
+        // delta = rowsum(dO * O) of the lane's query: 16 of the 64 columns per lane, summed over the 4 lane groups; saved for dK/dV
+        float delta = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            float a8[8], b8[8];
+            unpack8(__builtin_bit_cast(uint4, w.dof[kk]), a8);
+            unpack8(__builtin_bit_cast(uint4, w.of[kk]), b8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) delta = fmaf(a8[e], b8[e], delta);
+        }
+        delta = col_sum(delta);
+        if (qok && g == 0) p.delta[(int64_t)(b * p.H + h) * p.Lq + qrow] = delta;
         float4_t dq[4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) dq[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
@@ -335,7 +352,7 @@ __global__ __launch_bounds__(256, 3) void attn_head_dq_kernel(const AttnArgs p) 
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        s[f][r] = __builtin_amdgcn_exp2f(fmaf(s[f][r], c2, nm)) * (dp[r] - w.delta);      // P * (dP - delta)
+                        s[f][r] = __builtin_amdgcn_exp2f(fmaf(s[f][r], c2, nm)) * (dp[r] - delta);      // P * (dP - delta)
                 }
                 const bf16x8_t db[2] = {pack_b_operand(s[0], s[1]), pack_b_operand(s[2], s[3])};
 #pragma unroll
@@ -370,7 +387,7 @@ __global__ __launch_bounds__(256, 3) void attn_head_dq_kernel(const AttnArgs p) 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float pr = __expf(s[f][r] - w.m) * w.inv_l;      // 0 for keys >= Lk (score -inf) and dead queries (inv_l 0)
-                        s[f][r] = pr * (dp[r] - w.delta);                      // dS^T
+                        s[f][r] = pr * (dp[r] - delta);                      // dS^T
                     }
                 }
             }

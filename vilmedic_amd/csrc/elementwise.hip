@@ -95,7 +95,23 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (c0 < cols) {
         const bool full = c0 + 8 <= cols;
-        for (int r = blockIdx.y * 8 + ty; r < rows; r += gridDim.y * 8) {
+        const int step = gridDim.y * 8;
+        int r = blockIdx.y * 8 + ty;
+        if (full) {
+            for (; r + 3 * step < rows; r += 4 * step) {        // four independent 16-B loads in flight per thread
+                uint4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(x + (int64_t)(r + u * step) * ldx + c0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float f[8];
+                    unpack8(v[u], f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += f[j];
+                }
+            }
+        }
+        for (; r < rows; r += step) {
             const bf16_t* p = x + (int64_t)r * ldx + c0;
             if (full) {
                 float f[8];

@@ -216,7 +216,23 @@ extern "C" int vm_layernorm_bwd(const void* dy, const void* x, const float* gamm
 extern "C" int vm_layernorm_bwd_fused(const void* dy, const void* dy2, const void* dres, const void* x, const float* gamma,
                                       const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                                       int rows, int cols, void* ws, void* stream) {
-    VM_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && ws, "vm_layernorm_bwd: null pointer");
+    VM_REQUIRE(dgamma && dbeta, "vm_layernorm_bwd: null pointer");
+    int rc = vm_layernorm_bwd_partial(dy, dy2, dres, x, gamma, mean, rstd, dx, rows, cols, ws, stream);
+    if (rc) return rc;
+    return vm_layernorm_bwd_reduce(ws, dgamma, dbeta, rows, cols, stream);
+}
+
+extern "C" int vm_layernorm_bwd_reduce(const void* ws, float* dgamma, float* dbeta, int rows, int cols, void* stream) {
+    VM_REQUIRE(ws && dgamma && dbeta && rows > 0 && cols > 0, "vm_layernorm_bwd_reduce: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    VmProfScope prof(VM_FAM_LN, 0.0, s);
+    hipLaunchKernelGGL(ln_bwd_reduce, dim3((cols + 31) / 32, 2), dim3(256), 0, s, (const float*)ws, dgamma, dbeta, ln_grid(rows, LN_BWD_CAP), cols);
+    return vm_check_launch("vm_layernorm_bwd_reduce");
+}
+
+extern "C" int vm_layernorm_bwd_partial(const void* dy, const void* dy2, const void* dres, const void* x, const float* gamma,
+                                        const float* mean, const float* rstd, void* dx, int rows, int cols, void* ws, void* stream) {
+    VM_REQUIRE(dy && x && gamma && mean && rstd && dx && ws, "vm_layernorm_bwd: null pointer");
     VM_REQUIRE(rows > 0 && cols > 0 && (cols % 8) == 0 && cols <= 64 * 8 * LN_MAX_CHUNKS, "vm_layernorm_bwd: cols=%d must be a multiple of 8 and <= 2048", cols);
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_LN, 6.0 * rows * (double)cols, s);
@@ -231,6 +247,5 @@ extern "C" int vm_layernorm_bwd_fused(const void* dy, const void* dy2, const voi
         case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(grid), dim3(256), red_bytes, s, dyp, dy2p, drp, xp, gamma, mean, rstd, dxp, wsp, rows, cols); break;
         default: hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(grid), dim3(256), red_bytes, s, dyp, dy2p, drp, xp, gamma, mean, rstd, dxp, wsp, rows, cols); break;
     }
-    hipLaunchKernelGGL(ln_bwd_reduce, dim3((cols + 31) / 32, 2), dim3(256), 0, s, wsp, dgamma, dbeta, grid, cols);
     return vm_check_launch("vm_layernorm_bwd");
 }

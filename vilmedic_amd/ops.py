@@ -344,10 +344,12 @@ class LayerNormFn(torch.autograd.Function):
         if g_gamma is None:   # frozen affine: still need dx; send the param grads to scratch
             g_gamma = torch.zeros(cols, dtype=torch.float32, device=dy.device)
             g_beta = torch.zeros(cols, dtype=torch.float32, device=dy.device)
-        check(lib().vm_layernorm_bwd_fused(ptr(dy2), ptr(_2d(d2.contiguous())) if d2 is not None else None,
-                                           ptr(_2d(dres.contiguous())) if dres is not None else None,
-                                           ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(g_gamma), ptr(g_beta),
-                                           rows, cols, ptr(ws), stream()), "vm_layernorm_bwd")
+        check(lib().vm_layernorm_bwd_partial(ptr(dy2), ptr(_2d(d2.contiguous())) if d2 is not None else None,
+                                             ptr(_2d(dres.contiguous())) if dres is not None else None,
+                                             ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), rows, cols, ptr(ws), stream()),
+              "vm_layernorm_bwd")
+        with on_side(ws):          # the dgamma / dbeta reduction only feeds the optimizer: off the dgrad chain
+            check(lib().vm_layernorm_bwd_reduce(ptr(ws), ptr(g_gamma), ptr(g_beta), rows, cols, stream()), "vm_layernorm_bwd_reduce")
         return dx.view(xshape), None, None, None, None, None, None
 
 
