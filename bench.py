@@ -138,23 +138,26 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1 or os.environ.get("VM_FORCE_DDP"):      # VM_FORCE_DDP: exercise the RCCL path on a single GPU
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-
     from vilmedic_amd import ops
     from vilmedic_amd._lib import lib
     from vilmedic_amd.optim import FusedAdam
     from vilmedic_amd.parallel import ArenaDDP
 
+    # The model, its arena and the optimizer state are allocated BEFORE the RCCL communicator exists: on this stack
+    # (ROCm 7.0 / RCCL 2.26, dmabuf IPC) device memory allocated after init_process_group made every step 5.6 ms slower
+    # (tools/dbg/init_order.py: 35.65 vs 30.02 ms/step on one GPU with a 1-rank group).
     model = build_model(device)
     model.train()
     ops.manual_seed(1234 + rank)
-    ddp = ArenaDDP(model, dist) if dist is not None else None
     opt = FusedAdam(model, lr=1e-4)
+    dist, wire = None, None
+    if world > 1 or os.environ.get("VM_FORCE_DDP"):
+        wire = torch.empty(opt.arena.numel, dtype=torch.bfloat16, device=device)     # bf16 staging of the gradient all-reduce      # VM_FORCE_DDP: exercise the RCCL path on a single GPU
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    ddp = ArenaDDP(model, dist, wire=wire) if dist is not None else None
     B, L, V = args.batch, args.seq, DEC_12L["vocab_size"]
     images, ids, am = synthetic_batch(B, L, V, device, seed=rank)
 

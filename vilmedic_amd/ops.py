@@ -86,7 +86,7 @@ def _workspace(nbytes, device):
 # produced their inputs; the GPU then fills the thin last round of workgroups of a dgrad GEMM with wgrad workgroups
 # (and vice versa) instead of idling CUs.  The main stream re-joins the side stream when the backward pass ends
 # (autograd engine callback) -- or on join_side() for launches made outside a backward pass.
-_side = {"streams": {}, "pending": False, "callback_queued": False}
+_side = {"streams": {}, "pending": False, "callback_queued": False, "defer": False}
 SIDE_STREAM = os.environ.get("VM_SIDE_STREAM", "1") != "0"
 
 
@@ -108,6 +108,24 @@ def join_side():
 
 
 @contextlib.contextmanager
+def side_context(device, defer_join=None):
+    """make the side stream the current stream (after everything enqueued on the main stream so far) -- for callers
+    that order their own work behind the parameter-gradient kernels without stalling the main stream (ArenaDDP starts
+    its gradient all-reduce from here).  ``defer_join`` sets/clears the flag that suppresses the automatic end-of-backward
+    join; the caller then calls join_side() itself."""
+    if defer_join is not None:
+        _side["defer"] = bool(defer_join)
+    if not SIDE_STREAM or torch.device(device).type != "cuda":
+        yield
+        return
+    side = _side_stream(device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+        yield
+    _side["pending"] = True
+
+
+@contextlib.contextmanager
 def on_side(*inputs):
     """launch the enclosed kernels on the side stream, after everything enqueued on the current stream so far.
     ``inputs`` are the tensors those kernels read: they are recorded on the side stream so the caching allocator does
@@ -123,7 +141,7 @@ def on_side(*inputs):
     with torch.cuda.stream(side):
         yield
     _side["pending"] = True
-    if not _side["callback_queued"]:
+    if not _side["callback_queued"] and not _side["defer"]:
         try:
             torch.autograd.Variable._execution_engine.queue_callback(join_side)
             _side["callback_queued"] = True

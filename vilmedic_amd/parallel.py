@@ -73,7 +73,7 @@ class ArenaDDP:
     follows.  Explicit two-phase backward -- correct by construction, no reliance on autograd's scheduling order.
     ``finish()`` (no overlap) remains for callers that ran ``loss.backward()`` themselves."""
 
-    def __init__(self, model, dist, chunks=4, bf16_wire=True):
+    def __init__(self, model, dist, chunks=4, bf16_wire=True, wire=None):
         from . import ops
         from .arena import arena_of
         self.dist = dist
@@ -92,7 +92,9 @@ class ArenaDDP:
             if enc_offs and dec_offs and min(enc_offs) >= max(dec_offs):
                 self.split_at = min(enc_offs)
                 model.split_backward = True
-        self._wire = torch.empty(self.arena.numel, dtype=torch.bfloat16, device=self.arena.flat.device) if bf16_wire else None
+        # ``wire``: optional pre-allocated bf16 staging buffer (callers allocate it before init_process_group, see bench.py)
+        self._wire = (wire if wire is not None else
+                      torch.empty(self.arena.numel, dtype=torch.bfloat16, device=self.arena.flat.device)) if bf16_wire else None
 
     # ---- asynchronous all-reduce of gflat[s:e] in `chunks` pieces; returns the pending work items
     def _start(self, s, e, chunks):
@@ -120,12 +122,22 @@ class ArenaDDP:
             self._wait(self._start(0, n, self.chunks))
             return
         feats, leaf = split
-        loss.backward()                                  # decoder graph only (features were detached)
-        pending = self._start(0, self.split_at, max(1, self.chunks // 2))
-        if leaf.grad is not None:
-            feats.backward(leaf.grad)                    # encoder graph, overlapping the decoder's all-reduce
-        pending += self._start(self.split_at, n, max(1, self.chunks // 2))
-        self._wait(pending)
+        ops, dev = self._ops, self.arena.flat.device
+        # The collectives are enqueued from the SIDE stream (where the weight-gradient GEMMs run): they are ordered after
+        # the gradients they reduce without the main stream ever waiting for the side stream between the two phases.
+        ops._side["defer"] = True
+        try:
+            loss.backward()                              # decoder graph only (features were detached)
+            with ops.side_context(dev):
+                pending = self._start(0, self.split_at, max(1, self.chunks // 2))
+            if leaf.grad is not None:
+                feats.backward(leaf.grad)                # encoder graph, overlapping the decoder's all-reduce
+            with ops.side_context(dev):
+                pending += self._start(self.split_at, n, max(1, self.chunks // 2))
+                self._wait(pending)
+        finally:
+            ops._side["defer"] = False
+        ops.join_side()                                  # the optimizer (main stream) waits for the averaged gradients
         self.model._split = None
 
     def finish(self):
