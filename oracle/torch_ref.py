@@ -414,3 +414,95 @@ def beam_decode(enc, enc_mask, state, cfg, bos, eos, pad, max_length, num_beams,
             break
     out_len = prompt + int(seq_len[:, 0].max())
     return seqs[:, 0, :out_len], beam_scores[:, 0]
+
+
+# --------------------------------------------------------------------------- RRG_HF (VisionEncoderDecoder wiring)
+def rrg_hf_forward(images, input_ids, attention_mask, state, vit_cfg, dec_cfg, images_mask=None):
+    """ref:vilmedic/models/rrg/RRG_HF.py:107-176.  state keys as VisionEncoderDecoderModel under ``model.``:
+    ``model.encoder.*`` (ViT, pinned 4.55.3 names; the pooler is unused), ``model.decoder.*``, optional
+    ``model.enc_to_dec_proj.{weight,bias}``.  4-D images: encoder_attention_mask=None (:170); 5-D [B,N,C,H,W]: crops are
+    encoded flat, concatenated along the sequence (:131) and masked per crop through the cross-attention mask (:143)."""
+    dec_state = {k[len("model.decoder."):]: v for k, v in state.items() if k.startswith("model.decoder.")}
+    mask = None
+    if images.dim() == 5:
+        B, N = images.shape[:2]
+        flat = vit_forward(images.reshape(B * N, *images.shape[2:]), state, vit_cfg, prefix="model.encoder.")
+        S, D = flat.shape[1], flat.shape[2]
+        hidden = flat.reshape(B, N * S, D)
+        m = torch.ones(B, N, dtype=torch.bool) if images_mask is None else images_mask.bool()
+        mask = m.unsqueeze(-1).expand(B, N, S).reshape(B, N * S)
+    else:
+        hidden = vit_forward(images, state, vit_cfg, prefix="model.encoder.")
+    if "model.enc_to_dec_proj.weight" in state:
+        hidden = F.linear(hidden, state["model.enc_to_dec_proj.weight"], state["model.enc_to_dec_proj.bias"])
+    return decoder_forward(input_ids, attention_mask, hidden, mask, dec_state, dec_cfg)
+
+
+# --------------------------------------------------------------------------- GLoRIA word-piece aggregation
+def gloria_aggregate_tokens(embeddings, input_ids, idxtoword):
+    """ref:vilmedic/models/selfsup/GLoRIA.py:123-177, restated as plain loops (small cases only).
+    embeddings [layers, B, L, D], input_ids [B, L] -> ([B, layers, L, D], sentences)."""
+    nl, B, L, D = embeddings.shape
+    emb = embeddings.permute(1, 2, 0, 3)                       # [B, L, layers, D]
+    batch, sentences = [], []
+    for embs, ids in zip(emb, input_ids):
+        agg, bank, words, word_bank = [], [], [], []
+        for e, i in zip(embs, ids):
+            word = idxtoword[int(i)]
+            if word == "[SEP]":
+                agg.append(torch.stack(bank).sum(0)); words.append("".join(word_bank))
+                agg.append(e); words.append(word)
+                break
+            if not word.startswith("##"):
+                if len(word_bank) == 0:
+                    bank.append(e); word_bank.append(word)
+                else:
+                    agg.append(torch.stack(bank).sum(0)); words.append("".join(word_bank))
+                    bank, word_bank = [e], [word]
+            else:
+                bank.append(e); word_bank.append(word[2:])
+        agg = torch.stack(agg)
+        pad = L - len(agg)
+        batch.append(torch.cat([agg, torch.zeros(pad, nl, D, dtype=agg.dtype)]))
+        sentences.append(words + ["[PAD]"] * pad)
+    return torch.stack(batch).permute(0, 2, 1, 3), sentences
+
+
+def gloria_forward(images, input_ids, attention_mask, state, txt_cfg, visual, idxtoword, last_n_layers, fbs,
+                   temp1=4.0, temp2=5.0, temp3=10.0, local_loss_weight=1.0, global_loss_weight=1.0):
+    """ref:vilmedic/models/selfsup/GLoRIA.py:85-121 + GLoRIALoss.forward (blocks/losses/selfsup/GLoRIALoss.py:141-170).
+    ``visual``: the truncated torchvision-style CNN (``VisualEncoder.model``, an nn.Sequential whose [6] is ResNet layer3)
+    as a CPU torch module -- convolution arithmetic is not restated, the batch_first permute of
+    visual_encoder.py:196-203 is; ``state``: ``linguistic.encoder.*`` (BertGenerationEncoder names), ``global_embedder.*``,
+    ``local_embedder.weight``.  Towers are chunked by ``fbs`` like the reference (per-chunk BatchNorm statistics)."""
+    act = {}
+    handle = visual[6].register_forward_hook(lambda m, i, o: act.__setitem__("local", o))
+    enc = {k[len("linguistic.encoder."):]: v for k, v in state.items() if k.startswith("linguistic.encoder.")}
+    gfs, lfs, hss = [], [], []
+    bs = images.shape[0]
+    step = min(fbs, bs)
+    for s in range(0, bs, step):
+        img = F.interpolate(images[s:s + step], size=(299, 299), mode="bilinear", align_corners=True)
+        feats = visual(img)
+        feats = feats.view(*feats.shape[:2], -1).permute(0, 2, 1)
+        if feats.shape[1] == 1:
+            feats = feats.squeeze(1)
+        gfs.append(F.linear(feats, state["global_embedder.weight"], state["global_embedder.bias"]))
+        lfs.append(F.conv2d(act["local"], state["local_embedder.weight"]))
+        x = bert_embeddings(input_ids[s:s + step], enc, "embeddings.", txt_cfg["layer_norm_eps"], pad_token_id=txt_cfg.get("pad_token_id"))
+        hs = [x]
+        m = key_padding_mask(attention_mask[s:s + step])
+        for i in range(txt_cfg["num_hidden_layers"]):
+            x = bert_layer(x, enc, f"encoder.layer.{i}.", txt_cfg, m)
+            hs.append(x)
+        hss.append(torch.stack(hs))
+    handle.remove()
+    gf, lf, hidden = torch.cat(gfs), torch.cat(lfs), torch.cat(hss, dim=1)
+    emb, sents = gloria_aggregate_tokens(hidden[-last_n_layers:], input_ids, idxtoword)
+    sent = torch.sum(torch.mean(emb, dim=2), dim=1)
+    word = torch.sum(emb, dim=1).permute(0, 2, 1)
+    cap_lens = [len([w for w in s if not w.startswith("[")]) + 1 for s in sents]
+    l0, l1 = gloria_local_loss(lf, word, cap_lens, temp1, temp2, temp3)
+    g0, g1 = gloria_global_loss(gf, sent, temp3)
+    loss = (l0 + l1) * local_loss_weight + (g0 + g1) * global_loss_weight
+    return loss, gf, lf, word, sent

@@ -264,3 +264,64 @@ def test_two_phase_backward_equals_single_backward(golden):
         torch.testing.assert_close(b.grad, a.grad, rtol=1e-3, atol=1e-5, msg=n)
     # arena layout assumption of ArenaDDP: [decoder parameters | encoder parameters]
     assert min(p._vm_off for p in m2.enc.parameters()) >= max(p._vm_off + p.numel() for p in m2.dec.parameters())
+
+
+def _rrg_hf_pair(vit_cfg, dec_cfg, seed):
+    from vilmedic_amd.models import RRG_HF
+    m = RRG_HF(vision=dict(proto_model="vit", proto_config="vit", proto_config_args=dict(vit_cfg)),
+               decoder=dict(proto_model="bert-generation", proto_config="bert-generation",
+                            proto_config_args=dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **dec_cfg))).to(dev())
+    vst = R.rand_state(R.vit_shapes(vit_cfg), seed)
+    dst = R.rand_state(R.decoder_shapes(dec_cfg), seed + 1)
+    sd = {"model.encoder." + k: v for k, v in vst.items()}
+    sd.update({"model.decoder." + k: v for k, v in dst.items()})
+    sd["model.decoder.lm_head.decoder.weight"] = dst["bert.embeddings.word_embeddings.weight"]
+    sd["model.decoder.lm_head.decoder.bias"] = dst["lm_head.bias"]
+    own = m.state_dict()
+    for k in own:                      # pooler (unused by the path) and enc_to_dec_proj keep their own init
+        sd.setdefault(k, own[k])
+    m.load_state_dict(sd, strict=True)
+    return m, {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+
+
+def test_rrg_hf_single_image_equals_rrg_and_multi_image_matches_oracle(golden):
+    """RRG_HF: the VisionEncoderDecoder wiring of the same kernels.  4-D batch: identical loss / logits to
+    RRG on the same weights apart from the key mask (RRG masks all-zero feature rows, RRG_HF passes None: both attend
+    everything here).  5-D batch with images_mask and an enc_to_dec_proj: against the fp32 oracle."""
+    from oracle import torch_ref as O
+    from vilmedic_amd.models.rrg.RRG import RRG
+    g = golden("g5_rrg_tiny")
+    vit_cfg, dec_cfg = g["vit_cfg"], g["dec_cfg"]
+    hf, st = _rrg_hf_pair(vit_cfg, dec_cfg, g["seed"])
+    rrg = RRG(decoder=dict(proto=None, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **dec_cfg),
+              cnn=dict(proto="VisualEncoder", backbone="vit", permute="no_permute", dropout_out=0.0, **vit_cfg)).to(dev())
+    sd = {k.replace("model.encoder.", "enc.model.").replace("model.decoder.", "dec.decoder."): v for k, v in st.items() if "pooler" not in k}
+    rrg.load_state_dict(sd, strict=True)
+    images = R.make_images(g["B"], vit_cfg["image_size"], seed=g["seed"]).to(dev())
+    ids, am = R.make_reports(g["B"], g["L"], dec_cfg["vocab_size"], seed=g["seed"])
+    ids, am = ids.to(dev()), am.to(dev())
+    hf.train(); rrg.train()
+    a = hf(input_ids=ids, attention_mask=am, images=images)
+    b = rrg(input_ids=ids, attention_mask=am, images=images)
+    assert abs(a["loss"].item() - b["loss"].item()) <= 1e-4 and abs(a["loss"].item() - g["losses"][0].item()) <= 2e-3 * max(1.0, abs(g["losses"][0].item()))
+    assert torch.equal(a["logits"], b["logits"])
+    a["loss"].backward(); b["loss"].backward()
+    ga = hf.model.decoder.bert.encoder.layer[0].crossattention.self.key.weight.grad
+    gb = rrg.dec.decoder.bert.encoder.layer[0].crossattention.self.key.weight.grad
+    assert rel_l2(ga, gb) <= 1e-3 and ga.abs().sum().item() > 0
+
+    # ---- multi-image + projection against the oracle (decoder hidden 128, encoder hidden 64 -> enc_to_dec_proj)
+    vit2 = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=1, intermediate_size=128, image_size=32, patch_size=16,
+                num_channels=3, layer_norm_eps=1e-12)
+    hf2, st2 = _rrg_hf_pair(vit2, dec_cfg, 11)
+    B, N = 3, 2
+    imgs = R.make_images(B * N, 32, seed=5).view(B, N, 3, 32, 32)
+    imask = torch.tensor([[1, 1], [1, 0], [1, 1]], dtype=torch.bool)
+    ids2, am2 = R.make_reports(B, 12, dec_cfg["vocab_size"], seed=5)
+    ref_loss, ref_logits = O.rrg_hf_forward(imgs, ids2, am2, st2, vit2, dec_cfg, images_mask=imask)
+    hf2.train()
+    out = hf2(input_ids=ids2.to(dev()), attention_mask=am2.to(dev()), images=imgs.to(dev()), images_mask=imask.to(dev()))
+    assert abs(out["loss"].item() - ref_loss.item()) <= 2e-3 * max(1.0, abs(ref_loss.item())), (out["loss"].item(), ref_loss.item())
+    assert close_bf16(out["logits"].float().cpu(), ref_logits)
+    out["loss"].backward()
+    assert hf2.model.enc_to_dec_proj.weight.grad.abs().sum().item() > 0

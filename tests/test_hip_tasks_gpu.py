@@ -188,3 +188,51 @@ def test_trainor_runs_and_checkpoints(tmp_path):
     assert len(ckpts) == 1
     sd = torch.load(os.path.join(tmp_path, ckpts[0]), map_location="cpu")
     assert {"model", "training_scheduler", "optimizer", "config", "__version__"} <= set(sd)
+
+
+def test_gloria_model_vs_oracle():
+    """GLoRIA: CNN tower (MIOpen) + text tower, HIP embedders, on-device word-piece merge, GLoRIALoss --
+    against the oracle composition on the CPU (same CNN module class in fp32)."""
+    import types
+    from oracle import torch_ref as O
+    from vilmedic_amd.blocks.vision import VisualEncoder
+    from vilmedic_amd.models import GLoRIA
+    vocab = ["[CLS]", "[PAD]", "[SEP]"] + [f"w{i}" for i in range(40)] + [f"##p{i}" for i in range(20)]
+    V = len(vocab)
+    txt = dict(R.TXT_TINY, vocab_size=V, pad_token_id=1)
+    tok = types.SimpleNamespace(get_vocab=lambda: {w: i for i, w in enumerate(vocab)})
+    dl = types.SimpleNamespace(dataset=types.SimpleNamespace(tokenizer=tok))
+    torch.manual_seed(3)
+    cnn = dict(proto="VisualEncoder", backbone="resnet50", output_layer="avgpool", dropout_out=0.0, permute="batch_first", freeze=False)
+    model = GLoRIA(encoder=dict(proto=None, last_n_layers=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **txt),
+                   cnn=dict(cnn), visual_embedder=dict(interm_feature_dim=1024, feature_dim=2048), loss=dict(), dl=dl,
+                   forward_batch_size=3).to(dev())
+    model.train()
+    B, L = 5, 14
+    g = torch.Generator().manual_seed(9)
+    ids = torch.full((B, L), 1, dtype=torch.long)
+    am = torch.zeros(B, L, dtype=torch.long)
+    for b in range(B):
+        n = int(torch.randint(5, L - 1, (1,), generator=g))
+        ids[b, 0] = 0
+        ids[b, 1:n] = torch.randint(3, V, (n - 1,), generator=g)
+        ids[b, 1] = 3 + b                                    # the word after [CLS] is never a ## piece
+        ids[b, n] = 2
+        am[b, :n + 1] = 1
+    images = torch.randn(B, 3, 64, 64, generator=g)
+    out = model(input_ids=ids.to(dev()), attention_mask=am.to(dev()), images=images.to(dev()))
+    st = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    vis = VisualEncoder(**{k: v for k, v in cnn.items() if k != "proto"})
+    vis.load_state_dict({k[len("visual."):]: v for k, v in st.items() if k.startswith("visual.")})
+    vis.train()
+    ref_loss, gf, lf, word, sent = O.gloria_forward(images, ids, am, st, txt, vis.model, dict(enumerate(vocab)), 2, 3)
+    assert rel(out["global_features"].float().cpu(), gf) <= 3e-2
+    assert rel(out["local_features"].float().cpu(), lf) <= 3e-2
+    assert rel(out["word_embeddings"].float().cpu(), word) <= 3e-2
+    assert rel(out["sent_embeddings"].float().cpu(), sent) <= 3e-2
+    assert abs(out["loss"].item() - ref_loss.item()) <= 3e-2 * max(1.0, abs(ref_loss.item())), (out["loss"].item(), ref_loss.item())
+    out["loss"].backward()
+    for name in ["global_embedder.weight", "local_embedder.weight", "visual.model.0.weight",
+                 "linguistic.encoder.encoder.layer.0.attention.self.query.weight", "linguistic.encoder.embeddings.word_embeddings.weight"]:
+        p = dict(model.named_parameters())[name]
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum().item() > 0, name

@@ -51,6 +51,39 @@ def test_module_parameter_names_match_reference_checkpoints():
         assert tuple(dec.decoder.state_dict()[k].shape) == tuple(shape), k
 
 
+def test_rrg_hf_parameter_names_match_hf_vision_encoder_decoder():
+    """RRG_HF: same state-dict keys and shapes as transformers' VisionEncoderDecoderModel built from the
+    same two configs (ref: models/rrg/RRG_HF.py:27-92), including the default ViT pooler and enc_to_dec_proj."""
+    transformers = pytest.importorskip("transformers")
+    from vilmedic_amd.models import RRG_HF
+    venc = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=1, intermediate_size=96, image_size=32, patch_size=16)
+    vdec = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=160, vocab_size=70,
+                max_position_embeddings=24, bos_token_id=2, eos_token_id=1, pad_token_id=0)
+    mine = RRG_HF(vision=dict(proto_model="vit", proto_config="vit", proto_config_args=venc),
+                  decoder=dict(proto_model="bert-generation", proto_config="bert-generation", proto_config_args=dict(vdec)))
+    enc = transformers.ViTModel(transformers.ViTConfig(**venc))
+    dec = transformers.BertGenerationDecoder(transformers.BertGenerationConfig(is_decoder=True, add_cross_attention=True, **vdec))
+    ref = transformers.VisionEncoderDecoderModel(encoder=enc, decoder=dec)
+    ref_sd = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+
+    def to_installed_hf(name):      # this build keeps the pinned 4.55.3 ViT names; transformers >= 5 renamed them
+        if not name.startswith("encoder.") or "encoder.layers.0.attention.q_proj.weight" not in ref_sd:
+            return name
+        for a, b in (("encoder.encoder.layer.", "encoder.layers."), ("attention.attention.query", "attention.q_proj"),
+                     ("attention.attention.key", "attention.k_proj"), ("attention.attention.value", "attention.v_proj"),
+                     ("attention.output.dense", "attention.o_proj"), ("intermediate.dense", "mlp.fc1"), ("output.dense", "mlp.fc2")):
+            name = name.replace(a, b)
+        return name
+
+    my_sd = {to_installed_hf(k): tuple(v.shape) for k, v in mine.model.state_dict().items()}
+    assert set(my_sd) == set(ref_sd), (sorted(set(my_sd) ^ set(ref_sd))[:8])
+    for k in ref_sd:
+        assert my_sd[k] == ref_sd[k], k
+    assert "enc_to_dec_proj.weight" in my_sd and "encoder.pooler.dense.weight" in my_sd
+    with pytest.raises(NotImplementedError):
+        RRG_HF(encoderdecoder="some/pretrained-name")
+
+
 def test_cnn_backbones_have_torchvision_names_and_shapes():
     from vilmedic_amd.blocks.vision import VisualEncoder
     enc = VisualEncoder(backbone="resnet18", permute="batch_first", output_layer="layer4", pretrained=False)

@@ -351,8 +351,32 @@ def gen_scst():
                          delta_reward=dr, delta_reward_per_metric=drm))
 
 
+def gen_gloria_aggregate():
+    """G11: GLoRIA.aggregate_tokens (models/selfsup/GLoRIA.py:123-177) -- the method is lifted out of the class by AST
+    (the class itself cannot be constructed here: pretrained tokenizer / encoder downloads) and run with a stand-in
+    ``self`` that only carries ``idxtoword``."""
+    import ast
+    src = open(REF + "models/selfsup/GLoRIA.py").read()
+    cls = [n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "GLoRIA"][0]
+    fn = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "aggregate_tokens"][0]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "aggregate_tokens", "exec"), ns)
+    vocab = ["[PAD]", "[CLS]", "[SEP]", "the", "heart", "##s", "is", "en", "##larg", "##ed", "no", "pleural", "eff", "##usion", ".", "lung"]
+    idxtoword = dict(enumerate(vocab))
+    W = {w: i for i, w in idxtoword.items()}
+    caps = [["[CLS]", "the", "heart", "##s", "is", "en", "##larg", "##ed", ".", "[SEP]", "[PAD]", "[PAD]"],
+            ["[CLS]", "no", "pleural", "eff", "##usion", "[SEP]", "[PAD]", "[PAD]", "[PAD]", "[PAD]", "[PAD]", "[PAD]"],
+            ["[CLS]", "lung", "##s", "##s", "is", "the", "lung", ".", "no", "eff", "##usion", "[SEP]"],
+            ["[CLS]", "##s", "the", "[SEP]", "heart", "[SEP]", "[PAD]", "[PAD]", "[PAD]", "[PAD]", "[PAD]", "[PAD]"]]
+    input_ids = torch.tensor([[W[w] for w in c] for c in caps])
+    g = torch.Generator().manual_seed(111)
+    emb = torch.randn(3, len(caps), input_ids.shape[1], 8, generator=g)
+    out, sents = ns["aggregate_tokens"](types.SimpleNamespace(idxtoword=idxtoword), emb, input_ids)
+    save("g11_gloria_aggregate", dict(vocab=vocab, input_ids=input_ids, embeddings=emb, out=out.clone(), sentences=sents))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst"]
+    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate"]
     for w in which:
         globals()["gen_" + w]()

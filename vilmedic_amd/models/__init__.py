@@ -1,8 +1,10 @@
 """ref: vilmedic/models/__init__.py:5-17 -- the class names ``eval(proto)`` resolves (executors/utils.py:110)."""
 from .mvqa.MVQA import MVQA  # noqa: F401
 from .rrg.RRG import RRG  # noqa: F401
+from .rrg.RRG_HF import RRG_HF  # noqa: F401
 from .rrg.RRG_SCST import RRG_SCST  # noqa: F401
 from .selfsup.conVIRT import ConVIRT  # noqa: F401
+from .selfsup.GLoRIA import GLoRIA  # noqa: F401
 
 
 class _OutOfScope:
@@ -14,9 +16,3 @@ class RRS_HF(_OutOfScope):
     pass
 
 
-class RRG_HF(_OutOfScope):
-    pass
-
-
-class GLoRIA(_OutOfScope):
-    pass
