@@ -330,7 +330,16 @@ def scst_loss(logp, seq, reward_sampling, reward_greedy, scores_weights, pad_tok
 # --------------------------------------------------------------------------- decode
 def decoder_step_logits(ids, enc, enc_mask, state, cfg):
     """Full-prefix recompute of next-token fp32 log-softmax scores (no KV cache;
-    the cache is an optimisation, not part of the arithmetic)."""
+    the cache is an optimisation, not part of the arithmetic).
+
+    Ensemble decoding: ``state`` (and ``enc`` / ``enc_mask`` / ``cfg``) may be LISTS, one entry per model; the models'
+    next-token logits are SUMMED before the log-softmax
+    (ref:vilmedic/blocks/huggingface/decoder/beam_search.py:243-262, bin/ensemble.py:72-80)."""
+    if isinstance(state, (list, tuple)):
+        cfgs = cfg if isinstance(cfg, (list, tuple)) else [cfg] * len(state)
+        logits = sum(lm_logits(decoder_hidden(ids, None, e, m, st, c)[:, -1], st).float()
+                     for e, m, st, c in zip(enc, enc_mask, state, cfgs))
+        return torch.log_softmax(logits, dim=-1)
     h = decoder_hidden(ids, None, enc, enc_mask, state, cfg)
     return torch.log_softmax(lm_logits(h[:, -1], state).float(), dim=-1)
 
@@ -339,7 +348,7 @@ def greedy_decode(enc, enc_mask, state, cfg, bos, eos, pad, max_length):
     """HF GenerationMixin._sample with do_sample=False, as driven by
     ref:...decoder/evaluation.py:73-78 (num_beams unset).  Finished rows are
     padded with ``pad``; stops when every row has emitted ``eos`` or at max_length."""
-    B = enc.shape[0]
+    B = (enc[0] if isinstance(enc, (list, tuple)) else enc).shape[0]
     ids = torch.full((B, 1), bos, dtype=torch.long)
     unfinished = torch.ones(B, dtype=torch.bool)
     while ids.shape[1] < max_length:
@@ -358,10 +367,15 @@ def beam_decode(enc, enc_mask, state, cfg, bos, eos, pad, max_length, num_beams,
     num_return_sequences=1, one eos id, stopping criteria = {max_length, eos}.
 
     Returns (sequences [B, T] padded with ``pad``, sequences_scores [B])."""
-    B, V = enc.shape[0], state["lm_head.bias"].shape[0]
     nb, keep, prompt = num_beams, 2 * num_beams, 1
-    enc_b = enc.repeat_interleave(nb, 0)
-    mask_b = enc_mask.repeat_interleave(nb, 0) if enc_mask is not None else None
+    if isinstance(state, (list, tuple)):              # ensemble: per-model encoder states (see decoder_step_logits)
+        B, V = enc[0].shape[0], state[0]["lm_head.bias"].shape[0]
+        enc_b = [e.repeat_interleave(nb, 0) for e in enc]
+        mask_b = [m.repeat_interleave(nb, 0) if m is not None else None for m in enc_mask]
+    else:
+        B, V = enc.shape[0], state["lm_head.bias"].shape[0]
+        enc_b = enc.repeat_interleave(nb, 0)
+        mask_b = enc_mask.repeat_interleave(nb, 0) if enc_mask is not None else None
 
     def gather(t, idx):                       # _gather_beams
         while idx.dim() < t.dim():

@@ -325,3 +325,61 @@ def test_rrg_hf_single_image_equals_rrg_and_multi_image_matches_oracle(golden):
     assert close_bf16(out["logits"].float().cpu(), ref_logits)
     out["loss"].backward()
     assert hf2.model.enc_to_dec_proj.weight.grad.abs().sum().item() > 0
+
+
+def test_ensemble_greedy_and_beam_decode_vs_oracle(golden):
+    """n-best checkpoint ensembling: two decoders with their own encoder states and KV caches, logits
+    summed before the log-softmax (ref: blocks/huggingface/decoder/beam_search.py:243-262) -- against the fp32 oracle's
+    ensemble decode with the same margin-aware criterion as the single-model test (the reference's own ensemble path is
+    dead at HEAD, so this piece is pinned by the oracle restatement only)."""
+    from oracle import torch_ref as O
+    g = golden("g7_decode")
+    cfg, rc = g["cfg"], g["recipe"]
+    dec_a, st_a = build_decoder(cfg, g["seed"], **rc)
+    dec_b, st_b = build_decoder(cfg, g["seed"] + 40, **rc)
+    dec_a.eval(); dec_b.eval()
+    gen = torch.Generator().manual_seed(g["seed"] + 1)
+    B, S = g["B"], g["S"]
+    enc_a = torch.randn(B, S, cfg["hidden_size"], generator=gen)
+    enc_b = torch.randn(B, S, cfg["hidden_size"], generator=gen)
+    mask = g["enc_mask"]
+    encs, masks, sts = [enc_a, enc_b], [mask, mask], [st_a, st_b]
+    eo = [dict(encoder_hidden_states=e.to(dev()), encoder_attention_mask=mask.to(dev())) for e in encs]
+    start = torch.zeros(B, 1, dtype=torch.long, device=dev())
+    common = dict(bos_token_id=0, eos_token_id=2, pad_token_id=1, max_length=g["max_len"])
+
+    def ens_logp(seq):          # teacher-forced ensemble log-probs under the fp32 oracle
+        logits = sum(O.lm_logits(O.decoder_hidden(seq[:, :-1], None, e, m, st, cfg), st).float() for e, m, st in zip(encs, masks, sts))
+        return torch.log_softmax(logits, -1)
+
+    ids = dec_a.generate(input_ids=start, hf_models=[dec_a.decoder, dec_b.decoder], encoders_outputs=eo, **common).cpu()
+    lp = ens_logp(ids)
+    single = dec_a.generate(input_ids=start, encoder_hidden_states=eo[0]["encoder_hidden_states"],
+                            encoder_attention_mask=eo[0]["encoder_attention_mask"], **common).cpu()
+    assert not torch.equal(ids[:, :min(ids.shape[1], single.shape[1])], single[:, :min(ids.shape[1], single.shape[1])])   # the 2nd model matters
+    for b in range(B):
+        for t in range(1, ids.shape[1]):
+            if ids[b, t] == 1:
+                break
+            assert lp[b, t - 1].max() - lp[b, t - 1, ids[b, t]] <= 0.25, (b, t)
+    ref = O.greedy_decode(encs, masks, sts, cfg, 0, 2, 1, g["max_len"])
+    lp_ref = ens_logp(ref)
+    n_exact = 0
+    for b in range(B):
+        n = int((ref[b, 1:] != 1).sum())
+        top2 = lp_ref[b, :n].topk(2, dim=-1)[0]
+        if n == 0 or float((top2[:, 0] - top2[:, 1]).min()) > 0.25:
+            L = min(ids.shape[1], ref.shape[1])
+            assert torch.equal(ids[b, :L], ref[b, :L]), (b, ids[b], ref[b])
+            n_exact += 1
+    assert n_exact >= 1
+    refb, refs = O.beam_decode(encs, masks, sts, cfg, 0, 2, 1, g["max_len"], 4)
+    out = dec_a.generate(input_ids=start, hf_models=[dec_a.decoder, dec_b.decoder], encoders_outputs=eo, num_beams=4, return_dict_in_generate=True, **common)
+    seq = out.sequences.cpu()
+    lpb = ens_logp(seq)
+    for b in range(B):
+        toks = seq[b, 1:]
+        n = int((toks != 1).sum())
+        score = lpb[b, torch.arange(n), toks[:n]].sum() / n
+        assert score >= refs[b] - 0.1, (b, score, refs[b])
+        assert abs(out.sequences_scores[b].item() - score.item()) <= 0.1

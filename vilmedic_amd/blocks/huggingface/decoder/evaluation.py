@@ -36,10 +36,14 @@ def evaluation(models, config, dl, **kwargs):
         for batch in dl:
             batch = {k: v.cuda() if isinstance(v, torch.Tensor) else v for k, v in batch.items()}
             batch_size = batch[ref_str].shape[0]
-            encoder_outputs, encoder_attention_mask = models[0].encode(**batch)
-            hyps = hf_model.generate(input_ids=torch.ones((batch_size, 1), dtype=torch.long).cuda() * bos_token_id,
-                                     encoder_hidden_states=encoder_outputs, encoder_attention_mask=encoder_attention_mask,
-                                     **gen)
+            start = torch.ones((batch_size, 1), dtype=torch.long).cuda() * bos_token_id
+            if len(models) > 1:       # n-best ensembling: summed logits (ref: beam_search.py:243-262, bin/ensemble.py:72-80)
+                eo = [dict(zip(("encoder_hidden_states", "encoder_attention_mask"), m.encode(**batch))) for m in models]
+                hyps = hf_model.generate(input_ids=start, hf_models=[m.dec.decoder for m in models], encoders_outputs=eo, **gen)
+            else:
+                encoder_outputs, encoder_attention_mask = models[0].encode(**batch)
+                hyps = hf_model.generate(input_ids=start, encoder_hidden_states=encoder_outputs,
+                                         encoder_attention_mask=encoder_attention_mask, **gen)
             for h, r in zip(hyps, batch[ref_str]):
                 hyp_list.append(tokenizer.decode(h, skip_special_tokens=True, clean_up_tokenization_spaces=False))
                 ref_list.append(tokenizer.decode(r, skip_special_tokens=True, clean_up_tokenization_spaces=False))

@@ -121,6 +121,30 @@ class DecodeState:
         return ops.lm_logits_f32(x, self.emb_sh, self.dec.lm_head.bias, self.V)
 
 
+class EnsembleState:
+    """n-best checkpoint ensembling (ref: blocks/huggingface/decoder/beam_search.py:243-262,313-319, bin/ensemble.py:72-80):
+    every model keeps its own encoder states and KV caches; the next-token logits are SUMMED before the log-softmax."""
+
+    def __init__(self, decoders, encs, enc_masks, beams, max_length):
+        self.states = [DecodeState(d, e, m, beams, max_length) for d, e, m in zip(decoders, encs, enc_masks)]
+
+    def reorder(self, parent_rows, upto):
+        for st in self.states:
+            st.reorder(parent_rows, upto)
+
+    def step(self, tokens, t):
+        logits = self.states[0].step(tokens, t)
+        for st in self.states[1:]:
+            logits = logits + st.step(tokens, t)
+        return logits
+
+
+def _decode_state(decoder, enc, enc_mask, beams, max_length):
+    if isinstance(decoder, (list, tuple)):
+        return EnsembleState(decoder, enc, enc_mask, beams, max_length), decoder[0], enc[0]
+    return DecodeState(decoder, enc, enc_mask, beams, max_length), decoder, enc
+
+
 def log_softmax_f32(logits):
     rows, V = logits.shape
     out = torch.empty(rows, V, dtype=torch.float32, device=logits.device)
@@ -155,8 +179,8 @@ def sample(decoder, input_ids, enc, enc_mask, *, max_length, eos_token_id, pad_t
            bad_words_ids=None, output_scores=False, generator=None):
     """HF ``_sample``: greedy (argmax) or multinomial sampling, 1 sequence per batch row."""
     B = input_ids.shape[0]
-    dev = enc.device
-    st = DecodeState(decoder, enc, enc_mask, 1, max_length)
+    st, decoder, enc0 = _decode_state(decoder, enc, enc_mask, 1, max_length)
+    dev = enc0.device
     seq = torch.full((B, max_length), pad_token_id, dtype=torch.long, device=dev)
     seq[:, 0] = input_ids[:, 0]
     unfinished = torch.ones(B, dtype=torch.bool, device=dev)
@@ -200,9 +224,9 @@ def _gather(t, idx):
 def beam_search(decoder, input_ids, enc, enc_mask, *, max_length, eos_token_id, pad_token_id, num_beams, length_penalty=1.0):
     """HF ``_beam_search`` (early_stopping=False, do_sample=False, num_return_sequences=1)."""
     B, nb, keep, prompt = input_ids.shape[0], num_beams, 2 * num_beams, 1
-    dev = enc.device
+    st, decoder, enc0 = _decode_state(decoder, enc, enc_mask, nb, max_length)
+    dev = enc0.device
     V = decoder.config.vocab_size
-    st = DecodeState(decoder, enc, enc_mask, nb, max_length)
     running = torch.full((B, nb, max_length), pad_token_id, dtype=torch.long, device=dev)
     running[:, :, 0] = input_ids[:, :1]
     seqs = running.clone()
@@ -256,7 +280,14 @@ def generate(decoder, input_ids=None, encoder_hidden_states=None, encoder_attent
         src = generation_config if isinstance(generation_config, dict) else vars(generation_config)
         args.update({k: v for k, v in src.items() if not k.startswith("_")})
     args.update(kw)
-    cfg = decoder.config
+    # ensemble call (the reference's keyword names, beam_search.py:226-227): hf_models = [decoder, ...] and
+    # encoders_outputs = [{"encoder_hidden_states": ..., "encoder_attention_mask": ...}, ...]
+    if args.get("hf_models"):
+        decoder = list(args.pop("hf_models"))
+        eo = args.pop("encoders_outputs")
+        encoder_hidden_states = [e["encoder_hidden_states"] for e in eo]
+        encoder_attention_mask = [e.get("encoder_attention_mask") for e in eo]
+    cfg = (decoder[0] if isinstance(decoder, (list, tuple)) else decoder).config
     max_length = args.get("max_length") or 20
     eos = args.get("eos_token_id", cfg.eos_token_id)
     pad = args.get("pad_token_id", cfg.pad_token_id)
@@ -264,7 +295,8 @@ def generate(decoder, input_ids=None, encoder_hidden_states=None, encoder_attent
     ret_dict = args.get("return_dict_in_generate", False)
     if input_ids is None:
         bos = args.get("bos_token_id", cfg.bos_token_id)
-        input_ids = torch.full((encoder_hidden_states.shape[0], 1), bos, dtype=torch.long, device=encoder_hidden_states.device)
+        e0 = encoder_hidden_states[0] if isinstance(encoder_hidden_states, (list, tuple)) else encoder_hidden_states
+        input_ids = torch.full((e0.shape[0], 1), bos, dtype=torch.long, device=e0.device)
     if input_ids.shape[1] != 1:
         raise NotImplementedError("generate() starts from a single [bos] token (ref: evaluation.py:74)")
     if nb > 1:
