@@ -181,6 +181,19 @@ int vm_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16
 int vm_logsoftmax_f32(const float* logits, int64_t ldl, float* out, int rows, int V, void* stream);
 int vm_argmax_f32(const float* x, int64_t ldx, int64_t* idx, float* val, int rows, int cols, void* stream);
 
+/* ---- image input pipeline on the device (replaces, for decoded uint8 HWC images resident in HBM, the PIL / torchvision
+   chain of vilmedic/datasets/base/ImageDataset.py:96-108: Resize -> RandomCrop -> RandomHorizontalFlip -> ToTensor ->
+   Normalize for training (resize > 0), Resize((crop,crop)) -> ToTensor -> Normalize for evaluation (resize == 0)).
+   Bit-exact with Pillow's 8-bit bilinear resampler.  src: device, packed images; src_offset [B] (bytes), src_hw [B][2],
+   crop_top_left [B][2] (in the RESIZED image; NULL = 0,0), flip [B] (NULL = none), mean/std [3]: HOST arrays.
+   out: device fp32 [B,3,crop,crop].  max_taps >= 2*ceil(max(scale,1))+1 of the largest down-scale; ws: device workspace
+   of at most vm_image_pipeline_ws(B, max_out, max_taps) bytes (max_out = largest resized side in the batch; images of
+   equal size share their coefficient tables). */
+size_t vm_image_pipeline_ws(int B, int max_out, int max_taps);
+int vm_image_pipeline_u8(const uint8_t* src, const int64_t* src_offset, const int32_t* src_hw, int B, int resize, int crop,
+                         const int32_t* crop_top_left, const uint8_t* flip, const float* mean, const float* std,
+                         float* out, int max_taps, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

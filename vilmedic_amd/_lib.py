@@ -43,6 +43,8 @@ SIGNATURES = {
     "vm_layernorm_bwd_fused": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "vm_layernorm_bwd_partial": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "vm_layernorm_bwd_reduce": (_I, [_P, _P, _P, _I, _I, _P]),
+    "vm_image_pipeline_ws": (_SZ, [_I, _I, _I]),
+    "vm_image_pipeline_u8": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _SZ, _P]),
     "vm_attention_fwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _U64, _P, _L, _P]),
     "vm_attention_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _P, _L, _P, _L,
                               _I, _I, _I, _I, _I, _F, _I, _F, _U64, _P, _P]),
