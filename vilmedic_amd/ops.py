@@ -519,11 +519,13 @@ class EmbeddingFn(torch.autograd.Function):
         padding_idx, g_word, g_pos, D, past_len = ctx.meta
         B, L = ids.shape
         if g_word is not None:
-            join_side()       # the tied LM-head wgrad accumulates into the same g_word on the side stream
             d_out = d_out.contiguous()
             gp = g_pos[past_len:] if past_len else g_pos
-            check(lib().vm_embedding_bwd(ptr(ids), ptr(d_out), ptr(g_word), ptr(gp), B, L, D,
-                                         padding_idx if padding_idx is not None else -1, stream()), "vm_embedding_bwd")
+            # parameter gradients only: side stream, which also orders this scatter-add after the tied LM-head wgrad that
+            # accumulates into the same g_word there (same stream -> no race, and the main stream never waits)
+            with on_side(d_out, ids):
+                check(lib().vm_embedding_bwd(ptr(ids), ptr(d_out), ptr(g_word), ptr(gp), B, L, D,
+                                             padding_idx if padding_idx is not None else -1, stream()), "vm_embedding_bwd")
         return None, None, None, None, None, None, None, None
 
 
