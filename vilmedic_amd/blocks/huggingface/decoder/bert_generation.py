@@ -9,6 +9,7 @@ import torch.nn as nn
 
 from .... import ops
 from ....arena import arena_of
+from .... import nn as _nn
 from ....nn import BERT_GEN_DEFAULTS, BertEmbeddings, BertStack, Config, _Holder, make_config, to_key_mask
 
 
@@ -50,8 +51,12 @@ class BertGenerationEncoder(nn.Module):
         if enc is not None and enc.dtype != torch.bfloat16:
             enc = enc.to(torch.bfloat16)
         xr = None          # alias of x for the next residual (see nn.BertLayer: fuses the fork's gradient sum into LN backward)
-        for layer in self.encoder.layer:
-            x, xr = layer(x, arena, self_mask, bool(cfg.is_decoder), enc.contiguous() if enc is not None else None, enc_mask, xr=xr)
+        enc = enc.contiguous() if enc is not None else None
+        # cross-attention K|V of all layers in one GEMM (and one dgrad / wgrad in backward): nn.BertStack.cross_kv_all
+        kvs, slots = self.encoder.cross_kv_all(enc, arena) if (enc is not None and self.encoder.cross and _nn.KV_ALL) else (None, None)
+        for i, layer in enumerate(self.encoder.layer):
+            x, xr = layer(x, arena, self_mask, bool(cfg.is_decoder), enc, enc_mask, xr=xr,
+                          kv=kvs[i] if kvs else None, dkv_slot=slots[i] if slots else None)
             if hs is not None:
                 hs.append(x)
         return ModelOutput(last_hidden_state=x, hidden_states=tuple(hs) if hs is not None else None,

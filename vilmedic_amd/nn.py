@@ -76,6 +76,7 @@ def _linear(mod, arena, x, aff, **kw):
                       anchor=aff.weight, **kw)
 
 
+KV_ALL = os.environ.get("VM_CROSS_KV_ALL", "1") != "0"     # 0: one K|V projection GEMM per cross-attention layer (A/B switch)
 _LN_FORK = os.environ.get("VM_LN_FORK", "1") != "0"      # 0: leave the residual-fork gradient sums to autograd (A/B switch)
 
 
@@ -180,14 +181,17 @@ def _flat2(t, d):
 
 # ----------------------------------------------------------------------------- BERT blocks
 class BertSelfAttentionParams(nn.Module):
-    def __init__(self, cfg, kv_in=None):
+    def __init__(self, cfg, kv_in=None, cross=False):
         super().__init__()
         d, s = cfg.hidden_size, cfg.initializer_range
         kv_in = kv_in or d
         self.query, self.key, self.value = Affine(d, d, std=s), Affine(d, kv_in, std=s), Affine(d, kv_in, std=s)
-        self.fuse_q = kv_in == d
+        self.fuse_q = kv_in == d and not cross
+        self.cross = cross
 
     def arena_groups(self):
+        if self.cross:        # the stack glues the K|V parameters of ALL its cross-attention layers (BertStack.arena_groups)
+            return []
         if self.fuse_q:
             return [[self.query.weight, self.key.weight, self.value.weight], [self.query.bias, self.key.bias, self.value.bias]]
         return [[self.key.weight, self.value.weight], [self.key.bias, self.value.bias]]
@@ -200,7 +204,7 @@ class BertAttentionBlock(nn.Module):
         super().__init__()
         d, s = cfg.hidden_size, cfg.initializer_range
         self.cross = cross
-        self.self = BertSelfAttentionParams(cfg, kv_in if cross else None)
+        self.self = BertSelfAttentionParams(cfg, kv_in if cross else None, cross=cross)
         self.output = _Holder()
         self.output.dense = Affine(d, d, std=s)
         self.output.LayerNorm = Affine(d, init="ones")
@@ -247,8 +251,9 @@ class BertLayer(nn.Module):
                     grads=(arena.grad(i.weight), arena.grad(i.bias), arena.grad(o.weight), arena.grad(o.bias)), anchor=i.weight)
         return _ln(arena, s, self.output.LayerNorm, self.cfg.layer_norm_eps, fork="out")
 
-    def forward(self, x, arena, self_mask, causal, enc=None, enc_mask=None, xr=None):
-        """-> (y, alias of y); ``xr`` is the alias of x a previous layer returned (None: x itself)"""
+    def forward(self, x, arena, self_mask, causal, enc=None, enc_mask=None, xr=None, kv=None, dkv_slot=None):
+        """-> (y, alias of y); ``xr`` is the alias of x a previous layer returned (None: x itself); ``kv`` / ``dkv_slot``:
+        this layer's view of the all-layer cross K|V projection and of its gradient buffer (BertStack.cross_kv_all)"""
         cfg = self.cfg
         drop = cfg.hidden_dropout_prob if self.training else 0.0
         adrop = cfg.attention_probs_dropout_prob if self.training else 0.0
@@ -257,7 +262,7 @@ class BertLayer(nn.Module):
         x, xr = self._attn_out(self.attention, ctx, x if xr is None else xr, arena, drop)
         if enc is not None:
             q = _linear(self, arena, x, self.crossattention.self.query)
-            ctx = ops.cross_attention(q, self.cross_kv(enc, arena), enc_mask, H, adrop)
+            ctx = ops.cross_attention(q, kv if kv is not None else self.cross_kv(enc, arena), enc_mask, H, adrop, dkv_out=dkv_slot)
             x, xr = self._attn_out(self.crossattention, ctx, xr, arena, drop)
         return self._ffn(x, xr, arena, drop)
 
@@ -268,12 +273,30 @@ class BertStack(nn.Module):
     def __init__(self, cfg, cross=False, enc_dim=None):
         super().__init__()
         self.config = cfg
+        self.cross = bool(cross)
         self.layer = nn.ModuleList([BertLayer(cfg, cross, enc_dim) for _ in range(cfg.num_hidden_layers)])
+
+    def arena_groups(self):
+        """K|V weights (and biases) of every cross-attention layer adjacent in the arena: [k0 v0 k1 v1 ...]"""
+        if not self.cross:
+            return []
+        ca = [l.crossattention.self for l in self.layer]
+        return [[p for c in ca for p in (c.key.weight, c.value.weight)], [p for c in ca for p in (c.key.bias, c.value.bias)]]
+
+    def cross_kv_all(self, enc, arena):
+        """one GEMM for the K|V projections of all layers -> (per-layer K|V views, per-layer gradient slots)"""
+        ca = [l.crossattention.self for l in self.layer]
+        wl = [p for c in ca for p in (c.key.weight, c.value.weight)]
+        bl = [p for c in ca for p in (c.key.bias, c.value.bias)]
+        return ops.cross_kv_all(enc, arena.shadow_group(wl), arena.f32_group(bl), len(ca), wgrad_buf=arena.grad_group(wl),
+                                bgrad_buf=arena.grad_group(bl), anchor=wl[0])
 
     def forward(self, x, arena, self_mask=None, causal=False, enc=None, enc_mask=None):
         xr = None
-        for layer in self.layer:
-            x, xr = layer(x, arena, self_mask, causal, enc, enc_mask, xr=xr)
+        kvs, slots = self.cross_kv_all(enc, arena) if (enc is not None and self.cross and KV_ALL) else (None, None)
+        for i, layer in enumerate(self.layer):
+            x, xr = layer(x, arena, self_mask, causal, enc, enc_mask, xr=xr, kv=kvs[i] if kvs else None,
+                          dkv_slot=slots[i] if slots else None)
         return x
 
 

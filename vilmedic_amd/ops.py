@@ -455,50 +455,117 @@ class PackedSelfAttentionFn(torch.autograd.Function):
 
 
 class PackedCrossAttentionFn(torch.autograd.Function):
-    """q [B,Lq,D] from the decoder, kv [B,Lk,2*D] = fused K|V projection of the encoder features."""
+    """q [B,Lq,D] from the decoder, kv [B,Lk,2*D] = fused K|V projection of the encoder features (any row stride: the
+    view of one layer inside the all-layer projection of CrossKVAllFn).  ``dkv_out``: optional pre-allocated gradient
+    slot with kv's shape (written in place and returned as kv's gradient)."""
 
     @staticmethod
-    def forward(ctx, q, kv, key_mask, H, dropout_p):
+    def forward(ctx, q, kv, key_mask, H, dropout_p, dkv_out):
         B, Lq, D = q.shape
         Lk = kv.shape[1]
         dh = D // H
+        if kv.stride(2) != 1 or kv.stride(0) != Lk * kv.stride(1):
+            kv = kv.contiguous()
+        ldkv = kv.stride(1)
         o = torch.empty(B, Lq, D, dtype=BF16, device=q.device)
         stats = torch.empty(B, H, Lq, 2, dtype=torch.float32, device=q.device)
         seed = next_seed() if dropout_p > 0 else 0
         scale = dh ** -0.5
         k, v = kv[..., :D], kv[..., D:]
-        check(lib().vm_attention_fwd(ptr(q), D, ptr(k), 2 * D, ptr(v), 2 * D, ptr(o), D, ptr(stats),
+        check(lib().vm_attention_fwd(ptr(q), D, ptr(k), ldkv, ptr(v), ldkv, ptr(o), D, ptr(stats),
                                      ptr(key_mask) if key_mask is not None else None, B, H, Lq, Lk, dh, scale, 0,
                                      dropout_p, seed, None, 0, stream()), "vm_attention_fwd")
         ctx.save_for_backward(q, kv, o, stats, key_mask)
-        ctx.meta = (H, dropout_p, seed, scale)
+        ctx.meta = (H, dropout_p, seed, scale, dkv_out)
         return o
 
     @staticmethod
     def backward(ctx, d_o):
         q, kv, o, stats, key_mask = ctx.saved_tensors
-        H, dropout_p, seed, scale = ctx.meta
+        H, dropout_p, seed, scale, dkv_out = ctx.meta
         B, Lq, D = q.shape
         Lk = kv.shape[1]
         dh = D // H
         d_o = d_o.contiguous()
         dq = torch.empty_like(q)
-        dkv = torch.empty_like(kv)
+        dkv = dkv_out if dkv_out is not None else torch.empty(B, Lk, 2 * D, dtype=BF16, device=q.device)
+        ldkv, lddkv = kv.stride(1), dkv.stride(1)
         delta = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
         k, v = kv[..., :D], kv[..., D:]
         dk, dv = dkv[..., :D], dkv[..., D:]
-        check(lib().vm_attention_bwd(ptr(q), D, ptr(k), 2 * D, ptr(v), 2 * D, ptr(o), D, ptr(d_o), D, ptr(stats),
-                                     ptr(key_mask) if key_mask is not None else None, ptr(dq), D, ptr(dk), 2 * D, ptr(dv), 2 * D,
+        check(lib().vm_attention_bwd(ptr(q), D, ptr(k), ldkv, ptr(v), ldkv, ptr(o), D, ptr(d_o), D, ptr(stats),
+                                     ptr(key_mask) if key_mask is not None else None, ptr(dq), D, ptr(dk), lddkv, ptr(dv), lddkv,
                                      B, H, Lq, Lk, dh, scale, 0, dropout_p, seed, ptr(delta), stream()), "vm_attention_bwd")
-        return dq, dkv, None, None, None
+        return dq, dkv, None, None, None, None
+
+
+class CrossKVAllFn(torch.autograd.Function):
+    """The K|V projections of ALL decoder layers' cross-attention in one GEMM: enc [B,S,De] x W_all^T [n*2D, De] -> one
+    buffer [B*S, n*2D]; layer i reads the strided view [..., i*2D:(i+1)*2D].  Backward: every layer's attention kernel
+    writes dK|dV straight into its slice of one gradient buffer, then ONE dgrad GEMM (contraction n*2D) yields d_enc --
+    replacing n dgrad GEMMs plus n-1 gradient-accumulation adds on the encoder output -- and one wgrad GEMM / column
+    sum yields all the weight / bias gradients (needs the layers' K,V parameters adjacent in the arena)."""
+
+    @staticmethod
+    def forward(ctx, enc, w_all, b_all, n_layers, wgrad_buf, bgrad_buf, anchor, need_grad):
+        e2 = _2d(enc)
+        M, K = e2.shape
+        N = w_all.shape[0]
+        kv = torch.empty(M, N, dtype=BF16, device=enc.device)
+        gemm(e2, 0, w_all, 0, kv, M, N, K, bias=b_all)
+        dkv = torch.empty(M, N, dtype=BF16, device=enc.device) if need_grad else None
+        ctx.save_for_backward(e2, w_all)
+        ctx.meta = (dkv, n_layers, wgrad_buf, bgrad_buf, enc.shape)
+        B, S = enc.shape[0], enc.shape[1]
+        per = N // n_layers
+        outs = tuple(kv.view(B, S, N)[..., i * per:(i + 1) * per] for i in range(n_layers))
+        if dkv is None:
+            return outs + (None,) * n_layers
+        slots = tuple(dkv.view(B, S, N)[..., i * per:(i + 1) * per] for i in range(n_layers))
+        ctx.mark_non_differentiable(*slots)
+        return outs + slots
+
+    @staticmethod
+    def backward(ctx, *grads):
+        e2, w_all = ctx.saved_tensors
+        dkv, n, wgrad_buf, bgrad_buf, eshape = ctx.meta
+        M, K = e2.shape
+        N = w_all.shape[0]
+        per = N // n
+        B, S = eshape[0], eshape[1]
+        for i in range(n):                      # normally every gradient IS the slot (written in place by the attention backward)
+            g, slot = grads[i], dkv.view(B, S, N)[..., i * per:(i + 1) * per]
+            if g is None:
+                slot.zero_()
+            elif g.data_ptr() != slot.data_ptr():
+                slot.copy_(g)
+        if wgrad_buf is not None or bgrad_buf is not None:
+            with on_side(dkv, e2):
+                if wgrad_buf is not None:
+                    wgrad(dkv, e2, wgrad_buf)
+                if bgrad_buf is not None:
+                    colsum(dkv, bgrad_buf)
+        d_enc = None
+        if ctx.needs_input_grad[0]:
+            d_enc = torch.empty(M, K, dtype=BF16, device=e2.device)
+            gemm(dkv, 0, w_all, 1, d_enc, M, K, N)
+            d_enc = d_enc.view(eshape)
+        return d_enc, None, None, None, None, None, None, None
+
+
+def cross_kv_all(enc, w_all, b_all, n_layers, wgrad_buf=None, bgrad_buf=None, anchor=None):
+    """-> (list of n K|V views [B,S,2D], list of n gradient slots or Nones)"""
+    need_grad = torch.is_grad_enabled() and (enc.requires_grad or (anchor is not None and anchor.requires_grad))
+    out = CrossKVAllFn.apply(enc, w_all, b_all, n_layers, wgrad_buf, bgrad_buf, anchor, need_grad)
+    return list(out[:n_layers]), list(out[n_layers:])
 
 
 def self_attention(qkv, key_mask, H, causal, dropout_p=0.0):
     return PackedSelfAttentionFn.apply(qkv, key_mask, H, causal, dropout_p)
 
 
-def cross_attention(q, kv, key_mask, H, dropout_p=0.0):
-    return PackedCrossAttentionFn.apply(q, kv, key_mask, H, dropout_p)
+def cross_attention(q, kv, key_mask, H, dropout_p=0.0, dkv_out=None):
+    return PackedCrossAttentionFn.apply(q, kv, key_mask, H, dropout_p, dkv_out)
 
 
 # ----------------------------------------------------------------------------- embeddings
