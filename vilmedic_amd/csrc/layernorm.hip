@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 // Residual-fork fusion (both optional): dy2 is a second incoming gradient of y (summed in fp32 before use: the LN
 // output feeds a sub-layer AND its residual), dres a gradient added to dx (the LN input also feeds a residual).
 template <int NCH>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dy2,
+__global__ __launch_bounds__(256, NCH <= 2 ? 3 : 1) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dy2,
                                                      const bf16_t* __restrict__ dres, const bf16_t* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, bf16_t* __restrict__ dx,
@@ -81,8 +81,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 8; ++j) { dg[c][j] = 0.f; db[c][j] = 0.f; g[c][j] = ch < nchunks ? gamma[ch * 8 + j] : 0.f; }
     }
+    // the next row's operands are requested before the current row is reduced (two rows in flight per wave)
+    struct Raw { uint4 x[NCH], d[NCH], d2[NCH], r[NCH]; float mu, rs; };
+    auto load_row = [&](int row, Raw& w) {
+        if (row >= rows) return;
+        w.mu = mean[row]; w.rs = rstd[row];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nchunks) {
+                const int64_t off = (int64_t)row * cols + ch * 8;
+                w.x[c] = *reinterpret_cast<const uint4*>(x + off);
+                w.d[c] = *reinterpret_cast<const uint4*>(dy + off);
+                if (dy2) w.d2[c] = *reinterpret_cast<const uint4*>(dy2 + off);
+                if (dres) w.r[c] = *reinterpret_cast<const uint4*>(dres + off);
+            }
+        }
+    };
+    constexpr bool PREFETCH = NCH <= 2;       // wider rows (NCH = 4) would spill: they load the row they are about to reduce
+    Raw cur, nxt;
+    if (PREFETCH) load_row(wave_global, cur);
     for (int row = wave_global; row < rows; row += nwaves) {
-        const float mu = mean[row], rs = rstd[row];
+        if (PREFETCH) load_row(row + nwaves, nxt); else load_row(row, cur);
+        const float mu = cur.mu, rs = cur.rs;
         float xh[NCH][8], gy[NCH][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -90,11 +111,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             const int ch = lane + 64 * c;
             if (ch < nchunks) {
                 float xv[8], dv[8];
-                unpack8(*reinterpret_cast<const uint4*>(x + (int64_t)row * cols + ch * 8), xv);
-                unpack8(*reinterpret_cast<const uint4*>(dy + (int64_t)row * cols + ch * 8), dv);
+                unpack8(cur.x[c], xv);
+                unpack8(cur.d[c], dv);
                 if (dy2) {
                     float d2[8];
-                    unpack8(*reinterpret_cast<const uint4*>(dy2 + (int64_t)row * cols + ch * 8), d2);
+                    unpack8(cur.d2[c], d2);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) dv[j] += d2[j];
                 }
@@ -123,13 +144,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 for (int j = 0; j < 8; ++j) o[j] = rs * (gy[c][j] - s1 - xh[c][j] * s2);
                 if (dres) {
                     float r8[8];
-                    unpack8(*reinterpret_cast<const uint4*>(dres + (int64_t)row * cols + ch * 8), r8);
+                    unpack8(cur.r[c], r8);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] += r8[j];
                 }
                 *reinterpret_cast<uint4*>(dx + (int64_t)row * cols + ch * 8) = pack8(o);
             }
         }
+        if (PREFETCH) cur = nxt;
     }
     // block-level reduction of the 4 waves' partials through LDS, then one [2][cols] slab per block
     extern __shared__ float red[];   // [4][2*cols]
