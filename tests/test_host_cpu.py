@@ -124,3 +124,34 @@ def test_out_of_scope_models_raise():
     import vilmedic_amd.models as M
     with pytest.raises(NotImplementedError):
         M.RRS_HF()
+
+
+@pytest.mark.parametrize("rel", ["RRG/rrg-vit-synthetic.yml", "RRG/rrg-hf-synthetic.yml", "SELFSUP/convirt-synthetic.yml",
+                                 "SELFSUP/gloria-synthetic.yml", "MVQA/vqa-synthetic.yml"])
+def test_every_shipped_yaml_parses_and_constructs(rel):
+    """plugin-surface test: every YAML under config/ goes through the loader, ``eval(proto)`` resolves the
+    dataset and the model class and the model constructs (reduced depth / width so it stays a CPU-second test)."""
+    import copy
+    import types
+    from vilmedic_amd import datasets as D, models as M
+    from vilmedic_amd.config import executor_view, get_config
+    small = ["dataset.num_samples=4"]
+    if "RRG/rrg-vit" in rel:
+        small += ["model.decoder.num_hidden_layers=1", "model.cnn.num_hidden_layers=1"]
+    if "rrg-hf" in rel:
+        small += ["model.vision.proto_config_args.num_hidden_layers=1", "model.decoder.proto_config_args.num_hidden_layers=1"]
+    if "SELFSUP" in rel:
+        small += ["model.encoder.num_hidden_layers=1", "dataset.image_size=32"]
+    if "MVQA" in rel:
+        small += ["model.transformer.num_hidden_layers=1", "dataset.image_size=32"]
+    cfg = get_config(os.path.join(os.path.dirname(__file__), "..", "config", rel), small)
+    t = executor_view(cfg, "trainor")
+    dcfg = copy.deepcopy(t.dataset)
+    ds = getattr(D, dcfg.pop("proto"))(split="train", **dcfg)
+    batch = ds.get_collate_fn()([ds[0], ds[1]])
+    assert batch["images"].shape[0] == 2
+    dl = types.SimpleNamespace(dataset=ds)
+    mcfg = copy.deepcopy(t.model)
+    model = getattr(M, mcfg.pop("proto"))(**mcfg, dl=dl)
+    assert callable(model.eval_func) and sum(p.numel() for p in model.parameters()) > 1000
+    assert executor_view(cfg, "validator").batch_size > 0

@@ -13,6 +13,8 @@ class _IdTokenizer:
         self.cls_token, self.pad_token, self.sep_token = "[CLS]", "[PAD]", "[SEP]"
         self.vocab = {"[CLS]": cls, "[PAD]": pad, "[SEP]": sep}
         self.special = {cls, pad, sep}
+        # the id attributes HF tokenizers expose (read by RRG_HF, ref: models/rrg/RRG_HF.py:73-79)
+        self.cls_token_id, self.pad_token_id, self.sep_token_id, self.unk_token_id = cls, pad, sep, None
 
     def decode(self, ids, skip_special_tokens=True, clean_up_tokenization_spaces=False):
         ids = ids.tolist() if hasattr(ids, "tolist") else list(ids)
@@ -52,6 +54,27 @@ class SyntheticImSeq(Dataset):
             return {"images": torch.stack([x["images"] for x in items]), "images_mask": None,
                     "input_ids": torch.stack([x["input_ids"] for x in items]),
                     "attention_mask": torch.stack([x["attention_mask"] for x in items])}
+        return collate
+
+
+class SyntheticImLabel(Dataset):
+    """images ~ N(0,1) [3,S,S] + one class label each: the batch dict of the reference's ImLabel (``images``, ``labels``)."""
+
+    def __init__(self, split="train", num_samples=256, image_size=232, num_classes=330, seed=0, **kwargs):
+        g = torch.Generator().manual_seed(seed + {"train": 0, "validate": 1, "test": 2}.get(split, 3))
+        self.images = torch.randn(num_samples, 3, image_size, image_size, generator=g)
+        self.labels = torch.randint(0, num_classes, (num_samples,), generator=g)
+        self.num_classes = num_classes
+
+    def __len__(self):
+        return len(self.images)
+
+    def __getitem__(self, i):
+        return {"images": self.images[i], "labels": self.labels[i]}
+
+    def get_collate_fn(self):
+        def collate(items):
+            return {"images": torch.stack([x["images"] for x in items]), "labels": torch.stack([x["labels"] for x in items])}
         return collate
 
 
