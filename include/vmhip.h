@@ -66,6 +66,8 @@ typedef struct {
 } vm_gemm_epilogue;
 
 int vm_sizeof_gemm_epilogue(void);   /* lets a foreign binding verify its struct layout */
+/* re-read the VM_* diagnostic environment switches (they are cached at first use) */
+void vm_reload_env(void);
 int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void* B, int64_t ldb, int b_layout,
                  void* C, int64_t ldc, int M, int N, int K, const vm_gemm_epilogue* epi, void* stream);
 

@@ -11,6 +11,8 @@ torch.manual_seed(0)
 def run(kind, B, H, Lq, Lk, causal, p, tile, iters=20):
     if tile: os.environ["VM_ATTN_TILE"] = "1"
     else: os.environ.pop("VM_ATTN_TILE", None)
+    from vilmedic_amd._lib import lib
+    lib().vm_reload_env()
     D = H * 64
     g = torch.Generator(device="cuda").manual_seed(1)
     km = torch.ones(B, Lk, dtype=torch.uint8, device=dev)

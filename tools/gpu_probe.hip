@@ -173,7 +173,7 @@ static int test_ln(int rows, int cols) {
 int main(int argc, char** argv) {
     if (argc >= 8 && !strcmp(argv[1], "bench")) {   // gpu_probe.bin bench M N K la lb split   (for rocprofv3 --pmc runs)
         for (int dbg = 0; dbg < 3; ++dbg) {
-            char b[4]; snprintf(b, 4, "%d", dbg); setenv("VM_GEMM_DEBUG", b, 1);
+            char b[4]; snprintf(b, 4, "%d", dbg); setenv("VM_GEMM_DEBUG", b, 1); vm_reload_env();
             printf("dbg=%d ", dbg);
             bench_gemm(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]));
         }
@@ -189,7 +189,7 @@ int main(int argc, char** argv) {
             {8192, 2304, 768, 0, 0, 1}, {8192, 768, 3072, 0, 0, 49}, {12608, 2304, 768, 0, 1, 0},
         };
         for (auto& c : cs) for (int variant = 0; variant <= 4; variant += 4) {
-            { char b[4]; snprintf(b, 4, "%d", variant); setenv("VM_GEMM_VARIANT", b, 1); }
+            { char b[4]; snprintf(b, 4, "%d", variant); setenv("VM_GEMM_VARIANT", b, 1); vm_reload_env(); }
             printf("v%d ", variant);
             bench_gemm2(c.M, c.N, c.K, c.la, c.lb, c.flags, 6);
         }
@@ -203,7 +203,7 @@ int main(int argc, char** argv) {
     int fails = 0;
     for (int variant = 0; variant < 5; ++variant) {
         if (variant == 3) continue;
-        { char b[4]; snprintf(b, 4, "%d", variant); setenv("VM_GEMM_VARIANT", b, 1); }
+        { char b[4]; snprintf(b, 4, "%d", variant); setenv("VM_GEMM_VARIANT", b, 1); vm_reload_env(); }
         printf("---- VM_GEMM_VARIANT=%d correctness\n", variant);
         for (int la = 0; la < (variant == 4 ? 1 : 2); ++la) for (int lb = 0; lb < 2; ++lb) {
             fails += test_gemm(200, 136, 192, la, lb, 1, false);
@@ -214,7 +214,7 @@ int main(int argc, char** argv) {
         if (variant != 4) fails += test_gemm(256, 256, 1024, 1, 1, 4, true);
         fails += test_gemm(1000, 768, 768, 0, 0, 1, false);
     }
-    unsetenv("VM_GEMM_VARIANT");
+    unsetenv("VM_GEMM_VARIANT"); vm_reload_env();
     fails += test_ln(1000, 768);
     fails += test_ln(37, 64);
     fails += test_ln(50, 1664);
@@ -228,7 +228,7 @@ int main(int argc, char** argv) {
         {768, 3072, 12608, 1, 1, 4}, {30528, 768, 8192, 1, 1, 1}, {8192, 8192, 8192, 0, 0, 1}, {8192, 8192, 8192, 1, 1, 1},
     };
     for (auto& sh : shapes) for (int variant = 0; variant < 4; variant += 3) {
-        { char b[4]; snprintf(b, 4, "%d", variant); setenv("VM_GEMM_VARIANT", b, 1); }
+        { char b[4]; snprintf(b, 4, "%d", variant); setenv("VM_GEMM_VARIANT", b, 1); vm_reload_env(); }
         printf("v%d ", variant);
         bench_gemm(sh.M, sh.N, sh.K, sh.la, sh.lb, sh.split);
     }

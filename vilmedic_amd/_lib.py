@@ -34,6 +34,7 @@ SIGNATURES = {
     "vm_prof_enable": (_I, [_I]),
     "vm_prof_reset": (_I, []),
     "vm_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "vm_reload_env": (None, []),
     "vm_sizeof_gemm_epilogue": (_I, []),
     "vm_prof_dump": (_I, [C.c_char_p]),
     "vm_gemm_bf16": (_I, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, C.POINTER(GemmEpilogue), _P]),

@@ -477,9 +477,9 @@ extern "C" int vm_attention_fwd(const void* q, int64_t ldq, const void* k, int64
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_ATTN, 4.0 * B * H * (double)Lq * Lk * dh, s, "fwd_B%d_H%d_Lq%d_Lk%d_c%d_d%d", B, H, Lq, Lk, causal, dropout_p > 0.f);
     // dh = 64 with a short resident sequence (every ViT-B / BERT-base layer): one workgroup per (b, h), K/V loaded once
-    if (dh == 64 && Lk <= 256 && !kv_row_index && !getenv("VM_ATTN_TILE") && !getenv("VM_ATTN_STREAM")) return vm_attn_head_fwd(a, s);
+    if (dh == 64 && Lk <= 256 && !kv_row_index && !vm_env().attn_tile && !vm_env().attn_stream) return vm_attn_head_fwd(a, s);
     const dim3 grid((Lq + 63) / 64, H, B);
-    const bool res = Lk <= 256 && !getenv("VM_ATTN_STREAM");
+    const bool res = Lk <= 256 && !vm_env().attn_stream;
     a.nslot_k = (Lk + 63) / 64; a.nslot_q = (Lq + 63) / 64;
 #define LAUNCH_FWD(D) do { if (res) launch_attn(attn_fwd_kernel<D, true>, grid, attn_lds(D, a.nslot_k, 256), s, a); \
                            else launch_attn(attn_fwd_kernel<D, false>, grid, attn_lds(D, 1, 64), s, a); } while (0)
@@ -509,11 +509,11 @@ extern "C" int vm_attention_bwd(const void* q, int64_t ldq, const void* k, int64
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_ATTN, 14.0 * B * H * (double)Lq * Lk * dh, s, "bwd_B%d_H%d_Lq%d_Lk%d_c%d_d%d", B, H, Lq, Lk, causal, dropout_p > 0.f);
     // head-resident kernels: delta = rowsum(dO * O) is computed by the dQ kernel (which holds the rows anyway) and saved for dK/dV
-    if (dh == 64 && Lk <= 256 && Lq <= 256 && !getenv("VM_ATTN_TILE") && !getenv("VM_ATTN_STREAM")) return vm_attn_head_bwd(a, s);
+    if (dh == 64 && Lk <= 256 && Lq <= 256 && !vm_env().attn_tile && !vm_env().attn_stream) return vm_attn_head_bwd(a, s);
     const int64_t rows = (int64_t)B * H * Lq;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, a, dh);
     const dim3 gq((Lq + 63) / 64, H, B), gk((Lk + 63) / 64, H, B);
-    const bool resk = Lk <= 256 && !getenv("VM_ATTN_STREAM"), resq = Lq <= 256 && !getenv("VM_ATTN_STREAM");
+    const bool resk = Lk <= 256 && !vm_env().attn_stream, resq = Lq <= 256 && !vm_env().attn_stream;
     a.nslot_k = (Lk + 63) / 64; a.nslot_q = (Lq + 63) / 64;
 #define LAUNCH_BWD(D) do { \
         if (resk) launch_attn(attn_bwd_dq_kernel<D, true>, gq, attn_lds(D, a.nslot_k, 256), s, a); \

@@ -111,6 +111,16 @@ __device__ __forceinline__ void dropout_keep_n(const DropKey k, uint64_t idx0, u
 static inline uint32_t dropout_thresh16(float p) { return (uint32_t)((double)p * 65536.0 + 0.5); }
 
 // ---- host-side plumbing
+// diagnostic environment switches, read ONCE (getenv per launch costs host time; vm_reload_env() re-reads them)
+struct VmEnv {
+    int gemm_variant;      // VM_GEMM_VARIANT: force a tile variant (-1: cost model)
+    int gemm_debug;        // VM_GEMM_DEBUG: 1 skip the epilogue, 2 one K-tile only (timing breakdowns)
+    int gemm_groupw;       // VM_GEMM_GROUPW: column-group width of the tile order (0: heuristic)
+    bool gemm_generic;     // VM_GEMM_GENERIC: register-staged fallback kernel only
+    bool attn_tile;        // VM_ATTN_TILE: tile-streaming attention kernels instead of the head-resident ones
+    bool attn_stream;      // VM_ATTN_STREAM: streaming (non-resident) tile kernels
+};
+const VmEnv& vm_env();
 void vm_set_error(const char* fmt, ...);
 int vm_check_launch(const char* what);
 

@@ -287,9 +287,9 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
     VmProfScope prof(VM_FAM_GEMM, 2.0 * (double)M * (double)N * (double)K, s, "M%d_N%d_K%d_l%d%d_sk%d_b%d_a%d_z%d_g%d_d%d_r%d_f%d", M, N, K, a_layout, b_layout,
                      epi->split_k, epi->bias != nullptr, epi->act, epi->aux_out != nullptr, epi->mul_gelu_z != nullptr, epi->dropout_p > 0.f, epi->residual != nullptr, epi->out_dtype == VM_F32);
     const bool fast_ok = (K % 64) == 0 && (ldc % 8) == 0 && (!epi->bias || ((uintptr_t)epi->bias % 16) == 0) &&
-                         (!epi->residual || (epi->ldr % 8) == 0) && !getenv("VM_GEMM_GENERIC");
+                         (!epi->residual || (epi->ldr % 8) == 0) && !vm_env().gemm_generic;
     a.slabs = nullptr;
-    { const char* d = getenv("VM_GEMM_DEBUG"); a.dbg = d ? atoi(d) : 0; }
+    a.dbg = vm_env().gemm_debug;
     if (fast_ok) {
         if (split > 1) {
             const size_t need = (size_t)split * (size_t)M * (size_t)ldc * sizeof(float);
@@ -298,9 +298,9 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
         }
         // tile variant: 256x128 3-stage ring when it still yields enough workgroups (1 per CU), else 128x128 2-stage
         int variant = 0;
-        const char* force = getenv("VM_GEMM_VARIANT");
+        const int force = vm_env().gemm_variant;
         const int tiles_m256 = (M + 255) / 256;
-        if (force) variant = atoi(force);
+        if (force >= 0) variant = force;
         else if (K >= 4096 && (int64_t)tiles_m256 * a.tiles_n * split >= 1024) variant = 1;   // measured: only huge square-ish problems gain
         else if (a_layout == 0) {
             // 512 workgroup slots (256 CUs x 2 resident workgroups): compare rounds x rows-per-tile of the 128- and the
@@ -317,7 +317,7 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
         // column-group width of the tile order: wide outputs (N >= 3072) run in groups of 8 tile columns so that an XCD's
         // B working set stays L2-resident (measured +11 % on the N = 30528 LM head, +4 % at N = 3072, neutral below)
         a.group_w = a.tiles_n >= 24 ? 8 : a.tiles_n;
-        { const char* gw = getenv("VM_GEMM_GROUPW"); if (gw && atoi(gw) > 0) a.group_w = atoi(gw); }
+        if (vm_env().gemm_groupw > 0) a.group_w = vm_env().gemm_groupw;
         const int nb = a.tiles_m * a.tiles_n * split;
         int rc = vm_gemm_fast_dispatch(a, a_layout, b_layout, nb, variant, s);
         if (rc == VM_OK && split > 1) rc = vm_gemm_splitk_reduce(a, split, s);

@@ -2,6 +2,7 @@
 #include "common.h"
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -27,6 +28,25 @@ int vm_check_launch(const char* what) {
 }
 
 extern "C" const char* vm_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------- environment switches (cached)
+static VmEnv g_env;
+static bool g_env_loaded = false;
+static void load_env() {
+    const char* v;
+    g_env.gemm_variant = (v = getenv("VM_GEMM_VARIANT")) ? atoi(v) : -1;
+    g_env.gemm_debug = (v = getenv("VM_GEMM_DEBUG")) ? atoi(v) : 0;
+    g_env.gemm_groupw = (v = getenv("VM_GEMM_GROUPW")) ? atoi(v) : 0;
+    g_env.gemm_generic = getenv("VM_GEMM_GENERIC") != nullptr;
+    g_env.attn_tile = getenv("VM_ATTN_TILE") != nullptr;
+    g_env.attn_stream = getenv("VM_ATTN_STREAM") != nullptr;
+    g_env_loaded = true;
+}
+const VmEnv& vm_env() {
+    if (!g_env_loaded) load_env();
+    return g_env;
+}
+extern "C" void vm_reload_env(void) { load_env(); }
 extern "C" int vm_version(void) { return 100; }
 extern "C" int vm_sizeof_gemm_epilogue(void) { return (int)sizeof(vm_gemm_epilogue); }
 
