@@ -210,8 +210,11 @@ def main():
             fam[name] = (ms.value, work.value, n.value)
         gms, gwork, gn = fam["gemm"]
         ach = gwork / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all layouts, fwd+dgrad+wgrad)", "achieved": round(ach, 1),
+        roof = {"bound": "mfma", "kernel": "gemm_fast_kernel<LA,LB,...> (every instantiation: fwd + dgrad + wgrad launches of vm_gemm_bf16, "
+                                         "split-K reduce included)", "achieved": round(ach, 1),
                 "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                "traffic_note": "family of 33 shapes; PMC pass for the dominant shape (12608x2304x768: 168.7 MB per launch at the fabric vs "
+                                "81.0 MB algorithmic) in profiles/r01_c_pmc_gemm_12608x2304x768.txt",
                 "launches_per_step": gn // 2, "avg_launch_ms": round(gms / max(gn, 1), 4),
                 "family_ms_per_step": {k: round(v[0] / 2, 3) for k, v in fam.items()}}
         if os.environ.get("VM_PROF_DUMP"):
