@@ -12,9 +12,13 @@ MI355X-first differences (same results, different data flow):
     (HF repeats the encoder states per beam): the beams of a sample are simply extra query rows of one attention call;
   * a beam reorder never copies the self-attention KV cache (HF: hf:generation/utils.py:3478-3485): the attention
     kernel gathers keys through a small int32 row-index table, and reordering gathers that table;
-  * K|V of the new token are written straight into the cache by the projection GEMM (strided output).
+  * K|V of the new token are written straight into the cache by the projection GEMM (strided output);
+  * the ~170 kernel launches of one decode step are captured into a HIP graph per position (the step is launch-bound:
+    M = batch x beams rows), and the decode state -- caches, cross K|V buffers, graphs -- is kept on the decoder and
+    reused by later generate() calls of the same shape (VM_DECODE_GRAPH=0 turns both off).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -24,6 +28,7 @@ from .arena import arena_of
 from .nn import to_key_mask
 
 BF16 = torch.bfloat16
+DECODE_GRAPH = os.environ.get("VM_DECODE_GRAPH", "1") != "0"
 
 
 def _ln(x, aff, eps):
@@ -61,24 +66,35 @@ class DecodeState:
         self.D = cfg.hidden_size
         self.H = cfg.num_attention_heads
         dev = enc.device
-        enc = enc.to(BF16).contiguous()
         self.S = enc.shape[1]
-        self.enc_mask = to_key_mask(enc_mask)
-        a = self.arena
         self.layers = decoder.bert.encoder.layer
-        self.cross_kv = []
+        # static buffers (their addresses are baked into the captured graphs)
+        self.enc_mask = torch.ones(self.B, self.S, dtype=torch.uint8, device=dev) if enc_mask is not None else None
+        self.cross_kv = [torch.empty(self.B * self.S, 2 * self.D, dtype=BF16, device=dev) for _ in self.layers]
+        self.self_kv = [torch.empty(self.M * self.T, 2 * self.D, dtype=BF16, device=dev) for _ in self.layers]
+        self.index = torch.empty(self.M, self.T, dtype=torch.int32, device=dev)
+        self.tok = torch.zeros(self.M, dtype=torch.long, device=dev)
+        self.V = cfg.vocab_size
+        self.emb_sh = self.arena.shadow_rows(decoder.bert.embeddings.word_embeddings.weight, decoder.padded_vocab)
+        self.graphs = {}
+        self.load_encoder(enc, enc_mask)
+
+    def load_encoder(self, enc, enc_mask):
+        """(re)start a generation on this state: project the image features to every layer's cross K|V (once, shared by all
+        beams of a sample), reset the row-index table.  Buffers keep their addresses, so captured graphs stay valid."""
+        a = self.arena
+        a.refresh()
+        enc = enc.to(BF16).contiguous()
         enc2 = enc.view(self.B * self.S, enc.shape[2])
-        for layer in self.layers:
+        if self.enc_mask is not None:
+            self.enc_mask.copy_(to_key_mask(enc_mask))
+        for layer, kv in zip(self.layers, self.cross_kv):
             ca = layer.crossattention.self
-            kv = torch.empty(self.B * self.S, 2 * self.D, dtype=BF16, device=dev)
             ops.gemm(enc2, 0, a.shadow_group([ca.key.weight, ca.value.weight]), 0, kv, self.B * self.S, 2 * self.D, enc2.shape[1],
                      bias=a.f32_group([ca.key.bias, ca.value.bias]))
-            self.cross_kv.append(kv)
-        self.self_kv = [torch.empty(self.M * self.T, 2 * self.D, dtype=BF16, device=dev) for _ in self.layers]
-        self.index = (torch.arange(self.M, device=dev, dtype=torch.int32)[:, None] * self.T
-                      + torch.arange(self.T, device=dev, dtype=torch.int32)[None, :]).contiguous()
-        self.V = cfg.vocab_size
-        self.emb_sh = a.shadow_rows(decoder.bert.embeddings.word_embeddings.weight, decoder.padded_vocab)
+        dev = enc.device
+        self.index.copy_(torch.arange(self.M, device=dev, dtype=torch.int32)[:, None] * self.T
+                         + torch.arange(self.T, device=dev, dtype=torch.int32)[None, :])
 
     def reorder(self, parent_rows, upto):
         """beam j continues old beam parent_rows[j]: its history 0..upto-1 is the parent's (index-table gather, no cache copy)"""
@@ -86,7 +102,26 @@ class DecodeState:
 
     @torch.no_grad()
     def step(self, tokens, t):
-        """tokens int64 [M] at position t  ->  fp32 logits [M, V] for position t+1."""
+        """tokens int64 [M] at position t  ->  fp32 logits [M, V] for position t+1 (valid until the next step(.., t))."""
+        if not DECODE_GRAPH:
+            return self._step(tokens, t)
+        self.tok.copy_(tokens)
+        entry = self.graphs.get(t)
+        if entry is None:
+            cur = torch.cuda.current_stream()
+            warm = torch.cuda.Stream()
+            warm.wait_stream(cur)
+            with torch.cuda.stream(warm):              # one eager pass first: lazy kernel attributes / allocator warm-up
+                self._step(self.tok, t)
+            cur.wait_stream(warm)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._step(self.tok, t)
+            entry = self.graphs[t] = (graph, out)
+        entry[0].replay()
+        return entry[1]
+
+    def _step(self, tokens, t):
         a, cfg, D, H, M, T = self.arena, self.cfg, self.D, self.H, self.M, self.T
         emb = self.dec.bert.embeddings
         x = torch.empty(M, D, dtype=BF16, device=tokens.device)
@@ -126,7 +161,11 @@ class EnsembleState:
     every model keeps its own encoder states and KV caches; the next-token logits are SUMMED before the log-softmax."""
 
     def __init__(self, decoders, encs, enc_masks, beams, max_length):
-        self.states = [DecodeState(d, e, m, beams, max_length) for d, e, m in zip(decoders, encs, enc_masks)]
+        self.states, seen = [], set()
+        for d, e, m in zip(decoders, encs, enc_masks):      # a decoder listed twice must not share one cached state
+            fresh = id(d) in seen
+            seen.add(id(d))
+            self.states.append(DecodeState(d, e, m, beams, max_length) if fresh else _cached_state(d, e, m, beams, max_length))
 
     def reorder(self, parent_rows, upto):
         for st in self.states:
@@ -139,10 +178,28 @@ class EnsembleState:
         return logits
 
 
+def _cached_state(decoder, enc, enc_mask, beams, max_length):
+    """decode states (KV caches, cross K|V buffers, captured graphs) live on the decoder and are reused by generate()
+    calls of the same shape; the key includes the arena's shadow buffer so a re-flattened model starts afresh"""
+    if not DECODE_GRAPH:
+        return DecodeState(decoder, enc, enc_mask, beams, max_length)
+    cache = decoder.__dict__.setdefault("_vm_decode_states", {})
+    arena = arena_of(decoder)
+    key = (enc.shape[0], enc.shape[1], enc.shape[2], beams, max_length, enc_mask is not None, arena.shadow_flat.data_ptr(), str(enc.device))
+    st = cache.get(key)
+    if st is None:
+        if len(cache) >= 4:
+            cache.clear()
+        st = cache[key] = DecodeState(decoder, enc, enc_mask, beams, max_length)
+    else:
+        st.load_encoder(enc, enc_mask)
+    return st
+
+
 def _decode_state(decoder, enc, enc_mask, beams, max_length):
     if isinstance(decoder, (list, tuple)):
         return EnsembleState(decoder, enc, enc_mask, beams, max_length), decoder[0], enc[0]
-    return DecodeState(decoder, enc, enc_mask, beams, max_length), decoder, enc
+    return _cached_state(decoder, enc, enc_mask, beams, max_length), decoder, enc
 
 
 def log_softmax_f32(logits):
