@@ -19,6 +19,7 @@ MI355X-first differences (same results, different data flow):
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -178,12 +179,15 @@ class EnsembleState:
         return logits
 
 
+_STATE_CACHE = weakref.WeakKeyDictionary()
+
+
 def _cached_state(decoder, enc, enc_mask, beams, max_length):
     """decode states (KV caches, cross K|V buffers, captured graphs) live on the decoder and are reused by generate()
     calls of the same shape; the key includes the arena's shadow buffer so a re-flattened model starts afresh"""
     if not DECODE_GRAPH:
         return DecodeState(decoder, enc, enc_mask, beams, max_length)
-    cache = decoder.__dict__.setdefault("_vm_decode_states", {})
+    cache = _STATE_CACHE.setdefault(decoder, {})        # weak: dies with the decoder; never part of deepcopy / pickling of the model
     arena = arena_of(decoder)
     key = (enc.shape[0], enc.shape[1], enc.shape[2], beams, max_length, enc_mask is not None, arena.shadow_flat.data_ptr(), str(enc.device))
     st = cache.get(key)
