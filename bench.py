@@ -192,34 +192,39 @@ def main():
     final_loss = float(loss.detach())
 
     roof = None
-    if not args.no_roofline and rank == 0:
+    if not args.no_roofline:
+        # EVERY rank runs the two extra (untimed) steps -- they contain the gradient all-reduce when N > 1 -- but only rank 0
+        # records and reads the per-launch events
         L_ = lib()
-        L_.vm_prof_reset()
-        L_.vm_prof_enable(1)
+        if rank == 0:
+            L_.vm_prof_reset()
+            L_.vm_prof_enable(1)
         side = ops.SIDE_STREAM
         ops.SIDE_STREAM = False          # per-launch durations are taken with every kernel alone on the GPU (the timed
         for _ in range(2):               # steps above overlap parameter-gradient kernels with the dgrad chain)
             step()
         torch.cuda.synchronize()
         ops.SIDE_STREAM = side
-        L_.vm_prof_enable(0)
-        ms, work, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-        fam = {}
-        for f, name in enumerate(["gemm", "attention", "layernorm", "loss", "elementwise", "optimizer"]):
-            L_.vm_prof_read(f, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(n))
-            fam[name] = (ms.value, work.value, n.value)
-        gms, gwork, gn = fam["gemm"]
-        ach = gwork / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": "gemm_fast_kernel<LA,LB,...> (every instantiation: fwd + dgrad + wgrad launches of vm_gemm_bf16, "
-                                         "split-K reduce included)", "achieved": round(ach, 1),
-                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                "traffic_note": "family of 33 shapes; PMC pass for the dominant shape (12608x2304x768: 168.7 MB per launch at the fabric vs "
-                                "81.0 MB algorithmic) in profiles/r01_c_pmc_gemm_12608x2304x768.txt",
-                "launches_per_step": gn // 2, "avg_launch_ms": round(gms / max(gn, 1), 4),
-                "family_ms_per_step": {k: round(v[0] / 2, 3) for k, v in fam.items()}}
-        if os.environ.get("VM_PROF_DUMP"):
-            L_.vm_prof_dump(os.environ["VM_PROF_DUMP"].encode())
-        L_.vm_prof_reset()
+        if rank == 0:
+            L_.vm_prof_enable(0)
+            ms, work, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+            fam = {}
+            for f, name in enumerate(["gemm", "attention", "layernorm", "loss", "elementwise", "optimizer"]):
+                L_.vm_prof_read(f, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(n))
+                fam[name] = (ms.value, work.value, n.value)
+            gms, gwork, gn = fam["gemm"]
+            ach = gwork / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
+            roof = {"bound": "mfma", "kernel": "gemm_fast_kernel<LA,LB,...> (every instantiation: fwd + dgrad + wgrad launches of vm_gemm_bf16, "
+                                             "split-K reduce included)", "achieved": round(ach, 1),
+                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                    "traffic_note": "family of 33 shapes; PMC pass for the dominant shape (12608x2304x768: 168.7 MB per launch at the fabric vs "
+                                    "81.0 MB algorithmic) in profiles/r01_c_pmc_gemm_12608x2304x768.txt",
+                    "launches_per_step": gn // 2, "avg_launch_ms": round(gms / max(gn, 1), 4),
+                    "family_ms_per_step": {k: round(v[0] / 2, 3) for k, v in fam.items()}}
+            if os.environ.get("VM_PROF_DUMP"):
+                L_.vm_prof_dump(os.environ["VM_PROF_DUMP"].encode())
+            L_.vm_prof_reset()
+        barrier()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
