@@ -133,6 +133,18 @@ __global__ __launch_bounds__(256, 3) void attn_head_fwd_kernel(const AttnArgs p)
     bf16x8_t qn[2];
     load_q(wave, qn);
     __syncthreads();
+    // bit F of unmasked = every key of 16-key fragment F is attendable (key mask byte != 0; bytes past Lk are 1): decided at
+    // run time, so a mask that is all ones (real images, unpadded reports) costs nothing
+    uint32_t unmasked = 0xffffu;
+    if (has_mask) {
+        unmasked = 0;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const uint64_t ok = __ballot(smask[q4 * 64 + lane] != 0);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) unmasked |= (((ok >> (16 * f)) & 0xffffull) == 0xffffull ? 1u : 0u) << (4 * q4 + f);
+        }
+    }
     for (int grp = wave; grp < ngroups; grp += 4) {
         const int q0 = qc0 + grp * 16, qrow = q0 + c;
         const bool qok = qrow < p.Lq;
@@ -151,7 +163,7 @@ __global__ __launch_bounds__(256, 3) void attn_head_fwd_kernel(const AttnArgs p)
             const char* svt = sv + kt * 8192;
             // "clean" tile (the common case): 4 full fragments, no key mask, not touching the causal diagonal or the ragged
             // tail.  Scores stay unscaled; exp(s*scale - m) is one fma + one v_exp_f32 (base 2) per element.
-            if (nf == 4 && !has_mask && !(p.causal && 4 * kt + 3 >= diag) && !(ragged && 4 * kt + 3 >= kfr_all - 1)) {
+            if (nf == 4 && ((unmasked >> (4 * kt)) & 0xfu) == 0xfu && !(p.causal && 4 * kt + 3 >= diag) && !(ragged && 4 * kt + 3 >= kfr_all - 1)) {
                 float4_t s[4];
 #pragma unroll
                 for (int f = 0; f < 4; ++f) {
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(256, 3) void attn_head_fwd_kernel(const AttnArgs p)
 #pragma unroll
                     for (int kk = 0; kk < 2; ++kk)
                         s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_b128(skt + f * 2048 + L.row[kk]), qf[kk], s[f], 0, 0, 0);
-                    const bool plain = !has_mask && !(p.causal && F == diag) && !(ragged && F == kfr_all - 1);
+                    const bool plain = ((unmasked >> F) & 1u) && !(p.causal && F == diag) && !(ragged && F == kfr_all - 1);
                     mask_scores(s[f], plain, smask, 16 * F + 4 * g, qrow, p);
                     mt = fmaxf(fmaxf(mt, fmaxf(s[f][0], s[f][1])), fmaxf(s[f][2], s[f][3]));
                 } else {
@@ -303,6 +315,16 @@ __global__ __launch_bounds__(256, 3) void attn_head_dq_kernel(const AttnArgs p) 
     Own nx;
     load_own(wave, nx);
     __syncthreads();
+    uint32_t unmasked = 0xffffu;              // see attn_head_fwd_kernel
+    if (has_mask) {
+        unmasked = 0;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const uint64_t ok = __ballot(smask[q4 * 64 + lane] != 0);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) unmasked |= (((ok >> (16 * f)) & 0xffffull) == 0xffffull ? 1u : 0u) << (4 * q4 + f);
+        }
+    }
     for (int grp = wave; grp < ngroups; grp += 4) {
         const int q0 = qc0 + grp * 16, qrow = q0 + c;
         const bool qok = qrow < p.Lq;
@@ -331,7 +353,7 @@ __global__ __launch_bounds__(256, 3) void attn_head_dq_kernel(const AttnArgs p) 
             const int nf = min(4, nfr - 4 * kt);
             const char* skt = sk + kt * 8192;
             const char* svt = sv + kt * 8192;
-            if (nf == 4 && !has_mask && !(p.causal && 4 * kt + 3 >= diag) && !(ragged && 4 * kt + 3 >= kfr_all - 1)) {   // clean tile
+            if (nf == 4 && ((unmasked >> (4 * kt)) & 0xfu) == 0xfu && !(p.causal && 4 * kt + 3 >= diag) && !(ragged && 4 * kt + 3 >= kfr_all - 1)) {   // clean tile
                 float4_t s[4];
 #pragma unroll
                 for (int f = 0; f < 4; ++f) {
@@ -374,7 +396,7 @@ __global__ __launch_bounds__(256, 3) void attn_head_dq_kernel(const AttnArgs p) 
                         s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_b128(skt + f * 2048 + L.row[kk]), w.qf[kk], s[f], 0, 0, 0);
                         dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_b128(svt + f * 2048 + L.row[kk]), w.dof[kk], dp, 0, 0, 0);
                     }
-                    const bool plain = !has_mask && !(p.causal && F == diag) && !(ragged && F == kfr_all - 1);
+                    const bool plain = ((unmasked >> F) & 1u) && !(p.causal && F == diag) && !(ragged && F == kfr_all - 1);
                     mask_scores(s[f], plain, smask, 16 * F + 4 * g, qrow, p);
                     if (p.dropout_p > 0.f) {
                         const uint32_t pr0 = dbase + (uint32_t)(8 * F + 2 * g);
@@ -485,9 +507,10 @@ __global__ __launch_bounds__(256, 3) void attn_head_dkv_kernel(const AttnArgs p)
         for (int f = 0; f < 4; ++f) { dk[f] = (float4_t){0.f, 0.f, 0.f, 0.f}; dv[f] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
         const int fr_begin = p.causal ? (k0 >> 4) : 0;      // query fragments before the group's first key see none of its keys
         const bool group_full = k0 + 16 <= p.Lk;
+        const bool group_unmasked = !has_mask || __all(w.keep);         // run-time: an all-ones mask costs nothing
         for (int qt = fr_begin >> 2; qt * 4 < qfr_all; ++qt) {
             const int f_lo = max(0, fr_begin - 4 * qt), nf = min(4, qfr_all - 4 * qt);
-            if (f_lo == 0 && nf == 4 && group_full && !has_mask && !(F_part >= 0 && 4 * qt + 3 >= F_part) && !(p.causal && fr_begin >= 4 * qt)) {
+            if (f_lo == 0 && nf == 4 && group_full && group_unmasked && !(F_part >= 0 && 4 * qt + 3 >= F_part) && !(p.causal && fr_begin >= 4 * qt)) {
                 // clean tile: 4 full query fragments, every key of the group live, no mask / diagonal / partial rows
                 const char* sqt = sq + qt * 8192;
                 const char* sdt = sdo + qt * 8192;

@@ -515,6 +515,7 @@ class CrossKVAllFn(torch.autograd.Function):
         gemm(e2, 0, w_all, 0, kv, M, N, K, bias=b_all)
         dkv = torch.empty(M, N, dtype=BF16, device=enc.device) if need_grad else None
         ctx.save_for_backward(e2, w_all)
+        ctx.set_materialize_grads(False)      # no zero tensors for the (non-differentiable) gradient-slot outputs
         ctx.meta = (dkv, n_layers, wgrad_buf, bgrad_buf, enc.shape)
         B, S = enc.shape[0], enc.shape[1]
         per = N // n_layers
