@@ -101,7 +101,13 @@ def check(status, what=""):
         raise VmHipError(f"{what} failed ({status}): {lib().vm_last_error().decode()}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """raw hipStream_t of torch's current stream on the current device (the C accessor: no Stream object per launch)"""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -65,6 +65,7 @@ class ParamArena:
                 p._vm_off = o
                 self.offsets[id(p)] = o
         self._layout = layout
+        self._views = {}
         self._version = -1
         self.refresh()
 
@@ -90,10 +91,17 @@ class ParamArena:
         """call after a kernel that updated parameters AND shadows itself (fused Adam)"""
         self._version = self._param_version()
 
-    # ---- views
+    # ---- views (cached: they are requested for every launch of every step)
+    def _view(self, buf, tag, ps, n, shape):
+        key = (tag, id(ps[0]), n)
+        v = self._views.get(key)
+        if v is None:
+            o = ps[0]._vm_off
+            v = self._views[key] = buf[o:o + n].view(shape)
+        return v
+
     def shadow(self, p):
-        o = p._vm_off
-        return self.shadow_flat[o:o + p.numel()].view(p.shape)
+        return self._view(self.shadow_flat, 0, (p,), p.numel(), p.shape)
 
     def shadow_rows(self, p, rows):
         """bf16 view [rows, cols] starting at p (rows may exceed p.shape[0] into its zero padding)."""
@@ -102,26 +110,24 @@ class ParamArena:
         return self.shadow_flat[o:o + rows * cols].view(rows, cols)
 
     def shadow_group(self, ps):
-        o = ps[0]._vm_off
         n = sum(p.numel() for p in ps)
-        return self.shadow_flat[o:o + n].view(-1, *ps[0].shape[1:])
+        return self._view(self.shadow_flat, 1, ps, n, (-1, *ps[0].shape[1:]))
 
     def f32_group(self, ps):
-        o = ps[0]._vm_off
         n = sum(p.numel() for p in ps)
-        return self.flat[o:o + n].view(-1, *ps[0].shape[1:])
+        return self._view(self.flat, 2, ps, n, (-1, *ps[0].shape[1:]))
 
     def grad_group(self, ps):
         """fp32 gradient view of a fused group, or None if the group is frozen."""
-        if not all(p.requires_grad for p in ps):
-            return None
         for p in ps:
-            if p.grad is None or p.grad.data_ptr() != p._vm_grad_view.data_ptr():
-                p._vm_grad_view.zero_()
+            if not p.requires_grad:
+                return None
+            g = p.grad
+            if g is not p._vm_grad_view and (g is None or g.data_ptr() != p._vm_grad_view.data_ptr()):
+                p._vm_grad_view.zero_()       # an optimizer dropped / replaced .grad (zero_grad(set_to_none=True)): re-attach
                 p.grad = p._vm_grad_view
-        o = ps[0]._vm_off
         n = sum(p.numel() for p in ps)
-        return self.gflat[o:o + n].view(-1, *ps[0].shape[1:])
+        return self._view(self.gflat, 3, ps, n, (-1, *ps[0].shape[1:]))
 
     def grad(self, p):
         return self.grad_group([p])
