@@ -20,6 +20,7 @@ import ctypes
 import json
 import os
 import sys
+import tempfile
 import time
 
 import torch
@@ -42,6 +43,37 @@ def flops_per_pair_fwd(S=197, L=128, d=768, V=30522, layers=12):
     dec = layers * (4 * L * d * d + 2 * L * L * d + 2 * L * d * d + 2 * S * d * d + 2 * L * S * d + 8 * L * d * d)
     head = L * d * V
     return 2.0 * (vit + dec + head)
+
+
+def dominant_shape_roofline(dump_path):
+    """the single largest forward GEMM shape (QKV projection of the ViT, 12608 x 2304 x 768, bias epilogue): achieved rate from
+    this run's per-launch HIP events, HBM-side traffic per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2
+    gfx950 correction + WRITE_SIZE, profiles/r01_c_pmc_gemm_12608x2304x768.txt)."""
+    tag, M, N, K = "M12608_N2304_K768_l00", 12608, 2304, 768
+    ms = n = 0.0
+    try:
+        for line in open(dump_path):
+            f = line.split()
+            if len(f) >= 5 and f[0] == "0" and f[1].startswith(tag):
+                n += float(f[2]); ms += float(f[3])
+    except OSError:
+        return None
+    if n == 0:
+        return None
+    traffic = None
+    try:
+        for line in open(os.path.join(ROOT, "profiles", "r01_c_pmc_gemm_12608x2304x768.txt")):
+            if "traffic per launch" in line:
+                traffic = float(line.split("traffic per launch =")[1].split("MB")[0]) * 1e6
+    except (OSError, ValueError, IndexError):
+        pass
+    dur = ms / n * 1e-3
+    algo = 2.0 * (M * K + N * K + M * N)
+    return {"kernel": "gemm_fast_kernel<0,0,...> C[12608,2304] = A[12608,768] . B[2304,768]^T + bias (ViT QKV projection)",
+            "bound": "mfma", "achieved": round(2.0 * M * N * K / dur / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(2.0 * M * N * K / dur / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "avg_launch_ms": round(dur * 1e3, 4),
+            "launches": int(n), "algorithmic_bytes": algo, "traffic": traffic,
+            "hbm_frac_of_8TBps": round((traffic or algo) / dur / 8e12, 4)}
 
 
 def build_model(device):
@@ -221,8 +253,9 @@ def main():
                                     "81.0 MB algorithmic) in profiles/r01_c_pmc_gemm_12608x2304x768.txt",
                     "launches_per_step": gn // 2, "avg_launch_ms": round(gms / max(gn, 1), 4),
                     "family_ms_per_step": {k: round(v[0] / 2, 3) for k, v in fam.items()}}
-            if os.environ.get("VM_PROF_DUMP"):
-                L_.vm_prof_dump(os.environ["VM_PROF_DUMP"].encode())
+            dump = os.environ.get("VM_PROF_DUMP") or os.path.join(tempfile.gettempdir(), f"vm_prof_{os.getpid()}.txt")
+            L_.vm_prof_dump(dump.encode())
+            roof["dominant_shape"] = dominant_shape_roofline(dump)
             L_.vm_prof_reset()
         barrier()
 
