@@ -375,8 +375,26 @@ def gen_gloria_aggregate():
     save("g11_gloria_aggregate", dict(vocab=vocab, input_ids=input_ids, embeddings=emb, out=out.clone(), sentences=sents))
 
 
+def gen_report_cleaning():
+    """G12: the report normalisation the RRG configs name (``processing: r2gen_clean_report``,
+    datasets/base/papers/report_preprocessing.py:8-23), lifted out by AST and run on synthetic report strings."""
+    import ast
+    import re
+    src = open(REF + "datasets/base/papers/report_preprocessing.py").read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "r2gen_clean_report"][0]
+    ns = {"re": re}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "r2gen_clean_report", "exec"), ns)
+    reports = ["1. No acute cardiopulmonary process. 2. Stable cardiomegaly.  3. Small left pleural effusion...",
+               "FINDINGS:  The heart is ENLARGED (moderate); lungs are clear!\nNo pneumothorax / effusion.",
+               "____ was removed. __ ___ . There is a 5 mm nodule, unchanged.. ..",
+               "", ".", "  Multiple    spaces   and 'quotes' \"double\" back\\slash [brackets] {braces} 100% a+b a_b",
+               "Compared to prior: 1. improved aeration 4. new line placement. 5. ET tube 3 cm above carina",
+               "x" + "_" * 300 + "y" + " " * 70 + "z" + "." * 300 + " end"]
+    save("g12_report_cleaning", dict(reports=reports, cleaned=[ns["r2gen_clean_report"](r) for r in reports]))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate"]
+    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning"]
     for w in which:
         globals()["gen_" + w]()

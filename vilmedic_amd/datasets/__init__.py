@@ -87,3 +87,6 @@ class TensorImSeq(SyntheticImSeq):
         self.tokenizer = _IdTokenizer(int(d["vocab_size"]))
         self.tokenizer_max_len = self.ids.shape[1]
         self.seq = self
+
+
+from .imseq import DeviceBatchLoader, ImSeq  # noqa: E402,F401  (file-based dataset with the reference's config keys)

@@ -1,0 +1,294 @@
+"""File-based ImSeq dataset with the reference's config keys, feeding the device-side image pipeline.
+
+ref: vilmedic/datasets/ImSeq.py:8-32, base/ImageDataset.py:63-150 (file list, open_image, transforms, multi-image collate),
+     base/TextDataset.py:30-119 (sentence file, Vocab-built BertTokenizer, padding / truncation, collate),
+     base/utils.py:16-28 (Vocab).
+Differences: the worker processes only DECODE (PIL -> uint8 HWC); Resize / RandomCrop / RandomHorizontalFlip
+/ ToTensor / Normalize run as one HIP kernel on the whole batch (``DeviceImagePipeline``, bit-exact with the PIL transforms), so
+the host ships 3 B/pixel instead of 12.  ``DeviceBatchLoader`` applies it while iterating, so training / validation loops see
+the reference's batch dict (``images`` fp32 [B,3,crop,crop] or [B,N,3,crop,crop], ``images_mask``, ``input_ids``, ``attention_mask``).
+Pretrained tokenizers named by a hub id need a download; a local directory / vocab file works."""
+import itertools
+import os
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from .device_pipeline import DeviceImagePipeline
+
+
+def r2gen_clean_report(report):
+    """the report normalisation the RRG configs name (``processing: r2gen_clean_report``; ref:
+    vilmedic/datasets/base/papers/report_preprocessing.py:8-23, after R2Gen's tokenizer): bounded collapsing of ``__`` /
+    double spaces / ``..`` (7 / 6 / 8 passes, as the reference chains them), enumeration markers dropped, lower-cased sentences
+    stripped of punctuation and re-joined with `` . ``.  Pinned by tests/golden/g12_report_cleaning.pt."""
+    import re
+    t = report.replace("\n", " ")
+    for _ in range(7):
+        t = t.replace("__", "_")
+    for _ in range(6):
+        t = t.replace("  ", " ")
+    for _ in range(8):
+        t = t.replace("..", ".")
+    t = t.replace("1. ", "")
+    for k in (2, 3, 4, 5):
+        t = t.replace(". %d. " % k, ". ")
+    for k in (2, 3, 4, 5):
+        t = t.replace(" %d. " % k, ". ")
+    sents = t.strip().lower().split(". ")
+
+    def clean(x):
+        x = x.replace('"', "").replace("/", "").replace("\\", "").replace("'", "").strip().lower()
+        return re.sub(r"[.,?;*!%^&_+():-\[\]{}]", "", x)      # the reference's class includes the range ')'..'-' = ) * + , -
+    tokens = [clean(x) for x in sents]
+    if tokens == [""]:
+        return ""
+    return " . ".join(tokens) + " ."
+
+
+PROCESSING = {"r2gen_clean_report": r2gen_clean_report}
+
+
+def load_file(path):
+    with open(path, "r") as f:
+        content = f.read().strip()
+    return [s for s in content.split("\n")]
+
+
+class Vocab:
+    """ref: base/utils.py:16-28 -- specials first, then the sorted word set"""
+
+    def __init__(self, sentences, pad_token="[PAD]", eos_token="[SEP]", bos_token="[CLS]", unk_token="[UNK]", mask_token="[MASK]"):
+        words = list(itertools.chain(*sentences))
+        self.words = [bos_token, pad_token, eos_token, unk_token, mask_token] + sorted(set(words))
+
+    def dump(self, path):
+        open(path, "w").write("\n".join(str(w) for w in self.words))
+
+
+class _Encoding:
+    def __init__(self, input_ids, attention_mask):
+        self.input_ids, self.attention_mask = input_ids, attention_mask
+
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+
+class WordPieceTokenizer:
+    """``BertTokenizer(vocab_file=..., do_basic_tokenize=False)`` as the reference builds it (base/TextDataset.py:91-92) for the
+    call pattern of its collate (:99-107,113-115): whitespace split, greedy longest-match-first WordPiece with ``##``
+    continuations and a 100-character word limit (hf 4.55.3 models/bert/tokenization_bert.py: WordpieceTokenizer.tokenize),
+    ``[CLS] ... [SEP]``, truncation and ``[PAD]`` padding to ``max_length``.  (transformers >= 5 no longer builds a
+    BertTokenizer from a bare vocab file, hence this restatement; checked against the ``tokenizers`` library's WordPiece.)"""
+
+    def __init__(self, vocab_file, unk_token="[UNK]", sep_token="[SEP]", pad_token="[PAD]", cls_token="[CLS]", mask_token="[MASK]"):
+        words = open(vocab_file, encoding="utf-8").read().split("\n")
+        self.vocab = {w.rstrip("\n"): i for i, w in enumerate(words)}
+        self.ids_to_tokens = {i: w for w, i in self.vocab.items()}
+        self.unk_token, self.sep_token, self.pad_token, self.cls_token, self.mask_token = unk_token, sep_token, pad_token, cls_token, mask_token
+        self.unk_token_id, self.sep_token_id = self.vocab[unk_token], self.vocab[sep_token]
+        self.pad_token_id, self.cls_token_id = self.vocab[pad_token], self.vocab[cls_token]
+        self.all_special_ids = {self.vocab[t] for t in (unk_token, sep_token, pad_token, cls_token, mask_token) if t in self.vocab}
+        self.max_input_chars_per_word = 100
+
+    @property
+    def vocab_size(self):
+        return len(self.vocab)
+
+    def get_vocab(self):
+        return dict(self.vocab)
+
+    def tokenize(self, text):
+        out = []
+        for token in text.strip().split():
+            chars = list(token)
+            if len(chars) > self.max_input_chars_per_word:
+                out.append(self.unk_token)
+                continue
+            start, pieces, bad = 0, [], False
+            while start < len(chars):
+                end, cur = len(chars), None
+                while start < end:
+                    sub = "".join(chars[start:end])
+                    if start > 0:
+                        sub = "##" + sub
+                    if sub in self.vocab:
+                        cur = sub
+                        break
+                    end -= 1
+                if cur is None:
+                    bad = True
+                    break
+                pieces.append(cur)
+                start = end
+            out.extend([self.unk_token] if bad else pieces)
+        return out
+
+    def __call__(self, texts, return_tensors="pt", padding=True, add_special_tokens=True, truncation=False, max_length=None, **kw):
+        rows = []
+        for t in ([texts] if isinstance(texts, str) else texts):
+            ids = [self.vocab[w] for w in self.tokenize(t)]
+            room = (max_length - (2 if add_special_tokens else 0)) if (truncation and max_length is not None) else None
+            if room is not None:
+                ids = ids[:max(room, 0)]
+            rows.append(([self.cls_token_id] + ids + [self.sep_token_id]) if add_special_tokens else ids)
+        width = max_length if padding == "max_length" else max(len(r) for r in rows)
+        input_ids = torch.full((len(rows), width), self.pad_token_id, dtype=torch.long)
+        attention_mask = torch.zeros(len(rows), width, dtype=torch.long)
+        for b, r in enumerate(rows):
+            input_ids[b, :len(r)] = torch.tensor(r, dtype=torch.long)
+            attention_mask[b, :len(r)] = 1
+        return _Encoding(input_ids, attention_mask)
+
+    def decode(self, ids, skip_special_tokens=True, clean_up_tokenization_spaces=False):
+        ids = ids.tolist() if hasattr(ids, "tolist") else list(ids)
+        toks = [self.ids_to_tokens[int(i)] for i in ids if not (skip_special_tokens and int(i) in self.all_special_ids)]
+        return " ".join(toks).replace(" ##", "").strip()
+
+
+def open_image(image, ext):
+    """-> uint8 [H,W,3] numpy (ref: base/ImageDataset.py:111-140; DICOM needs pydicom, which this image lacks)"""
+    if isinstance(image, np.ndarray):
+        arr = image
+    elif ext in (".npy", ".npz"):
+        arr = np.load(image)
+    elif ext in (".jpg", ".jpeg", ".png"):
+        from PIL import Image
+        arr = np.asarray(Image.open(image).convert("RGB"))
+    else:
+        raise NotImplementedError("Image extension {} not implemented".format(ext))
+    if arr.dtype != np.uint8 or arr.ndim != 3 or arr.shape[2] != 3:
+        raise ValueError("decoded image must be uint8 [H,W,3], got {} {}".format(arr.dtype, arr.shape))
+    return np.array(arr, order="C")      # an owned, writable copy (PIL hands out read-only buffers)
+
+
+class ImageDataset(Dataset):
+    def __init__(self, root=None, file=None, split=None, image_path=None, resize=256, crop=224, ext=".jpg", multi_image=None,
+                 called_by_ensemblor=None, **kwargs):
+        assert split is not None, "Argument split cant be None"
+        self.root, self.file, self.split, self.image_path = root, file, split, image_path
+        self.resize, self.crop, self.ext = int(resize), int(crop), ext
+        self.multi_image = multi_image or 0
+        lines = load_file(os.path.join(root, split + "." + file))
+        self.images = []
+        for line in lines:
+            paths = [os.path.join(image_path, p.strip()) if image_path else p.strip() for p in line.split(",")]
+            for p in paths:
+                assert os.path.exists(p), f"Image path does not exist: {p}"
+            self.images.append(paths)
+        self.pipeline_split = "validate" if called_by_ensemblor else split
+
+    def __len__(self):
+        return len(self.images)
+
+    def __getitem__(self, index):
+        return {"image": [open_image(p, self.ext) for p in self.images[index]]}
+
+    def get_collate_fn(self):
+        def collate_fn(batch):
+            n = self.multi_image if self.multi_image and self.multi_image > 1 else 1
+            imgs, mask = [], []
+            for s in batch:
+                cur = list(s["image"][:n])
+                mask.append([1] * len(cur) + [0] * (n - len(cur)))
+                imgs.extend(cur + [None] * (n - len(cur)))
+            return {"images_u8": imgs, "images_n": n, "images_mask": torch.tensor(mask, dtype=torch.bool) if n > 1 else None}
+        return collate_fn
+
+
+class TextDataset(Dataset):
+    def __init__(self, root=None, file=None, split=None, ckpt_dir=None, processing=None, tokenizer=None, tokenizer_max_len=None,
+                 vocab_file=None, source="src", **kwargs):
+        assert source in ["src", "tgt"]
+        assert split is not None, "Argument split cannot be None"
+        self.split, self.source, self.tokenizer_max_len = split, source, tokenizer_max_len
+        self.processing = PROCESSING[processing] if processing in PROCESSING else eval(processing or "lambda x: x")
+        self.sentences = [self.processing(s.strip()).split() for s in load_file(os.path.join(root, split + "." + file))]
+        if tokenizer is not None:
+            from transformers import AutoTokenizer
+            self.tokenizer = AutoTokenizer.from_pretrained(tokenizer)       # a local directory works; hub ids need a download
+        else:
+            if vocab_file is None:
+                vocab_file = os.path.join(ckpt_dir, "vocab.{}".format(source))
+                if split == "train" and not os.path.exists(vocab_file):
+                    os.makedirs(ckpt_dir, exist_ok=True)
+                    Vocab(self.sentences).dump(vocab_file)
+            self.tokenizer = WordPieceTokenizer(vocab_file)
+        self.tokenizer_args = {"return_tensors": "pt", "padding": True, "add_special_tokens": True}
+        if source == "src":
+            self.tokenizer_args.update({"add_special_tokens": False})
+        if tokenizer_max_len is not None:
+            self.tokenizer_args.update({"padding": "max_length", "truncation": True, "max_length": tokenizer_max_len})
+
+    def __len__(self):
+        return len(self.sentences)
+
+    def __getitem__(self, index):
+        return {"{}_seq".format(self.source): " ".join(self.sentences[index])}
+
+    def get_collate_fn(self):
+        def collate_fn(batch):
+            seq = self.tokenizer([s["{}_seq".format(self.source)] for s in batch], **self.tokenizer_args)
+            return {"input_ids": seq.input_ids, "attention_mask": seq.attention_mask}
+        return collate_fn
+
+
+class ImSeq(Dataset):
+    def __init__(self, seq, image, split, ckpt_dir=None, **kwargs):
+        self.split = split
+        self.seq = TextDataset(**dict(seq), split=split, ckpt_dir=ckpt_dir)
+        self.image = ImageDataset(**dict(image), split=split)
+        assert len(self.image) == len(self.seq)
+        self.tokenizer = self.seq.tokenizer
+        self.tokenizer_max_len = self.seq.tokenizer_max_len
+        self.tokenizer_args = self.seq.tokenizer_args
+        self._pipeline = None
+
+    def __getitem__(self, index):
+        return {**self.image[index], **self.seq[index]}
+
+    def __len__(self):
+        return len(self.image)
+
+    def get_collate_fn(self):
+        def collate_fn(batch):
+            return {**self.seq.get_collate_fn()(batch), **self.image.get_collate_fn()(batch)}
+        return collate_fn
+
+    def device_transform(self, batch):
+        """decoded uint8 images of a collated batch -> the reference's ``images`` tensor, on the device"""
+        if "images_u8" not in batch:
+            return batch
+        if self._pipeline is None:
+            self._pipeline = DeviceImagePipeline(self.image.pipeline_split, self.image.resize, self.image.crop)
+        batch = dict(batch)
+        imgs, n = batch.pop("images_u8"), batch.pop("images_n")
+        real = [im for im in imgs if im is not None]
+        out = self._pipeline(real)
+        if n > 1:                                       # multi-image: zero images where the sample has fewer (ref vilmedic_collate)
+            full = out.new_zeros(len(imgs), *out.shape[1:])
+            idx = torch.tensor([i for i, im in enumerate(imgs) if im is not None], device=out.device)
+            full.index_copy_(0, idx, out)
+            out = full.view(len(imgs) // n, n, *out.shape[1:])
+        batch["images"] = out
+        return batch
+
+    def __repr__(self):
+        return "ImSeq\n{} sentences, {} image lists".format(len(self.seq), len(self.image))
+
+
+class DeviceBatchLoader:
+    """wraps a DataLoader whose dataset has ``device_transform``: iterating yields device-side pre-processed batches"""
+
+    def __init__(self, loader):
+        self.loader = loader
+        self.dataset = loader.dataset
+
+    def __iter__(self):
+        base = self.dataset.dataset if isinstance(self.dataset, torch.utils.data.Subset) else self.dataset
+        for batch in self.loader:
+            yield base.device_transform(batch)
+
+    def __len__(self):
+        return len(self.loader)

@@ -95,6 +95,10 @@ def create_optimizer(config, logger, model, state_dict=None):
 def create_data_loader(config, split, logger, called_by_validator=False, rank=0, world=1):
     dcfg = copy.deepcopy(config.dataset)
     proto = dcfg.pop("proto")
+    if proto == "ImSeq":
+        dcfg.setdefault("ckpt_dir", config.get("ckpt_dir") or "ckpt")
+        if called_by_validator and isinstance(dcfg.get("image"), dict) and split == "train":
+            dcfg["image"]["called_by_ensemblor"] = True       # evaluation transform on the train split (ImageDataset.py:83-84)
     dataset = eval(proto)(split=split, **dcfg)
     if hasattr(dataset, "get_collate_fn"):
         collate = dataset.get_collate_fn()
@@ -110,8 +114,13 @@ def create_data_loader(config, split, logger, called_by_validator=False, rank=0,
     else:
         sampler = BatchSampler(SequentialSampler(dataset), batch_size=config.batch_size, drop_last=False)
     logger.settings("DataLoader {} ({}, {} samples) created".format(proto, split, len(dataset)))
-    return DataLoader(dataset, num_workers=int(config.get("num_workers") or 0), collate_fn=collate, batch_sampler=sampler,
-                      pin_memory=True)
+    loader = DataLoader(dataset, num_workers=int(config.get("num_workers") or 0), collate_fn=collate, batch_sampler=sampler,
+                        pin_memory=not hasattr(dataset, "device_transform"))
+    base = dataset.dataset if isinstance(dataset, torch.utils.data.Subset) else dataset
+    if hasattr(base, "device_transform"):          # decoded uint8 images -> the device-side Resize / crop / flip / normalise kernel
+        from ..datasets import DeviceBatchLoader
+        return DeviceBatchLoader(loader)
+    return loader
 
 
 class CheckpointSaver(object):
