@@ -457,6 +457,17 @@ def rrg_hf_forward(images, input_ids, attention_mask, state, vit_cfg, dec_cfg, i
     return decoder_forward(input_ids, attention_mask, hidden, mask, dec_state, dec_cfg)
 
 
+# --------------------------------------------------------------------------- RRS (text -> text)
+def rrs_forward(input_ids, attention_mask, decoder_input_ids, decoder_attention_mask, state, enc_cfg, dec_cfg):
+    """RRS.forward (ref:vilmedic/models/rrs/RRS.py:30-52): EncoderModel's last hidden state is the decoder's cross-attention
+    memory, keyed by the source attention mask.  state keys: ``enc.encoder.*`` (BertGenerationEncoder), ``dec.decoder.*``.
+    Returns (loss, logits, encoder_hidden).  Pinned by tests/golden/g13_rrs_tiny.pt."""
+    hidden = text_encoder_forward(input_ids, attention_mask, state, enc_cfg, prefix="enc.encoder.")
+    dec_state = {k[len("dec.decoder."):]: v for k, v in state.items() if k.startswith("dec.decoder.")}
+    loss, logits = decoder_forward(decoder_input_ids, decoder_attention_mask, hidden, attention_mask, dec_state, dec_cfg)
+    return loss, logits, hidden
+
+
 # --------------------------------------------------------------------------- GLoRIA word-piece aggregation
 def gloria_aggregate_tokens(embeddings, input_ids, idxtoword):
     """ref:vilmedic/models/selfsup/GLoRIA.py:123-177, restated as plain loops (small cases only).

@@ -29,6 +29,16 @@ def test_report_cleaning_matches_reference_fixture(golden):
     from vilmedic_amd.datasets.imseq import r2gen_clean_report
     g = golden("g12_report_cleaning")
     assert [r2gen_clean_report(r) for r in g["reports"]] == g["cleaned"]
+    from vilmedic_amd.datasets.imseq import rouge
+    assert [rouge(r) for r in g["reports_rouge"]] == g["rouge"]
+
+
+def test_nltk_based_cleaners_follow_the_documented_token_patterns():
+    """ifcc / gloria cleaners (nltk wordpunct_tokenize = ``\\w+|[^\\w\\s]+``; RegexpTokenizer(``\\w+``)); nltk is absent here, so these are
+    known-answer cases worked out from the reference's code by hand."""
+    from vilmedic_amd.datasets.imseq import gloria_clean_report_chexpert, ifcc_clean_report
+    assert ifcc_clean_report("No acute (process). Heart's size: 3.5cm") == "no acute ( process ). heart ' s size : 3 . 5cm"
+    assert gloria_clean_report_chexpert("1. No acute process.\n2. x. Stable cardiomegaly \u00e9. 12. ok") == "no acute process stable cardiomegaly"
 
 
 def test_wordpiece_tokenizer_matches_the_tokenizers_library(tmp_path):
@@ -75,6 +85,48 @@ def test_imseq_reads_files_builds_vocab_and_collates(tmp_path):
                image=dict(root=root, file="image.tok", image_path=root, resize=64, crop=56, ext=".png"), split="validate",
                ckpt_dir=os.path.join(root, "ckpt"))
     assert dv.tokenizer.vocab_size == ds.tokenizer.vocab_size and len(dv) == 3
+
+
+def test_label_and_seq2seq_compositions(tmp_path):
+    """ImLabel / ImSeqLabel / Seq2Seq / ImSeq2Seq: the reference's files, label-map file and batch-dict keys
+    (datasets/{ImLabel,ImSeqLabel,Seq2Seq,ImSeq2Seq}.py, base/LabelDataset.py)"""
+    from vilmedic_amd.datasets import ImLabel, ImSeq2Seq, ImSeqLabel, Seq2Seq
+    root, ck = str(tmp_path), os.path.join(str(tmp_path), "ckpt")
+    _make_corpus(root)
+    single = {"train": ["a", "b", "a", "c", "b", "a"], "validate": ["c", "zz", "a"]}
+    multi = {"train": ["a,b", "b", "a", "c,a", "b", "a"], "validate": ["c", "a,b", "b"]}
+    for split in ("train", "validate"):
+        open(os.path.join(root, f"{split}.label.tok"), "w").write("\n".join(single[split]))
+        open(os.path.join(root, f"{split}.mlabel.tok"), "w").write("\n".join(multi[split]))
+        n = len(single[split])
+        open(os.path.join(root, f"{split}.findings.tok"), "w").write("\n".join("The heart is normal, lungs clear!" for _ in range(n)))
+        open(os.path.join(root, f"{split}.impression.tok"), "w").write("\n".join("No change." for _ in range(n)))
+    image = dict(root=root, file="image.tok", image_path=root, resize=64, crop=56, ext=".png")
+    tr = ImLabel(label=dict(root=root, file="label.tok"), image=image, split="train", ckpt_dir=ck)
+    assert open(os.path.join(ck, "labels.tok")).read().split("\n") == ["multi-label:False", "a", "b", "c"]
+    b = tr.get_collate_fn()([tr[i] for i in range(4)])
+    assert b["labels"].tolist() == [0, 1, 0, 2] and b["labels"].dtype == torch.long and len(b["images_u8"]) == 4
+    va = ImLabel(label=dict(root=root, file="label.tok"), image=image, split="validate", ckpt_dir=ck)
+    assert va.get_collate_fn()([va[i] for i in range(3)])["labels"].tolist() == [2, -100, 0]         # unseen label -> ignore_index
+    os.remove(os.path.join(ck, "labels.tok"))
+    seq = dict(root=root, file="report.tok", tokenizer=None, tokenizer_max_len=12, processing="r2gen_clean_report", source="tgt")
+    ml = ImSeqLabel(seq=seq, label=dict(root=root, file="mlabel.tok"), image=image, split="train", ckpt_dir=ck)
+    b = ml.get_collate_fn()([ml[0], ml[3]])
+    assert b["labels"].tolist() == [[1.0, 1.0, 0.0], [1.0, 0.0, 1.0]] and b["input_ids"].shape == (2, 12) and len(b["images_u8"]) == 2
+    assert ml.tokenizer is ml.seq.tokenizer and hasattr(ml, "device_transform")
+    ck = os.path.join(root, "ckpt_s2s")          # (a ckpt_dir that already holds vocab.tgt would be reused, as in the reference)
+    s2s = Seq2Seq(src=dict(root=root, file="findings.tok", tokenizer=None, tokenizer_max_len=10, processing="rouge"),
+                  tgt=dict(root=root, file="impression.tok", tokenizer=None, tokenizer_max_len=6, processing="rouge"), split="train", ckpt_dir=ck)
+    b = s2s.get_collate_fn()([s2s[0], s2s[1]])
+    src_vocab = open(os.path.join(ck, "vocab.src")).read().split("\n")
+    assert [src_vocab[i] for i in b["input_ids"][0].tolist()] == ["the", "heart", "is", "normal", "lungs", "clear"] + ["[PAD]"] * 4   # no specials
+    assert b["decoder_input_ids"][0].tolist()[:4] == [0, 6, 5, 2] and b["decoder_attention_mask"][0].tolist() == [1, 1, 1, 1, 0, 0]
+    assert s2s.tgt_tokenizer is s2s.tgt.tokenizer and s2s.tgt_tokenizer_max_len == 6
+    i2s = ImSeq2Seq(src=dict(root=root, file="findings.tok", tokenizer=None, tokenizer_max_len=10, processing="rouge"),
+                    tgt=dict(root=root, file="impression.tok", tokenizer=None, tokenizer_max_len=6, processing="rouge"),
+                    image=image, split="validate", ckpt_dir=ck)
+    b = i2s.get_collate_fn()([i2s[0]])
+    assert set(b) == {"input_ids", "attention_mask", "decoder_input_ids", "decoder_attention_mask", "images_u8", "images_n", "images_mask"}
 
 
 @pytest.mark.gpu

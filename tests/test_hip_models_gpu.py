@@ -383,3 +383,57 @@ def test_ensemble_greedy_and_beam_decode_vs_oracle(golden):
         score = lpb[b, torch.arange(n), toks[:n]].sum() / n
         assert score >= refs[b] - 0.1, (b, score, refs[b])
         assert abs(out.sequences_scores[b].item() - score.item()) <= 0.1
+
+
+def build_rrs(g, device=None):
+    """RRS on the fixture's weights; returns (model, source batch, target batch)"""
+    from vilmedic_amd.models import RRS
+    nodrop = dict(proto=None, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = RRS(encoder=dict(nodrop, **g["enc_cfg"]), decoder=dict(nodrop, **g["dec_cfg"]))
+    est = R.rand_state(R.text_encoder_shapes(g["enc_cfg"]), g["seed"])
+    dst = R.rand_state(R.decoder_shapes(g["dec_cfg"]), g["seed"] + 1)
+    sd = {"enc.encoder." + k: v for k, v in est.items()}
+    sd.update({"dec.decoder." + k: v for k, v in dst.items()})
+    sd["dec.decoder.lm_head.decoder.weight"] = dst["bert.embeddings.word_embeddings.weight"]
+    sd["dec.decoder.lm_head.decoder.bias"] = dst["lm_head.bias"]
+    m.load_state_dict(sd, strict=True)
+    src = R.make_reports(g["B"], g["Ls"], g["enc_cfg"]["vocab_size"], seed=g["seed"])
+    tgt = R.make_reports(g["B"], g["Lt"], g["dec_cfg"]["vocab_size"], seed=g["seed"] + 1)
+    return (m.to(device) if device is not None else m), src, tgt
+
+
+def test_rrs_loss_logits_grads_vs_golden_and_decode_vs_oracle(golden):
+    """RRS (the text -> text caller of the same encoder / decoder kernels): loss, logits, encoder memory and
+    gradients on both sides of the cross-attention against the reference's fixture (G13); greedy decode against the oracle."""
+    g = golden("g13_rrs_tiny")
+    m, (sid, sam), (tid, tam) = build_rrs(g, dev())
+    m.train()
+    out = m(input_ids=sid.to(dev()), attention_mask=sam.to(dev()), decoder_input_ids=tid.to(dev()), decoder_attention_mask=tam.to(dev()))
+    assert abs(out["loss"].item() - g["loss"].item()) <= 2e-3 * max(1.0, abs(g["loss"].item())), (out["loss"].item(), g["loss"].item())
+    assert close_bf16(out["logits"].float().cpu(), g["logits"])
+    out["loss"].backward()
+    en, dn = dict(m.enc.encoder.named_parameters()), dict(m.dec.decoder.named_parameters())
+    for n, ref in list(g["enc_grads"].items()) + list(g["dec_grads"].items()):
+        got = (en[n] if n in g["enc_grads"] else dn[n]).grad.float().cpu()
+        assert cosine(got, ref) >= 0.999 and rel_l2(got, ref) <= 3e-2, (n, cosine(got, ref), rel_l2(got, ref))
+    m.eval()
+    with torch.no_grad():
+        hidden, mask = m.encode(sid.to(dev()), sam.to(dev()))
+    assert close_bf16(hidden.float().cpu(), g["encoder_hidden"])
+    # greedy decode from the encoder memory: every emitted token is an fp32-oracle arg-max of its own prefix up to a 0.25-nat
+    # margin (same criterion as test_greedy_and_beam_decode_vs_golden_and_oracle)
+    dcfg = g["dec_cfg"]
+    dst = R.rand_state(R.decoder_shapes(dcfg), g["seed"] + 1)
+    start = torch.full((g["B"], 1), dcfg["bos_token_id"], dtype=torch.long, device=dev())
+    with torch.no_grad():
+        hyp = m.dec.decoder.generate(input_ids=start, encoder_hidden_states=hidden, encoder_attention_mask=mask,
+                                     bos_token_id=dcfg["bos_token_id"], eos_token_id=dcfg["eos_token_id"], pad_token_id=dcfg["pad_token_id"],
+                                     max_length=10).cpu()
+    assert hyp.shape[0] == g["B"] and 2 <= hyp.shape[1] <= 10 and (hyp[:, 0] == dcfg["bos_token_id"]).all()
+    lp = _oracle_logp_of(hyp, g["encoder_hidden"], sam.bool(), dst, dcfg)
+    for b in range(g["B"]):
+        for t in range(1, hyp.shape[1]):
+            if hyp[b, t] == dcfg["pad_token_id"]:
+                break
+            margin = lp[b, t - 1].max() - lp[b, t - 1, hyp[b, t]]
+            assert margin <= 0.25, (b, t, margin)

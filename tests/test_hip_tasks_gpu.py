@@ -255,6 +255,9 @@ def test_gloria_model_vs_oracle():
                                       "model.encoder.num_hidden_layers=2", "model.encoder.max_position_embeddings=64", "model.encoder.vocab_size=97",
                                       "model.encoder.last_n_layers=2", "model.forward_batch_size=4"]),
     ("MVQA/vqa-synthetic.yml", ["dataset.image_size=64", "model.transformer.num_hidden_layers=2"]),
+    ("RRS/rrs-synthetic.yml", ["dataset.vocab_size=97", "dataset.src_max_len=24", "dataset.tgt_max_len=12"] + [
+        f"model.{side}.{k}" for side in ("encoder", "decoder") for k in ("hidden_size=128", "num_attention_heads=2", "intermediate_size=256",
+                                                                          "num_hidden_layers=2", "max_position_embeddings=64")]),
 ])
 def test_trainor_runs_every_task_config(tmp_path, rel, small):
     """bin/train.py's path (Trainor + Validator) on a reduced version of each shipped task config: loss finite and decreasing

@@ -34,6 +34,14 @@ def test_ops_fail_loudly_on_cpu_tensors():
         ops.gemm(a, 0, a, 0, torch.zeros(8, 8, dtype=torch.bfloat16), 8, 8, 8)
 
 
+def test_rrs_parameter_names_match_reference_checkpoints():
+    """RRS = ``enc`` (EncoderModel.encoder = BertGenerationEncoder) + ``dec`` (DecoderModel.decoder), ref models/rrs/RRS.py:15-23"""
+    from vilmedic_amd.models import RRS
+    m = RRS(encoder=dict(proto=None, **R.TXT_TINY), decoder=dict(proto=None, **R.DEC_TINY))
+    want = {"enc.encoder." + k for k in R.text_encoder_shapes(R.TXT_TINY)} | {"dec.decoder." + k for k in R.decoder_shapes(R.DEC_TINY)}
+    assert set(m.state_dict()) == want | {"dec.decoder.lm_head.decoder.weight", "dec.decoder.lm_head.decoder.bias"}
+
+
 def test_module_parameter_names_match_reference_checkpoints():
     from vilmedic_amd.blocks.huggingface.decoder.decoder_model import DecoderModel
     from vilmedic_amd.blocks.vision import VisualEncoder
@@ -127,7 +135,7 @@ def test_out_of_scope_models_raise():
 
 
 @pytest.mark.parametrize("rel", ["RRG/rrg-vit-synthetic.yml", "RRG/rrg-hf-synthetic.yml", "SELFSUP/convirt-synthetic.yml",
-                                 "SELFSUP/gloria-synthetic.yml", "MVQA/vqa-synthetic.yml"])
+                                 "SELFSUP/gloria-synthetic.yml", "MVQA/vqa-synthetic.yml", "RRS/rrs-synthetic.yml"])
 def test_every_shipped_yaml_parses_and_constructs(rel):
     """plugin-surface test: every YAML under config/ goes through the loader, ``eval(proto)`` resolves the
     dataset and the model class and the model constructs (reduced depth / width so it stays a CPU-second test)."""
@@ -144,12 +152,14 @@ def test_every_shipped_yaml_parses_and_constructs(rel):
         small += ["model.encoder.num_hidden_layers=1", "dataset.image_size=32"]
     if "MVQA" in rel:
         small += ["model.transformer.num_hidden_layers=1", "dataset.image_size=32"]
+    if "RRS" in rel:
+        small += ["model.encoder.num_hidden_layers=1", "model.decoder.num_hidden_layers=1"]
     cfg = get_config(os.path.join(os.path.dirname(__file__), "..", "config", rel), small)
     t = executor_view(cfg, "trainor")
     dcfg = copy.deepcopy(t.dataset)
     ds = getattr(D, dcfg.pop("proto"))(split="train", **dcfg)
     batch = ds.get_collate_fn()([ds[0], ds[1]])
-    assert batch["images"].shape[0] == 2
+    assert batch["input_ids" if "RRS" in rel else "images"].shape[0] == 2
     dl = types.SimpleNamespace(dataset=ds)
     mcfg = copy.deepcopy(t.model)
     model = getattr(M, mcfg.pop("proto"))(**mcfg, dl=dl)

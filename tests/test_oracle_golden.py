@@ -189,3 +189,31 @@ def test_gloria_aggregate_tokens_oracle_and_device_segment_sum_vs_reference(gold
     # a caption without [SEP] loses its last open word (the reference never flushes it)
     seg, words = word_segments(["[CLS]", "no", "eff", "##usion"])
     assert seg == [0, 1, -1, -1] and words == ["[CLS]", "no"]
+
+
+def _rrs_state(g):
+    est = R.rand_state(R.text_encoder_shapes(g["enc_cfg"]), g["seed"])
+    dst = R.rand_state(R.decoder_shapes(g["dec_cfg"]), g["seed"] + 1)
+    assert abs(R.state_checksum(est) + R.state_checksum(dst) - g["checksum"]) < 1e-6 * g["checksum"]
+    st = {"enc.encoder." + k: v for k, v in est.items()}
+    st.update({"dec.decoder." + k: v for k, v in dst.items()})
+    src = R.make_reports(g["B"], g["Ls"], g["enc_cfg"]["vocab_size"], seed=g["seed"])
+    tgt = R.make_reports(g["B"], g["Lt"], g["dec_cfg"]["vocab_size"], seed=g["seed"] + 1)
+    return st, src, tgt
+
+
+def test_g13_rrs_loss_logits_grads(golden):
+    """RRS: the reference's EncoderModel -> DecoderModel chain (models/rrs/RRS.py:30-52): loss, logits, encoder memory and
+    gradients on both sides of the cross-attention."""
+    g = golden("g13_rrs_tiny")
+    st, (sid, sam), (tid, tam) = _rrs_state(g)
+    st = {k: v.requires_grad_(True) for k, v in st.items()}
+    loss, logits, hidden = O.rrs_forward(sid, sam, tid, tam, st, g["enc_cfg"], g["dec_cfg"])
+    close(hidden, g["encoder_hidden"])
+    close(loss, g["loss"])
+    close(logits, g["logits"])
+    loss.backward()
+    for n, ref in g["enc_grads"].items():
+        close(st["enc.encoder." + n].grad, ref, rtol=1e-3, atol=1e-6)
+    for n, ref in g["dec_grads"].items():
+        close(st["dec.decoder." + n].grad, ref, rtol=1e-3, atol=1e-6)

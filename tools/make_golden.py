@@ -376,25 +376,58 @@ def gen_gloria_aggregate():
 
 
 def gen_report_cleaning():
-    """G12: the report normalisation the RRG configs name (``processing: r2gen_clean_report``,
-    datasets/base/papers/report_preprocessing.py:8-23), lifted out by AST and run on synthetic report strings."""
+    """G12: the report normalisations the RRG / RRS configs name (``processing: r2gen_clean_report`` / ``rouge``,
+    datasets/base/papers/report_preprocessing.py:8-23,69-108), lifted out by AST and run on synthetic report strings.
+    (``ifcc_clean_report`` / ``gloria_clean_report_chexpert`` need nltk, which this image lacks: not pinned.)"""
     import ast
     import re
     src = open(REF + "datasets/base/papers/report_preprocessing.py").read()
-    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "r2gen_clean_report"][0]
-    ns = {"re": re}
-    exec(compile(ast.Module(body=[fn], type_ignores=[]), "r2gen_clean_report", "exec"), ns)
+    import six
+    fns = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name in ("r2gen_clean_report", "rouge")]
+    ns = {"re": re, "six": six}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "report_preprocessing", "exec"), ns)
     reports = ["1. No acute cardiopulmonary process. 2. Stable cardiomegaly.  3. Small left pleural effusion...",
                "FINDINGS:  The heart is ENLARGED (moderate); lungs are clear!\nNo pneumothorax / effusion.",
                "____ was removed. __ ___ . There is a 5 mm nodule, unchanged.. ..",
                "", ".", "  Multiple    spaces   and 'quotes' \"double\" back\\slash [brackets] {braces} 100% a+b a_b",
                "Compared to prior: 1. improved aeration 4. new line placement. 5. ET tube 3 cm above carina",
                "x" + "_" * 300 + "y" + " " * 70 + "z" + "." * 300 + " end"]
-    save("g12_report_cleaning", dict(reports=reports, cleaned=[ns["r2gen_clean_report"](r) for r in reports]))
+    reports_rouge = reports[:7] + ["Ünïcode résumé, CT-scan #2: 3.5cm\tmass;\nT1/T2 weighted", "already clean tokens 123"]
+    save("g12_report_cleaning", dict(reports=reports, cleaned=[ns["r2gen_clean_report"](r) for r in reports],
+                                     reports_rouge=reports_rouge, rouge=[ns["rouge"](r) for r in reports_rouge]))
+
+
+# ------------------------------------------------------------------ G13: RRS (text encoder -> cross-attending decoder)
+def gen_rrs():
+    """RRS.forward == enc(input_ids, attention_mask).last_hidden_state -> dec(decoder ids, encoder mask = source attention mask)
+    (ref: vilmedic/models/rrs/RRS.py:30-52), with the reference's EncoderModel and DecoderModel blocks."""
+    tcfg, dcfg, seed, B, Ls, Lt = R.TXT_TINY, R.DEC_TINY, 71, 4, 18, 12
+    assert tcfg["hidden_size"] == dcfg["hidden_size"]
+    e = em.EncoderModel(AttrDict(proto=None, add_pooling_layer=False, hidden_act="gelu", attention_probs_dropout_prob=0.0,
+                                 hidden_dropout_prob=0.0, **tcfg))
+    e.encoder.config._attn_implementation = "eager"
+    est = R.rand_state(R.text_encoder_shapes(tcfg), seed)
+    load_into(e.encoder, est)
+    dec, dst = build_ref_decoder(dcfg, seed + 1)
+    src_ids, src_am = R.make_reports(B, Ls, tcfg["vocab_size"], seed=seed)
+    tgt_ids, tgt_am = R.make_reports(B, Lt, dcfg["vocab_size"], seed=seed + 1)
+    e.train(), dec.train()
+    hidden = e(src_ids, src_am, return_dict=True).last_hidden_state
+    out = dec(input_ids=tgt_ids, attention_mask=tgt_am, encoder_outputs=hidden, encoder_attention_mask=src_am)
+    out["loss"].backward()
+    en, dn = dict(e.encoder.named_parameters()), dict(dec.decoder.named_parameters())
+    enc_grads = ["embeddings.word_embeddings.weight", "encoder.layer.0.attention.self.query.weight", "encoder.layer.1.output.dense.weight",
+                 "encoder.layer.1.output.LayerNorm.bias"]
+    dec_grads = ["bert.encoder.layer.0.crossattention.self.key.weight", "bert.encoder.layer.1.intermediate.dense.weight", "lm_head.bias"]
+    save("g13_rrs_tiny", dict(enc_cfg=tcfg, dec_cfg=dcfg, seed=seed, B=B, Ls=Ls, Lt=Lt,
+                              checksum=R.state_checksum(est) + R.state_checksum(dst),
+                              encoder_hidden=hidden.detach(), loss=out["loss"].detach(), logits=out["logits"].detach(),
+                              enc_grads={n: en[n].grad.clone() for n in enc_grads},
+                              dec_grads={n: dn[n].grad.clone() for n in dec_grads}))
 
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning"]
+    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs"]
     for w in which:
         globals()["gen_" + w]()

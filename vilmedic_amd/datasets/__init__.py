@@ -78,6 +78,40 @@ class SyntheticImLabel(Dataset):
         return collate
 
 
+class SyntheticSeq2Seq(Dataset):
+    """source / target token sequences with the batch dict of the reference's Seq2Seq (``input_ids``, ``attention_mask``,
+    ``decoder_input_ids``, ``decoder_attention_mask``): findings -> impression shaped lengths (target ~ a quarter of source)."""
+
+    def __init__(self, split="train", num_samples=256, vocab_size=30522, src_max_len=128, tgt_max_len=32, seed=0, **kwargs):
+        g = torch.Generator().manual_seed(seed + {"train": 0, "validate": 1, "test": 2}.get(split, 3))
+
+        def make(L, special):
+            ids = torch.full((num_samples, L), 1, dtype=torch.long)
+            mask = torch.zeros(num_samples, L, dtype=torch.long)
+            for b in range(num_samples):
+                n = int(torch.randint(L // 2, L - 1, (1,), generator=g))
+                body = torch.randint(3, vocab_size, (n + 1,), generator=g)
+                if special:                      # tgt: [CLS] ... [SEP]; src is tokenised without special tokens (TextDataset.py)
+                    body[0], body[n] = 0, 2
+                ids[b, :n + 1], mask[b, :n + 1] = body, 1
+            return ids, mask
+        self.src_ids, self.src_mask = make(src_max_len, False)
+        self.tgt_ids, self.tgt_mask = make(tgt_max_len, True)
+        tok = _IdTokenizer(vocab_size)
+        self.src = self.tgt = type("_Side", (), {"tokenizer": tok})()
+        self.tgt_tokenizer, self.tgt_tokenizer_max_len = tok, tgt_max_len
+
+    def __len__(self):
+        return len(self.src_ids)
+
+    def __getitem__(self, i):
+        return {"input_ids": self.src_ids[i], "attention_mask": self.src_mask[i],
+                "decoder_input_ids": self.tgt_ids[i], "decoder_attention_mask": self.tgt_mask[i]}
+
+    def get_collate_fn(self):
+        return torch.utils.data.dataloader.default_collate
+
+
 class TensorImSeq(SyntheticImSeq):
     """pre-processed tensors on disk: ``{root}/{split}.pt`` = dict(images, input_ids, attention_mask, vocab_size)."""
 
@@ -89,4 +123,5 @@ class TensorImSeq(SyntheticImSeq):
         self.seq = self
 
 
-from .imseq import DeviceBatchLoader, ImSeq  # noqa: E402,F401  (file-based dataset with the reference's config keys)
+from .imseq import DeviceBatchLoader, ImSeq  # noqa: E402,F401  (file-based datasets with the reference's config keys)
+from .combos import ImLabel, ImSeq2Seq, ImSeqLabel, Seq2Seq  # noqa: E402,F401

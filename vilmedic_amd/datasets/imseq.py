@@ -47,7 +47,41 @@ def r2gen_clean_report(report):
     return " . ".join(tokens) + " ."
 
 
-PROCESSING = {"r2gen_clean_report": r2gen_clean_report}
+def rouge(text, use_stemmer=False):
+    """ROUGE-style normalisation the RRS configs name (``processing: rouge``; ref: report_preprocessing.py:69-108, after
+    google-research/rouge tokenize.py): lower-case, every run of characters outside [a-z0-9] becomes one space, empty tokens
+    dropped.  Pinned by tests/golden/g12_report_cleaning.pt (use_stemmer needs nltk's Porter stemmer: not available here)."""
+    import re
+    if use_stemmer:
+        raise NotImplementedError("rouge(use_stemmer=True) needs nltk's PorterStemmer")
+    return " ".join(t for t in re.sub(r"[^a-z0-9]+", " ", text.lower()).split(" ") if t)
+
+
+def ifcc_clean_report(report):
+    """lower-case + nltk ``wordpunct_tokenize`` (= the regular expression ``\\w+|[^\\w\\s]+``), space-joined
+    (ref: report_preprocessing.py:26-30).  nltk is absent from this image: restated from its documented pattern, not pinned."""
+    import re
+    return " ".join(re.findall(r"\w+|[^\w\s]+", report.lower()))
+
+
+def gloria_clean_report_chexpert(report):
+    """GLoRIA's report normalisation (ref: report_preprocessing.py:33-65): split on ``<digits>.`` and ``.``, keep the
+    ``\\w+`` tokens (nltk RegexpTokenizer) of each lower-cased piece with more than one token, ASCII-only, space-joined.
+    Restated from the documented tokenizer pattern (nltk absent here), not pinned."""
+    import re
+    pieces = [s for point in re.split(r"[0-9]+\.", report.replace("\n", " ")) for s in point.split(".")]
+    out = []
+    for piece in pieces:
+        tokens = re.findall(r"\w+", piece.replace("\ufffd\ufffd", " ").lower())
+        if len(tokens) <= 1:
+            continue
+        tokens = [t.encode("ascii", "ignore").decode("ascii") for t in tokens]
+        out.append(" ".join(t for t in tokens if t))
+    return " ".join(out)
+
+
+PROCESSING = {"r2gen_clean_report": r2gen_clean_report, "rouge": rouge, "ifcc_clean_report": ifcc_clean_report,
+              "gloria_clean_report_chexpert": gloria_clean_report_chexpert}
 
 
 def load_file(path):
@@ -234,7 +268,31 @@ class TextDataset(Dataset):
         return collate_fn
 
 
-class ImSeq(Dataset):
+class _DeviceImages:
+    """datasets with an ``image`` ImageDataset: the collated batch carries decoded uint8 images; this turns them into the
+    reference's ``images`` tensor on the device (one launch of the Resize / crop / flip / normalise kernel per batch)"""
+    _pipeline = None
+
+    def device_transform(self, batch):
+        """decoded uint8 images of a collated batch -> the reference's ``images`` tensor, on the device"""
+        if "images_u8" not in batch:
+            return batch
+        if self._pipeline is None:
+            self._pipeline = DeviceImagePipeline(self.image.pipeline_split, self.image.resize, self.image.crop)
+        batch = dict(batch)
+        imgs, n = batch.pop("images_u8"), batch.pop("images_n")
+        real = [im for im in imgs if im is not None]
+        out = self._pipeline(real)
+        if n > 1:                                       # multi-image: zero images where the sample has fewer (ref vilmedic_collate)
+            full = out.new_zeros(len(imgs), *out.shape[1:])
+            idx = torch.tensor([i for i, im in enumerate(imgs) if im is not None], device=out.device)
+            full.index_copy_(0, idx, out)
+            out = full.view(len(imgs) // n, n, *out.shape[1:])
+        batch["images"] = out
+        return batch
+
+
+class ImSeq(_DeviceImages, Dataset):
     def __init__(self, seq, image, split, ckpt_dir=None, **kwargs):
         self.split = split
         self.seq = TextDataset(**dict(seq), split=split, ckpt_dir=ckpt_dir)
@@ -255,24 +313,6 @@ class ImSeq(Dataset):
         def collate_fn(batch):
             return {**self.seq.get_collate_fn()(batch), **self.image.get_collate_fn()(batch)}
         return collate_fn
-
-    def device_transform(self, batch):
-        """decoded uint8 images of a collated batch -> the reference's ``images`` tensor, on the device"""
-        if "images_u8" not in batch:
-            return batch
-        if self._pipeline is None:
-            self._pipeline = DeviceImagePipeline(self.image.pipeline_split, self.image.resize, self.image.crop)
-        batch = dict(batch)
-        imgs, n = batch.pop("images_u8"), batch.pop("images_n")
-        real = [im for im in imgs if im is not None]
-        out = self._pipeline(real)
-        if n > 1:                                       # multi-image: zero images where the sample has fewer (ref vilmedic_collate)
-            full = out.new_zeros(len(imgs), *out.shape[1:])
-            idx = torch.tensor([i for i, im in enumerate(imgs) if im is not None], device=out.device)
-            full.index_copy_(0, idx, out)
-            out = full.view(len(imgs) // n, n, *out.shape[1:])
-        batch["images"] = out
-        return batch
 
     def __repr__(self):
         return "ImSeq\n{} sentences, {} image lists".format(len(self.seq), len(self.image))

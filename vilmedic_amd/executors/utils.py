@@ -95,7 +95,7 @@ def create_optimizer(config, logger, model, state_dict=None):
 def create_data_loader(config, split, logger, called_by_validator=False, rank=0, world=1):
     dcfg = copy.deepcopy(config.dataset)
     proto = dcfg.pop("proto")
-    if proto == "ImSeq":
+    if proto in ("ImSeq", "ImLabel", "ImSeqLabel", "Seq2Seq", "ImSeq2Seq"):
         dcfg.setdefault("ckpt_dir", config.get("ckpt_dir") or "ckpt")
         if called_by_validator and isinstance(dcfg.get("image"), dict) and split == "train":
             dcfg["image"]["called_by_ensemblor"] = True       # evaluation transform on the train split (ImageDataset.py:83-84)
@@ -106,7 +106,7 @@ def create_data_loader(config, split, logger, called_by_validator=False, rank=0,
         collate = torch.utils.data.dataloader.default_collate
     if world > 1:   # shard the samples by rank (what accelerator.prepare(dl) does, trainor_accelerate.py:91-93)
         dataset = torch.utils.data.Subset(dataset, list(range(rank, len(dataset), world)))
-        for attr in ("tokenizer", "tokenizer_max_len", "seq"):
+        for attr in ("tokenizer", "tokenizer_max_len", "seq", "src", "tgt", "tgt_tokenizer", "tgt_tokenizer_max_len", "labels_map"):
             if hasattr(dataset.dataset, attr):
                 setattr(dataset, attr, getattr(dataset.dataset, attr))
     if split == "train" and not called_by_validator:

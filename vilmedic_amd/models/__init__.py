@@ -3,6 +3,7 @@ from .mvqa.MVQA import MVQA  # noqa: F401
 from .rrg.RRG import RRG  # noqa: F401
 from .rrg.RRG_HF import RRG_HF  # noqa: F401
 from .rrg.RRG_SCST import RRG_SCST  # noqa: F401
+from .rrs.RRS import RRS  # noqa: F401
 from .selfsup.conVIRT import ConVIRT  # noqa: F401
 from .selfsup.GLoRIA import GLoRIA  # noqa: F401
 
