@@ -166,29 +166,32 @@ class GLoRIALoss(nn.Module):
         return loss, attn_maps
 
     def _local(self, img, words, cap_lens):
-        """ref: GLoRIALoss.py:78-129; the per-caption python loop is batched over equal caption lengths."""
-        B = img.shape[0]
-        sims = torch.empty(B, B, device=img.device, dtype=torch.float32)
-        att_maps = [None] * B
-        by_len = {}
-        for i, T in enumerate(cap_lens):
-            by_len.setdefault(T, []).append(i)
+        """ref: GLoRIALoss.py:78-129.  The reference loops over captions, repeating each caption B times and attending the whole
+        image batch (two bmm's with the feature dimension and a [B,D,T] weighted context per caption).  Here every
+        (caption i, image j) pair is handled at once from ONE product, S[i,t,j,p] = <word_it, ctx_jp>:
+          a1 = softmax over the caption's words t (ragged lengths masked), a2 = softmax over pixels p of temp1 * a1,
+          <word_it, wctx_ijt> = sum_p a2 * S          (wctx = ctx_j a2 is never formed),
+          |wctx_ijt|^2 = a2^T (ctx_j^T ctx_j) a2      (one [P,P] Gram matrix per image),
+        so the feature dimension is contracted once, nothing is repeated, and captions of any length share the launch."""
+        B, D = img.shape[0], img.shape[1]
         ih, iw = img.shape[2], img.shape[3]
-        ctx = img.view(B, -1, ih * iw)
-        for T, idxs in by_len.items():
-            w = words[idxs][:, :, :T]                                      # [n,D,T]
-            n = len(idxs)
-            q = w[:, None].expand(n, B, -1, T).reshape(n * B, -1, T)        # caption-major, image-minor
-            c = img[None].expand(n, B, -1, ih, iw).reshape(n * B, -1, ih, iw)
-            wctx, attn = gloria_attention_fn(q, c, self.temp1)
-            qf = q.transpose(1, 2).reshape(n * B * T, -1)
-            cf = wctx.transpose(1, 2).reshape(n * B * T, -1)
-            row = cosine_similarity(qf, cf).view(n, B, T)
-            row = torch.log(torch.exp(row * self.temp2).sum(-1))           # [n,B]
-            sims[:, idxs] = row.t()
-            attn = attn.view(n, B, T, ih, iw)
-            for k, i in enumerate(idxs):
-                att_maps[i] = attn[k, i].unsqueeze(0).contiguous()
-        sims = sims * self.temp3
+        P = ih * iw
+        T = int(max(cap_lens))
+        ctx = img.reshape(B, D, P)
+        w = words[:, :, :T]                                                        # [B,D,T]
+        lens = torch.tensor(cap_lens, device=img.device)
+        valid = torch.arange(T, device=img.device)[None, :] < lens[:, None]        # [B,T]
+        S = (w.transpose(1, 2).reshape(B * T, D) @ ctx.permute(1, 0, 2).reshape(D, B * P)).view(B, T, B, P)
+        a1 = torch.softmax(S.masked_fill(~valid[:, :, None, None], float("-inf")), dim=1)
+        a2 = torch.softmax(a1 * self.temp1, dim=3)                                 # [B(cap),T,B(img),P]
+        dot = (a2 * S).sum(3)                                                      # [B,T,B]
+        gram = torch.bmm(ctx.transpose(1, 2), ctx)                                 # [B(img),P,P]
+        a2j = a2.permute(2, 0, 1, 3).reshape(B, B * T, P)                          # image-major
+        wn2 = (torch.bmm(a2j, gram) * a2j).sum(2).view(B, B, T).permute(1, 2, 0)   # |wctx|^2 as [B(cap),T,B(img)]
+        wnorm = w.norm(dim=1)                                                      # [B,T]
+        cos = dot / (wnorm[:, :, None] * wn2.clamp_min(1e-30).sqrt()).clamp(min=1e-8)
+        row = torch.log((torch.exp(cos * self.temp2) * valid[:, :, None]).sum(1))  # [B(cap),B(img)]
+        sims = row.t() * self.temp3                                                # [B(img),B(cap)]
         labels = torch.arange(B, device=img.device)
+        att_maps = [a2[i, :cap_lens[i], i].reshape(1, cap_lens[i], ih, iw) for i in range(B)]
         return nn.functional.cross_entropy(sims, labels), nn.functional.cross_entropy(sims.t(), labels), att_maps
