@@ -263,6 +263,20 @@ def infonce_loss(linguistic, visual):
     return ((loss_i + loss_t) / 2).mean(), loss_t, loss_i
 
 
+def vicreg_loss(z1, z2, sim_w=25.0, var_w=25.0, cov_w=1.0):
+    """ref:vilmedic/blocks/losses/selfsup/VICREGLoss.py:18-91: MSE + std hinge (eps 1e-4, unbiased var) + squared off-diagonal
+    covariance / D of each view.  Pinned by tests/golden/g14_vicreg.pt."""
+    N, D = z1.shape
+    sim = F.mse_loss(z1, z2)
+    var = sum(torch.mean(F.relu(1 - torch.sqrt(z.var(dim=0) + 1e-4))) for z in (z1, z2))
+    cov = 0.0
+    for z in (z1, z2):
+        zc = z - z.mean(dim=0)
+        c = (zc.T @ zc) / (N - 1)
+        cov = cov + (c - torch.diag(torch.diagonal(c))).pow(2).sum() / D
+    return sim_w * sim + var_w * var + cov_w * cov
+
+
 def label_smoothing_ce(output, target, smoothing=0.1):
     """ref:vilmedic/blocks/losses/mvqa/LabelSmoothingCrossEntropyLoss.py:38-48 (reduction='mean')."""
     c = output.shape[-1]

@@ -273,3 +273,22 @@ def test_trainor_runs_every_task_config(tmp_path, rel, small):
     tr = Trainor(t, seed=0)
     tr.start()
     assert len([f for f in os.listdir(tmp_path) if f.endswith(".pth")]) == 1
+
+
+def test_vicreg_loss_vs_golden(golden):
+    """VICREGLoss (exported by the reference's losses package): invariance / variance terms in fp32, both [D,D] covariance products
+    and their gradients on the bf16 MFMA GEMM.  Loss within 2e-3 relative, covariance term within 5e-3, gradients within 1e-2."""
+    from vilmedic_amd.blocks.losses import VICREGLoss
+    for case in golden("g14_vicreg").values():
+        N, D = case["N"], case["D"]
+        gen = torch.Generator().manual_seed(4321 + N)
+        z1 = 0.7 * torch.randn(N, D, generator=gen) + 0.1
+        z2 = z1 + 0.3 * torch.randn(N, D, generator=gen)
+        a, b = z1.to(dev()).requires_grad_(True), z2.to(dev()).requires_grad_(True)
+        crit = VICREGLoss(sim_loss_weight=25.0, var_loss_weight=25.0, cov_loss_weight=1.0)
+        loss = crit(a, b)
+        loss.backward()
+        assert abs(loss.item() - case["loss"].item()) <= 2e-3 * abs(case["loss"].item()), (loss.item(), case["loss"].item())
+        cov = VICREGLoss.covariance_loss(a.detach(), b.detach()).item()
+        assert abs(cov - case["cov"].item()) <= 5e-3 * case["cov"].item(), (cov, case["cov"].item())
+        assert rel(a.grad.cpu(), case["g1"]) <= 1e-2 and rel(b.grad.cpu(), case["g2"]) <= 1e-2

@@ -217,3 +217,20 @@ def test_g13_rrs_loss_logits_grads(golden):
         close(st["enc.encoder." + n].grad, ref, rtol=1e-3, atol=1e-6)
     for n, ref in g["dec_grads"].items():
         close(st["dec.decoder." + n].grad, ref, rtol=1e-3, atol=1e-6)
+
+
+def _vicreg_inputs(N, D):
+    g = torch.Generator().manual_seed(4321 + N)
+    z1 = 0.7 * torch.randn(N, D, generator=g) + 0.1
+    z2 = z1 + 0.3 * torch.randn(N, D, generator=g)
+    return z1, z2
+
+
+def test_g14_vicreg_loss(golden):
+    for case in golden("g14_vicreg").values():
+        z1, z2 = (z.requires_grad_(True) for z in _vicreg_inputs(case["N"], case["D"]))
+        loss = O.vicreg_loss(z1, z2)
+        loss.backward()
+        close(loss, case["loss"])
+        close(z1.grad, case["g1"], rtol=1e-3, atol=1e-6)
+        close(z2.grad, case["g2"], rtol=1e-3, atol=1e-6)

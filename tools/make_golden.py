@@ -397,6 +397,23 @@ def gen_report_cleaning():
                                      reports_rouge=reports_rouge, rouge=[ns["rouge"](r) for r in reports_rouge]))
 
 
+# ------------------------------------------------------------------ G14: VICReg loss
+def gen_vicreg():
+    lv = load_ref("ref_vicreg", "blocks/losses/selfsup/VICREGLoss.py")
+    out = {}
+    for N, D in ((16, 64), (50, 128)):
+        g = torch.Generator().manual_seed(4321 + N)
+        z1 = (0.7 * torch.randn(N, D, generator=g) + 0.1).requires_grad_(True)      # std < 1: the variance hinge is active
+        z2 = (z1.detach() + 0.3 * torch.randn(N, D, generator=g)).requires_grad_(True)
+        crit = lv.VICREGLoss(sim_loss_weight=25.0, var_loss_weight=25.0, cov_loss_weight=1.0)
+        loss = crit(z1, z2)
+        loss.backward()
+        out[f"n{N}_d{D}"] = dict(N=N, D=D, loss=loss.detach(), sim=lv.VICREGLoss.invariance_loss(z1, z2).detach(),
+                                 var=lv.VICREGLoss.variance_loss(z1, z2).detach(), cov=lv.VICREGLoss.covariance_loss(z1, z2).detach(),
+                                 g1=z1.grad.clone(), g2=z2.grad.clone())
+    save("g14_vicreg", out)
+
+
 # ------------------------------------------------------------------ G13: RRS (text encoder -> cross-attending decoder)
 def gen_rrs():
     """RRS.forward == enc(input_ids, attention_mask).last_hidden_state -> dec(decoder ids, encoder mask = source attention mask)
@@ -428,6 +445,6 @@ def gen_rrs():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs"]
+    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs", "vicreg"]
     for w in which:
         globals()["gen_" + w]()

@@ -2,4 +2,4 @@
 from torch.nn.modules.loss import *  # noqa: F401,F403
 
 from .mvqa import LabelSmoothingCrossEntropy  # noqa: F401
-from .selfsup import ConVIRTLoss, GLoRIALoss, InfoNCELoss, cosine_similarity, gloria_attention_fn  # noqa: F401
+from .selfsup import ConVIRTLoss, GLoRIALoss, InfoNCELoss, VICREGLoss, cosine_similarity, gloria_attention_fn  # noqa: F401

@@ -130,6 +130,70 @@ class InfoNCELoss(nn.Module):
         return "InfoNCELoss(\n\t(tau): {}\n)".format(self.tau)
 
 
+# ----------------------------------------------------------------------------- VICReg
+class _CovOffDiagFn(torch.autograd.Function):
+    """z [N,D] -> sum of the squared OFF-diagonal entries of cov(z) = zc^T zc / (N-1), zc = z - mean_0(z).  The [D,D] product
+    (contraction over the batch rows) and its gradient dz = 4/(N-1) zc C_off are bf16 MFMA GEMMs with fp32 output."""
+
+    @staticmethod
+    def forward(ctx, z):
+        N, D = z.shape
+        if D % 8:
+            raise ValueError("embedding dim must be a multiple of 8")
+        zc = z.detach().float()
+        zc = zc - zc.mean(0)
+        Np = _pad8(N)
+        zh = torch.zeros(Np, D, dtype=BF16, device=z.device)
+        zh[:N] = zc
+        cov = torch.empty(D, D, dtype=torch.float32, device=z.device)
+        ops.gemm(zh, 1, zh, 1, cov, D, D, Np, alpha=1.0 / (N - 1))
+        cov.diagonal().zero_()
+        ctx.save_for_backward(zh, cov)
+        ctx.N = N
+        return cov.pow(2).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        zh, cov = ctx.saved_tensors
+        N, (Np, D) = ctx.N, zh.shape
+        dz = torch.empty(Np, D, dtype=torch.float32, device=zh.device)
+        ops.gemm(zh, 0, cov.to(BF16), 0, dz, Np, D, D, alpha=4.0 / (N - 1))
+        dz = dz[:N]
+        return (dz - dz.mean(0)) * g
+
+
+class VICREGLoss(nn.Module):
+    """ref: vilmedic/blocks/losses/selfsup/VICREGLoss.py:6-99 -- invariance (MSE) + variance hinge on the per-dimension std +
+    covariance (squared off-diagonal entries of each view's [D,D] covariance, / D)."""
+
+    def __init__(self, sim_loss_weight=25.0, var_loss_weight=25.0, cov_loss_weight=1.0, **kwargs):
+        super().__init__()
+        self.sim_loss_weight, self.var_loss_weight, self.cov_loss_weight = sim_loss_weight, var_loss_weight, cov_loss_weight
+
+    def forward(self, z1, z2):
+        return (self.sim_loss_weight * self.invariance_loss(z1, z2) + self.var_loss_weight * self.variance_loss(z1, z2)
+                + self.cov_loss_weight * self.covariance_loss(z1, z2))
+
+    @staticmethod
+    def invariance_loss(z1, z2):
+        return nn.functional.mse_loss(z1.float(), z2.float())
+
+    @staticmethod
+    def variance_loss(z1, z2):
+        eps = 1e-4
+        std1, std2 = torch.sqrt(z1.float().var(dim=0) + eps), torch.sqrt(z2.float().var(dim=0) + eps)
+        return torch.mean(torch.relu(1 - std1)) + torch.mean(torch.relu(1 - std2))
+
+    @staticmethod
+    def covariance_loss(z1, z2):
+        D = z1.shape[1]
+        return _CovOffDiagFn.apply(z1) / D + _CovOffDiagFn.apply(z2) / D
+
+    def __repr__(self):
+        return ("VICREGLoss(\n\t(sim_loss_weight): {}\n\t(var_loss_weight): {}\n\t(cov_loss_weight): {}\n)"
+                .format(self.sim_loss_weight, self.var_loss_weight, self.cov_loss_weight))
+
+
 # ----------------------------------------------------------------------------- GLoRIA (global: HIP similarity; local: batched torch ops)
 def cosine_similarity(x1, x2, dim=1, eps=1e-8):
     w12 = torch.sum(x1 * x2, dim)
