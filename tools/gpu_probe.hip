@@ -170,6 +170,53 @@ static int test_ln(int rows, int cols) {
     return bad != 0;
 }
 
+// A/B of VM_GEMM_PIPE on one shape with one set of (rotating) buffers: pipe 0,1,0,1
+static void bench_ab(int M, int N, int K, int la, int lb, int flags, int split) {
+    const int rot = 4;
+    int64_t lda = la == 0 ? K : M, ldb = lb == 0 ? K : N;
+    size_t na = (size_t)M * K, nb = (size_t)N * K, nc = (size_t)M * N;
+    std::vector<uint16_t> h(std::max(std::max(na, nb), nc));
+    uint32_t x = 12345u;
+    for (auto& v : h) { x = x * 1664525u + 1013904223u; v = f2bf(((x >> 8) & 0xffff) / 32768.f - 1.f); }
+    std::vector<void*> dA(rot), dB(rot), dC(rot), dZ(rot);
+    void *dbias, *ws = nullptr; hipMalloc(&dbias, N * 4); hipMemset(dbias, 0, N * 4);
+    if (split > 1) hipMalloc(&ws, (size_t)split * nc * 4);
+    for (int r = 0; r < rot; ++r) {
+        hipMalloc(&dA[r], na * 2); hipMalloc(&dB[r], nb * 2); hipMalloc(&dC[r], nc * (split > 1 ? 4 : 2)); hipMalloc(&dZ[r], nc * 2);
+        hipMemcpy(dA[r], h.data(), na * 2, hipMemcpyHostToDevice); hipMemcpy(dB[r], h.data(), nb * 2, hipMemcpyHostToDevice);
+        hipMemcpy(dZ[r], h.data(), nc * 2, hipMemcpyHostToDevice);
+        if (split > 1) hipMemset(dC[r], 0, nc * 4);
+    }
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    float us[2][2];
+    for (int rep = 0; rep < 2; ++rep) for (int pipe = 0; pipe < 2; ++pipe) {
+        setenv("VM_GEMM_PIPE", pipe ? "1" : "0", 1); vm_reload_env();
+        const int it = 16;
+        for (int i = -2; i < it; ++i) {
+            if (i == 0) hipEventRecord(a, nullptr);
+            const int r = (i + 2) % rot;
+            vm_gemm_epilogue e = {}; e.alpha = 1.f; e.out_dtype = split > 1 ? VM_F32 : VM_BF16; e.split_k = split; e.accumulate = split > 1;
+            if (split > 1) { e.workspace = ws; e.workspace_bytes = (size_t)split * nc * 4; }
+            if (flags & 1) e.bias = (const float*)dbias;
+            if (flags & 2) e.act = 1;
+            if (flags & 4) e.aux_out = dZ[r];
+            if (flags & 8) e.mul_gelu_z = dZ[r];
+            if (flags & 16) { e.dropout_p = 0.1f; e.dropout_seed = 1234 + i; }
+            if (flags & 32) { e.residual = dZ[r]; e.ldr = N; }
+            int rc = vm_gemm_bf16(dA[r], lda, la, dB[r], ldb, lb, dC[r], N, M, N, K, &e, nullptr);
+            if (rc) { printf("rc=%d %s\n", rc, vm_last_error()); return; }
+        }
+        hipEventRecord(b, nullptr); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b); us[rep][pipe] = ms / it * 1e3f;
+    }
+    const double gf = 2.0 * M * N * K * 1e-6;
+    printf("ab M=%d N=%d K=%d l%d%d flags=%2d split=%2d: pipe0 %7.1f %7.1f us (%6.1f TF)  pipe1 %7.1f %7.1f us (%6.1f TF)  ratio %.3f\n", M, N, K, la, lb, flags, split,
+           us[0][0], us[1][0], gf / std::min(us[0][0], us[1][0]), us[0][1], us[1][1], gf / std::min(us[0][1], us[1][1]),
+           std::min(us[0][0], us[1][0]) / std::min(us[0][1], us[1][1]));
+    for (int r = 0; r < rot; ++r) { hipFree(dA[r]); hipFree(dB[r]); hipFree(dC[r]); hipFree(dZ[r]); }
+    hipFree(dbias); if (ws) hipFree(ws);
+}
+
 int main(int argc, char** argv) {
     if (argc >= 8 && !strcmp(argv[1], "bench")) {   // gpu_probe.bin bench M N K la lb split   (for rocprofv3 --pmc runs)
         for (int dbg = 0; dbg < 3; ++dbg) {
@@ -178,6 +225,33 @@ int main(int argc, char** argv) {
             bench_gemm(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]));
         }
         return 0;
+    }
+    if (argc >= 2 && !strcmp(argv[1], "pipe")) {   // A/B of the software-pipelined main loop (VM_GEMM_PIPE=1) on the training step's shapes
+        int fails = 0;
+        setenv("VM_GEMM_PIPE", "1", 1);
+        for (int variant = 0; variant <= 4; variant += 4) {
+            { char b[4]; snprintf(b, 4, "%d", variant); setenv("VM_GEMM_VARIANT", b, 1); vm_reload_env(); }
+            for (int la = 0; la < (variant == 4 ? 1 : 2); ++la) for (int lb = 0; lb < 2; ++lb) {
+                fails += test_gemm(200, 136, 192, la, lb, 1, false);
+                fails += test_gemm(333, 97, 128, la, lb, 1, true);
+                fails += test_gemm(700, 260, 448, la, lb, 1, true);
+            }
+            if (variant != 4) fails += test_gemm(256, 256, 1024, 1, 1, 4, true);
+            fails += test_gemm(1000, 768, 768, 0, 0, 1, false);
+        }
+        unsetenv("VM_GEMM_VARIANT");
+        printf("pipe correctness fails=%d\n", fails);
+        struct { int M, N, K, la, lb, flags, split; } cs[] = {
+            {12608, 2304, 768, 0, 0, 1, 1}, {12608, 3072, 768, 0, 0, 7, 1}, {12608, 768, 3072, 0, 0, 49, 1}, {12608, 768, 768, 0, 0, 49, 1},
+            {8192, 2304, 768, 0, 0, 1, 1}, {8192, 768, 768, 0, 0, 49, 1}, {8192, 3072, 768, 0, 0, 7, 1}, {8192, 768, 3072, 0, 0, 49, 1},
+            {8192, 30528, 768, 0, 0, 1, 1},
+            {12608, 3072, 768, 0, 1, 8, 1}, {12608, 768, 3072, 0, 1, 0, 1}, {12608, 768, 768, 0, 1, 0, 1}, {12608, 768, 2304, 0, 1, 0, 1},
+            {8192, 768, 768, 0, 1, 0, 1}, {8192, 768, 30528, 0, 1, 0, 1},
+            {2304, 768, 12608, 1, 1, 0, 4}, {3072, 768, 12608, 1, 1, 0, 3}, {768, 3072, 12608, 1, 1, 0, 3}, {768, 768, 8192, 1, 1, 0, 14},
+            {30528, 768, 8192, 1, 1, 0, 1},
+        };
+        for (auto& c : cs) bench_ab(c.M, c.N, c.K, c.la, c.lb, c.flags, c.split);
+        return fails;
     }
     if (argc >= 2 && !strcmp(argv[1], "epi")) {
         struct { int M, N, K, la, lb, flags; } cs[] = {

@@ -60,7 +60,10 @@ __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF>
+//                      PIPE = 1 (2-stage, k-tile 64 only): the fragments of BOTH 32-wide k-halves of a tile are requested right after
+//                             the barrier and the MFMAs follow behind a scheduling barrier, so one LDS latency is exposed per
+//                             K-tile instead of one per dependent read group of the compiler's own schedule
+template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF, int PIPE>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fast_kernel(const GemmArgs p) {
     constexpr int WR = MF * 16;                     // rows per wave (MF 16-row A fragments; 4 or 5)
     constexpr int FBM = WM * WR, FBN = WN * 64, NW = WM * WN, NT = NW * 64;
@@ -144,6 +147,42 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
     auto compute = [&](int buf) {
         const char* sa = smem + buf * F_STAGE;
         const char* sb = sa + F_OPER_A;
+        if constexpr (PIPE == 1 && BKT == 64) {
+            // software-pipelined K-tile: the first 32-wide k-half's fragments are requested up front, the second half's
+            // reads are slotted one per MFMA behind the first MFMAs of the first half (sched_group_barrier: 0x100 = LDS read, 0x008 = MFMA),
+            // so only the first reads' latency is exposed per K-tile
+            bf16x8_t fa[2][MF], fb[2][4];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    fb[kk][j] = LB == 0 ? read_frag0(sb, b_rb, j, kk) : read_frag1(sb, b_rb, j, kk, FBN * 2);
+                    if (j < MF) fa[kk][j] = LA == 0 ? read_frag0(sa, a_rb, j, kk) : read_frag1(sa, a_rb, j, kk, FBM * 2);
+                }
+#pragma unroll
+                for (int i = 4; i < MF; ++i) fa[kk][i] = LA == 0 ? read_frag0(sa, a_rb, i, kk) : read_frag1(sa, a_rb, i, kk, FBM * 2);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int d = 0; d < 4 + MF - 1; ++d)          // anti-diagonal order: the first MFMAs need only the first reads
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = d - j;
+                        if (i >= 0 && i < MF) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[j][i], 0, 0, 0);
+                    }
+            constexpr int NRD = (LA == 0 ? MF : 2 * MF) + (LB == 0 ? 4 : 8);      // LDS read instructions per k-half
+            constexpr int NMF = 4 * MF;
+            static_assert(NRD <= NMF, "one read slot per first-half MFMA");
+            __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+#pragma unroll
+            for (int n = 0; n < NRD; ++n) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NMF - NRD, 0);
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < BKT / 32; ++kk) {
             bf16x8_t fa[MF], fb[4];
@@ -328,16 +367,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
     }   // passes
 }
 
-template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF>
+template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF, int PIPE = 0>
 static int launch_fast(const GemmArgs& a, int nblocks, hipStream_t s) {
     constexpr int RING = STAGES * (WM * MF * 16 + WN * 64) * BKT * 2, STAGE_MIN = MF * 16 * WN * 64 * 4;
     constexpr int LDS = RING >= STAGE_MIN ? RING : STAGE_MIN;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<LA, LB, WM, WN, STAGES, BKT, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<LA, LB, WM, WN, STAGES, BKT, MF, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_fast_kernel<LA, LB, WM, WN, STAGES, BKT, MF>), dim3(nblocks), dim3(WM * WN * 64), LDS, s, a);
+    hipLaunchKernelGGL((gemm_fast_kernel<LA, LB, WM, WN, STAGES, BKT, MF, PIPE>), dim3(nblocks), dim3(WM * WN * 64), LDS, s, a);
     return vm_check_launch("vm_gemm_bf16(fast)");
 }
 
@@ -374,25 +413,28 @@ int vm_gemm_splitk_reduce(const GemmArgs& a, int nsplit, hipStream_t s) {
     return vm_check_launch("vm_gemm_bf16(split-k reduce)");
 }
 
-template <int WM, int WN, int STAGES, int BKT, int MF>
+template <int WM, int WN, int STAGES, int BKT, int MF, int PIPE = 0>
 static int dispatch_layout(const GemmArgs& a, int a_layout, int b_layout, int nblocks, hipStream_t s) {
-    if (a_layout == 0 && b_layout == 0) return launch_fast<0, 0, WM, WN, STAGES, BKT, MF>(a, nblocks, s);
-    if (a_layout == 0 && b_layout == 1) return launch_fast<0, 1, WM, WN, STAGES, BKT, MF>(a, nblocks, s);
-    if (a_layout == 1 && b_layout == 0) return launch_fast<1, 0, WM, WN, STAGES, BKT, MF>(a, nblocks, s);
-    return launch_fast<1, 1, WM, WN, STAGES, BKT, MF>(a, nblocks, s);
+    if (a_layout == 0 && b_layout == 0) return launch_fast<0, 0, WM, WN, STAGES, BKT, MF, PIPE>(a, nblocks, s);
+    if (a_layout == 0 && b_layout == 1) return launch_fast<0, 1, WM, WN, STAGES, BKT, MF, PIPE>(a, nblocks, s);
+    if (a_layout == 1 && b_layout == 0) return launch_fast<1, 0, WM, WN, STAGES, BKT, MF, PIPE>(a, nblocks, s);
+    return launch_fast<1, 1, WM, WN, STAGES, BKT, MF, PIPE>(a, nblocks, s);
 }
 
 // variant 0: 128x128 tile, 2-stage (2 workgroups/CU); 1: 256x128, 3-stage ring; 2: 256x256, 16 waves, 2-stage
 //         4: 160x128 (5 A fragments per wave), row-major A only
 // (measured and dropped: 128x128 with k-tile 32 x 4-stage ring, 256x128 with 128x64 per wave -- both slower on every hot shape)
 int vm_gemm_fast_dispatch(const GemmArgs& a0, int a_layout, int b_layout, int nblocks, int variant, hipStream_t s) {
+    const bool pipe = vm_env().gemm_pipe == 1;
     if (variant == 1) return dispatch_layout<4, 2, 3, 64, 4>(a0, a_layout, b_layout, nblocks, s);
     if (variant == 2) return dispatch_layout<4, 4, 2, 64, 4>(a0, a_layout, b_layout, nblocks, s);
     if (variant == 4) {                  // 160x128 tile (A row-major only): evens out the tile count when 128-row tiles leave a thin last round
         if (a_layout != 0) { vm_set_error("vm_gemm_bf16: 160-row tile needs a row-major A"); return VM_EINVAL; }
+        if (pipe) return b_layout == 0 ? launch_fast<0, 0, 2, 2, 2, 64, 5, 1>(a0, nblocks, s) : launch_fast<0, 1, 2, 2, 2, 64, 5, 1>(a0, nblocks, s);
         if (b_layout == 0) return launch_fast<0, 0, 2, 2, 2, 64, 5>(a0, nblocks, s);
         return launch_fast<0, 1, 2, 2, 2, 64, 5>(a0, nblocks, s);
     }
+    if (pipe) return dispatch_layout<2, 2, 2, 64, 4, 1>(a0, a_layout, b_layout, nblocks, s);
     return dispatch_layout<2, 2, 2, 64, 4>(a0, a_layout, b_layout, nblocks, s);
 }
 void vm_gemm_variant_tile(int variant, int* bm, int* bn) {

@@ -37,6 +37,7 @@ static void load_env() {
     g_env.gemm_variant = (v = getenv("VM_GEMM_VARIANT")) ? atoi(v) : -1;
     g_env.gemm_debug = (v = getenv("VM_GEMM_DEBUG")) ? atoi(v) : 0;
     g_env.gemm_groupw = (v = getenv("VM_GEMM_GROUPW")) ? atoi(v) : 0;
+    g_env.gemm_pipe = (v = getenv("VM_GEMM_PIPE")) ? atoi(v) : VM_GEMM_PIPE_DEFAULT;
     g_env.gemm_generic = getenv("VM_GEMM_GENERIC") != nullptr;
     g_env.gemm_no_skinny = getenv("VM_GEMM_NO_SKINNY") != nullptr;
     g_env.attn_tile = getenv("VM_ATTN_TILE") != nullptr;
