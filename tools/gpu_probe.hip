@@ -171,6 +171,7 @@ static int test_ln(int rows, int cols) {
 }
 
 // A/B of VM_GEMM_PIPE on one shape with one set of (rotating) buffers: pipe 0,1,0,1
+static int g_pipe_a = 0, g_pipe_b = 1;
 static void bench_ab(int M, int N, int K, int la, int lb, int flags, int split) {
     const int rot = 4;
     int64_t lda = la == 0 ? K : M, ldb = lb == 0 ? K : N;
@@ -190,7 +191,7 @@ static void bench_ab(int M, int N, int K, int la, int lb, int flags, int split) 
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     float us[2][2];
     for (int rep = 0; rep < 2; ++rep) for (int pipe = 0; pipe < 2; ++pipe) {
-        setenv("VM_GEMM_PIPE", pipe ? "1" : "0", 1); vm_reload_env();
+        { char pb[4]; snprintf(pb, 4, "%d", pipe ? g_pipe_b : g_pipe_a); setenv("VM_GEMM_PIPE", pb, 1); vm_reload_env(); }
         const int it = 16;
         for (int i = -2; i < it; ++i) {
             if (i == 0) hipEventRecord(a, nullptr);
@@ -228,12 +229,15 @@ int main(int argc, char** argv) {
     }
     if (argc >= 2 && !strcmp(argv[1], "pipe")) {   // A/B of the software-pipelined main loop (VM_GEMM_PIPE=1) on the training step's shapes
         int fails = 0;
-        setenv("VM_GEMM_PIPE", "1", 1);
+        if (argc >= 4) { g_pipe_a = atoi(argv[2]); g_pipe_b = atoi(argv[3]); }
+        printf("A = VM_GEMM_PIPE=%d (pipe0 columns), B = VM_GEMM_PIPE=%d (pipe1 columns)\n", g_pipe_a, g_pipe_b);
+        { char pb[4]; snprintf(pb, 4, "%d", g_pipe_b); setenv("VM_GEMM_PIPE", pb, 1); }
         for (int variant = 0; variant <= 4; variant += 4) {
             { char b[4]; snprintf(b, 4, "%d", variant); setenv("VM_GEMM_VARIANT", b, 1); vm_reload_env(); }
             for (int la = 0; la < (variant == 4 ? 1 : 2); ++la) for (int lb = 0; lb < 2; ++lb) {
                 fails += test_gemm(200, 136, 192, la, lb, 1, false);
                 fails += test_gemm(333, 97, 128, la, lb, 1, true);
+                fails += test_gemm(130, 140, 64, la, lb, 1, true);
                 fails += test_gemm(700, 260, 448, la, lb, 1, true);
             }
             if (variant != 4) fails += test_gemm(256, 256, 1024, 1, 1, 4, true);

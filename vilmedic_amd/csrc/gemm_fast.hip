@@ -423,18 +423,20 @@ static int dispatch_layout(const GemmArgs& a, int a_layout, int b_layout, int nb
 
 // variant 0: 128x128 tile, 2-stage (2 workgroups/CU); 1: 256x128, 3-stage ring; 2: 256x256, 16 waves, 2-stage
 //         4: 160x128 (5 A fragments per wave), row-major A only
-// (measured and dropped: 128x128 with k-tile 32 x 4-stage ring, 256x128 with 128x64 per wave -- both slower on every hot shape)
+// (measured and dropped: 128x128 with k-tile 32 x 4-stage ring, 256x128 with 128x64 per wave -- both slower on every hot shape;
+//  issuing the next tile's DMA pieces from between the first MFMAs of the K-tile instead of right after the barrier: equal to
+//  -13 % with row-major operands, 1.3-2.7x slower with ds_read_b64_tr operands -- profiles/r01_e_gemm_pipe_ab.txt)
 int vm_gemm_fast_dispatch(const GemmArgs& a0, int a_layout, int b_layout, int nblocks, int variant, hipStream_t s) {
-    const bool pipe = vm_env().gemm_pipe == 1;
+    const int pipe = vm_env().gemm_pipe;
     if (variant == 1) return dispatch_layout<4, 2, 3, 64, 4>(a0, a_layout, b_layout, nblocks, s);
     if (variant == 2) return dispatch_layout<4, 4, 2, 64, 4>(a0, a_layout, b_layout, nblocks, s);
     if (variant == 4) {                  // 160x128 tile (A row-major only): evens out the tile count when 128-row tiles leave a thin last round
         if (a_layout != 0) { vm_set_error("vm_gemm_bf16: 160-row tile needs a row-major A"); return VM_EINVAL; }
-        if (pipe) return b_layout == 0 ? launch_fast<0, 0, 2, 2, 2, 64, 5, 1>(a0, nblocks, s) : launch_fast<0, 1, 2, 2, 2, 64, 5, 1>(a0, nblocks, s);
+        if (pipe == 1) return b_layout == 0 ? launch_fast<0, 0, 2, 2, 2, 64, 5, 1>(a0, nblocks, s) : launch_fast<0, 1, 2, 2, 2, 64, 5, 1>(a0, nblocks, s);
         if (b_layout == 0) return launch_fast<0, 0, 2, 2, 2, 64, 5>(a0, nblocks, s);
         return launch_fast<0, 1, 2, 2, 2, 64, 5>(a0, nblocks, s);
     }
-    if (pipe) return dispatch_layout<2, 2, 2, 64, 4, 1>(a0, a_layout, b_layout, nblocks, s);
+    if (pipe == 1) return dispatch_layout<2, 2, 2, 64, 4, 1>(a0, a_layout, b_layout, nblocks, s);
     return dispatch_layout<2, 2, 2, 64, 4>(a0, a_layout, b_layout, nblocks, s);
 }
 void vm_gemm_variant_tile(int variant, int* bm, int* bn) {
