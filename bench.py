@@ -156,7 +156,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--graph", type=int, default=int(os.environ.get("VM_BENCH_GRAPH", "0")))
     args = ap.parse_args()
     if args.cpu_baseline_child:
         cpu_baseline_child()
