@@ -87,6 +87,42 @@ def test_imseq_reads_files_builds_vocab_and_collates(tmp_path):
     assert dv.tokenizer.vocab_size == ds.tokenizer.vocab_size and len(dv) == 3
 
 
+def test_tensor_images_dicom_arithmetic_and_unsupported_keys(tmp_path):
+    """ext .npy: pre-processed tensors pass through untouched (identity transform) with the reference's multi-image zero padding
+    and sum != 0 mask (base/ImageDataset.py:25-54,93-94); the DICOM branch's grey -> uint8 arithmetic (:124-132); keys that would
+    silently change the transform are rejected."""
+    from vilmedic_amd.datasets.imseq import ImageDataset, grey_to_u8_rgb
+    root = str(tmp_path)
+    rng = np.random.default_rng(3)
+    paths = []
+    for i in range(5):
+        np.save(os.path.join(root, f"im{i}.npy"), rng.standard_normal((3, 8, 8)).astype(np.float32))
+        paths.append(os.path.join(root, f"im{i}.npy"))
+    open(os.path.join(root, "train.image.tok"), "w").write("\n".join([paths[0], paths[1] + "," + paths[2], ",".join(paths[2:5])]))
+    ds = ImageDataset(root=root, file="image.tok", split="train", ext=".npy", multi_image=2)
+    b = ds.get_collate_fn()([ds[0], ds[1], ds[2]])
+    assert b["images"].shape == (3, 2, 3, 8, 8) and b["images"].dtype == torch.float32
+    assert b["images_mask"].tolist() == [[True, False], [True, True], [True, True]]
+    assert torch.equal(b["images"][0, 0], torch.from_numpy(np.load(paths[0]))) and not b["images"][0, 1].any()
+    assert torch.equal(b["images"][2, 1], torch.from_numpy(np.load(paths[3])))           # truncated to the first two of three
+    single = ImageDataset(root=root, file="image.tok", split="train", ext=".npy")
+    b1 = single.get_collate_fn()([single[0], single[2]])
+    assert b1["images"].shape == (2, 3, 8, 8) and b1["images_mask"] is None
+    # one .npy holding every sample (file name contains '.npy', ImageDataset.py:65-66)
+    np.save(os.path.join(root, "validate.all.npy"), rng.standard_normal((4, 3, 8, 8)).astype(np.float32))
+    whole = ImageDataset(root=root, file="all.npy", split="validate", ext=".npy")
+    assert len(whole) == 4 and whole.get_collate_fn()([whole[1], whole[3]])["images"].shape == (2, 3, 8, 8)
+    g = grey_to_u8_rgb(np.array([[-5.0, 0.0], [100.0, 400.0]]))
+    assert g.dtype == np.uint8 and g.shape == (2, 2, 3) and g[:, :, 0].tolist() == [[0, 0], [63, 255]] and (g[:, :, 0] == g[:, :, 2]).all()
+    with pytest.raises(NotImplementedError):
+        ImageDataset(root=root, file="image.tok", split="train", ext=".npy", custom_transform_train="transforms.Compose([])")
+    # relative names resolved against image_path when they do not exist as given
+    os.makedirs(os.path.join(root, "sub"), exist_ok=True)
+    np.save(os.path.join(root, "sub", "x.npy"), np.zeros((3, 4, 4), np.float32))
+    open(os.path.join(root, "test.image.tok"), "w").write("x.npy")
+    assert ImageDataset(root=root, file="image.tok", split="test", ext=".npy", image_path=os.path.join(root, "sub")).images == [[os.path.join(root, "sub", "x.npy")]]
+
+
 def test_label_and_seq2seq_compositions(tmp_path):
     """ImLabel / ImSeqLabel / Seq2Seq / ImSeq2Seq: the reference's files, label-map file and batch-dict keys
     (datasets/{ImLabel,ImSeqLabel,Seq2Seq,ImSeq2Seq}.py, base/LabelDataset.py)"""

@@ -181,15 +181,34 @@ class WordPieceTokenizer:
         return " ".join(toks).replace(" ##", "").strip()
 
 
+def _dicom_to_u8(path):
+    """ref: base/ImageDataset.py:124-132 -- VOI LUT when the file carries a window, clip at 0, scale by the maximum to 0..255,
+    grey replicated to three channels (what ``Image.fromarray(img).convert('RGB')`` does with an 8-bit grey image)"""
+    try:
+        import pydicom
+        from pydicom.pixel_data_handlers.util import apply_voi_lut
+    except ImportError as e:
+        raise NotImplementedError("ext '.dcm' needs the pydicom package, which is not installed here") from e
+    ds = pydicom.dcmread(path)
+    img = (apply_voi_lut(ds.pixel_array, ds) if "WindowWidth" in ds else ds.pixel_array).astype(float)
+    return grey_to_u8_rgb(img)
+
+
+def grey_to_u8_rgb(img):
+    """float grey image -> uint8 [H,W,3]: ``uint8(max(img,0) / img.max() * 255)`` replicated (the DICOM branch's arithmetic)"""
+    img = np.uint8((np.maximum(img, 0) / img.max()) * 255.0)
+    return np.repeat(img[:, :, None], 3, axis=2)
+
+
 def open_image(image, ext):
-    """-> uint8 [H,W,3] numpy (ref: base/ImageDataset.py:111-140; DICOM needs pydicom, which this image lacks)"""
+    """-> uint8 [H,W,3] numpy for the device pipeline (ref: base/ImageDataset.py:111-140)"""
     if isinstance(image, np.ndarray):
         arr = image
-    elif ext in (".npy", ".npz"):
-        arr = np.load(image)
     elif ext in (".jpg", ".jpeg", ".png"):
         from PIL import Image
         arr = np.asarray(Image.open(image).convert("RGB"))
+    elif ext == ".dcm":
+        arr = _dicom_to_u8(image)
     else:
         raise NotImplementedError("Image extension {} not implemented".format(ext))
     if arr.dtype != np.uint8 or arr.ndim != 3 or arr.shape[2] != 3:
@@ -197,31 +216,63 @@ def open_image(image, ext):
     return np.array(arr, order="C")      # an owned, writable copy (PIL hands out read-only buffers)
 
 
+def open_tensor_image(image):
+    """ext .npy / .npz: already pre-processed tensors, identity transform (ref: base/ImageDataset.py:93-94,134-139)"""
+    if isinstance(image, str):
+        image = np.load(image)
+    return torch.from_numpy(image) if isinstance(image, np.ndarray) else image
+
+
 class ImageDataset(Dataset):
     def __init__(self, root=None, file=None, split=None, image_path=None, resize=256, crop=224, ext=".jpg", multi_image=None,
-                 called_by_ensemblor=None, **kwargs):
+                 called_by_ensemblor=None, custom_transform_train=None, custom_transform_validate=None, hf_dataset=None,
+                 hf_processor=None, **kwargs):
         assert split is not None, "Argument split cant be None"
+        for name, val in (("custom_transform_train", custom_transform_train), ("custom_transform_validate", custom_transform_validate),
+                          ("hf_dataset", hf_dataset), ("hf_processor", hf_processor)):
+            if val is not None:       # torchvision transform strings / hub datasets / HF processors: not available in this build
+                raise NotImplementedError(f"ImageDataset({name}=...) is not supported by the device image pipeline")
         self.root, self.file, self.split, self.image_path = root, file, split, image_path
         self.resize, self.crop, self.ext = int(resize), int(crop), ext
         self.multi_image = multi_image or 0
-        lines = load_file(os.path.join(root, split + "." + file))
-        self.images = []
-        for line in lines:
-            paths = [os.path.join(image_path, p.strip()) if image_path else p.strip() for p in line.split(",")]
-            for p in paths:
-                assert os.path.exists(p), f"Image path does not exist: {p}"
-            self.images.append(paths)
+        self.tensor_images = ext in (".npy", ".npz")
+        file_path = os.path.join(root, split + "." + file)
+        if ".npy" in file_path:                       # one array holding every sample's (pre-processed) image (ImageDataset.py:65-66)
+            self.images = [[x] for x in np.load(file_path)]
+        else:
+            self.images = []
+            for line in load_file(file_path):
+                paths = []
+                for p in line.split(","):
+                    p = p.strip()
+                    if not os.path.exists(p) and image_path and os.path.exists(os.path.join(image_path, p)):
+                        p = os.path.join(image_path, p)
+                    assert os.path.exists(p), f"Image path does not exist: {p}"
+                    paths.append(p)
+                self.images.append(paths)
         self.pipeline_split = "validate" if called_by_ensemblor else split
 
     def __len__(self):
         return len(self.images)
 
     def __getitem__(self, index):
+        if self.tensor_images:
+            return {"image": [open_tensor_image(p) for p in self.images[index]]}
         return {"image": [open_image(p, self.ext) for p in self.images[index]]}
 
     def get_collate_fn(self):
         def collate_fn(batch):
             n = self.multi_image if self.multi_image and self.multi_image > 1 else 1
+            if self.tensor_images:                     # vilmedic_collate (ImageDataset.py:25-54): stack, pad with zero images
+                if n == 1:
+                    return {"images": torch.stack([s["image"][0] for s in batch]), "images_mask": None}
+                rows = []
+                for s in batch:
+                    cur = list(s["image"][:n])
+                    cur += [cur[0].new_zeros(cur[0].size()) for _ in range(n - len(cur))]
+                    rows.append(torch.stack(cur))
+                images = torch.stack(rows)
+                return {"images": images, "images_mask": images.sum(dim=(2, 3, 4)) != 0}
             imgs, mask = [], []
             for s in batch:
                 cur = list(s["image"][:n])
