@@ -7,7 +7,7 @@ import os
 import torch
 from torch.utils.data import Dataset
 
-from .imseq import ImageDataset, ImSeq, TextDataset, _DeviceImages, load_file
+from .imseq import ImageDataset, ImSeq, TextDataset, _DeviceImages, _same_batch_size, load_file
 
 
 class Labels:
@@ -66,6 +66,11 @@ class LabelDataset(Dataset):
             return {"labels": torch.stack([s["label"] for s in batch])}
         return collate_fn
 
+    def inference(self, label):
+        if not isinstance(label, list):
+            label = [label]
+        return self.get_collate_fn()([{"label": self.get_processed_label(l)} for l in label])
+
     def get_processed_label(self, label):
         try:
             classes = label.split(",")
@@ -100,6 +105,15 @@ class ImLabel(_DeviceImages, Dataset):
         def collate_fn(batch):
             return {**self.image.get_collate_fn()(batch), **self.label.get_collate_fn()(batch)}
         return collate_fn
+
+    def inference(self, image=None, label=None):
+        """ref: datasets/ImLabel.py:29-41"""
+        batch = {}
+        if image is not None:
+            batch.update(self.device_transform(self.image.inference(image)))
+        if label is not None:
+            batch.update(self.label.inference(label))
+        return _same_batch_size(batch)
 
     def __repr__(self):
         return "ImLabel\n" + str(self.image) + "\n" + str(self.label)
@@ -151,6 +165,16 @@ class Seq2Seq(Dataset):
             tgt["decoder_attention_mask"] = tgt.pop("attention_mask")
             return {**self.src.get_collate_fn()(batch), **tgt}
         return collate_fn
+
+    def inference(self, src=None, tgt=None):
+        """ref: datasets/Seq2Seq.py:36-51"""
+        batch = {}
+        if src is not None:
+            batch.update(self.src.inference(src))
+        if tgt is not None:
+            t = self.tgt.inference(tgt)
+            batch["decoder_input_ids"], batch["decoder_attention_mask"] = t["input_ids"], t["attention_mask"]
+        return _same_batch_size(batch)
 
     def __repr__(self):
         return "Seq2Seq\n{} source / {} target sentences".format(len(self.src), len(self.tgt))

@@ -236,8 +236,10 @@ class ImageDataset(Dataset):
         self.resize, self.crop, self.ext = int(resize), int(crop), ext
         self.multi_image = multi_image or 0
         self.tensor_images = ext in (".npy", ".npz")
-        file_path = os.path.join(root, split + "." + file)
-        if ".npy" in file_path:                       # one array holding every sample's (pre-processed) image (ImageDataset.py:65-66)
+        file_path = os.path.join(root, split + "." + file) if file is not None else None
+        if file_path is None:                         # no data file: transform only, for inference on a shipped checkpoint
+            self.images = None
+        elif ".npy" in file_path:                     # one array holding every sample's (pre-processed) image (ImageDataset.py:65-66)
             self.images = [[x] for x in np.load(file_path)]
         else:
             self.images = []
@@ -253,7 +255,17 @@ class ImageDataset(Dataset):
         self.pipeline_split = "validate" if called_by_ensemblor else split
 
     def __len__(self):
-        return len(self.images)
+        return len(self.images or [])
+
+    def inference(self, image):
+        """image path(s) / decoded arrays -> the collated batch: one sample per list entry; an entry may itself be a list (the
+        sample's several images, with ``multi_image``)"""
+        samples = image if isinstance(image, (list, tuple)) else [image]
+        rows = []
+        for smp in samples:
+            items = smp if isinstance(smp, (list, tuple)) else [smp]
+            rows.append({"image": [open_tensor_image(i) if self.tensor_images else open_image(i, self.ext) for i in items]})
+        return self.get_collate_fn()(rows)
 
     def __getitem__(self, index):
         if self.tensor_images:
@@ -287,9 +299,17 @@ class TextDataset(Dataset):
                  vocab_file=None, source="src", **kwargs):
         assert source in ["src", "tgt"]
         assert split is not None, "Argument split cannot be None"
+        assert not (file is not None and vocab_file is not None), "You cannot mention both a data file and a vocab file"
+        assert not (vocab_file is not None and tokenizer is not None), "You cannot mention both a pretrained tokenizer and a vocab file"
+        assert not (source == "tgt" and tokenizer_max_len is None), "You must specify tokenizer_max_len for source tgt"
+        assert file is not None or vocab_file is not None, "Either a data file or a vocab file must be specified"
+        if kwargs.get("hf_dataset") is not None:
+            raise NotImplementedError("TextDataset(hf_dataset=...): hub datasets cannot be fetched here (no network)")
         self.split, self.source, self.tokenizer_max_len = split, source, tokenizer_max_len
         self.processing = PROCESSING[processing] if processing in PROCESSING else eval(processing or "lambda x: x")
-        self.sentences = [self.processing(s.strip()).split() for s in load_file(os.path.join(root, split + "." + file))]
+        # a vocab_file without a data file: tokenizer only, for inference on a shipped checkpoint (TextDataset.py:46-49,70-72)
+        self.sentences = None if file is None else \
+            [self.processing(s.strip()).split() for s in load_file(os.path.join(root, split + "." + file))]
         if tokenizer is not None:
             from transformers import AutoTokenizer
             self.tokenizer = AutoTokenizer.from_pretrained(tokenizer)       # a local directory works; hub ids need a download
@@ -307,10 +327,17 @@ class TextDataset(Dataset):
             self.tokenizer_args.update({"padding": "max_length", "truncation": True, "max_length": tokenizer_max_len})
 
     def __len__(self):
-        return len(self.sentences)
+        return len(self.sentences or [])
 
     def __getitem__(self, index):
         return {"{}_seq".format(self.source): " ".join(self.sentences[index])}
+
+    def inference(self, sentences):
+        """raw sentence(s) -> the collated batch (processing + tokenizer), the entry point the zoo loader's datasets expose"""
+        if isinstance(sentences, str):
+            sentences = [sentences]
+        key = "{}_seq".format(self.source)
+        return self.get_collate_fn()([{key: " ".join(self.processing(s.strip()).split())} for s in sentences])
 
     def get_collate_fn(self):
         def collate_fn(batch):
@@ -343,6 +370,12 @@ class _DeviceImages:
         return batch
 
 
+def _same_batch_size(batch):
+    sizes = {len(v) for k, v in batch.items() if v is not None and hasattr(v, "__len__") and k not in ("images_u8",)}
+    assert len(sizes) <= 1, "elements in batch do not have the same size"
+    return batch
+
+
 class ImSeq(_DeviceImages, Dataset):
     def __init__(self, seq, image, split, ckpt_dir=None, **kwargs):
         self.split = split
@@ -364,6 +397,15 @@ class ImSeq(_DeviceImages, Dataset):
         def collate_fn(batch):
             return {**self.seq.get_collate_fn()(batch), **self.image.get_collate_fn()(batch)}
         return collate_fn
+
+    def inference(self, seq=None, image=None):
+        """ref: datasets/ImSeq.py:39-52 -- raw sentences and / or image paths -> a model-ready batch"""
+        batch = {}
+        if image is not None:
+            batch.update(self.device_transform(self.image.inference(image)))
+        if seq is not None:
+            batch.update(self.seq.inference(seq))
+        return _same_batch_size(batch)
 
     def __repr__(self):
         return "ImSeq\n{} sentences, {} image lists".format(len(self.seq), len(self.image))
