@@ -88,3 +88,20 @@ def test_allgather_negatives_equals_single_process_contrastive_loss():
         torch.testing.assert_close(r[rank]["loss"], r[rank]["lref"])
         torch.testing.assert_close(r[rank]["gt"], r[rank]["rt"], rtol=1e-4, atol=1e-6)
         torch.testing.assert_close(r[rank]["gv"], r[rank]["rv"], rtol=1e-4, atol=1e-6)
+
+
+def _eval_merge(rank, world):
+    from vilmedic_amd.parallel import gather_interleaved, mean_over_ranks
+    full = [f"sample {i}" for i in range(7)]
+    mine = full[rank::world]                                     # create_data_loader's round-robin shard
+    merged = gather_interleaved(mine, dist)
+    loss = mean_over_ranks([2.0, 5.0][rank], dist, weight=len(mine))
+    return merged, loss
+
+
+def test_validation_outputs_and_losses_are_identical_on_every_rank():
+    """every rank must see the same merged refs / hyps (dataset order) and the same sample-weighted loss, so that early stopping and
+    checkpointing decide identically on all ranks"""
+    r = _run(_eval_merge)
+    assert r[0][0] == r[1][0] == [f"sample {i}" for i in range(7)]
+    assert r[0][1] == r[1][1] == pytest.approx((2.0 * 4 + 5.0 * 3) / 7)

@@ -88,8 +88,11 @@ def _normalize_bwd(x, norms, dxh, eps):
 
 
 def _maybe_gather(*xs):
+    """global negatives under data parallelism -- in TRAINING only: validation shards may differ by one batch between ranks, and a
+    collective inside the loss would then wait forever; under no_grad the loss contrasts within the local shard (what the reference
+    does under DDP)"""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and torch.is_grad_enabled():
         from ...parallel import all_gather_with_grad
         n = xs[0].shape[0]
         r = dist.get_rank()

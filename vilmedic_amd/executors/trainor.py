@@ -102,6 +102,9 @@ class Trainor(object):
                         epoch, iteration, self.optimizer.param_groups[0]["lr"], float(torch.stack(losses[-50:]).mean()),
                         out.get("custom_print", "")))
             training_loss = float(torch.stack(losses).mean()) if losses else float("nan")
+            if self.dist is not None:       # the same number on every rank: it can drive early stopping / lr decay (a per-rank value
+                from ..parallel import mean_over_ranks      # would let ranks leave the loop at different epochs)
+                training_loss = mean_over_ranks(training_loss, self.dist, weight=max(1, len(losses)))
             self.logger.info("Epoch {} done: training_loss {:.4f}".format(epoch, training_loss))
             self.training_scheduler.epoch_step()
             early_stop_score = None

@@ -12,6 +12,11 @@ class Validator(object):
         self.splits = [(s, create_data_loader(config, s, logger, called_by_validator=True, rank=rank, world=world))
                        for s in (config.get("splits") or ["validate"])]
         self.scores = []
+        self.world = world
+
+    def _dist(self):
+        import torch.distributed as dist
+        return dist if (self.world > 1 and dist.is_available() and dist.is_initialized()) else None
 
     def start(self):
         models = [m.eval() for m in self.models]
@@ -21,6 +26,14 @@ class Validator(object):
             for split, dl in self.splits:
                 self.logger.info("Running split: {} by ensembling {} models. Using {}.".format(split, len(models), eval_func.__name__))
                 results = eval_func(models, self.config, dl, from_training=self.from_training)
+                dist = self._dist()
+                if dist is not None:       # every rank evaluated its shard: merge, so that all ranks score the SAME full split
+                    from ..parallel import gather_interleaved, mean_over_ranks
+                    results = dict(results)
+                    if "loss" in results:
+                        results["loss"] = mean_over_ranks(float(results["loss"]), dist, weight=max(1, len(dl.dataset)))
+                    if isinstance(results.get("hyps"), list) and isinstance(results.get("refs"), list):
+                        results["refs"], results["hyps"] = gather_interleaved(results["refs"], dist), gather_interleaved(results["hyps"], dist)
                 scores = {}
                 if "loss" in results:
                     scores["validation_loss"] = float(results["loss"])

@@ -165,3 +165,32 @@ class _AllGather(torch.autograd.Function):
         g = g.contiguous()
         dist.all_reduce(g, op=dist.ReduceOp.SUM)      # reduce-scatter expressed as all-reduce + slice (small payload)
         return g[rank * n:(rank + 1) * n], None
+
+
+# ---- rank-consistent evaluation: every rank must take the same early-stop / checkpoint decision, otherwise one rank leaves the
+# training loop while the others wait in the next gradient all-reduce
+def gather_interleaved(items, dist):
+    """per-rank lists of a round-robin sharded dataset (rank r holds samples r, r + world, ...) -> the full list in dataset
+    order, on every rank"""
+    world = dist.get_world_size()
+    if world == 1:
+        return list(items)
+    parts = [None] * world
+    dist.all_gather_object(parts, list(items))
+    out = []
+    for i in range(max(len(p) for p in parts)):
+        for p in parts:
+            if i < len(p):
+                out.append(p[i])
+    return out
+
+
+def mean_over_ranks(value, dist, weight=1.0, device=None):
+    """weighted mean of a python scalar over ranks (weight = the number of samples it averages), identical on every rank"""
+    if dist.get_world_size() == 1:
+        return float(value)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([float(value) * float(weight), float(weight)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t[0] / t[1]) if float(t[1]) > 0 else float("nan")
