@@ -192,3 +192,19 @@ def test_gloria_all_pairs_local_loss_matches_reference_fixture(golden):
     r0, r1 = O.gloria_local_loss(loc.detach(), words.detach(), lens[:B], 4.0, 5.0, 10.0)
     torch.testing.assert_close(torch.stack([a0, a1]), torch.stack([r0, r1]), rtol=1e-5, atol=1e-5)
     assert [m.shape[1] for m in maps] == lens[:B]
+
+
+def test_data_parallel_training_shards_have_equal_batch_counts():
+    """create_data_loader under WORLD_SIZE > 1: every rank iterates the same number of training batches (an extra batch on one rank
+    would hang its gradient all-reduce); validation keeps every sample"""
+    import logging
+    from vilmedic_amd.config import wrap
+    from vilmedic_amd.executors.utils import create_data_loader
+    logger = logging.getLogger("t"); logger.settings = logger.info
+    for n, world, bs in [(17, 2, 4), (16, 2, 8), (23, 3, 4), (9, 4, 2)]:
+        cfg = wrap({"dataset": {"proto": "SyntheticImSeq", "num_samples": n, "image_size": 8, "vocab_size": 50, "tokenizer_max_len": 8},
+                    "batch_size": bs, "num_workers": 0})
+        counts = [len(create_data_loader(cfg, "train", logger, rank=r, world=world)) for r in range(world)]
+        assert len(set(counts)) == 1, (n, world, bs, counts)
+        val = [len(create_data_loader(cfg, "validate", logger, called_by_validator=True, rank=r, world=world).dataset) for r in range(world)]
+        assert sum(val) == n

@@ -105,7 +105,10 @@ def create_data_loader(config, split, logger, called_by_validator=False, rank=0,
     else:
         collate = torch.utils.data.dataloader.default_collate
     if world > 1:   # shard the samples by rank (what accelerator.prepare(dl) does, trainor_accelerate.py:91-93)
-        dataset = torch.utils.data.Subset(dataset, list(range(rank, len(dataset), world)))
+        # the TRAINING shards are cut to equal length (the remainder of N / world is dropped, like DistributedSampler(drop_last)):
+        # one rank with an extra batch would wait alone in that batch's gradient all-reduce
+        n = len(dataset) // world * world if (split == "train" and not called_by_validator) else len(dataset)
+        dataset = torch.utils.data.Subset(dataset, list(range(rank, n, world)))
         for attr in ("tokenizer", "tokenizer_max_len", "seq", "src", "tgt", "tgt_tokenizer", "tgt_tokenizer_max_len", "labels_map"):
             if hasattr(dataset.dataset, attr):
                 setattr(dataset, attr, getattr(dataset.dataset, attr))
