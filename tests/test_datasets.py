@@ -163,6 +163,13 @@ def test_label_and_seq2seq_compositions(tmp_path):
                     image=image, split="validate", ckpt_dir=ck)
     b = i2s.get_collate_fn()([i2s[0]])
     assert set(b) == {"input_ids", "attention_mask", "decoder_input_ids", "decoder_attention_mask", "images_u8", "images_n", "images_mask"}
+    from vilmedic_amd.datasets import ImSeqAny
+    for split in ("train", "validate"):
+        open(os.path.join(root, f"{split}.meta.tok"), "w").write("\n".join("study-%d" % i for i in range(len(single[split]))))
+    isa = ImSeqAny(seq=seq, any=dict(root=root, file="meta.tok", name="study", processing="lambda x: x.upper()"), image=image, split="train",
+                   ckpt_dir=os.path.join(root, "ckpt"))
+    b = isa.get_collate_fn()([isa[1], isa[4]])
+    assert b["study"] == ["STUDY-1", "STUDY-4"] and b["input_ids"].shape == (2, 12) and len(b["images_u8"]) == 2
 
 
 @pytest.mark.gpu

@@ -124,4 +124,5 @@ class TensorImSeq(SyntheticImSeq):
 
 
 from .imseq import DeviceBatchLoader, ImSeq  # noqa: E402,F401  (file-based datasets with the reference's config keys)
-from .combos import ImLabel, ImSeq2Seq, ImSeqLabel, Seq2Seq  # noqa: E402,F401
+from .combos import AnyDataset, ImLabel, ImSeq2Seq, ImSeqAny, ImSeqLabel, LabelDataset, Seq2Seq  # noqa: E402,F401
+from .imseq import ImageDataset, TextDataset  # noqa: E402,F401

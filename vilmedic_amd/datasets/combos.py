@@ -144,6 +144,58 @@ class ImSeqLabel(_DeviceImages, Dataset):
         return "ImSeqLabel\n" + str(self.imgseq) + "\n" + str(self.label)
 
 
+class AnyDataset(Dataset):
+    """one processed line of ``{split}.{file}`` per sample under the key ``name`` (collated as a plain list); ref: base/AnyDataset.py"""
+
+    def __init__(self, root=None, file=None, split=None, processing=None, name=None, **kwargs):
+        assert split is not None, "Argument split cannot be None"
+        self.root, self.file, self.split, self.name = root, file, split, name or "any"
+        self.processing = eval(processing or "lambda x: x")
+        with open(os.path.join(root, split + "." + file)) as f:
+            self.lines = [self.processing(line.strip()) for line in f]
+
+    def __getitem__(self, index):
+        return {self.name: self.lines[index]}
+
+    def __len__(self):
+        return len(self.lines)
+
+    def get_collate_fn(self):
+        def collate_fn(batch):
+            return {self.name: [s[self.name] for s in batch]}
+        return collate_fn
+
+    def inference(self, sentences):
+        raise NotImplementedError()
+
+
+class ImSeqAny(_DeviceImages, Dataset):
+    """ImSeq + a free-form per-sample field (ref: datasets/ImSeqAny.py)"""
+
+    def __init__(self, seq, any, image, split, ckpt_dir=None, **kwargs):
+        self.split = split
+        self.imgseq = ImSeq(seq, image, split=split, ckpt_dir=ckpt_dir)
+        self.any = AnyDataset(**dict(any), split=split)
+        assert len(self.imgseq) == len(self.any), str(len(self.imgseq)) + "vs " + str(len(self.any))
+        self.seq, self.image = self.imgseq.seq, self.imgseq.image
+        self.tokenizer, self.tokenizer_max_len, self.tokenizer_args = self.seq.tokenizer, self.seq.tokenizer_max_len, self.seq.tokenizer_args
+        self._pipeline = None
+
+    def __getitem__(self, index):
+        return {**self.imgseq[index], **self.any[index]}
+
+    def __len__(self):
+        return len(self.any)
+
+    def get_collate_fn(self):
+        def collate_fn(batch):
+            return {**self.imgseq.get_collate_fn()(batch), **self.any.get_collate_fn()(batch)}
+        return collate_fn
+
+    def __repr__(self):
+        return "ImSeqAny\n" + str(self.imgseq) + "\n{} lines".format(len(self.any))
+
+
 class Seq2Seq(Dataset):
     def __init__(self, src, tgt, split, ckpt_dir=None, **kwargs):
         self.split = split

@@ -95,7 +95,7 @@ def create_optimizer(config, logger, model, state_dict=None):
 def create_data_loader(config, split, logger, called_by_validator=False, rank=0, world=1):
     dcfg = copy.deepcopy(config.dataset)
     proto = dcfg.pop("proto")
-    if proto in ("ImSeq", "ImLabel", "ImSeqLabel", "Seq2Seq", "ImSeq2Seq"):
+    if proto in ("ImSeq", "ImLabel", "ImSeqLabel", "ImSeqAny", "Seq2Seq", "ImSeq2Seq"):
         dcfg.setdefault("ckpt_dir", config.get("ckpt_dir") or "ckpt")
         if called_by_validator and isinstance(dcfg.get("image"), dict) and split == "train":
             dcfg["image"]["called_by_ensemblor"] = True       # evaluation transform on the train split (ImageDataset.py:83-84)
