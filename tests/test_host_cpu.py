@@ -208,3 +208,25 @@ def test_data_parallel_training_shards_have_equal_batch_counts():
         assert len(set(counts)) == 1, (n, world, bs, counts)
         val = [len(create_data_loader(cfg, "validate", logger, called_by_validator=True, rank=r, world=world).dataset) for r in range(world)]
         assert sum(val) == n
+
+
+def test_bleu_matches_reference_scorer_and_compute_scores_dumps(golden, tmp_path):
+    """BLEU against the reference's vendored COCO-caption scorer (fixture G15, exact); ROUGE-N known answers; compute_scores: the
+    config's metric list, dumps next to the checkpoints, unknown metrics skipped"""
+    import json
+    import logging
+    import numpy as np
+    from vilmedic_amd.blocks.scorers import Bleu, Rouge1, Rouge2, compute_scores
+    g = golden("g15_bleu")
+    for n in (4, 2):
+        corpus, per = Bleu(n)(g["refs"], g["hyps"])
+        assert corpus == pytest.approx(g[f"n{n}"]["corpus"], rel=1e-12, abs=1e-15)
+        assert per == pytest.approx(g[f"n{n}"]["per_sentence"], rel=1e-12, abs=1e-15)
+    assert Rouge1()(["the cat sat"], ["the cat"])[0] == pytest.approx(0.8) and Rouge2()(["a b c d"], ["a b x d"])[0] == pytest.approx(1 / 3)
+    logger = logging.getLogger("scores")
+    s = compute_scores(["BLEU", "ROUGEL", "ROUGE2", {"chexbert": {}}], g["refs"], g["hyps"], "validate", 7, str(tmp_path), 3, logger)
+    assert set(s) == {"BLEU", "ROUGEL", "ROUGE2"} and s["BLEU"] == pytest.approx(g["n4"]["corpus"])
+    assert open(tmp_path / "validate_7_hyps.txt").read().split("\n") == g["hyps"]
+    assert json.loads(open(tmp_path / "validate_7_metrics.txt").read())["epoch"] == 3
+    c = compute_scores(["accuracy"], np.array([1, 0, 2, 2]), np.eye(3)[[1, 0, 2, 0]], "test", 0, str(tmp_path), 0, logger)
+    assert c["accuracy"] == 75.0

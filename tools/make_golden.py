@@ -397,6 +397,26 @@ def gen_report_cleaning():
                                      reports_rouge=reports_rouge, rouge=[ns["rouge"](r) for r in reports_rouge]))
 
 
+# ------------------------------------------------------------------ G15: BLEU (the vendored COCO-caption scorer)
+def gen_bleu():
+    """the reference's Bleu wrapper (blocks/scorers/NLG/bleu/bleu.py:24-46) adds (hypothesis, [reference]) pairs to its vendored
+    BleuScorer and asks for option='closest'; the scorer module is loaded by path (pure Python, needs ``six``)."""
+    bs = load_ref("ref_bleu_scorer", "blocks/scorers/NLG/bleu/bleu_scorer.py")
+    refs = ["the heart is normal in size . no pleural effusion .", "no acute cardiopulmonary process .", "lungs are clear",
+            "there is a small left pleural effusion with adjacent atelectasis .", "a", "stable cardiomegaly . no edema .",
+            "no focal consolidation pleural effusion or pneumothorax"]
+    hyps = ["the heart is normal . no effusion .", "no acute cardiopulmonary process .", "the lungs are clear bilaterally without focal consolidation",
+            "small left effusion .", "", "cardiomegaly is stable . no pulmonary edema . no effusion .", "no focal consolidation pleural effusion or pneumothorax is seen"]
+    out = {}
+    for n in (4, 2):
+        scorer = bs.BleuScorer(n=n)
+        for r, h in zip(refs, hyps):
+            scorer += (h, [r])
+        score, scores = scorer.compute_score(option="closest", verbose=0)
+        out[f"n{n}"] = dict(corpus=score[n - 1], per_sentence=list(scores[n - 1]))
+    save("g15_bleu", dict(refs=refs, hyps=hyps, **out))
+
+
 # ------------------------------------------------------------------ G14: VICReg loss
 def gen_vicreg():
     lv = load_ref("ref_vicreg", "blocks/losses/selfsup/VICREGLoss.py")
@@ -445,6 +465,6 @@ def gen_rrs():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs", "vicreg"]
+    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs", "vicreg", "bleu"]
     for w in which:
         globals()["gen_" + w]()

@@ -1,5 +1,6 @@
 """Validator -- ref: vilmedic/executors/validator.py:52-114 (eval_func dispatch under no_grad; metrics reduced to the
 loss and the decode outputs -- the reference's text scorers are CPU metrics over absent packages)."""
+import numpy as np
 import torch
 
 from .utils import create_data_loader, get_eval_func
@@ -12,7 +13,7 @@ class Validator(object):
         self.splits = [(s, create_data_loader(config, s, logger, called_by_validator=True, rank=rank, world=world))
                        for s in (config.get("splits") or ["validate"])]
         self.scores = []
-        self.world = world
+        self.world, self.rank = world, rank
 
     def _dist(self):
         import torch.distributed as dist
@@ -34,10 +35,18 @@ class Validator(object):
                         results["loss"] = mean_over_ranks(float(results["loss"]), dist, weight=max(1, len(dl.dataset)))
                     if isinstance(results.get("hyps"), list) and isinstance(results.get("refs"), list):
                         results["refs"], results["hyps"] = gather_interleaved(results["refs"], dist), gather_interleaved(results["hyps"], dist)
+                    elif isinstance(results.get("hyps"), np.ndarray) and isinstance(results.get("refs"), np.ndarray):   # classifier outputs
+                        results["refs"] = np.stack(gather_interleaved(list(results["refs"]), dist))
+                        results["hyps"] = np.stack(gather_interleaved(list(results["hyps"]), dist))
                 scores = {}
                 if "loss" in results:
                     scores["validation_loss"] = float(results["loss"])
-                if "refs" in results and "hyps" in results and isinstance(results["hyps"], list):
+                metrics = self.config.get("metrics")
+                if metrics and "refs" in results and "hyps" in results:     # the config's metric list (scorers/scores.py:34-151)
+                    from ..blocks.scorers import compute_scores
+                    scores.update(compute_scores(list(metrics), results["refs"], results["hyps"], split, self.seed,
+                                                 self.config.get("ckpt_dir"), self.epoch, self.logger, dump=self.rank == 0))
+                elif "refs" in results and "hyps" in results and isinstance(results["hyps"], list):
                     from ..blocks.scorers import RougeL
                     scores["ROUGEL"] = RougeL()(results["refs"], results["hyps"])[0]
                     scores["n_hyps"] = len(results["hyps"])
