@@ -1,3 +1,4 @@
+# one gpurun call: full GPU test suite, default bench line, rocprofv3 kernel stats of a short bench (outputs under gpurun_out/r01_e)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r01_e
 timeout 110 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > gpurun_out/r01_e/pytest.txt; cat gpurun_out/r01_e/pytest.txt

@@ -1,3 +1,5 @@
+"""torch.profiler pass over one RRG training step: which aten copies / adds / fills are still issued by torch (not by the HIP
+library) and from which Python frames -- the list that drove the LN-fork / arena-view clean-ups.  GPU box only."""
 import os, sys, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import bench

@@ -1,3 +1,4 @@
+"""cost of the two-phase (decoder, then encoder) backward used by ArenaDDP against a single backward call, on one GPU."""
 import os, sys, time, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import bench
