@@ -230,3 +230,28 @@ def test_bleu_matches_reference_scorer_and_compute_scores_dumps(golden, tmp_path
     assert json.loads(open(tmp_path / "validate_7_metrics.txt").read())["epoch"] == 3
     c = compute_scores(["accuracy"], np.array([1, 0, 2, 2]), np.eye(3)[[1, 0, 2, 0]], "test", 0, str(tmp_path), 0, logger)
     assert c["accuracy"] == 75.0
+
+
+@pytest.mark.parametrize("layer_type,hidden_sizes,depths,extra", [
+    ("basic", [16, 32, 48, 64], [2, 1, 2, 1], {}),
+    ("bottleneck", [32, 64, 96, 128], [1, 2, 1, 1], {"downsample_in_bottleneck": True, "downsample_in_first_stage": True}),
+])
+def test_hfresnet_backbone_matches_transformers_resnet(layer_type, hidden_sizes, depths, extra):
+    """``backbone: hfresnet``: state-dict names, feature map and input gradient against the installed transformers ResNetModel
+    (fp32, CPU, train-mode BatchNorm)"""
+    tr = pytest.importorskip("transformers")
+    from vilmedic_amd.blocks.vision import VisualEncoder
+    kw = dict(num_channels=3, embedding_size=8, hidden_sizes=hidden_sizes, depths=depths, layer_type=layer_type, hidden_act="relu", **extra)
+    enc = VisualEncoder(backbone="hfresnet", permute="batch_first", dropout_out=0.0, **kw)
+    ref = tr.ResNetModel(tr.ResNetConfig(**kw))
+    sd = ref.state_dict()
+    assert set(enc.model.state_dict()) == set(sd)
+    enc.model.load_state_dict(sd, strict=True)
+    x = torch.randn(2, 3, 64, 64)
+    a, b = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    enc.model.train(); ref.train()
+    got, want = enc.model(a), ref(b).last_hidden_state
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    got.square().mean().backward(); want.square().mean().backward()
+    torch.testing.assert_close(a.grad, b.grad, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(enc.model.state_dict()["embedder.embedder.normalization.running_mean"], ref.state_dict()["embedder.embedder.normalization.running_mean"])

@@ -1,6 +1,7 @@
 """CNN backbones for VisualEncoder.  torchvision is not installed in this image, so the architectures the shipped
 YAMLs name (resnet18/34/50/101, densenet121/169) are declared here with torchvision's module / parameter names
-(``conv1, bn1, layer1.0.conv1 ...``, ``features.denseblock1.denselayer1.norm1 ...``) so reference checkpoints load.
+(``conv1, bn1, layer1.0.conv1 ...``, ``features.denseblock1.denselayer1.norm1 ...``) so reference checkpoints load;
+``hfresnet`` is the HuggingFace-style ResNet (HF names, ResNetConfig kwargs).
 They run through MIOpen via PyTorch-ROCm (CNN stems are NOT hand-written kernels).
 ref: vilmedic/blocks/vision/visual_encoder.py:71-81 (eval(backbone)(pretrained=...) truncated at output_layer)."""
 from collections import OrderedDict
@@ -148,7 +149,113 @@ _FACTORY = {
 }
 
 
+# ----------------------------------------------------------------------------- HuggingFace-style ResNet (``backbone: hfresnet``)
+_ACT = {"relu": nn.ReLU, "gelu": nn.GELU, "silu": nn.SiLU, "swish": nn.SiLU, "tanh": nn.Tanh}
+
+
+class _HFConvLayer(nn.Module):
+    """convolution (no bias, ``same``-style padding k // 2) -> BatchNorm -> activation, HF parameter names"""
+
+    def __init__(self, cin, cout, kernel_size=3, stride=1, activation="relu"):
+        super().__init__()
+        self.convolution = nn.Conv2d(cin, cout, kernel_size, stride, kernel_size // 2, bias=False)
+        self.normalization = nn.BatchNorm2d(cout)
+        self.activation = _ACT[activation]() if activation is not None else nn.Identity()
+
+    def forward(self, x):
+        return self.activation(self.normalization(self.convolution(x)))
+
+
+class _HFShortCut(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.convolution = nn.Conv2d(cin, cout, 1, stride, bias=False)
+        self.normalization = nn.BatchNorm2d(cout)
+
+    def forward(self, x):
+        return self.normalization(self.convolution(x))
+
+
+class _HFResLayer(nn.Module):
+    """basic (two 3x3) or bottleneck (1x1 -> 3x3 -> 1x1, reduction 4) residual layer; the stride sits on the first 3x3 unless
+    ``downsample_in_bottleneck`` puts it on the first 1x1"""
+
+    def __init__(self, cin, cout, stride, activation, bottleneck, downsample_in_bottleneck):
+        super().__init__()
+        self.shortcut = _HFShortCut(cin, cout, stride) if (cin != cout or stride != 1) else nn.Identity()
+        if bottleneck:
+            mid = cout // 4
+            self.layer = nn.Sequential(
+                _HFConvLayer(cin, mid, 1, stride if downsample_in_bottleneck else 1, activation),
+                _HFConvLayer(mid, mid, 3, 1 if downsample_in_bottleneck else stride, activation),
+                _HFConvLayer(mid, cout, 1, 1, None))
+        else:
+            self.layer = nn.Sequential(_HFConvLayer(cin, cout, 3, stride, activation), _HFConvLayer(cout, cout, 3, 1, None))
+        self.activation = _ACT[activation]()
+
+    def forward(self, x):
+        return self.activation(self.layer(x) + self.shortcut(x))
+
+
+class _HFStage(nn.Module):
+    def __init__(self, cin, cout, stride, depth, **kw):
+        super().__init__()
+        self.layers = nn.Sequential(_HFResLayer(cin, cout, stride, **kw), *[_HFResLayer(cout, cout, 1, **kw) for _ in range(depth - 1)])
+
+    def forward(self, x):
+        return self.layers(x)
+
+
+class _HFEmbeddings(nn.Module):
+    def __init__(self, num_channels, embedding_size, activation):
+        super().__init__()
+        self.embedder = _HFConvLayer(num_channels, embedding_size, 7, 2, activation)
+        self.pooler = nn.MaxPool2d(3, 2, 1)
+
+    def forward(self, x):
+        return self.pooler(self.embedder(x))
+
+
+class _HFEncoder(nn.Module):
+    def __init__(self, embedding_size, hidden_sizes, depths, downsample_in_first_stage, **kw):
+        super().__init__()
+        sizes = [embedding_size] + list(hidden_sizes)
+        self.stages = nn.ModuleList([_HFStage(sizes[i], sizes[i + 1], 2 if (i > 0 or downsample_in_first_stage) else 1, depths[i], **kw)
+                                     for i in range(len(hidden_sizes))])
+
+    def forward(self, x):
+        for stage in self.stages:
+            x = stage(x)
+        return x
+
+
+class HFResNetModel(nn.Module):
+    """``VisualEncoder(backbone='hfresnet', **ResNetConfig kwargs)`` (ref: visual_encoder.py:63-65): the architecture and the
+    state-dict names of HuggingFace's ResNetModel (``embedder.embedder.convolution.weight``,
+    ``encoder.stages.i.layers.j.{shortcut,layer.k}.{convolution,normalization}.*``), returning the last feature map -- what the
+    reference reads as ``.last_hidden_state`` (visual_encoder.py:188-190).  Convolutions run through MIOpen like every CNN
+    backbone here.  Checked against the installed transformers ResNetModel in tests/test_host_cpu.py."""
+
+    def __init__(self, num_channels=3, embedding_size=64, hidden_sizes=(256, 512, 1024, 2048), depths=(3, 4, 6, 3),
+                 layer_type="bottleneck", hidden_act="relu", downsample_in_first_stage=False, downsample_in_bottleneck=False, **kwargs):
+        super().__init__()
+        if layer_type not in ("basic", "bottleneck"):
+            raise ValueError(f"layer_type={layer_type} is not one of basic, bottleneck")
+        self.embedder = _HFEmbeddings(num_channels, embedding_size, hidden_act)
+        self.encoder = _HFEncoder(embedding_size, hidden_sizes, depths, downsample_in_first_stage, activation=hidden_act,
+                                  bottleneck=layer_type == "bottleneck", downsample_in_bottleneck=downsample_in_bottleneck)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, pixel_values):
+        return self.encoder(self.embedder(pixel_values))
+
+
 def build(backbone, output_layer, pretrained, **kwargs):
+    if "hfresnet" in backbone.lower():
+        kwargs.pop("return_dict", None)
+        return HFResNetModel(**kwargs)
     if "densenet" in backbone and output_layer == "avgpool":          # visual_encoder.py:48-53
         sub = build(backbone, "features", pretrained, **kwargs)
         sub.add_module("relu", nn.ReLU(inplace=True))
