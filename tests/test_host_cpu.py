@@ -135,7 +135,8 @@ def test_out_of_scope_models_raise():
 
 
 @pytest.mark.parametrize("rel", ["RRG/rrg-vit-synthetic.yml", "RRG/rrg-hf-synthetic.yml", "SELFSUP/convirt-synthetic.yml",
-                                 "SELFSUP/gloria-synthetic.yml", "MVQA/vqa-synthetic.yml", "RRS/rrs-synthetic.yml"])
+                                 "SELFSUP/gloria-synthetic.yml", "MVQA/vqa-synthetic.yml", "RRS/rrs-synthetic.yml",
+                                 "RRG/rrg-scst-synthetic.yml"])
 def test_every_shipped_yaml_parses_and_constructs(rel):
     """plugin-surface test: every YAML under config/ goes through the loader, ``eval(proto)`` resolves the
     dataset and the model class and the model constructs (reduced depth / width so it stays a CPU-second test)."""
@@ -144,7 +145,7 @@ def test_every_shipped_yaml_parses_and_constructs(rel):
     from vilmedic_amd import datasets as D, models as M
     from vilmedic_amd.config import executor_view, get_config
     small = ["dataset.num_samples=4"]
-    if "RRG/rrg-vit" in rel:
+    if "RRG/rrg-vit" in rel or "rrg-scst" in rel:
         small += ["model.decoder.num_hidden_layers=1", "model.cnn.num_hidden_layers=1"]
     if "rrg-hf" in rel:
         small += ["model.vision.proto_config_args.num_hidden_layers=1", "model.decoder.proto_config_args.num_hidden_layers=1"]
