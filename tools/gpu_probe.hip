@@ -172,6 +172,7 @@ static int test_ln(int rows, int cols) {
 
 // A/B of VM_GEMM_PIPE on one shape with one set of (rotating) buffers: pipe 0,1,0,1
 static int g_pipe_a = 0, g_pipe_b = 1;
+static const char* g_ab_env = "VM_GEMM_PIPE";     // the switch bench_ab toggles (VM_GEMM_PIPE, VM_GEMM_VARIANT, ...)
 static void bench_ab(int M, int N, int K, int la, int lb, int flags, int split) {
     const int rot = 4;
     int64_t lda = la == 0 ? K : M, ldb = lb == 0 ? K : N;
@@ -191,7 +192,7 @@ static void bench_ab(int M, int N, int K, int la, int lb, int flags, int split) 
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     float us[2][2];
     for (int rep = 0; rep < 2; ++rep) for (int pipe = 0; pipe < 2; ++pipe) {
-        { char pb[4]; snprintf(pb, 4, "%d", pipe ? g_pipe_b : g_pipe_a); setenv("VM_GEMM_PIPE", pb, 1); vm_reload_env(); }
+        { char pb[4]; snprintf(pb, 4, "%d", pipe ? g_pipe_b : g_pipe_a); setenv(g_ab_env, pb, 1); vm_reload_env(); }
         const int it = 16;
         for (int i = -2; i < it; ++i) {
             if (i == 0) hipEventRecord(a, nullptr);
@@ -227,13 +228,19 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
-    if (argc >= 2 && !strcmp(argv[1], "pipe")) {   // A/B of the software-pipelined main loop (VM_GEMM_PIPE=1) on the training step's shapes
+    // gpu_probe.bin pipe [A B]        A/B of two VM_GEMM_PIPE settings (default 0 1) on the training step's shapes
+    // gpu_probe.bin ab ENV A B        the same for any integer switch of the library, e.g.  ab VM_GEMM_VARIANT 0 7
+    if (argc >= 2 && (!strcmp(argv[1], "pipe") || (!strcmp(argv[1], "ab") && argc >= 5))) {
         int fails = 0;
-        if (argc >= 4) { g_pipe_a = atoi(argv[2]); g_pipe_b = atoi(argv[3]); }
-        printf("A = VM_GEMM_PIPE=%d (pipe0 columns), B = VM_GEMM_PIPE=%d (pipe1 columns)\n", g_pipe_a, g_pipe_b);
-        { char pb[4]; snprintf(pb, 4, "%d", g_pipe_b); setenv("VM_GEMM_PIPE", pb, 1); }
+        const bool generic = !strcmp(argv[1], "ab");
+        if (generic) { g_ab_env = argv[2]; g_pipe_a = atoi(argv[3]); g_pipe_b = atoi(argv[4]); }
+        else if (argc >= 4) { g_pipe_a = atoi(argv[2]); g_pipe_b = atoi(argv[3]); }
+        printf("A = %s=%d (pipe0 columns), B = %s=%d (pipe1 columns)\n", g_ab_env, g_pipe_a, g_ab_env, g_pipe_b);
+        { char pb[4]; snprintf(pb, 4, "%d", g_pipe_b); setenv(g_ab_env, pb, 1); }
+        const bool variant_ab = !strcmp(g_ab_env, "VM_GEMM_VARIANT");
         for (int variant = 0; variant <= 4; variant += 4) {
-            { char b[4]; snprintf(b, 4, "%d", variant); setenv("VM_GEMM_VARIANT", b, 1); vm_reload_env(); }
+            if (variant_ab) { if (variant) break; vm_reload_env(); variant = g_pipe_b; }      // correctness of setting B itself
+            else { char b[4]; snprintf(b, 4, "%d", variant); setenv("VM_GEMM_VARIANT", b, 1); vm_reload_env(); }
             for (int la = 0; la < (variant == 4 ? 1 : 2); ++la) for (int lb = 0; lb < 2; ++lb) {
                 fails += test_gemm(200, 136, 192, la, lb, 1, false);
                 fails += test_gemm(333, 97, 128, la, lb, 1, true);
@@ -242,9 +249,10 @@ int main(int argc, char** argv) {
             }
             if (variant != 4) fails += test_gemm(256, 256, 1024, 1, 1, 4, true);
             fails += test_gemm(1000, 768, 768, 0, 0, 1, false);
+            if (variant_ab) break;
         }
-        unsetenv("VM_GEMM_VARIANT");
-        printf("pipe correctness fails=%d\n", fails);
+        if (!variant_ab) unsetenv("VM_GEMM_VARIANT");
+        printf("correctness with setting B: fails=%d\n", fails);
         struct { int M, N, K, la, lb, flags, split; } cs[] = {
             {12608, 2304, 768, 0, 0, 1, 1}, {12608, 3072, 768, 0, 0, 7, 1}, {12608, 768, 3072, 0, 0, 49, 1}, {12608, 768, 768, 0, 0, 49, 1},
             {8192, 2304, 768, 0, 0, 1, 1}, {8192, 768, 768, 0, 0, 49, 1}, {8192, 3072, 768, 0, 0, 7, 1}, {8192, 768, 3072, 0, 0, 49, 1},

@@ -11,6 +11,7 @@
 //     touches HBM only in whole 256-B rows.
 // Out-of-range rows/columns are clamped to valid addresses (they only feed outputs that are never stored); the
 // contraction dim has no tail by construction (K % 64 == 0), so no zero-fill is needed.
+#include <type_traits>
 #include "common.h"
 #include "gemm_args.h"
 
@@ -94,8 +95,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
         tm = rr / w; tn = grp * gw + (rr - tm * w);
     }
     const int m0 = tm * FBM, n0 = tn * FBN;
-    const int kt_begin = split * p.ktiles_per_split;
-    int kt_end = min(p.ktiles, kt_begin + p.ktiles_per_split);
+    constexpr int KSC = FBK / BKT;              // the host counts K-tiles of 64; a 32-wide k-tile kernel runs two per host tile
+    const int kt_begin = split * p.ktiles_per_split * KSC;
+    int kt_end = min(p.ktiles, split * p.ktiles_per_split + p.ktiles_per_split) * KSC;
     if (kt_begin >= kt_end) return;
     if (p.dbg == 2) kt_end = kt_begin + 1;
 
@@ -197,7 +199,77 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
         }
     };
-    if (STAGES == 2) {
+    if constexpr (PIPE == 3) {
+        // EXPERIMENT (unmeasured; reached only through VM_GEMM_VARIANT=7): 3-slot ring with the fragments of tile t+1 read into a
+        // second register set WHILE tile t's MFMAs issue.  Every wave drains its LDS reads before each barrier, so after barrier t-1
+        // nobody reads slot (t-1) % 3 any more: tile t+2 is requested into it at the very top of iteration t, BEFORE barrier t, and
+        // has a whole iteration plus the barrier wait to land; behind barrier t the wave goes straight to MFMAs (tile t's fragments
+        // are already in registers) with tile t+1's reads slotted one per MFMA.
+        static_assert(STAGES == 3 && BKT == 32, "ring + register prefetch: 3 slots of 32-wide k-tiles");
+        constexpr int NLD = NA_I + NB_I, NFR = MF + 4, NMF = 4 * MF, RA = LA == 0 ? 1 : 2, RB = LB == 0 ? 1 : 2;
+        static_assert(NFR <= NMF, "one fragment per MFMA slot");
+        const int nk = kt_end - kt_begin;
+        bf16x8_t fa[2][MF], fb[2][4];
+        auto read_tile = [&](int slot, auto set_c) {          // fragment order b0 a0 b1 a1 b2 a2 b3 a3 a4 ...
+            constexpr int SET = decltype(set_c)::value;
+            const char* sa = smem + slot * F_STAGE;
+            const char* sb = sa + F_OPER_A;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                fb[SET][j] = LB == 0 ? read_frag0(sb, b_rb, j, 0) : read_frag1(sb, b_rb, j, 0, FBN * 2);
+                fa[SET][j] = LA == 0 ? read_frag0(sa, a_rb, j, 0) : read_frag1(sa, a_rb, j, 0, FBM * 2);
+            }
+#pragma unroll
+            for (int i = 4; i < MF; ++i) fa[SET][i] = LA == 0 ? read_frag0(sa, a_rb, i, 0) : read_frag1(sa, a_rb, i, 0, FBM * 2);
+        };
+        auto mfma_tile = [&](auto set_c) {
+            constexpr int SET = decltype(set_c)::value;
+#pragma unroll
+            for (int d = 0; d < 4 + MF - 1; ++d)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = d - j;
+                    if (i >= 0 && i < MF) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[SET][j], fa[SET][i], acc[j][i], 0, 0, 0);
+                }
+        };
+        auto iteration = [&](int it, int slot, auto cur_c) {   // slot = it % 3
+            constexpr int CUR = decltype(cur_c)::value;
+            const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot == 0 ? 2 : slot - 1;     // (it + 1) % 3, (it + 2) % 3
+            if (it + 2 < nk) stage(slot2);
+            if (it + 1 < nk) {
+                if (it + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLD) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                  // tile it+1 landed for every wave
+                read_tile(slot1, std::integral_constant<int, CUR ^ 1>{});
+                mfma_tile(cur_c);
+#pragma unroll
+                for (int n = 0; n < NFR; ++n) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (n < 8 && (n & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x100, RB, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x100, RA, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NMF - NFR, 0);
+            } else {
+                mfma_tile(cur_c);
+            }
+        };
+        stage(0);
+        if (nk > 1) {
+            stage(1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        read_tile(0, std::integral_constant<int, 0>{});
+        int slot = 0;
+        for (int it = 0; it < nk; it += 2) {
+            iteration(it, slot, std::integral_constant<int, 0>{});
+            slot = slot == 2 ? 0 : slot + 1;
+            if (it + 1 < nk) iteration(it + 1, slot, std::integral_constant<int, 1>{});
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+    } else if (STAGES == 2) {
         stage(0);
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             const int buf = (kt - kt_begin) & 1;
@@ -430,6 +502,10 @@ int vm_gemm_fast_dispatch(const GemmArgs& a0, int a_layout, int b_layout, int nb
     const int pipe = vm_env().gemm_pipe;
     if (variant == 1) return dispatch_layout<4, 2, 3, 64, 4>(a0, a_layout, b_layout, nblocks, s);
     if (variant == 2) return dispatch_layout<4, 4, 2, 64, 4>(a0, a_layout, b_layout, nblocks, s);
+    if (variant == 7)                    // EXPERIMENT (unmeasured): 128x128 tile, k-tile 32, 3-slot ring + register prefetch
+        return dispatch_layout<2, 2, 3, 32, 4, 3>(a0, a_layout, b_layout, nblocks, s);
+    if (variant == 5)                    // EXPERIMENT (unmeasured, only via VM_GEMM_VARIANT=5): 256x128 tile, 4 waves of 128x64, k-tile 32,
+        return dispatch_layout<2, 2, 3, 32, 8>(a0, a_layout, b_layout, nblocks, s);   // 3-stage ring (two tiles in flight), 72 KiB LDS
     if (variant == 4) {                  // 160x128 tile (A row-major only): evens out the tile count when 128-row tiles leave a thin last round
         if (a_layout != 0) { vm_set_error("vm_gemm_bf16: 160-row tile needs a row-major A"); return VM_EINVAL; }
         if (pipe == 1) return b_layout == 0 ? launch_fast<0, 0, 2, 2, 2, 64, 5, 1>(a0, nblocks, s) : launch_fast<0, 1, 2, 2, 2, 64, 5, 1>(a0, nblocks, s);
@@ -440,6 +516,6 @@ int vm_gemm_fast_dispatch(const GemmArgs& a0, int a_layout, int b_layout, int nb
     return dispatch_layout<2, 2, 2, 64, 4>(a0, a_layout, b_layout, nblocks, s);
 }
 void vm_gemm_variant_tile(int variant, int* bm, int* bn) {
-    *bm = (variant == 1 || variant == 2) ? 256 : variant == 4 ? 160 : 128;
+    *bm = (variant == 1 || variant == 2 || variant == 5) ? 256 : variant == 4 ? 160 : 128;
     *bn = variant == 2 ? 256 : 128;
 }
