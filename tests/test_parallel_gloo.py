@@ -105,3 +105,74 @@ def test_validation_outputs_and_losses_are_identical_on_every_rank():
     r = _run(_eval_merge)
     assert r[0][0] == r[1][0] == [f"sample {i}" for i in range(7)]
     assert r[0][1] == r[1][1] == pytest.approx((2.0 * 4 + 5.0 * 3) / 7)
+
+
+class _FakeArena:
+    """the slice of ParamArena that ArenaDDP uses (flat parameters, flat gradients with ``p.grad`` views, offsets), on the CPU: the
+    real arena refuses CPU tensors by design, the orchestration under test does not care where the buffers live"""
+
+    def __init__(self, model):
+        params = list(model.parameters())
+        self.numel = sum(p.numel() for p in params)
+        self.flat, self.gflat = torch.zeros(self.numel), torch.zeros(self.numel)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                n = p.numel()
+                self.flat[off:off + n].copy_(p.reshape(-1))
+                p.data = self.flat[off:off + n].view(p.shape)
+                p.grad = self.gflat[off:off + n].view(p.shape)
+                p._vm_off = off
+                off += n
+
+    def valid(self):
+        return True
+
+    def refresh(self, force=False):
+        pass
+
+
+class _TwoPhase(torch.nn.Module):
+    """decoder parameters first, encoder parameters last (the arena order ArenaDDP's split needs), RRG's detach protocol"""
+
+    def __init__(self):
+        super().__init__()
+        self.dec = torch.nn.Sequential(torch.nn.Linear(12, 24), torch.nn.Tanh(), torch.nn.Linear(24, 3))
+        self.enc = torch.nn.Sequential(torch.nn.Linear(10, 12), torch.nn.Tanh())
+        self.split_backward, self._split = False, None
+
+    def forward(self, x, y):
+        feats = self.enc(x)
+        if self.split_backward and torch.is_grad_enabled():
+            leaf = feats.detach().requires_grad_(True)
+            self._split = (feats, leaf)
+            feats = leaf
+        return torch.nn.functional.mse_loss(self.dec(feats), y)
+
+
+def _arena_ddp(rank, world):
+    from vilmedic_amd.parallel import ArenaDDP
+    torch.manual_seed(3 + rank)                      # replicas start DIFFERENT: the constructor's broadcast must align them
+    model = _TwoPhase()
+    model.__dict__["_vm_arena_cache"] = _FakeArena(model)
+    ddp = ArenaDDP(model, dist, chunks=4, bf16_wire=False)
+    assert ddp.split_at == sum(p.numel() for p in model.dec.parameters()) and model.split_backward
+    g = torch.Generator().manual_seed(11)
+    X, Y = torch.randn(8, 10, generator=g), torch.randn(8, 3, generator=g)
+    loss = model(X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4])
+    ddp.backward(loss)                               # decoder range reduced first, then the encoder range
+    assert model._split is None
+    ref = _TwoPhase()
+    ref.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+    ref(X, Y).backward()
+    return (ddp.arena.flat.clone(), ddp.arena.gflat.clone(),
+            torch.cat([p.grad.reshape(-1) for p in ref.parameters()]))
+
+
+def test_arena_ddp_two_phase_backward_equals_single_process_gradient():
+    """ArenaDDP end to end on two gloo ranks: parameter broadcast, decoder / encoder split point, two-phase backward with the chunked
+    all-reduce of each range, result = the gradient of the loss on the concatenated batch"""
+    r = _run(_arena_ddp)
+    torch.testing.assert_close(r[0][0], r[1][0], rtol=0, atol=0)                 # identical replicas after the broadcast
+    for rank in (0, 1):
+        torch.testing.assert_close(r[rank][1], r[rank][2], rtol=1e-5, atol=1e-6)
