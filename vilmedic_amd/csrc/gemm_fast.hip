@@ -149,7 +149,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
     auto compute = [&](int buf) {
         const char* sa = smem + buf * F_STAGE;
         const char* sb = sa + F_OPER_A;
-        if constexpr (PIPE == 1 && BKT == 64) {
+        if constexpr ((PIPE == 1 || PIPE == 2) && BKT == 64) {
             // software-pipelined K-tile: the first 32-wide k-half's fragments are requested up front, the second half's
             // reads are slotted one per MFMA behind the first MFMAs of the first half (sched_group_barrier: 0x100 = LDS read, 0x008 = MFMA),
             // so only the first reads' latency is exposed per K-tile
@@ -164,6 +164,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
 #pragma unroll
                 for (int i = 4; i < MF; ++i) fa[kk][i] = LA == 0 ? read_frag0(sa, a_rb, i, kk) : read_frag1(sa, a_rb, i, kk, FBM * 2);
             }
+            // PIPE == 2 (EXPERIMENT, unmeasured, VM_GEMM_PIPE=2): the same schedule with the wave's issue priority raised while it
+            // has MFMAs to issue, so that the SIMD's other wave (DMA issue, barrier, epilogue) does not delay them
+            if constexpr (PIPE == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -183,6 +186,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 2 * NMF - NRD, 0);
+            if constexpr (PIPE == 2) __builtin_amdgcn_s_setprio(0);
             return;
         }
 #pragma unroll
@@ -508,10 +512,12 @@ int vm_gemm_fast_dispatch(const GemmArgs& a0, int a_layout, int b_layout, int nb
         return dispatch_layout<2, 2, 3, 32, 8>(a0, a_layout, b_layout, nblocks, s);   // 3-stage ring (two tiles in flight), 72 KiB LDS
     if (variant == 4) {                  // 160x128 tile (A row-major only): evens out the tile count when 128-row tiles leave a thin last round
         if (a_layout != 0) { vm_set_error("vm_gemm_bf16: 160-row tile needs a row-major A"); return VM_EINVAL; }
+        if (pipe == 2) return b_layout == 0 ? launch_fast<0, 0, 2, 2, 2, 64, 5, 2>(a0, nblocks, s) : launch_fast<0, 1, 2, 2, 2, 64, 5, 2>(a0, nblocks, s);
         if (pipe == 1) return b_layout == 0 ? launch_fast<0, 0, 2, 2, 2, 64, 5, 1>(a0, nblocks, s) : launch_fast<0, 1, 2, 2, 2, 64, 5, 1>(a0, nblocks, s);
         if (b_layout == 0) return launch_fast<0, 0, 2, 2, 2, 64, 5>(a0, nblocks, s);
         return launch_fast<0, 1, 2, 2, 2, 64, 5>(a0, nblocks, s);
     }
+    if (pipe == 2) return dispatch_layout<2, 2, 2, 64, 4, 2>(a0, a_layout, b_layout, nblocks, s);
     if (pipe == 1) return dispatch_layout<2, 2, 2, 64, 4, 1>(a0, a_layout, b_layout, nblocks, s);
     return dispatch_layout<2, 2, 2, 64, 4>(a0, a_layout, b_layout, nblocks, s);
 }
