@@ -108,6 +108,52 @@ def vit_forward(images, state, cfg, prefix=""):
     return layer_norm(x, state, prefix + "layernorm", eps)
 
 
+def hf_resnet_forward(images, state, cfg, prefix="", training=True):
+    """HuggingFace-style ResNet feature map (``backbone: hfresnet``, ref:vilmedic/blocks/vision/visual_encoder.py:63-65,188-190 ->
+    hf:models/resnet/modeling_resnet.py): stem conv7x7/2 + BN + act + maxpool3x3/2, then stages of basic (3x3, 3x3) or bottleneck
+    (1x1, 3x3, 1x1 with reduction 4) residual layers; the stride sits on the first 3x3 (on the first 1x1 with
+    ``downsample_in_bottleneck``); stage 0 is strided only with ``downsample_in_first_stage``.  BatchNorm uses batch statistics when
+    ``training`` (running statistics are not updated here).  Pinned against transformers' ResNetModel in tests/test_oracle_golden.py."""
+    act = {"relu": F.relu, "gelu": F.gelu}[cfg.get("hidden_act", "relu")]
+
+    def conv_bn(x, p, stride, activate):
+        w = state[p + ".convolution.weight"]
+        x = F.conv2d(x, w, None, stride, w.shape[-1] // 2)
+        x = F.batch_norm(x, state[p + ".normalization.running_mean"].clone(), state[p + ".normalization.running_var"].clone(),
+                         state[p + ".normalization.weight"], state[p + ".normalization.bias"], training, 0.1, 1e-5)
+        return act(x) if activate else x
+
+    bottleneck = cfg.get("layer_type", "bottleneck") == "bottleneck"
+    dib = bool(cfg.get("downsample_in_bottleneck", False))
+    x = conv_bn(images, prefix + "embedder.embedder", 2, True)
+    x = F.max_pool2d(x, 3, 2, 1)
+    for si, depth in enumerate(cfg["depths"]):
+        for li in range(depth):
+            p = f"{prefix}encoder.stages.{si}.layers.{li}"
+            stride = (2 if (si > 0 or cfg.get("downsample_in_first_stage", False)) else 1) if li == 0 else 1
+            short = conv_bn(x, p + ".shortcut", stride, False) if (p + ".shortcut.convolution.weight") in state else x
+            if bottleneck:
+                h = conv_bn(x, p + ".layer.0", stride if dib else 1, True)
+                h = conv_bn(h, p + ".layer.1", 1 if dib else stride, True)
+                h = conv_bn(h, p + ".layer.2", 1, False)
+            else:
+                h = conv_bn(x, p + ".layer.0", stride, True)
+                h = conv_bn(h, p + ".layer.1", 1, False)
+            x = act(h + short)
+    return x
+
+
+def rrg_cnn_forward(images, input_ids, attention_mask, state, cnn_cfg, dec_cfg, training=True):
+    """RRG.forward with an hfresnet VisualEncoder, ``permute: batch_first`` and an optional visual_projection (BASELINE.json
+    configs[0]; ref:vilmedic/models/rrg/RRG.py:25-41, visual_encoder.py:196-203,137-139).  state keys as the model's:
+    ``enc.model.*``, ``enc.visual_projection.*``, ``dec.decoder.*``."""
+    fmap = hf_resnet_forward(images, state, cnn_cfg, prefix="enc.model.", training=training)
+    feats = fmap.view(*fmap.shape[:2], -1).permute(0, 2, 1)                  # [B, HW, C]
+    feats, mask = visual_encode(feats, state, "enc.visual_projection")
+    dec_state = {k[len("dec.decoder."):]: v for k, v in state.items() if k.startswith("dec.decoder.")}
+    return decoder_forward(input_ids, attention_mask, feats, mask, dec_state, dec_cfg)
+
+
 def visual_encode(features, state, prefix="visual_projection"):
     """VisualEncoder.encode tail: mask from feature magnitude, then optional
     projection (ref:vilmedic/blocks/vision/visual_encoder.py:137-139)."""

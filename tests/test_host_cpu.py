@@ -136,7 +136,7 @@ def test_out_of_scope_models_raise():
 
 @pytest.mark.parametrize("rel", ["RRG/rrg-vit-synthetic.yml", "RRG/rrg-hf-synthetic.yml", "SELFSUP/convirt-synthetic.yml",
                                  "SELFSUP/gloria-synthetic.yml", "MVQA/vqa-synthetic.yml", "RRS/rrs-synthetic.yml",
-                                 "RRG/rrg-scst-synthetic.yml"])
+                                 "RRG/rrg-scst-synthetic.yml", "RRG/rrg-resnet18-synthetic.yml"])
 def test_every_shipped_yaml_parses_and_constructs(rel):
     """plugin-surface test: every YAML under config/ goes through the loader, ``eval(proto)`` resolves the
     dataset and the model class and the model constructs (reduced depth / width so it stays a CPU-second test)."""
@@ -145,6 +145,8 @@ def test_every_shipped_yaml_parses_and_constructs(rel):
     from vilmedic_amd import datasets as D, models as M
     from vilmedic_amd.config import executor_view, get_config
     small = ["dataset.num_samples=4"]
+    if "rrg-resnet18" in rel:
+        small += ["dataset.image_size=64"]
     if "RRG/rrg-vit" in rel or "rrg-scst" in rel:
         small += ["model.decoder.num_hidden_layers=1", "model.cnn.num_hidden_layers=1"]
     if "rrg-hf" in rel:
@@ -256,3 +258,24 @@ def test_hfresnet_backbone_matches_transformers_resnet(layer_type, hidden_sizes,
     got.square().mean().backward(); want.square().mean().backward()
     torch.testing.assert_close(a.grad, b.grad, rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(enc.model.state_dict()["embedder.embedder.normalization.running_mean"], ref.state_dict()["embedder.embedder.normalization.running_mean"])
+
+
+def test_c1_model_state_dict_drives_the_oracle():
+    """BASELINE configs[0] (hfresnet-18 + projection + 2-layer decoder): the product model's own state dict (HF / reference names)
+    is exactly what oracle.rrg_cnn_forward consumes -- the CPU half of the C1 parity test (the HIP half needs a GPU)"""
+    from oracle import torch_ref as O
+    from vilmedic_amd.models import RRG
+    cnn = dict(proto="VisualEncoder", backbone="hfresnet", permute="batch_first", dropout_out=0.0, layer_type="basic", embedding_size=8,
+               hidden_sizes=[8, 16, 24, 32], depths=[1, 1, 1, 1], hidden_act="relu", visual_projection=dict(in_features=32, out_features=128))
+    model = RRG(decoder=dict(proto=None, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **R.DEC_TINY), cnn=dict(cnn))
+    st = {k: v.detach().clone() for k, v in model.state_dict().items() if "lm_head.decoder" not in k}
+    images = R.make_images(2, 64, seed=3)
+    ids, am = R.make_reports(2, 12, R.DEC_TINY["vocab_size"], seed=3)
+    cnn_cfg = {k: cnn[k] for k in ("layer_type", "hidden_sizes", "depths", "hidden_act")}
+    loss, logits = O.rrg_cnn_forward(images, ids, am, st, cnn_cfg, R.DEC_TINY, training=True)
+    assert torch.isfinite(loss) and logits.shape == (2, 12, R.DEC_TINY["vocab_size"])
+    # the product's CNN half (plain torch modules) gives the feature map the oracle computed
+    model.train()
+    fmap = model.enc.model(images)
+    torch.testing.assert_close(fmap, O.hf_resnet_forward(images, st, cnn_cfg, prefix="enc.model.", training=True), rtol=1e-5, atol=1e-5)
+    assert fmap.shape == (2, 32, 2, 2)

@@ -234,3 +234,24 @@ def test_g14_vicreg_loss(golden):
         close(loss, case["loss"])
         close(z1.grad, case["g1"], rtol=1e-3, atol=1e-6)
         close(z2.grad, case["g2"], rtol=1e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("layer_type,hidden_sizes,depths,extra", [
+    ("basic", [16, 32, 48, 64], [2, 1, 2, 1], {}),
+    ("bottleneck", [32, 64, 96, 128], [1, 2, 1, 1], {"downsample_in_bottleneck": True, "downsample_in_first_stage": True}),
+])
+def test_hf_resnet_oracle_matches_transformers(layer_type, hidden_sizes, depths, extra):
+    """the functional hfresnet restatement (BASELINE configs[0]'s encoder) against the installed transformers ResNetModel: feature
+    map and input gradient, train-mode and eval-mode BatchNorm"""
+    tr = pytest.importorskip("transformers")
+    cfg = dict(num_channels=3, embedding_size=8, hidden_sizes=hidden_sizes, depths=depths, layer_type=layer_type, hidden_act="relu", **extra)
+    ref = tr.ResNetModel(tr.ResNetConfig(**cfg))
+    x = torch.randn(3, 3, 64, 64)
+    for training in (True, False):
+        ref.train(training)
+        st = {k: v.detach().clone() for k, v in ref.state_dict().items()}      # (the train-mode pass moves the running statistics)
+        a, b = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        got, want = O.hf_resnet_forward(a, st, cfg, training=training), ref(b).last_hidden_state
+        close(got, want, rtol=1e-5, atol=1e-5)
+        got.square().mean().backward(); want.square().mean().backward()
+        close(a.grad, b.grad, rtol=1e-4, atol=1e-6)
