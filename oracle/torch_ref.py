@@ -163,6 +163,20 @@ def visual_encode(features, state, prefix="visual_projection"):
     return features, mask
 
 
+def visual_encode_multi(images, images_mask, state, vit_cfg, prefix="model.", proj_prefix="visual_projection"):
+    """VisualEncoder.encode on [B, N, C, H, W] (ref:vilmedic/blocks/vision/visual_encoder.py:161-178, intended semantics): the
+    N images of a sample are encoded flat, the features of images with ``images_mask`` False are zeroed, the N token sequences are
+    concatenated and the key mask comes from the feature magnitude (so masked images' tokens are masked).  Pinned by
+    tests/golden/g16_vit_multi_image.pt (N = 3, where the reference's image-count quirk coincides with this)."""
+    B, N = images.shape[:2]
+    feats = vit_forward(images.reshape(B * N, *images.shape[2:]), state, vit_cfg, prefix=prefix)
+    feats = feats.view(B, N, feats.shape[-2], feats.shape[-1])
+    if images_mask is not None:
+        feats = feats * images_mask.unsqueeze(-1).unsqueeze(-1).to(feats.dtype)
+    feats = feats.reshape(B, N * feats.shape[2], feats.shape[3])
+    return visual_encode(feats, state, proj_prefix)
+
+
 # --------------------------------------------------------------------------- BERT blocks
 def bert_self_output(ctx, residual, state, p, eps):
     """LN(dense(ctx) + residual)  (hf:...bert_generation.py:45-56)."""

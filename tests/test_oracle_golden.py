@@ -255,3 +255,22 @@ def test_hf_resnet_oracle_matches_transformers(layer_type, hidden_sizes, depths,
         close(got, want, rtol=1e-5, atol=1e-5)
         got.square().mean().backward(); want.square().mean().backward()
         close(a.grad, b.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_g16_multi_image_encode(golden):
+    """VisualEncoder.encode on 5-D images with images_mask: masked images give zero features -> mask False, projected rows = bias"""
+    g = golden("g16_vit_multi_image")
+    cfg, vp = g["cfg"], g["visual_projection"]
+    st = {"model." + k: v for k, v in R.rand_state(R.vit_shapes(cfg), g["seed"]).items()}
+    gen = torch.Generator().manual_seed(g["seed"] + 77)                       # tools/make_golden.py build_ref_vit
+    st["visual_projection.weight"] = 0.05 * torch.randn(vp["out_features"], vp["in_features"], generator=gen)
+    st["visual_projection.bias"] = 0.02 * torch.randn(vp["out_features"], generator=gen)
+    assert abs(R.state_checksum(st) - g["checksum"]) < 1e-6 * g["checksum"]
+    B, N, size = g["B"], g["N"], cfg["image_size"]
+    images = R.make_images(B * N, size, seed=g["seed"]).view(B, N, 3, size, size)
+    feats, mask = O.visual_encode_multi(images, g["images_mask"], st, cfg)
+    close(feats, g["features"])
+    assert torch.equal(mask, g["mask"])
+    S = feats.shape[1] // N
+    assert not mask[0, 2 * S:].any() and mask[0, :2 * S].all() and not mask[1, S:2 * S].any()
+    close(feats[0, 2 * S], st["visual_projection.bias"])

@@ -150,6 +150,23 @@ def gen_vit():
                        features_full_sum=float(feats.double().sum()), mask=mask))
 
 
+# ------------------------------------------------------------------ G16: multi-image encode (5-D images + images_mask)
+def gen_vit_multi():
+    """VisualEncoder.encode on [B, N, C, H, W] (visual_encoder.py:161-178).  The reference reads the image count from
+    ``images.shape[1]`` AFTER flattening to 4-D, i.e. it takes the CHANNEL count for it: the path is only
+    self-consistent when N == C == 3, which is what this fixture uses; with a visual_projection so that masked rows (zero
+    features, mask False) still come out as the projection's bias."""
+    cfg, seed, B, N = R.VIT_TINY, 41, 2, 3
+    vp = dict(in_features=cfg["hidden_size"], out_features=96)
+    enc, st = build_ref_vit(cfg, seed, visual_projection=vp)
+    images = R.make_images(B * N, cfg["image_size"], seed=seed).view(B, N, 3, cfg["image_size"], cfg["image_size"])
+    images_mask = torch.tensor([[1, 1, 0], [1, 0, 1]], dtype=torch.bool)
+    with torch.no_grad():
+        feats, mask = enc.encode(images, images_mask)
+    save("g16_vit_multi_image", dict(cfg=cfg, seed=seed, B=B, N=N, visual_projection=vp, checksum=R.state_checksum(st),
+                                     images_mask=images_mask, features=feats, mask=mask))
+
+
 # ------------------------------------------------------------------ G3/G4: decoder fwd + grads
 def gen_decoder():
     cfg, seed, B, L, S = R.DEC_TINY, 21, 4, 24, 10
@@ -465,6 +482,6 @@ def gen_rrs():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs", "vicreg", "bleu"]
+    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs", "vicreg", "bleu", "vit_multi"]
     for w in which:
         globals()["gen_" + w]()
