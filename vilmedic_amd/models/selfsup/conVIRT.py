@@ -37,17 +37,24 @@ class ConVIRT(nn.Module):
         self.lin_proj = nn.Sequential(nn.Linear(projection["textual_embedding_dim"], pd), nn.ReLU(), nn.Linear(pd, pd))
         loss = dict(loss)
         self.loss_fn = eval(loss.pop("proto"))(**loss)
-        self.fbs = forward_batch_size          # kept for config compatibility: the towers run on the whole batch at once
+        self.fbs = forward_batch_size          # micro-batch of the reference's tower loop; only BatchNorm statistics depend on it
+        self._visual_has_bn = any(isinstance(m, nn.modules.batchnorm._BatchNorm) for m in self.visual.modules())
         self.eval_func = evaluation
 
     def forward(self, input_ids, attention_mask, images, **kwargs):
         images, input_ids, attention_mask = images.cuda(), input_ids.cuda(), attention_mask.cuda()
         arena_of(self).refresh()
-        # the reference chunks the towers into forward_batch_size micro-batches inside ONE autograd graph
-        # (conVIRT.py:83-95) -- numerically identical to a single pass, which is what 288 GB of HBM allows.
+        # The reference runs both towers in forward_batch_size micro-batches inside ONE autograd graph (conVIRT.py:83-95).  For the
+        # text tower (LayerNorm only) that equals a single pass over the batch, which is what runs here.  A CNN image tower in
+        # training mode normalises with the statistics of each MICRO-batch, so it keeps the reference's chunks; in eval mode
+        # (running statistics) and for BatchNorm-free towers the whole batch goes through at once.
         text = self.linguistic(input_ids=input_ids, attention_mask=attention_mask)
         linguistics = self.lin_proj(text["pooler_output"].float())
-        vis = self.visual(images)
+        bs = images.shape[0]
+        if self.training and self._visual_has_bn and self.fbs < bs:
+            vis = torch.cat([self.visual(images[i:i + self.fbs]) for i in range(0, bs, self.fbs)])
+        else:
+            vis = self.visual(images)
         visuals = self.vis_proj(vis.float() if vis.dim() == 2 else vis[:, 0].float())
         loss, loss_l, loss_v = self.loss_fn(linguistics, visuals)
         return {"loss": loss, "loss_l": loss_l, "loss_v": loss_v, "linguistic": linguistics, "visual": visuals}
