@@ -279,3 +279,36 @@ def test_c1_model_state_dict_drives_the_oracle():
     fmap = model.enc.model(images)
     torch.testing.assert_close(fmap, O.hf_resnet_forward(images, st, cnn_cfg, prefix="enc.model.", training=True), rtol=1e-5, atol=1e-5)
     assert fmap.shape == (2, 32, 2, 2)
+
+
+def test_reference_lr_schedulers(golden):
+    """LinearWarmupCosineAnnealingLR (closed form) reproduces the reference's chainable recurrence step for step, also past
+    max_epochs (fixture G17); the YAML name resolves in the training scheduler; DecreasingCosineAnnealingWarmRestarts known answer"""
+    import types
+    from vilmedic_amd.blocks import schedulers as S
+    from vilmedic_amd.executors.utils import TrainingScheduler
+    g = golden("g17_schedulers")
+
+    def run(make, steps):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=0.02)
+        sch = make(opt)
+        lrs = [opt.param_groups[0]["lr"]]
+        for _ in range(steps):
+            opt.step(); sch.step()
+            lrs.append(opt.param_groups[0]["lr"])
+        return lrs
+    assert run(lambda o: S.LinearWarmupCosineAnnealingLR(o, 10, 40), 55) == pytest.approx(g["lwca_10_40"], abs=1e-12)
+    assert run(lambda o: S.LinearWarmupCosineAnnealingLR(o, 5, 20, warmup_start_lr=0.001, eta_min=0.002), 24) == pytest.approx(g["lwca_5_20_start_eta"], abs=1e-12)
+    fn = S.linear_warmup_decay(3, 10, cosine=True)
+    assert [fn(i) for i in range(12)] == pytest.approx(g["lambda_cosine"], abs=1e-15)
+    lrs = run(lambda o: S.DecreasingCosineAnnealingWarmRestarts(factor=0.5, epochs=[2, 3], min_lr=1e-4, optimizer=o, T_0=4, T_mult=1, eta_min=0.0), 17)
+    assert lrs[0] == lrs[4] == lrs[16] == pytest.approx(0.02) and lrs[8] == lrs[12] == pytest.approx(0.01) and lrs[10] == pytest.approx(0.005)
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=0.02)
+    ts = TrainingScheduler("LinearWarmupCosineAnnealingLR", opt, "training_loss", 5, {"warmup_epochs": 2, "max_epochs": 6})
+    seen = []
+    for _ in range(4):
+        opt.step(); ts.epoch_step()
+        seen.append(opt.param_groups[0]["lr"])
+    assert seen[0] == pytest.approx(0.02) and seen[1] == pytest.approx(0.02) and seen[-1] < seen[1]

@@ -414,6 +414,31 @@ def gen_report_cleaning():
                                      reports_rouge=reports_rouge, rouge=[ns["rouge"](r) for r in reports_rouge]))
 
 
+# ------------------------------------------------------------------ G17: the reference's own LR schedulers
+def gen_schedulers():
+    lw = load_ref("ref_lwca", "blocks/schedulers/LinearWarmupCosineAnnealingLR.py")
+    out = {}
+
+    def run(make, steps):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=0.02)
+        sch = make(opt)
+        lrs = [opt.param_groups[0]["lr"]]
+        for _ in range(steps):
+            opt.step()
+            sch.step()
+            lrs.append(opt.param_groups[0]["lr"])
+        return lrs
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out["lwca_10_40"] = run(lambda o: lw.LinearWarmupCosineAnnealingLR(o, warmup_epochs=10, max_epochs=40), 55)
+        out["lwca_5_20_start_eta"] = run(lambda o: lw.LinearWarmupCosineAnnealingLR(o, warmup_epochs=5, max_epochs=20, warmup_start_lr=0.001, eta_min=0.002), 24)
+    fn = lw.linear_warmup_decay(3, 10, cosine=True)
+    out["lambda_cosine"] = [fn(i) for i in range(12)]
+    save("g17_schedulers", out)
+
+
 # ------------------------------------------------------------------ G15: BLEU (the vendored COCO-caption scorer)
 def gen_bleu():
     """the reference's Bleu wrapper (blocks/scorers/NLG/bleu/bleu.py:24-46) adds (hypothesis, [reference]) pairs to its vendored
@@ -482,6 +507,6 @@ def gen_rrs():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs", "vicreg", "bleu", "vit_multi"]
+    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs", "vicreg", "bleu", "vit_multi", "schedulers"]
     for w in which:
         globals()["gen_" + w]()

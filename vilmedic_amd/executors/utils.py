@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 from torch.optim import *  # noqa: F401,F403
 from torch.optim.lr_scheduler import *  # noqa: F401,F403
+from ..blocks.schedulers import DecreasingCosineAnnealingWarmRestarts, LinearWarmupCosineAnnealingLR  # noqa: F401  (eval(lr_decay) namespace)
 from torch.utils.data import DataLoader
 from torch.utils.data.sampler import BatchSampler, RandomSampler, SequentialSampler
 
