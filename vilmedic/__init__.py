@@ -13,7 +13,7 @@ _ALIASES = [
     "blocks.huggingface.encoder.encoder_model", "blocks.losses", "blocks.classifier", "blocks.classifier.evaluation",
     "blocks.rl", "blocks.rl.SCST", "blocks.scorers", "models", "models.utils", "models.rrg.RRG", "models.rrg.RRG_SCST",
     "models.selfsup.conVIRT", "models.mvqa.MVQA", "executors", "executors.utils", "datasets",
-    "models.rrg.RRG_HF", "models.rrs.RRS", "models.selfsup.GLoRIA", "zoo", "zoo.modeling_auto",
+    "models.rrg.RRG_HF", "models.rrs.RRS", "models.selfsup.GLoRIA", "zoo", "zoo.modeling_auto", "blocks.schedulers",
 ]
 for _name in _ALIASES:
     sys.modules["vilmedic." + _name] = importlib.import_module("vilmedic_amd." + _name)
