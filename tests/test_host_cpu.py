@@ -312,3 +312,17 @@ def test_reference_lr_schedulers(golden):
         opt.step(); ts.epoch_step()
         seen.append(opt.param_groups[0]["lr"])
     assert seen[0] == pytest.approx(0.02) and seen[1] == pytest.approx(0.02) and seen[-1] < seen[1]
+
+
+def test_train_cli_run_directory_conventions(tmp_path):
+    """bin/train.py: <ckpt_dir>/<name>/ run directory, relative ``ckpt=`` resolved inside it, seed taken from the checkpoint's name"""
+    import importlib.util
+    from vilmedic_amd.config import wrap
+    spec = importlib.util.spec_from_file_location("train_cli", os.path.join(os.path.dirname(__file__), "..", "bin", "train.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    cfg, seed = cli.prepare(wrap({"name": "exp1", "ckpt_dir": str(tmp_path), "seed": 7}))
+    assert cfg["ckpt_dir"] == str(tmp_path / "exp1") and os.path.isdir(cfg["ckpt_dir"]) and seed == 7
+    open(tmp_path / "exp1" / "1.68_10_560435.pth", "w").close()
+    cfg, seed = cli.prepare(wrap({"name": "exp1", "ckpt_dir": str(tmp_path), "seed": 7, "ckpt": "1.68_10_560435.pth"}))
+    assert cfg["ckpt"] == str(tmp_path / "exp1" / "1.68_10_560435.pth") and seed == 560435
