@@ -183,6 +183,24 @@ int vm_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16
 int vm_logsoftmax_f32(const float* logits, int64_t ldl, float* out, int rows, int V, void* stream);
 int vm_argmax_f32(const float* x, int64_t ldx, int64_t* idx, float* val, int rows, int cols, void* stream);
 
+/* ------------------------------------------------------------------ fp32 decode step (csrc/decode_f32.hip)
+ * The same step as above with NOTHING rounded below fp32, so that greedy / beam token indices are those of the reference's
+ * fp32 path (ref:vilmedic/blocks/huggingface/decoder/evaluation.py:73-78 -> hf:generation/utils.py _sample / _beam_search;
+ * block arithmetic hf:models/bert_generation/modeling_bert_generation.py:45-231,264-358,394-426,590-610).
+ * vm_gemm_f32: C[M,N] (ldc) = act(A[M,K] (lda) . W[N,K]^T (ldw) + bias) + residual (ldr); exact f32 MFMA; act 1 = erf-GELU (libm erff);
+ *   K % 16 == 0; W is a fp32 master weight straight from the caller's parameter storage (no bf16 shadow). */
+int vm_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int M, int N, int K,
+                const float* bias, int act, const float* residual, int64_t ldr, void* stream);
+int vm_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int rows, int cols, float eps, void* stream);
+int vm_embedding_fwd_f32(const int64_t* ids, const float* word, const float* pos, float* out /* fp32 [B*L, D] */,
+                         int B, int L, int D, int past_len, void* stream);
+/* one query row per (row, head): softmax(q . K^T * scale + mask) V.  Query row r reads key/value batch r / q_per_kv; key j of
+ * row r is K row kv_row_index[r*kv_index_ld + j] when the table is given (beam-search cache indirection), else
+ * (r / q_per_kv)*Lk + j.  key_mask uint8 [rows / q_per_kv, Lk] (1 = attend) or NULL. */
+int vm_attention_decode_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                            float* o, int64_t ldo, const uint8_t* key_mask, const int32_t* kv_row_index, int64_t kv_index_ld,
+                            int rows, int H, int Lk, int dh, int q_per_kv, float scale, void* stream);
+
 /* ---- image input pipeline on the device (replaces, for decoded uint8 HWC images resident in HBM, the PIL / torchvision
    chain of vilmedic/datasets/base/ImageDataset.py:96-108: Resize -> RandomCrop -> RandomHorizontalFlip -> ToTensor ->
    Normalize for training (resize > 0), Resize((crop,crop)) -> ToTensor -> Normalize for evaluation (resize == 0)).

@@ -179,16 +179,7 @@ def _oracle_logp_of(seq, enc, enc_mask, st, cfg):
     return torch.log_softmax(O.lm_logits(h, st).float(), -1)
 
 
-def test_greedy_and_beam_decode_vs_golden_and_oracle(golden):
-    """KV-cached greedy / beam-4 decode on the HIP path (bf16 activations) vs the reference's generate() (fixture G7).
-
-    The fixture decoder is deliberately chaotic (large random weights), so a bf16 rounding can flip a
-    near-tie; parity is therefore stated as:
-      greedy: every emitted token is an fp32-oracle arg-max of ITS OWN prefix up to a 0.25-nat margin, and rows whose
-              reference path never passes a near-tie (top-2 gap > 0.25 nat at every step) are BIT-IDENTICAL;
-      beam:   the returned hypothesis scores (under the fp32 oracle, with the length penalty) within 0.1 of the
-              reference's best hypothesis, and at least one row is bit-identical.
-    """
+def _g7_setup(golden):
     g = golden("g7_decode")
     cfg, rc = g["cfg"], g["recipe"]
     dec, st = build_decoder(cfg, g["seed"], **rc)
@@ -196,45 +187,65 @@ def test_greedy_and_beam_decode_vs_golden_and_oracle(golden):
     gen = torch.Generator().manual_seed(g["seed"] + 1)
     enc = torch.randn(g["B"], g["S"], cfg["hidden_size"], generator=gen)
     enc[~g["enc_mask"]] = 0.0
-    enc_d, mask_d = enc.to(dev()), g["enc_mask"].to(dev())
     start = torch.zeros(g["B"], 1, dtype=torch.long, device=dev())
     common = dict(bos_token_id=0, eos_token_id=2, pad_token_id=1, max_length=g["max_len"])
+    return g, cfg, dec, st, enc, start, common
+
+
+def test_greedy_and_beam_decode_bit_exact_vs_golden(golden):
+    """north_star: "bit-exact token indices for greedy decode".  The default decode step is the fp32 one (csrc/decode_f32.hip):
+    EVERY row of the reference's generate() output (fixture G7, written by the reference's own DecoderModel + HF generate) must
+    be reproduced token for token -- greedy, and beam-4 under both length penalties, with the hypothesis scores within 1e-4.
+    The fixture decoder is deliberately chaotic (large random weights): top-2 logit gaps below 0.1 nat are common,
+    which is what makes this a test."""
+    g, cfg, dec, st, enc, start, common = _g7_setup(golden)
+    enc_d, mask_d = enc.to(dev()), g["enc_mask"].to(dev())
     ids = dec.generate(input_ids=start, encoder_hidden_states=enc_d, encoder_attention_mask=mask_d, **common).cpu()
     ref = g["beams1_lp1.0"]["sequences"]
-    lp = _oracle_logp_of(ids, enc, g["enc_mask"], st, cfg)
-    for b in range(g["B"]):
-        n_same = 0
-        for t in range(1, ids.shape[1]):
-            if ids[b, t] == 1:        # padding after eos
-                break
-            margin = lp[b, t - 1].max() - lp[b, t - 1, ids[b, t]]
-            assert margin <= 0.25, (b, t, margin)
-    # rows whose reference path never passes a near-tie (fp32 top-2 gap > 0.25 nat at every step) must be BIT-EXACT
-    lp_ref = _oracle_logp_of(ref, enc, g["enc_mask"], st, cfg)
-    n_exact = 0
-    for b in range(g["B"]):
-        n = int((ref[b, 1:] != 1).sum())
-        top2 = lp_ref[b, :n].topk(2, dim=-1)[0]
-        if n == 0 or float((top2[:, 0] - top2[:, 1]).min()) > 0.25:
-            L = min(ids.shape[1], ref.shape[1])
-            assert torch.equal(ids[b, :L], ref[b, :L]), (b, ids[b], ref[b])
-            n_exact += 1
-    assert n_exact >= 1
+    assert ids.shape == ref.shape and torch.equal(ids, ref), (ids, ref)
+    # eager launches (no HIP graph) and a second call on the cached state give the same ids
+    again = dec.generate(input_ids=start, encoder_hidden_states=enc_d, encoder_attention_mask=mask_d, decode_dtype="fp32", **common).cpu()
+    assert torch.equal(again, ref)
     for lpen in (1.0, 2.0):
         refb = g[f"beams4_lp{lpen}"]
         out = dec.generate(input_ids=start, encoder_hidden_states=enc_d, encoder_attention_mask=mask_d, num_beams=4,
                            length_penalty=lpen, return_dict_in_generate=True, **common)
         seq = out.sequences.cpu()
-        lpb = _oracle_logp_of(seq, enc, g["enc_mask"], st, cfg)
-        for b in range(g["B"]):
-            toks = seq[b, 1:]
-            n = int((toks != 1).sum())
-            score = lpb[b, torch.arange(n), toks[:n]].sum() / (n ** lpen)
-            assert score >= refb["scores"][b] - 0.1, (lpen, b, score, refb["scores"][b])
-            assert abs(out.sequences_scores[b].item() - score.item()) <= 0.1
-        same_rows = sum(int(torch.equal(seq[b, :min(seq.shape[1], refb["sequences"].shape[1])],
-                                        refb["sequences"][b, :min(seq.shape[1], refb["sequences"].shape[1])])) for b in range(g["B"]))
-        assert same_rows >= 1, (lpen, seq, refb["sequences"])
+        assert seq.shape == refb["sequences"].shape and torch.equal(seq, refb["sequences"]), (lpen, seq, refb["sequences"])
+        err = (out.sequences_scores.cpu() - refb["scores"]).abs().max().item()
+        print(f"[parity] beam-4 lp={lpen}: sequences identical on all {g['B']} rows, max |score err| = {err:.2e}")
+        assert err <= 1e-4
+
+
+def test_bf16_decode_step_stays_within_margin_of_fp32_oracle(golden):
+    """the training-precision decode step (decode_dtype="bf16": SCST rollouts, throughput runs): every emitted token is an
+    fp32-oracle arg-max of ITS OWN prefix up to a margin, where the margin is what bf16 activations can move a logit gap by
+    (measured and printed); rows whose reference path never passes a near-tie are identical to the reference."""
+    g, cfg, dec, st, enc, start, common = _g7_setup(golden)
+    enc_d, mask_d = enc.to(dev()), g["enc_mask"].to(dev())
+    ids = dec.generate(input_ids=start, encoder_hidden_states=enc_d, encoder_attention_mask=mask_d, decode_dtype="bf16", **common).cpu()
+    ref = g["beams1_lp1.0"]["sequences"]
+    lp = _oracle_logp_of(ids, enc, g["enc_mask"], st, cfg)
+    worst = 0.0
+    for b in range(g["B"]):
+        for t in range(1, ids.shape[1]):
+            if ids[b, t] == 1:        # padding after eos
+                break
+            worst = max(worst, float(lp[b, t - 1].max() - lp[b, t - 1, ids[b, t]]))
+    lp_ref = _oracle_logp_of(ref, enc, g["enc_mask"], st, cfg)
+    n_clear = n_same = 0
+    for b in range(g["B"]):
+        n = int((ref[b, 1:] != 1).sum())
+        top2 = lp_ref[b, :n].topk(2, dim=-1)[0]
+        L = min(ids.shape[1], ref.shape[1])
+        same = torch.equal(ids[b, :L], ref[b, :L])
+        n_same += int(same)
+        if n == 0 or float((top2[:, 0] - top2[:, 1]).min()) > 0.25:
+            n_clear += 1
+            assert same, (b, ids[b], ref[b])
+    print(f"[parity] bf16 greedy decode: worst arg-max margin {worst:.3f} nat, {n_same}/{g['B']} rows identical to the reference "
+          f"({n_clear} rows have no near-tie)")
+    assert worst <= 0.25
 
 
 def test_two_phase_backward_equals_single_backward(golden):
@@ -353,36 +364,25 @@ def test_ensemble_greedy_and_beam_decode_vs_oracle(golden):
         return torch.log_softmax(logits, -1)
 
     ids = dec_a.generate(input_ids=start, hf_models=[dec_a.decoder, dec_b.decoder], encoders_outputs=eo, **common).cpu()
-    lp = ens_logp(ids)
     single = dec_a.generate(input_ids=start, encoder_hidden_states=eo[0]["encoder_hidden_states"],
                             encoder_attention_mask=eo[0]["encoder_attention_mask"], **common).cpu()
     assert not torch.equal(ids[:, :min(ids.shape[1], single.shape[1])], single[:, :min(ids.shape[1], single.shape[1])])   # the 2nd model matters
-    for b in range(B):
-        for t in range(1, ids.shape[1]):
-            if ids[b, t] == 1:
-                break
-            assert lp[b, t - 1].max() - lp[b, t - 1, ids[b, t]] <= 0.25, (b, t)
+    # fp32 decode step (the default): token for token the oracle's ensemble decode, on every row
     ref = O.greedy_decode(encs, masks, sts, cfg, 0, 2, 1, g["max_len"])
-    lp_ref = ens_logp(ref)
-    n_exact = 0
-    for b in range(B):
-        n = int((ref[b, 1:] != 1).sum())
-        top2 = lp_ref[b, :n].topk(2, dim=-1)[0]
-        if n == 0 or float((top2[:, 0] - top2[:, 1]).min()) > 0.25:
-            L = min(ids.shape[1], ref.shape[1])
-            assert torch.equal(ids[b, :L], ref[b, :L]), (b, ids[b], ref[b])
-            n_exact += 1
-    assert n_exact >= 1
+    assert ids.shape == ref.shape and torch.equal(ids, ref), (ids, ref)
     refb, refs = O.beam_decode(encs, masks, sts, cfg, 0, 2, 1, g["max_len"], 4)
     out = dec_a.generate(input_ids=start, hf_models=[dec_a.decoder, dec_b.decoder], encoders_outputs=eo, num_beams=4, return_dict_in_generate=True, **common)
     seq = out.sequences.cpu()
-    lpb = ens_logp(seq)
+    assert seq.shape == refb.shape and torch.equal(seq, refb), (seq, refb)
+    assert (out.sequences_scores.cpu() - torch.as_tensor(refs)).abs().max().item() <= 1e-4
+    # training-precision step: margin criterion under the fp32 oracle's ensemble log-probs
+    idb = dec_a.generate(input_ids=start, hf_models=[dec_a.decoder, dec_b.decoder], encoders_outputs=eo, decode_dtype="bf16", **common).cpu()
+    lp = ens_logp(idb)
     for b in range(B):
-        toks = seq[b, 1:]
-        n = int((toks != 1).sum())
-        score = lpb[b, torch.arange(n), toks[:n]].sum() / n
-        assert score >= refs[b] - 0.1, (b, score, refs[b])
-        assert abs(out.sequences_scores[b].item() - score.item()) <= 0.1
+        for t in range(1, idb.shape[1]):
+            if idb[b, t] == 1:
+                break
+            assert lp[b, t - 1].max() - lp[b, t - 1, idb[b, t]] <= 0.25, (b, t)
 
 
 def build_rrs(g, device=None):

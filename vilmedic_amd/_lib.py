@@ -70,6 +70,10 @@ SIGNATURES = {
     "vm_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _F, _F, _P]),
     "vm_logsoftmax_f32": (_I, [_P, _L, _P, _I, _I, _P]),
     "vm_argmax_f32": (_I, [_P, _L, _P, _P, _I, _I, _P]),
+    "vm_gemm_f32": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _I, _P, _L, _P]),
+    "vm_layernorm_f32": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
+    "vm_embedding_fwd_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vm_attention_decode_f32": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _F, _P]),
 }
 
 

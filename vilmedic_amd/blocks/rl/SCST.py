@@ -6,6 +6,7 @@ log-probabilities of the sampled tokens are then recomputed WITH grad by ONE tea
 LM-head kernel applies the same logit filters (bad words, top-k) and the policy-gradient weights
 ``mask * (r_sample - r_greedy) / sum(mask)`` -- the same loss and gradient, L-fold fewer launches."""
 import json
+import os
 
 import torch
 import torch.nn as nn
@@ -40,6 +41,9 @@ class SCST(nn.Module):
             raise NotImplementedError("Where is tokenizer in dataset?")
         self.__dict__["decoder"] = decoder            # not registered: the parameters belong to RRG
         self.top_k, self.use_nll = top_k, use_nll
+        # rollouts run on the training-precision decode step (the sampled one is stochastic anyway; the reference's are under the
+        # trainer's autocast when use_amp is set); VM_SCST_DECODE_DTYPE=fp32 makes them exact-fp32
+        self.decode_dtype = os.environ.get("VM_SCST_DECODE_DTYPE", "bf16")
         cfg = decoder.config
         self.bos_token_id, self.eos_token_id, self.pad_token_id = cfg.bos_token_id, cfg.eos_token_id, cfg.pad_token_id
         assert scores is not None
@@ -72,7 +76,7 @@ class SCST(nn.Module):
         assert not torch.is_grad_enabled(), "Please add torch.no_grad() decorator"
         out = self.decoder.generate(input_ids=torch.full((input_ids.shape[0], 1), self.bos_token_id, dtype=torch.long,
                                                          device=encoder_hidden_states.device),
-                                    max_length=self.max_length, num_beams=1, return_dict_in_generate=True,
+                                    max_length=self.max_length, num_beams=1, return_dict_in_generate=True, decode_dtype=self.decode_dtype,
                                     encoder_hidden_states=encoder_hidden_states.detach(),
                                     encoder_attention_mask=encoder_attention_mask.detach())
         return self.get_reward(out.sequences.detach(), input_ids)
@@ -89,7 +93,7 @@ class SCST(nn.Module):
         with torch.no_grad():
             out = self.decoder.generate(input_ids=torch.full((input_ids.shape[0], 1), self.bos_token_id, dtype=torch.long, device=dev),
                                         max_length=self.max_length, num_beams=1, do_sample=True, top_k=self.top_k,
-                                        bad_words_ids=[[b] for b in banned], return_dict_in_generate=True,
+                                        bad_words_ids=[[b] for b in banned], return_dict_in_generate=True, decode_dtype=self.decode_dtype,
                                         encoder_hidden_states=encoder_hidden_states.detach(),
                                         encoder_attention_mask=encoder_attention_mask.detach())
         seq = out.sequences                       # [B, T] with bos at 0

@@ -1,0 +1,217 @@
+// decode_f32.hip -- the fp32 decode step: every kernel of vilmedic_amd.generation's step in full fp32, so that greedy / beam
+// token indices are those of the reference's fp32 CPU path (north_star: "bit-exact token indices for greedy decode").
+//
+// The bf16 step rounds every activation to 8 mantissa bits; a near-tie between the two best logits (a random-weight decoder
+// has many) can then flip an arg-max.  Here nothing is rounded below fp32: fp32 master weights straight from the parameter
+// arena (no shadows), fp32 activations and KV caches, matrix products on the exact f32-input MFMA
+// (v_mfma_f32_16x16x4_f32 == an fmaf chain, MI355X_MICROARCH.md "Matrix cores"), fp32 softmax / LayerNorm / erf-GELU.
+// What still differs from the CPU reference is the summation order only (~1e-6 relative), which token selection survives
+// unless the top-2 logits tie within that noise.
+//
+// Replaces (in fp32 mode) hf:models/bert_generation/modeling_bert_generation.py:45-231,264-358,394-426,590-610 as reached
+// from ref:vilmedic/blocks/huggingface/decoder/evaluation.py:73-78 (generate) -- same call sites as the bf16 step.
+#include "common.h"
+
+// ------------------------------------------------------------------ C[M,N] = epi(A[M,K] . W[N,K]^T), all fp32
+// One workgroup owns 16 output columns for a block of 16*MF rows; its 4 waves split the contraction four ways (operands go
+// straight from global / L2 into MFMA fragments, W is streamed exactly once per row block), partial accumulators meet in LDS.
+// A lane loads 4 consecutive k of its row (16 B): MFMA sub-step j contracts k = k0 + 4g + j, g = lane / 16 -- any bijection
+// of the contraction index works as long as both operands use the same one.
+// Operands are swapped (D^T = W_frag x A_frag) so a lane ends with 4 consecutive output columns of one row.
+struct GemmF32Args {
+    const float* A; const float* W; float* C; const float* bias; const float* residual;
+    int64_t lda, ldw, ldc, ldr;
+    int M, N, K, act;
+};
+
+__device__ __forceinline__ float gelu_erf_f32(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <int MF>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args p) {
+    extern __shared__ __attribute__((aligned(16))) float red[];          // [4 waves][MF][64 lanes][4]
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (16 * MF);
+    const int ksteps = p.K >> 4;                                          // 16-deep steps (4 MFMAs each)
+    const int per = (ksteps + 3) >> 2;
+    const int ks0 = wave * per, ks1 = min(ksteps, ks0 + per);
+    const float* wrow = p.W + (int64_t)min(n0 + c, p.N - 1) * p.ldw + g * 4;
+    const float* arow[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) arow[i] = p.A + (int64_t)min(m0 + 16 * i + c, p.M - 1) * p.lda + g * 4;
+    float4_t acc[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) acc[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    float4 wf, af[MF], wn, an[MF];
+    auto load = [&](int ks, float4& w_, float4 (&a_)[MF]) {
+        w_ = *reinterpret_cast<const float4*>(wrow + ks * 16);
+#pragma unroll
+        for (int i = 0; i < MF; ++i) a_[i] = *reinterpret_cast<const float4*>(arow[i] + ks * 16);
+    };
+    if (ks0 < ks1) load(ks0, wf, af);
+    for (int ks = ks0; ks < ks1; ++ks) {
+        if (ks + 1 < ks1) load(ks + 1, wn, an);
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.x, af[i].x, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.y, af[i].y, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.z, af[i].z, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.w, af[i].w, acc[i], 0, 0, 0);
+        }
+        wf = wn;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) af[i] = an[i];
+    }
+    // D^T layout: lane (c, g) of fragment i holds row m0 + 16 i + c, columns n0 + 4 g .. + 3
+    float4_t* mine = reinterpret_cast<float4_t*>(red) + (wave * MF) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < MF; ++i) mine[i * 64] = acc[i];
+    __syncthreads();
+    const int gn = n0 + 4 * g;
+    for (int i = wave; i < MF; i += 4) {
+        const int gm = m0 + 16 * i + c;
+        float4_t s = reinterpret_cast<const float4_t*>(red)[(0 * MF + i) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {                                      // fixed order: deterministic
+            const float4_t t = reinterpret_cast<const float4_t*>(red)[(w * MF + i) * 64 + lane];
+            s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+        }
+        if (gm >= p.M || gn >= p.N) continue;
+        float v[4] = {s[0], s[1], s[2], s[3]};
+        const int nvalid = min(4, p.N - gn);
+        if (p.bias) for (int r = 0; r < nvalid; ++r) v[r] += p.bias[gn + r];
+        if (p.act == 1) for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f32(v[r]);
+        if (p.residual) for (int r = 0; r < nvalid; ++r) v[r] += p.residual[(int64_t)gm * p.ldr + gn + r];
+        float* cp = p.C + (int64_t)gm * p.ldc + gn;
+        if (nvalid == 4 && (p.ldc & 3) == 0) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+        else for (int r = 0; r < nvalid; ++r) cp[r] = v[r];
+    }
+}
+
+template <int MF>
+static int launch_gemm_f32(const GemmF32Args& a, hipStream_t s) {
+    const size_t lds = (size_t)4 * MF * 64 * sizeof(float4_t);
+    hipLaunchKernelGGL((gemm_f32_kernel<MF>), dim3((a.N + 15) / 16, (a.M + 16 * MF - 1) / (16 * MF)), dim3(256), lds, s, a);
+    return vm_check_launch("vm_gemm_f32");
+}
+
+extern "C" int vm_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int M, int N, int K,
+                           const float* bias, int act, const float* residual, int64_t ldr, void* stream) {
+    VM_REQUIRE(A && W && C, "vm_gemm_f32: null pointer");
+    VM_REQUIRE(M > 0 && N > 0 && K > 0 && (K % 16) == 0, "vm_gemm_f32: K must be a positive multiple of 16 (M=%d N=%d K=%d)", M, N, K);
+    VM_REQUIRE((lda % 4) == 0 && (ldw % 4) == 0, "vm_gemm_f32: lda / ldw must be multiples of 4");
+    VM_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)C % 16) == 0, "vm_gemm_f32: pointers must be 16-byte aligned");
+    VM_REQUIRE(act == 0 || act == 1, "vm_gemm_f32: act must be 0 or 1 (erf-GELU)");
+    GemmF32Args a = {A, W, C, bias, residual, lda, ldw, ldc, ldr, M, N, K, act};
+    hipStream_t s = (hipStream_t)stream;
+    VmProfScope prof(VM_FAM_DECODE, 2.0 * M * (double)N * K, s, "f32_M%d_N%d_K%d", M, N, K);
+    const int mf = (M + 15) / 16;
+    if (mf <= 1) return launch_gemm_f32<1>(a, s);
+    if (mf <= 2) return launch_gemm_f32<2>(a, s);
+    if (mf <= 4) return launch_gemm_f32<4>(a, s);
+    if (mf <= 8) return launch_gemm_f32<8>(a, s);
+    return launch_gemm_f32<16>(a, s);          // 256 rows per workgroup (64 KiB of LDS for the cross-wave reduction); more rows -> grid.y
+}
+
+// ------------------------------------------------------------------ LayerNorm, fp32 in / out (one wave per row)
+__global__ __launch_bounds__(256) void ln_f32_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ y, int rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (int64_t)row * cols;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += xr[c];
+    const float mu = wave_sum(s) / (float)cols;
+    float q = 0.f;
+    for (int c = lane; c < cols; c += 64) { const float d = xr[c] - mu; q += d * d; }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)cols + eps);
+    float* yr = y + (int64_t)row * cols;
+    for (int c = lane; c < cols; c += 64) yr[c] = (xr[c] - mu) * rs * gamma[c] + beta[c];
+}
+
+extern "C" int vm_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int rows, int cols, float eps, void* stream) {
+    VM_REQUIRE(x && gamma && beta && y && rows > 0 && cols > 0, "vm_layernorm_f32: bad arguments");
+    hipLaunchKernelGGL(ln_f32_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, rows, cols, eps);
+    return vm_check_launch("vm_layernorm_f32");
+}
+
+// ------------------------------------------------------------------ embeddings, fp32 out: word[ids] + pos[past_len + t]
+__global__ __launch_bounds__(256) void embedding_f32_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word, const float* __restrict__ pos,
+                                                            float* __restrict__ out, int L, int D, int past_len, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / D; const int d = (int)(i - row * D);
+        const int t = (int)(row % L);
+        out[i] = word[ids[row] * (int64_t)D + d] + pos[(int64_t)(past_len + t) * D + d];
+    }
+}
+
+extern "C" int vm_embedding_fwd_f32(const int64_t* ids, const float* word, const float* pos, float* out, int B, int L, int D, int past_len, void* stream) {
+    VM_REQUIRE(ids && word && pos && out && B > 0 && L > 0 && D > 0, "vm_embedding_fwd_f32: bad arguments");
+    const int64_t total = (int64_t)B * L * D;
+    int64_t blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(embedding_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ids, word, pos, out, L, D, past_len, total);
+    return vm_check_launch("vm_embedding_fwd_f32");
+}
+
+// ------------------------------------------------------------------ attention of the decode step, fp32
+// One wave per (query row, head).  Query row r belongs to key/value batch r / q_per_kv (cross-attention: the beams of a
+// sample share its projected image features; self-attention: q_per_kv = 1).  Key j of the row is K row
+//   kv_index ? kv_index[r * kv_index_ld + j]  :  (r / q_per_kv) * Lk + j
+// (the beam-search cache indirection of vm_attention_fwd).  key_mask [n_kv_batches, Lk] (1 = attend) or NULL; a masked key
+// gets the additive float-min of hf:modeling_attn_mask_utils (so a fully masked row degrades to uniform, as in HF).
+// Scores live in LDS (Lk <= 4096); lanes split the keys for QK^T / softmax and the head dim for PV.
+struct AttnF32Args {
+    const float* q; const float* k; const float* v; float* o; const uint8_t* key_mask; const int32_t* kv_index;
+    int64_t ldq, ldk, ldv, ldo, kv_index_ld;
+    int rows, H, Lk, dh, q_per_kv; float scale;
+};
+
+__global__ __launch_bounds__(64) void attn_decode_f32_kernel(const AttnF32Args p) {
+    extern __shared__ float sc[];                                          // [Lk] scores, then probabilities; [dh] query after them
+    const int lane = threadIdx.x;
+    const int r = blockIdx.x / p.H, h = blockIdx.x - r * p.H;
+    const int kvb = r / p.q_per_kv;
+    float* qs = sc + p.Lk;
+    const float* qr = p.q + (int64_t)r * p.ldq + h * p.dh;
+    for (int d = lane; d < p.dh; d += 64) qs[d] = qr[d];
+    __syncthreads();
+    auto krow = [&](int j) -> int64_t { return p.kv_index ? (int64_t)p.kv_index[(int64_t)r * p.kv_index_ld + j] : (int64_t)kvb * p.Lk + j; };
+    float mx = -INFINITY;
+    for (int j = lane; j < p.Lk; j += 64) {
+        const float* kr = p.k + krow(j) * p.ldk + h * p.dh;
+        float s = 0.f;
+        for (int d = 0; d < p.dh; d += 4) {
+            const float4 kk = *reinterpret_cast<const float4*>(kr + d);
+            s = fmaf(qs[d], kk.x, s); s = fmaf(qs[d + 1], kk.y, s); s = fmaf(qs[d + 2], kk.z, s); s = fmaf(qs[d + 3], kk.w, s);
+        }
+        s *= p.scale;
+        if (p.key_mask && !p.key_mask[(int64_t)kvb * p.Lk + j]) s += -3.4028234663852886e38f;
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int j = lane; j < p.Lk; j += 64) { const float e = expf(sc[j] - mx); sc[j] = e; se += e; }
+    se = wave_sum(se);
+    __syncthreads();
+    const float inv = 1.0f / se;
+    for (int d = lane; d < p.dh; d += 64) {
+        float acc = 0.f;
+        for (int j = 0; j < p.Lk; ++j) acc = fmaf(sc[j], p.v[krow(j) * p.ldv + h * p.dh + d], acc);
+        p.o[(int64_t)r * p.ldo + h * p.dh + d] = acc * inv;
+    }
+}
+
+extern "C" int vm_attention_decode_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                       float* o, int64_t ldo, const uint8_t* key_mask, const int32_t* kv_row_index, int64_t kv_index_ld,
+                                       int rows, int H, int Lk, int dh, int q_per_kv, float scale, void* stream) {
+    VM_REQUIRE(q && k && v && o, "vm_attention_decode_f32: null pointer");
+    VM_REQUIRE(rows > 0 && H > 0 && Lk > 0 && Lk <= 4096 && dh > 0 && (dh % 4) == 0 && q_per_kv > 0, "vm_attention_decode_f32: bad shape (rows=%d H=%d Lk=%d dh=%d)", rows, H, Lk, dh);
+    VM_REQUIRE((ldk % 4) == 0 && ((uintptr_t)k % 16) == 0, "vm_attention_decode_f32: K rows must be 16-byte aligned");
+    AttnF32Args a = {q, k, v, o, key_mask, kv_row_index, ldq, ldk, ldv, ldo, kv_index_ld, rows, H, Lk, dh, q_per_kv, scale};
+    hipStream_t s = (hipStream_t)stream;
+    VmProfScope prof(VM_FAM_DECODE, 4.0 * rows * H * (double)Lk * dh, s, "attn_f32_r%d_H%d_Lk%d", rows, H, Lk);
+    hipLaunchKernelGGL(attn_decode_f32_kernel, dim3((unsigned)(rows * H)), dim3(64), (size_t)(Lk + dh) * sizeof(float), s, a);
+    return vm_check_launch("vm_attention_decode_f32");
+}

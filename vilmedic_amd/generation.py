@@ -29,7 +29,13 @@ from .arena import arena_of
 from .nn import to_key_mask
 
 BF16 = torch.bfloat16
+F32 = torch.float32
 DECODE_GRAPH = os.environ.get("VM_DECODE_GRAPH", "1") != "0"
+# Arithmetic of the decode step.  "fp32" (default): nothing is rounded below fp32 (csrc/decode_f32.hip: fp32 master weights, exact
+# f32 MFMA, fp32 caches) so greedy / beam token ids are those of the reference's fp32 path; "bf16": the training-precision
+# kernels (half the weight bytes per step; a near-tie between the two best logits may resolve differently).  Per call:
+# generate(..., decode_dtype="bf16"); SCST's rollouts ask for bf16 (they are sampled anyway).
+DECODE_DTYPE = os.environ.get("VM_DECODE_DTYPE", "fp32")
 
 
 def _ln(x, aff, eps):
@@ -51,10 +57,37 @@ def _attn(q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, dh, key_mask=None, kv_index=None
     return o
 
 
+def _gemm32(x, w, bias, out, M, N, K, *, ldc=None, act=0, residual=None):
+    """out[M,N] = act(x[M,K] w[N,K]^T + bias) + residual, everything fp32 (vm_gemm_f32)"""
+    check(lib().vm_gemm_f32(ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(out), ldc if ldc is not None else out.stride(0), M, N, K,
+                            ptr(bias) if bias is not None else None, act, ptr(residual) if residual is not None else None,
+                            residual.stride(0) if residual is not None else 0, stream()), "vm_gemm_f32")
+    return out
+
+
+def _ln32(x, aff, eps):
+    y = torch.empty_like(x)
+    check(lib().vm_layernorm_f32(ptr(x), ptr(aff.weight), ptr(aff.bias), ptr(y), x.shape[0], x.shape[1], eps, stream()), "vm_layernorm_f32")
+    return y
+
+
+def _attn32(q, k, ldk, v, ldv, rows, H, Lk, dh, q_per_kv, key_mask=None, kv_index=None, kv_index_ld=0):
+    o = torch.empty(rows, H * dh, dtype=F32, device=q.device)
+    check(lib().vm_attention_decode_f32(ptr(q), q.stride(0), ptr(k), ldk, ptr(v), ldv, ptr(o), H * dh,
+                                        ptr(key_mask) if key_mask is not None else None,
+                                        ptr(kv_index) if kv_index is not None else None, kv_index_ld,
+                                        rows, H, Lk, dh, q_per_kv, dh ** -0.5, stream()), "vm_attention_decode_f32")
+    return o
+
+
 class DecodeState:
     """Per-generate() state: cross K|V per layer, self K|V cache [rows*T, 2D] per layer, row-index table [rows, T]."""
 
-    def __init__(self, decoder, enc, enc_mask, beams, max_length):
+    def __init__(self, decoder, enc, enc_mask, beams, max_length, dtype="bf16"):
+        if dtype not in ("bf16", "fp32"):
+            raise ValueError(f"decode_dtype must be 'bf16' or 'fp32', got {dtype!r}")
+        self.f32 = dtype == "fp32"
+        self.act = F32 if self.f32 else BF16
         self.dec = decoder
         cfg = decoder.config
         self.cfg = cfg
@@ -71,8 +104,8 @@ class DecodeState:
         self.layers = decoder.bert.encoder.layer
         # static buffers (their addresses are baked into the captured graphs)
         self.enc_mask = torch.ones(self.B, self.S, dtype=torch.uint8, device=dev) if enc_mask is not None else None
-        self.cross_kv = [torch.empty(self.B * self.S, 2 * self.D, dtype=BF16, device=dev) for _ in self.layers]
-        self.self_kv = [torch.empty(self.M * self.T, 2 * self.D, dtype=BF16, device=dev) for _ in self.layers]
+        self.cross_kv = [torch.empty(self.B * self.S, 2 * self.D, dtype=self.act, device=dev) for _ in self.layers]
+        self.self_kv = [torch.empty(self.M * self.T, 2 * self.D, dtype=self.act, device=dev) for _ in self.layers]
         self.index = torch.empty(self.M, self.T, dtype=torch.int32, device=dev)
         self.tok = torch.zeros(self.M, dtype=torch.long, device=dev)
         self.V = cfg.vocab_size
@@ -85,12 +118,16 @@ class DecodeState:
         beams of a sample), reset the row-index table.  Buffers keep their addresses, so captured graphs stay valid."""
         a = self.arena
         a.refresh()
-        enc = enc.to(BF16).contiguous()
+        enc = enc.to(self.act).contiguous()
         enc2 = enc.view(self.B * self.S, enc.shape[2])
         if self.enc_mask is not None:
             self.enc_mask.copy_(to_key_mask(enc_mask))
         for layer, kv in zip(self.layers, self.cross_kv):
             ca = layer.crossattention.self
+            if self.f32:
+                _gemm32(enc2, a.f32_group([ca.key.weight, ca.value.weight]), a.f32_group([ca.key.bias, ca.value.bias]), kv,
+                        self.B * self.S, 2 * self.D, enc2.shape[1])
+                continue
             ops.gemm(enc2, 0, a.shadow_group([ca.key.weight, ca.value.weight]), 0, kv, self.B * self.S, 2 * self.D, enc2.shape[1],
                      bias=a.f32_group([ca.key.bias, ca.value.bias]))
         dev = enc.device
@@ -122,7 +159,49 @@ class DecodeState:
         entry[0].replay()
         return entry[1]
 
+    def _step_f32(self, tokens, t):
+        """the step below with every tensor and every product in fp32 (csrc/decode_f32.hip); same data flow: K|V of the new token
+        written straight into the cache by the projection, keys gathered through the row-index table, cross K|V shared by beams"""
+        a, cfg, D, H, M, T = self.arena, self.cfg, self.D, self.H, self.M, self.T
+        emb = self.dec.bert.embeddings
+        dev = tokens.device
+        x = torch.empty(M, D, dtype=F32, device=dev)
+        check(lib().vm_embedding_fwd_f32(ptr(tokens.contiguous()), ptr(emb.word_embeddings.weight), ptr(emb.position_embeddings.weight),
+                                         ptr(x), M, 1, D, t, stream()), "vm_embedding_fwd_f32")
+        x = _ln32(x, emb.LayerNorm, cfg.layer_norm_eps)
+        q = torch.empty(M, D, dtype=F32, device=dev)
+        s = torch.empty(M, D, dtype=F32, device=dev)
+        for li, layer in enumerate(self.layers):
+            sa = layer.attention.self
+            _gemm32(x, sa.query.weight, sa.query.bias, q, M, D, D)
+            cache = self.self_kv[li]
+            _gemm32(x, a.f32_group([sa.key.weight, sa.value.weight]), a.f32_group([sa.key.bias, sa.value.bias]), cache[t:], M, 2 * D, D,
+                    ldc=T * 2 * D)
+            ctx = _attn32(q, cache, 2 * D, cache[:, D:], 2 * D, M, H, t + 1, D // H, 1, kv_index=self.index, kv_index_ld=T)
+            blk = layer.attention.output
+            _gemm32(ctx, blk.dense.weight, blk.dense.bias, s, M, D, D, residual=x)
+            x = _ln32(s, blk.LayerNorm, cfg.layer_norm_eps)
+            ca = layer.crossattention.self
+            _gemm32(x, ca.query.weight, ca.query.bias, q, M, D, D)
+            kv = self.cross_kv[li]
+            ctx = _attn32(q, kv, 2 * D, kv[:, D:], 2 * D, M, H, self.S, D // H, self.nb, key_mask=self.enc_mask)
+            blk = layer.crossattention.output
+            _gemm32(ctx, blk.dense.weight, blk.dense.bias, s, M, D, D, residual=x)
+            x = _ln32(s, blk.LayerNorm, cfg.layer_norm_eps)
+            i, o = layer.intermediate.dense, layer.output.dense
+            F = i.weight.shape[0]
+            h = torch.empty(M, F, dtype=F32, device=dev)
+            _gemm32(x, i.weight, i.bias, h, M, F, D, act=1)
+            _gemm32(h, o.weight, o.bias, s, M, D, F, residual=x)
+            x = _ln32(s, layer.output.LayerNorm, cfg.layer_norm_eps)
+        V = self.V
+        logits = torch.empty(M, (V + 3) // 4 * 4, dtype=F32, device=dev)
+        _gemm32(x, emb.word_embeddings.weight, self.dec.lm_head.bias, logits, M, V, D)
+        return logits[:, :V]
+
     def _step(self, tokens, t):
+        if self.f32:
+            return self._step_f32(tokens, t)
         a, cfg, D, H, M, T = self.arena, self.cfg, self.D, self.H, self.M, self.T
         emb = self.dec.bert.embeddings
         x = torch.empty(M, D, dtype=BF16, device=tokens.device)
@@ -161,12 +240,12 @@ class EnsembleState:
     """n-best checkpoint ensembling (ref: blocks/huggingface/decoder/beam_search.py:243-262,313-319, bin/ensemble.py:72-80):
     every model keeps its own encoder states and KV caches; the next-token logits are SUMMED before the log-softmax."""
 
-    def __init__(self, decoders, encs, enc_masks, beams, max_length):
+    def __init__(self, decoders, encs, enc_masks, beams, max_length, dtype="bf16"):
         self.states, seen = [], set()
         for d, e, m in zip(decoders, encs, enc_masks):      # a decoder listed twice must not share one cached state
             fresh = id(d) in seen
             seen.add(id(d))
-            self.states.append(DecodeState(d, e, m, beams, max_length) if fresh else _cached_state(d, e, m, beams, max_length))
+            self.states.append(DecodeState(d, e, m, beams, max_length, dtype) if fresh else _cached_state(d, e, m, beams, max_length, dtype))
 
     def reorder(self, parent_rows, upto):
         for st in self.states:
@@ -182,28 +261,29 @@ class EnsembleState:
 _STATE_CACHE = weakref.WeakKeyDictionary()
 
 
-def _cached_state(decoder, enc, enc_mask, beams, max_length):
+def _cached_state(decoder, enc, enc_mask, beams, max_length, dtype="bf16"):
     """decode states (KV caches, cross K|V buffers, captured graphs) live on the decoder and are reused by generate()
     calls of the same shape; the key includes the arena's shadow buffer so a re-flattened model starts afresh"""
     if not DECODE_GRAPH:
-        return DecodeState(decoder, enc, enc_mask, beams, max_length)
+        return DecodeState(decoder, enc, enc_mask, beams, max_length, dtype)
     cache = _STATE_CACHE.setdefault(decoder, {})        # weak: dies with the decoder; never part of deepcopy / pickling of the model
     arena = arena_of(decoder)
-    key = (enc.shape[0], enc.shape[1], enc.shape[2], beams, max_length, enc_mask is not None, arena.shadow_flat.data_ptr(), str(enc.device))
+    key = (enc.shape[0], enc.shape[1], enc.shape[2], beams, max_length, enc_mask is not None, arena.shadow_flat.data_ptr(), str(enc.device), dtype)
     st = cache.get(key)
     if st is None:
         if len(cache) >= 4:
             cache.clear()
-        st = cache[key] = DecodeState(decoder, enc, enc_mask, beams, max_length)
+        st = cache[key] = DecodeState(decoder, enc, enc_mask, beams, max_length, dtype)
     else:
         st.load_encoder(enc, enc_mask)
     return st
 
 
-def _decode_state(decoder, enc, enc_mask, beams, max_length):
+def _decode_state(decoder, enc, enc_mask, beams, max_length, dtype=None):
+    dtype = dtype or DECODE_DTYPE
     if isinstance(decoder, (list, tuple)):
-        return EnsembleState(decoder, enc, enc_mask, beams, max_length), decoder[0], enc[0]
-    return _cached_state(decoder, enc, enc_mask, beams, max_length), decoder, enc
+        return EnsembleState(decoder, enc, enc_mask, beams, max_length, dtype), decoder[0], enc[0]
+    return _cached_state(decoder, enc, enc_mask, beams, max_length, dtype), decoder, enc
 
 
 def log_softmax_f32(logits):
@@ -237,10 +317,10 @@ def _process(logits, bad_ids, top_k):
 
 @torch.no_grad()
 def sample(decoder, input_ids, enc, enc_mask, *, max_length, eos_token_id, pad_token_id, do_sample=False, top_k=None,
-           bad_words_ids=None, output_scores=False, generator=None):
+           bad_words_ids=None, output_scores=False, generator=None, decode_dtype=None):
     """HF ``_sample``: greedy (argmax) or multinomial sampling, 1 sequence per batch row."""
     B = input_ids.shape[0]
-    st, decoder, enc0 = _decode_state(decoder, enc, enc_mask, 1, max_length)
+    st, decoder, enc0 = _decode_state(decoder, enc, enc_mask, 1, max_length, decode_dtype)
     dev = enc0.device
     seq = torch.full((B, max_length), pad_token_id, dtype=torch.long, device=dev)
     seq[:, 0] = input_ids[:, 0]
@@ -282,10 +362,11 @@ def _gather(t, idx):
 
 
 @torch.no_grad()
-def beam_search(decoder, input_ids, enc, enc_mask, *, max_length, eos_token_id, pad_token_id, num_beams, length_penalty=1.0):
+def beam_search(decoder, input_ids, enc, enc_mask, *, max_length, eos_token_id, pad_token_id, num_beams, length_penalty=1.0,
+                decode_dtype=None):
     """HF ``_beam_search`` (early_stopping=False, do_sample=False, num_return_sequences=1)."""
     B, nb, keep, prompt = input_ids.shape[0], num_beams, 2 * num_beams, 1
-    st, decoder, enc0 = _decode_state(decoder, enc, enc_mask, nb, max_length)
+    st, decoder, enc0 = _decode_state(decoder, enc, enc_mask, nb, max_length, decode_dtype)
     dev = enc0.device
     V = decoder.config.vocab_size
     running = torch.full((B, nb, max_length), pad_token_id, dtype=torch.long, device=dev)
@@ -364,10 +445,11 @@ def generate(decoder, input_ids=None, encoder_hidden_states=None, encoder_attent
         if args.get("do_sample"):
             raise NotImplementedError("beam sampling is outside the reference's call sites")
         out = beam_search(decoder, input_ids, encoder_hidden_states, encoder_attention_mask, max_length=max_length,
-                          eos_token_id=eos, pad_token_id=pad, num_beams=nb, length_penalty=args.get("length_penalty", 1.0) or 1.0)
+                          eos_token_id=eos, pad_token_id=pad, num_beams=nb, length_penalty=args.get("length_penalty", 1.0) or 1.0,
+                          decode_dtype=args.get("decode_dtype"))
     else:
         out = sample(decoder, input_ids, encoder_hidden_states, encoder_attention_mask, max_length=max_length, eos_token_id=eos,
                      pad_token_id=pad, do_sample=bool(args.get("do_sample")), top_k=args.get("top_k"),
                      bad_words_ids=args.get("bad_words_ids"), output_scores=bool(args.get("output_scores")),
-                     generator=args.get("generator"))
+                     generator=args.get("generator"), decode_dtype=args.get("decode_dtype"))
     return out if ret_dict else out.sequences
