@@ -108,8 +108,8 @@ def run_decode(args):
     enc = torch.randn(B, S, 768, device=dev).bfloat16()
     mask = torch.ones(B, S, dtype=torch.bool, device=dev)
     start = torch.zeros(B, 1, dtype=torch.long, device=dev)
-    for beams in (1, 4):
-        kw = dict(bos_token_id=0, eos_token_id=2, pad_token_id=1, max_length=T)      # rows that emit eos early still occupy their batch slot
+    for beams, dtype in ((1, "bf16"), (4, "bf16"), (1, "fp32"), (4, "fp32")):
+        kw = dict(bos_token_id=0, eos_token_id=2, pad_token_id=1, max_length=T, decode_dtype=dtype)      # rows that emit eos early still occupy their batch slot
         if beams > 1:
             kw["num_beams"] = beams
         with torch.no_grad():
@@ -120,7 +120,7 @@ def run_decode(args):
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         steps = out.shape[1] - 1
-        print(json.dumps({"task": "decode", "metric": f"decode beams={beams}", "value": round(B * steps / dt, 1), "unit": "tokens/s",
+        print(json.dumps({"task": "decode", "metric": f"decode beams={beams} {dtype}", "value": round(B * steps / dt, 1), "unit": "tokens/s",
                           "ms_per_step": round(dt / max(1, steps) * 1e3, 3), "batch": B, "steps": steps}), flush=True)
 
 

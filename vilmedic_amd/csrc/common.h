@@ -117,7 +117,7 @@ struct VmEnv {
     int gemm_variant;      // VM_GEMM_VARIANT: force a tile variant (-1: cost model)
     int gemm_debug;        // VM_GEMM_DEBUG: 1 skip the epilogue, 2 one K-tile only (timing breakdowns)
     int gemm_groupw;       // VM_GEMM_GROUPW: column-group width of the tile order (0: heuristic)
-    int gemm_pipe;         // VM_GEMM_PIPE: 1 = software-pipelined K-tile, 0 = compiler-scheduled, 2 = 1 + s_setprio around the MFMAs (unmeasured)
+    int gemm_pipe;         // VM_GEMM_PIPE: 1 = software-pipelined K-tile (default), 0 = compiler-scheduled
     bool gemm_generic;     // VM_GEMM_GENERIC: register-staged fallback kernel only
     bool gemm_no_skinny;   // VM_GEMM_NO_SKINNY: never take the M <= 128 decode-step kernel
     bool attn_tile;        // VM_ATTN_TILE: tile-streaming attention kernels instead of the head-resident ones

@@ -315,6 +315,10 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
             const int64_t c128 = (t128 + slots - 1) / slots * 128, c160 = (t160 + slots - 1) / slots * 160;
             if (c160 <= c128) variant = 4;   // ties: the larger tile re-reads less of B
         }
+        // the 8-wave 256 x 256 kernel keeps both fragment sets of a 128 x 64 wave tile in registers: with a strided A operand
+        // (two transpose reads per fragment, per-fragment swizzled addresses) that spills inside the main loop -> 128 x 128 form
+        if ((variant == 8 || variant == 9) && a_layout != 0) variant += 2;
+        if (variant == 12 && a_layout != 0) variant = 10;
         int vbm, vbn;
         vm_gemm_variant_tile(variant, &vbm, &vbn);
         a.tiles_m = (M + vbm - 1) / vbm;

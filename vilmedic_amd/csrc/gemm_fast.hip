@@ -61,9 +61,20 @@ __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// Same DMA as glds16 but hidden from the compiler.  With the builtin, hipcc (ROCm 7.2) puts "s_waitcnt vmcnt(0)" in front of the first
+// ds_read_b64_tr_b16 that follows a DMA issue (the transpose-read builtin carries no memory operand, so the waitcnt pass assumes it
+// may alias the pending LDS write): the tile just requested is waited for at once and the pipeline is serial for every strided
+// operand.  The inline-asm form is invisible to that pass; ordering is then entirely by the explicit s_waitcnt vmcnt + s_barrier of
+// the main loop (MI355X_MICROARCH.md, "Two waves per SIMD" item 7: nothing else orders a ds_read behind an LDS-DMA anyway).
+__device__ __forceinline__ void glds16_asm(const bf16_t* src, char* lds_dst) {
+    const uint32_t l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_dst;      // wave-uniform
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(l) : "memory", "m0");
+}
+
 //                      PIPE = 1 (2-stage, k-tile 64 only): the fragments of BOTH 32-wide k-halves of a tile are requested right after
 //                             the barrier and the MFMAs follow behind a scheduling barrier, so one LDS latency is exposed per
 //                             K-tile instead of one per dependent read group of the compiler's own schedule
+//                      PIPE = 4 / 5: cross-tile register pipeline with the barrier in the middle of the K-tile (see the main loop)
 template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF, int PIPE>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fast_kernel(const GemmArgs p) {
     constexpr int WR = MF * 16;                     // rows per wave (MF 16-row A fragments; 4 or 5)
@@ -110,12 +121,19 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
     for (int i = 0; i < NA_I; ++i) srcA[i] = stage_src<LA, FBM, BKT>(p.A, p.lda, m0, p.M, wave * NA_I + i, lane) + kt_begin * stepA;
 #pragma unroll
     for (int i = 0; i < NB_I; ++i) srcB[i] = stage_src<LB, FBN, BKT>(p.B, p.ldb, n0, p.N, wave * NB_I + i, lane) + kt_begin * stepB;
+    constexpr bool ASM_DMA = (PIPE == 4 || PIPE == 5) && (LA != 0 || LB != 0);
     auto stage = [&](int buf) {
         char* da = smem + buf * F_STAGE;
 #pragma unroll
-        for (int i = 0; i < NA_I; ++i) { glds16(srcA[i], da + (wave * NA_I + i) * 1024); srcA[i] += stepA; }
+        for (int i = 0; i < NA_I; ++i) {
+            if constexpr (ASM_DMA) glds16_asm(srcA[i], da + (wave * NA_I + i) * 1024); else glds16(srcA[i], da + (wave * NA_I + i) * 1024);
+            srcA[i] += stepA;
+        }
 #pragma unroll
-        for (int i = 0; i < NB_I; ++i) { glds16(srcB[i], da + F_OPER_A + (wave * NB_I + i) * 1024); srcB[i] += stepB; }
+        for (int i = 0; i < NB_I; ++i) {
+            if constexpr (ASM_DMA) glds16_asm(srcB[i], da + F_OPER_A + (wave * NB_I + i) * 1024); else glds16(srcB[i], da + F_OPER_A + (wave * NB_I + i) * 1024);
+            srcB[i] += stepB;
+        }
     };
 
     // ---- per-lane fragment read offsets
@@ -149,7 +167,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
     auto compute = [&](int buf) {
         const char* sa = smem + buf * F_STAGE;
         const char* sb = sa + F_OPER_A;
-        if constexpr ((PIPE == 1 || PIPE == 2) && BKT == 64) {
+        if constexpr (PIPE == 1 && BKT == 64) {
             // software-pipelined K-tile: the first 32-wide k-half's fragments are requested up front, the second half's
             // reads are slotted one per MFMA behind the first MFMAs of the first half (sched_group_barrier: 0x100 = LDS read, 0x008 = MFMA),
             // so only the first reads' latency is exposed per K-tile
@@ -164,9 +182,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
 #pragma unroll
                 for (int i = 4; i < MF; ++i) fa[kk][i] = LA == 0 ? read_frag0(sa, a_rb, i, kk) : read_frag1(sa, a_rb, i, kk, FBM * 2);
             }
-            // PIPE == 2 (EXPERIMENT, unmeasured, VM_GEMM_PIPE=2): the same schedule with the wave's issue priority raised while it
-            // has MFMAs to issue, so that the SIMD's other wave (DMA issue, barrier, epilogue) does not delay them
-            if constexpr (PIPE == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -186,7 +201,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 2 * NMF - NRD, 0);
-            if constexpr (PIPE == 2) __builtin_amdgcn_s_setprio(0);
             return;
         }
 #pragma unroll
@@ -203,60 +217,59 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
         }
     };
-    if constexpr (PIPE == 3) {
-        // EXPERIMENT (unmeasured; reached only through VM_GEMM_VARIANT=7): 3-slot ring with the fragments of tile t+1 read into a
-        // second register set WHILE tile t's MFMAs issue.  Every wave drains its LDS reads before each barrier, so after barrier t-1
-        // nobody reads slot (t-1) % 3 any more: tile t+2 is requested into it at the very top of iteration t, BEFORE barrier t, and
-        // has a whole iteration plus the barrier wait to land; behind barrier t the wave goes straight to MFMAs (tile t's fragments
-        // are already in registers) with tile t+1's reads slotted one per MFMA.
-        static_assert(STAGES == 3 && BKT == 32, "ring + register prefetch: 3 slots of 32-wide k-tiles");
-        constexpr int NLD = NA_I + NB_I, NFR = MF + 4, NMF = 4 * MF, RA = LA == 0 ? 1 : 2, RB = LB == 0 ? 1 : 2;
-        static_assert(NFR <= NMF, "one fragment per MFMA slot");
+    if constexpr (PIPE == 4 || PIPE == 5) {
+        // Cross-tile register pipeline.  Two fragment sets live in registers: set kk holds the kk-th 32-wide k-half of a K-tile.
+        // Per K-tile t (LDS slot t & 1):
+        //   phase A:  MFMAs of set 0 (tile t), with the LDS reads of set 1 (tile t) slotted behind them one per MFMA;
+        //   s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier in the MIDDLE of the tile: tile t+1 (requested a whole K-tile ago) has
+        //             landed for every wave, and every wave has drained its reads of slot t & 1 -> that slot is free;
+        //   phase C:  tile t+2 is requested into the freed slot, and the MFMAs of set 1 (tile t) run with the reads of set 0
+        //             of tile t+1 slotted behind them.
+        // So no LDS latency is exposed behind the barrier (the MFMAs that follow it have their operands in registers), every
+        // DMA has a full K-tile of MFMA time to land, and there is ONE barrier per K-tile.  PIPE 4 issues the DMA pieces as a
+        // burst right behind the barrier, PIPE 5 slots them one per MFMA behind the fragment reads.
+        static_assert(STAGES == 2 && BKT == 64, "cross-tile register pipeline: 2 LDS slots of 64-wide k-tiles");
+        constexpr int NLD = NA_I + NB_I, NMF = 4 * MF, RA = LA == 0 ? 1 : 2, RB = LB == 0 ? 1 : 2;
+        constexpr int NRD = MF * RA + 4 * RB;                       // LDS read instructions per k-half
+        constexpr int DSPER = (PIPE == 5 && NRD + NLD > NMF) ? 2 : 1;   // reads slotted per MFMA
+        constexpr int NS1 = (NRD + DSPER - 1) / DSPER;
+        static_assert(NS1 + (PIPE == 5 ? NLD : 0) <= NMF, "one slot per MFMA");
         const int nk = kt_end - kt_begin;
         bf16x8_t fa[2][MF], fb[2][4];
-        auto read_tile = [&](int slot, auto set_c) {          // fragment order b0 a0 b1 a1 b2 a2 b3 a3 a4 ...
-            constexpr int SET = decltype(set_c)::value;
-            const char* sa = smem + slot * F_STAGE;
+        auto read_half = [&](const char* sa, auto kk_c) {
+            constexpr int KK = decltype(kk_c)::value;
             const char* sb = sa + F_OPER_A;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                fb[SET][j] = LB == 0 ? read_frag0(sb, b_rb, j, 0) : read_frag1(sb, b_rb, j, 0, FBN * 2);
-                fa[SET][j] = LA == 0 ? read_frag0(sa, a_rb, j, 0) : read_frag1(sa, a_rb, j, 0, FBM * 2);
+                fb[KK][j] = LB == 0 ? read_frag0(sb, b_rb, j, KK) : read_frag1(sb, b_rb, j, KK, FBN * 2);
+                if (j < MF) fa[KK][j] = LA == 0 ? read_frag0(sa, a_rb, j, KK) : read_frag1(sa, a_rb, j, KK, FBM * 2);
             }
 #pragma unroll
-            for (int i = 4; i < MF; ++i) fa[SET][i] = LA == 0 ? read_frag0(sa, a_rb, i, 0) : read_frag1(sa, a_rb, i, 0, FBM * 2);
+            for (int i = 4; i < MF; ++i) fa[KK][i] = LA == 0 ? read_frag0(sa, a_rb, i, KK) : read_frag1(sa, a_rb, i, KK, FBM * 2);
         };
-        auto mfma_tile = [&](auto set_c) {
-            constexpr int SET = decltype(set_c)::value;
+        auto mfma_half = [&](auto kk_c) {
+            constexpr int KK = decltype(kk_c)::value;
 #pragma unroll
-            for (int d = 0; d < 4 + MF - 1; ++d)
+            for (int i = 0; i < MF; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = d - j;
-                    if (i >= 0 && i < MF) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[SET][j], fa[SET][i], acc[j][i], 0, 0, 0);
-                }
+                for (int j = 0; j < 4; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[KK][j], fa[KK][i], acc[j][i], 0, 0, 0);
         };
-        auto iteration = [&](int it, int slot, auto cur_c) {   // slot = it % 3
-            constexpr int CUR = decltype(cur_c)::value;
-            const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot == 0 ? 2 : slot - 1;     // (it + 1) % 3, (it + 2) % 3
-            if (it + 2 < nk) stage(slot2);
-            if (it + 1 < nk) {
-                if (it + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLD) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();                  // tile it+1 landed for every wave
-                read_tile(slot1, std::integral_constant<int, CUR ^ 1>{});
-                mfma_tile(cur_c);
+        auto slot_reads = [&]() {                                   // NRD reads behind the first MFMAs, then the remaining MFMAs
 #pragma unroll
-                for (int n = 0; n < NFR; ++n) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (n < 8 && (n & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x100, RB, 0);
-                    else __builtin_amdgcn_sched_group_barrier(0x100, RA, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, NMF - NFR, 0);
-            } else {
-                mfma_tile(cur_c);
+            for (int n = 0; n < NRD; ++n) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
         };
+        auto mid_tile_barrier = [&]() {
+            __builtin_amdgcn_sched_barrier(0);       // MFMAs are register-only: without this the scheduler sinks phase A's tail below
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the wait and exposes the last reads' latency
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using K0 = std::integral_constant<int, 0>;
+        using K1 = std::integral_constant<int, 1>;
         stage(0);
         if (nk > 1) {
             stage(1);
@@ -265,13 +278,54 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        read_tile(0, std::integral_constant<int, 0>{});
-        int slot = 0;
-        for (int it = 0; it < nk; it += 2) {
-            iteration(it, slot, std::integral_constant<int, 0>{});
-            slot = slot == 2 ? 0 : slot + 1;
-            if (it + 1 < nk) iteration(it + 1, slot, std::integral_constant<int, 1>{});
-            slot = slot == 2 ? 0 : slot + 1;
+        read_half(smem, K0{});
+        int t = 0;
+        for (; t + 2 < nk; ++t) {                                   // steady state: there is a tile t+2 to request
+            const int slot = t & 1;
+            const char* cur = smem + slot * F_STAGE;
+            const char* nxt = smem + (slot ^ 1) * F_STAGE;
+            read_half(cur, K1{});
+            mfma_half(K0{});
+            slot_reads();
+            mid_tile_barrier();
+            if constexpr (PIPE == 4) { stage(slot); __builtin_amdgcn_sched_barrier(0); }     // DMA pieces as one burst
+            read_half(nxt, K0{});
+            if constexpr (PIPE == 5) stage(slot);
+            mfma_half(K1{});
+            if constexpr (PIPE == 5) {
+#pragma unroll
+                for (int n = 0; n < NS1; ++n) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, DSPER, 0);
+                }
+#pragma unroll
+                for (int n = 0; n < NLD; ++n) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NMF - NS1 - NLD, 0);
+            } else {
+                slot_reads();
+            }
+        }
+        if (t + 1 < nk) {                                           // second-to-last tile: nothing left to request
+            const char* cur = smem + (t & 1) * F_STAGE;
+            const char* nxt = smem + ((t & 1) ^ 1) * F_STAGE;
+            read_half(cur, K1{});
+            mfma_half(K0{});
+            slot_reads();
+            mid_tile_barrier();
+            read_half(nxt, K0{});
+            mfma_half(K1{});
+            slot_reads();
+            ++t;
+        }
+        {                                                           // last tile
+            const char* cur = smem + (t & 1) * F_STAGE;
+            read_half(cur, K1{});
+            mfma_half(K0{});
+            slot_reads();
+            mfma_half(K1{});
         }
     } else if (STAGES == 2) {
         stage(0);
@@ -500,28 +554,30 @@ static int dispatch_layout(const GemmArgs& a, int a_layout, int b_layout, int nb
 // variant 0: 128x128 tile, 2-stage (2 workgroups/CU); 1: 256x128, 3-stage ring; 2: 256x256, 16 waves, 2-stage
 //         4: 160x128 (5 A fragments per wave), row-major A only
 // (measured and dropped: 128x128 with k-tile 32 x 4-stage ring, 256x128 with 128x64 per wave -- both slower on every hot shape;
+//  round 2: k-tile 32 x 3-slot ring with register prefetch 0.72-0.97x, 256x128 / 128x64-per-wave k-tile 32 3-slot ring 0.51-0.98x,
+//  s_setprio around the MFMA stream 0.83-1.0x -- profiles/r02_a_gemm_candidates_ab.txt;
 //  issuing the next tile's DMA pieces from between the first MFMAs of the K-tile instead of right after the barrier: equal to
 //  -13 % with row-major operands, 1.3-2.7x slower with ds_read_b64_tr operands -- profiles/r01_e_gemm_pipe_ab.txt)
 int vm_gemm_fast_dispatch(const GemmArgs& a0, int a_layout, int b_layout, int nblocks, int variant, hipStream_t s) {
     const int pipe = vm_env().gemm_pipe;
     if (variant == 1) return dispatch_layout<4, 2, 3, 64, 4>(a0, a_layout, b_layout, nblocks, s);
     if (variant == 2) return dispatch_layout<4, 4, 2, 64, 4>(a0, a_layout, b_layout, nblocks, s);
-    if (variant == 7)                    // EXPERIMENT (unmeasured): 128x128 tile, k-tile 32, 3-slot ring + register prefetch
-        return dispatch_layout<2, 2, 3, 32, 4, 3>(a0, a_layout, b_layout, nblocks, s);
-    if (variant == 5)                    // EXPERIMENT (unmeasured, only via VM_GEMM_VARIANT=5): 256x128 tile, 4 waves of 128x64, k-tile 32,
-        return dispatch_layout<2, 2, 3, 32, 8>(a0, a_layout, b_layout, nblocks, s);   // 3-stage ring (two tiles in flight), 72 KiB LDS
-    if (variant == 4) {                  // 160x128 tile (A row-major only): evens out the tile count when 128-row tiles leave a thin last round
+    // 8 waves x (128 x 64) = 256 x 256 tile, one workgroup per CU, cross-tile register pipeline (8: DMA burst, 9: DMA slotted)
+    if (variant == 8) return dispatch_layout<2, 4, 2, 64, 8, 4>(a0, a_layout, b_layout, nblocks, s);
+    if (variant == 9) return dispatch_layout<2, 4, 2, 64, 8, 5>(a0, a_layout, b_layout, nblocks, s);
+    if (variant == 10) return dispatch_layout<2, 2, 2, 64, 4, 4>(a0, a_layout, b_layout, nblocks, s);   // 128 x 128 tile with the same pipelines
+    if (variant == 11) return dispatch_layout<2, 2, 2, 64, 4, 5>(a0, a_layout, b_layout, nblocks, s);
+    if (variant == 4 || variant == 12) {  // 160x128 tile (A row-major only): evens out the tile count when 128-row tiles leave a thin last round
         if (a_layout != 0) { vm_set_error("vm_gemm_bf16: 160-row tile needs a row-major A"); return VM_EINVAL; }
-        if (pipe == 2) return b_layout == 0 ? launch_fast<0, 0, 2, 2, 2, 64, 5, 2>(a0, nblocks, s) : launch_fast<0, 1, 2, 2, 2, 64, 5, 2>(a0, nblocks, s);
+        if (variant == 12) return b_layout == 0 ? launch_fast<0, 0, 2, 2, 2, 64, 5, 4>(a0, nblocks, s) : launch_fast<0, 1, 2, 2, 2, 64, 5, 4>(a0, nblocks, s);
         if (pipe == 1) return b_layout == 0 ? launch_fast<0, 0, 2, 2, 2, 64, 5, 1>(a0, nblocks, s) : launch_fast<0, 1, 2, 2, 2, 64, 5, 1>(a0, nblocks, s);
         if (b_layout == 0) return launch_fast<0, 0, 2, 2, 2, 64, 5>(a0, nblocks, s);
         return launch_fast<0, 1, 2, 2, 2, 64, 5>(a0, nblocks, s);
     }
-    if (pipe == 2) return dispatch_layout<2, 2, 2, 64, 4, 2>(a0, a_layout, b_layout, nblocks, s);
     if (pipe == 1) return dispatch_layout<2, 2, 2, 64, 4, 1>(a0, a_layout, b_layout, nblocks, s);
     return dispatch_layout<2, 2, 2, 64, 4>(a0, a_layout, b_layout, nblocks, s);
 }
 void vm_gemm_variant_tile(int variant, int* bm, int* bn) {
-    *bm = (variant == 1 || variant == 2 || variant == 5) ? 256 : variant == 4 ? 160 : 128;
-    *bn = variant == 2 ? 256 : 128;
+    *bm = (variant == 1 || variant == 2 || variant == 8 || variant == 9) ? 256 : (variant == 4 || variant == 12) ? 160 : 128;
+    *bn = (variant == 2 || variant == 8 || variant == 9) ? 256 : 128;
 }
