@@ -71,6 +71,22 @@ void vm_reload_env(void);
 int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void* B, int64_t ldb, int b_layout,
                  void* C, int64_t ldc, int M, int N, int K, const vm_gemm_epilogue* epi, void* stream);
 
+/* Grouped weight gradients: for i < n   dW_i[n_out, k_in] (ld_dw) += alpha_i * dY_i[rows, n_out]^T (ld_dy) . X_i[rows, k_in] (ld_x)
+ * and, when db_i is given, db_i[n_out] += alpha_i * column sums of dY_i -- all problems in one launch (per 8), no split-K workspace,
+ * no separate reduce / column-sum kernels.  What autograd computes for nn.Linear weight / bias in the reference's backward
+ * (hf:models/bert_generation/modeling_bert_generation.py:104-106,264-291; hf:models/vit/modeling_vit.py:192-251).
+ * alpha_i: optional DEVICE scalar (upstream dL/dloss).  Returns VM_EUNSUPPORTED (nothing launched) unless every problem has
+ * rows % 64 == 0, leading dims % 8 == 0 and 16-byte aligned pointers -- the caller then uses vm_gemm_bf16 + vm_colsum_bf16. */
+typedef struct {
+    const void* dY; int64_t ld_dy;      /* bf16 [rows, n_out]  */
+    const void* X; int64_t ld_x;        /* bf16 [rows, k_in]   */
+    float* dW; int64_t ld_dw;           /* fp32 [n_out, k_in], accumulated */
+    float* db;                          /* fp32 [n_out] accumulated, or NULL */
+    int rows, n_out, k_in;
+    const float* alpha_dev;
+} vm_wgrad_problem;
+int vm_wgrad_grouped(const vm_wgrad_problem* problems, int n, void* stream);
+
 /* ------------------------------------------------------------------ LayerNorm
  * hf:...bert_generation.py:49,55 (post-LN, eps from YAML), hf:models/vit/modeling_vit.py:261-262,348 (pre-LN).
  * y = (x-mean)*rstd*gamma+beta over the last dim; x,y bf16 [rows,cols]; mean/rstd fp32 [rows]. */

@@ -121,9 +121,11 @@ class _FakeArena:
                 n = p.numel()
                 self.flat[off:off + n].copy_(p.reshape(-1))
                 p.data = self.flat[off:off + n].view(p.shape)
-                p.grad = self.gflat[off:off + n].view(p.shape)
+                p._vm_grad_view = self.gflat[off:off + n].view(p.shape)
+                p.grad = p._vm_grad_view
                 p._vm_off = off
                 off += n
+        self._layout = [(p, p._vm_off) for p in params]
 
     def valid(self):
         return True
@@ -176,3 +178,41 @@ def test_arena_ddp_two_phase_backward_equals_single_process_gradient():
     torch.testing.assert_close(r[0][0], r[1][0], rtol=0, atol=0)                 # identical replicas after the broadcast
     for rank in (0, 1):
         torch.testing.assert_close(r[rank][1], r[rank][2], rtol=1e-5, atol=1e-6)
+
+
+def _arena_ddp_grad_accu(rank, world):
+    """two micro-batches per optimizer step: the first backward must NOT reduce but MUST run both phases (with the split
+    enabled and a plain loss.backward() the encoder received no gradient at all); between them an optimizer drops .grad
+    (zero_grad(set_to_none=True) style) on one native parameter, which must be folded back into the arena before the all-reduce"""
+    from vilmedic_amd.parallel import ArenaDDP
+    torch.manual_seed(5)
+    model = _TwoPhase()
+    model.__dict__["_vm_arena_cache"] = _FakeArena(model)
+    ddp = ArenaDDP(model, dist, chunks=2, bf16_wire=False)
+    g = torch.Generator().manual_seed(12)
+    X, Y = torch.randn(16, 10, generator=g), torch.randn(16, 3, generator=g)
+    xs, ys = X[rank * 8:(rank + 1) * 8], Y[rank * 8:(rank + 1) * 8]
+    ddp.backward(model(xs[:4], ys[:4]), sync=False)
+    enc_after_first = ddp.arena.gflat[ddp.split_at:].abs().sum().item()
+    stray = model.enc[0].bias
+    saved = stray.grad.clone()
+    stray.grad = None                                   # what torch.optim's zero_grad(set_to_none=True) / a foreign hook may leave behind
+    stray.grad = saved.clone()                          # ... and autograd then accumulates into a tensor OUTSIDE the arena
+    stray._vm_grad_view.zero_()
+    ddp.backward(model(xs[4:], ys[4:]), sync=True)
+    ref = _TwoPhase()
+    ref.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+    total = 0.0
+    for r in range(world):                              # mean over ranks of the SUM over each rank's micro-batches
+        for lo in (0, 4):
+            total = total + ref(X[r * 8 + lo:r * 8 + lo + 4], Y[r * 8 + lo:r * 8 + lo + 4])
+    (total / world).backward()
+    return enc_after_first, ddp.arena.gflat.clone(), torch.cat([p.grad.reshape(-1) for p in ref.parameters()]), stray.grad is stray._vm_grad_view
+
+
+def test_arena_ddp_gradient_accumulation_trains_the_encoder_and_folds_stray_grads():
+    r = _run(_arena_ddp_grad_accu)
+    for rank in (0, 1):
+        assert r[rank][0] > 0, "encoder gradient missing after a non-stepping micro-batch"
+        torch.testing.assert_close(r[rank][1], r[rank][2], rtol=1e-5, atol=1e-6)
+        assert r[rank][3]

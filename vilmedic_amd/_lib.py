@@ -23,6 +23,11 @@ class GemmEpilogue(C.Structure):
     ]
 
 
+class WgradProblem(C.Structure):
+    _fields_ = [("dY", C.c_void_p), ("ld_dy", C.c_int64), ("X", C.c_void_p), ("ld_x", C.c_int64), ("dW", C.c_void_p), ("ld_dw", C.c_int64),
+                ("db", C.c_void_p), ("rows", C.c_int), ("n_out", C.c_int), ("k_in", C.c_int), ("alpha_dev", C.c_void_p)]
+
+
 _lib = None
 
 _P, _I, _L, _F, _U64, _SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
@@ -38,6 +43,7 @@ SIGNATURES = {
     "vm_sizeof_gemm_epilogue": (_I, []),
     "vm_prof_dump": (_I, [C.c_char_p]),
     "vm_gemm_bf16": (_I, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, C.POINTER(GemmEpilogue), _P]),
+    "vm_wgrad_grouped": (_I, [C.POINTER(WgradProblem), _I, _P]),
     "vm_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "vm_layernorm_bwd_ws": (_SZ, [_I, _I]),
     "vm_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),

@@ -289,6 +289,8 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
     const bool fast_ok = (K % 64) == 0 && (ldc % 8) == 0 && (!epi->bias || ((uintptr_t)epi->bias % 16) == 0) &&
                          (!epi->residual || (epi->ldr % 8) == 0) && !vm_env().gemm_generic;
     a.slabs = nullptr;
+    a.bias_grad = nullptr;
+    a.stagger = vm_env().gemm_stagger;
     a.dbg = vm_env().gemm_debug;
     // decode-step shapes: few rows -> one workgroup per 16 output columns, K split over its waves (gemm_skinny.hip)
     if (M <= 128 && a_layout == 0 && b_layout == 0 && (K % 32) == 0 && split == 1 && !epi->aux_out && !epi->mul_gelu_z &&
@@ -315,9 +317,13 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
             const int64_t c128 = (t128 + slots - 1) / slots * 128, c160 = (t160 + slots - 1) / slots * 160;
             if (c160 <= c128) variant = 4;   // ties: the larger tile re-reads less of B
         }
+        // strided operands (dgrad: B, wgrad: A and B) run the cross-tile register pipeline with the inline-asm LDS-DMA: the
+        // builtin DMA is followed by a compiler-inserted vmcnt(0) in front of the first transpose read, i.e. the tile just
+        // requested is waited for at once (measured 1.1-1.37x on every strided shape of the step, profiles/r02_b_gemm_pipe4_asmdma_ab.txt)
+        if (force < 0 && (a_layout != 0 || b_layout != 0)) variant = variant == 4 ? 12 : variant == 0 ? 10 : variant;
         // the 8-wave 256 x 256 kernel keeps both fragment sets of a 128 x 64 wave tile in registers: with a strided A operand
         // (two transpose reads per fragment, per-fragment swizzled addresses) that spills inside the main loop -> 128 x 128 form
-        if ((variant == 8 || variant == 9) && a_layout != 0) variant += 2;
+        if (variant == 8 && a_layout != 0) variant = 10;
         if (variant == 12 && a_layout != 0) variant = 10;
         int vbm, vbn;
         vm_gemm_variant_tile(variant, &vbm, &vbn);
@@ -339,4 +345,52 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
     if (a_layout == 1 && b_layout == 1) return launch<1, 1>(a, nblocks, s);
     vm_set_error("vm_gemm_bf16: bad layout flags");
     return VM_EINVAL;
+}
+
+
+// ------------------------------------------------------------------ grouped weight gradients
+// dW_i[N_i, K_i] += alpha_i * dY_i[M_i, N_i]^T X_i[M_i, K_i]   and   db_i[N_i] += alpha_i * colsum(dY_i)   for i < n, in ONE launch
+// per <= VM_GEMM_MAX_GROUP problems.  Replaces, for the weight gradients of one transformer layer, 4-6 split-K GEMM launches +
+// their slab-reduce kernels + the column-sum kernels (nn.Linear backward: hf:models/bert_generation/modeling_bert_generation.py
+// :104-106,264-291 as differentiated by autograd in the reference).
+extern "C" int vm_wgrad_grouped(const vm_wgrad_problem* pr, int n, void* stream) {
+    VM_REQUIRE(pr && n > 0, "vm_wgrad_grouped: no problems");
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < n; ++i) {
+        const vm_wgrad_problem& q = pr[i];
+        VM_REQUIRE(q.dY && q.X && q.dW, "vm_wgrad_grouped: null pointer in problem %d", i);
+        VM_REQUIRE(q.rows > 0 && q.n_out > 0 && q.k_in > 0, "vm_wgrad_grouped: empty problem %d", i);
+        if ((q.rows % 64) != 0 || (q.ld_dy % 8) != 0 || (q.ld_x % 8) != 0 || (q.ld_dw % 8) != 0 || ((uintptr_t)q.dY % 16) != 0 ||
+            ((uintptr_t)q.X % 16) != 0 || ((uintptr_t)q.dW % 16) != 0) {
+            vm_set_error("vm_wgrad_grouped: problem %d is not eligible (rows %% 64, leading dims %% 8, 16-byte pointers)", i);
+            return VM_EUNSUPPORTED;
+        }
+    }
+    double work = 0;
+    for (int i = 0; i < n; ++i) work += 2.0 * pr[i].rows * (double)pr[i].n_out * pr[i].k_in;
+    VmProfScope prof(VM_FAM_GEMM, work, s, "wgrad_grouped_n%d_rows%d", n, pr[0].rows);
+    for (int base = 0; base < n; base += VM_GEMM_MAX_GROUP) {
+        GemmGroupArgs ga = {};
+        ga.n = n - base < VM_GEMM_MAX_GROUP ? n - base : VM_GEMM_MAX_GROUP;
+        int tiles = 0;
+        for (int i = 0; i < ga.n; ++i) {
+            const vm_wgrad_problem& q = pr[base + i];
+            GemmArgs& a = ga.g[i];
+            a.A = (const bf16_t*)q.dY; a.B = (const bf16_t*)q.X; a.C = q.dW;
+            a.lda = q.ld_dy; a.ldb = q.ld_x; a.ldc = q.ld_dw;
+            a.M = q.n_out; a.N = q.k_in; a.K = q.rows;
+            a.tiles_m = (a.M + 127) / 128; a.tiles_n = (a.N + 127) / 128;
+            a.ktiles = a.K / 64; a.ktiles_per_split = a.ktiles;
+            a.group_w = a.tiles_n;
+            a.e = vm_gemm_epilogue{};
+            a.e.alpha = 1.0f; a.e.alpha_dev = q.alpha_dev; a.e.out_dtype = VM_F32; a.e.accumulate = 1; a.e.split_k = 1;
+            a.drop_thresh = 0; a.drop_scale = 1.0f; a.dbg = 0; a.slabs = nullptr; a.bias_grad = q.db; a.stagger = 0;
+            ga.tile_start[i] = tiles;
+            tiles += a.tiles_m * a.tiles_n;
+        }
+        for (int i = ga.n; i <= VM_GEMM_MAX_GROUP; ++i) ga.tile_start[i] = tiles;
+        const int rc = vm_gemm_grouped_tn_launch(ga, tiles, s);
+        if (rc != VM_OK) return rc;
+    }
+    return VM_OK;
 }

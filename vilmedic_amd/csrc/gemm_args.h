@@ -12,7 +12,17 @@ struct GemmArgs {
     uint32_t drop_thresh; float drop_scale;
     int dbg;                 // VM_GEMM_DEBUG experiments (0 in production): 1 skip epilogue, 2 single K-tile
     float* slabs;            // split-K partial slabs [split][M][ldc] fp32 (fast path), or null
+    float* bias_grad;        // grouped weight-gradient launch: fp32 [M] += alpha * sum_k A(m, k), or null
+    int stagger;             // VM_GEMM_STAGGER experiment: late start of the second workgroup of every CU (units of 1024 cycles)
 };
+
+#define VM_GEMM_MAX_GROUP 8
+struct GemmGroupArgs {
+    int n;
+    int tile_start[VM_GEMM_MAX_GROUP + 1];
+    GemmArgs g[VM_GEMM_MAX_GROUP];
+};
+int vm_gemm_grouped_tn_launch(const GemmGroupArgs& ga, int nblocks, hipStream_t s);
 
 // tuned path (gemm_fast.hip): requires K % 64 == 0
 int vm_gemm_splitk_reduce(const GemmArgs& a, int nsplit, hipStream_t s);

@@ -74,25 +74,20 @@ __device__ __forceinline__ void glds16_asm(const bf16_t* src, char* lds_dst) {
 //                      PIPE = 1 (2-stage, k-tile 64 only): the fragments of BOTH 32-wide k-halves of a tile are requested right after
 //                             the barrier and the MFMAs follow behind a scheduling barrier, so one LDS latency is exposed per
 //                             K-tile instead of one per dependent read group of the compiler's own schedule
-//                      PIPE = 4 / 5: cross-tile register pipeline with the barrier in the middle of the K-tile (see the main loop)
-template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF, int PIPE>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fast_kernel(const GemmArgs p) {
+//                      PIPE = 4: cross-tile register pipeline with the barrier in the middle of the K-tile (see the main loop)
+//                      BG   = 1: the workgroups of tile column 0 also produce the bias gradient sum_k A(m, k) (one extra MFMA per A
+//                             fragment against an all-ones B fragment) -- the grouped weight-gradient launch
+// ``bid`` = logical work item (XCD-remapped by the caller): split * tiles + tile
+template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF, int PIPE, int BG>
+__device__ __forceinline__ void gemm_fast_body(const GemmArgs& p, const int bid, char* smem) {
     constexpr int WR = MF * 16;                     // rows per wave (MF 16-row A fragments; 4 or 5)
     constexpr int FBM = WM * WR, FBN = WN * 64, NW = WM * WN, NT = NW * 64;
     constexpr int F_OPER_A = FBM * BKT * 2, F_OPER_B = FBN * BKT * 2, F_STAGE = F_OPER_A + F_OPER_B;
     constexpr int NA_I = F_OPER_A / 1024 / NW, NB_I = F_OPER_B / 1024 / NW;   // A- / B-tile DMA instructions (1 KiB each) per wave
     static_assert(NA_I * NW * 1024 == F_OPER_A && NB_I * NW * 1024 == F_OPER_B, "tile must split evenly over the waves");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN, g = lane >> 4, c = lane & 15;
-
-    const int nwg = gridDim.x;
-    int bid;
-    {
-        const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    }
     const int tiles = p.tiles_m * p.tiles_n;
     const int split = bid / tiles;
     const int t = bid - split * tiles;
@@ -121,7 +116,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
     for (int i = 0; i < NA_I; ++i) srcA[i] = stage_src<LA, FBM, BKT>(p.A, p.lda, m0, p.M, wave * NA_I + i, lane) + kt_begin * stepA;
 #pragma unroll
     for (int i = 0; i < NB_I; ++i) srcB[i] = stage_src<LB, FBN, BKT>(p.B, p.ldb, n0, p.N, wave * NB_I + i, lane) + kt_begin * stepB;
-    constexpr bool ASM_DMA = (PIPE == 4 || PIPE == 5) && (LA != 0 || LB != 0);
+    constexpr bool ASM_DMA = PIPE == 4 && (LA != 0 || LB != 0);
     auto stage = [&](int buf) {
         char* da = smem + buf * F_STAGE;
 #pragma unroll
@@ -163,6 +158,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < MF; ++i) acc[j][i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    float4_t accb[BG ? MF : 1];                     // bias gradient (BG): lane (c, g) ends with rowsum_k A(a_rb + 16 i + c, k) in all 4 slots
+#pragma unroll
+    for (int i = 0; i < (BG ? MF : 1); ++i) accb[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    const bool bias_wg = BG && p.bias_grad != nullptr && tn == 0 && split == 0;
 
     auto compute = [&](int buf) {
         const char* sa = smem + buf * F_STAGE;
@@ -217,7 +216,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
         }
     };
-    if constexpr (PIPE == 4 || PIPE == 5) {
+    if constexpr (PIPE == 4) {
         // Cross-tile register pipeline.  Two fragment sets live in registers: set kk holds the kk-th 32-wide k-half of a K-tile.
         // Per K-tile t (LDS slot t & 1):
         //   phase A:  MFMAs of set 0 (tile t), with the LDS reads of set 1 (tile t) slotted behind them one per MFMA;
@@ -226,14 +225,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
         //   phase C:  tile t+2 is requested into the freed slot, and the MFMAs of set 1 (tile t) run with the reads of set 0
         //             of tile t+1 slotted behind them.
         // So no LDS latency is exposed behind the barrier (the MFMAs that follow it have their operands in registers), every
-        // DMA has a full K-tile of MFMA time to land, and there is ONE barrier per K-tile.  PIPE 4 issues the DMA pieces as a
-        // burst right behind the barrier, PIPE 5 slots them one per MFMA behind the fragment reads.
+        // DMA has a full K-tile of MFMA time to land, and there is ONE barrier per K-tile.  The DMA pieces go out as a burst right
+        // behind the barrier (slotting them one per MFMA behind the fragment reads measured equal: profiles/r02_b_gemm_pipe4_asmdma_ab.txt).
         static_assert(STAGES == 2 && BKT == 64, "cross-tile register pipeline: 2 LDS slots of 64-wide k-tiles");
-        constexpr int NLD = NA_I + NB_I, NMF = 4 * MF, RA = LA == 0 ? 1 : 2, RB = LB == 0 ? 1 : 2;
+        constexpr int NLD = NA_I + NB_I, RA = LA == 0 ? 1 : 2, RB = LB == 0 ? 1 : 2;
         constexpr int NRD = MF * RA + 4 * RB;                       // LDS read instructions per k-half
-        constexpr int DSPER = (PIPE == 5 && NRD + NLD > NMF) ? 2 : 1;   // reads slotted per MFMA
-        constexpr int NS1 = (NRD + DSPER - 1) / DSPER;
-        static_assert(NS1 + (PIPE == 5 ? NLD : 0) <= NMF, "one slot per MFMA");
+        static_assert(NRD <= 4 * MF, "one read slot per MFMA");
         const int nk = kt_end - kt_begin;
         bf16x8_t fa[2][MF], fb[2][4];
         auto read_half = [&](const char* sa, auto kk_c) {
@@ -247,21 +244,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
 #pragma unroll
             for (int i = 4; i < MF; ++i) fa[KK][i] = LA == 0 ? read_frag0(sa, a_rb, i, KK) : read_frag1(sa, a_rb, i, KK, FBM * 2);
         };
-        auto mfma_half = [&](auto kk_c) {
-            constexpr int KK = decltype(kk_c)::value;
-#pragma unroll
-            for (int i = 0; i < MF; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[KK][j], fa[KK][i], acc[j][i], 0, 0, 0);
-        };
-        auto slot_reads = [&]() {                                   // NRD reads behind the first MFMAs, then the remaining MFMAs
-#pragma unroll
-            for (int n = 0; n < NRD; ++n) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
-        };
         auto mid_tile_barrier = [&]() {
             __builtin_amdgcn_sched_barrier(0);       // MFMAs are register-only: without this the scheduler sinks phase A's tail below
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the wait and exposes the last reads' latency
@@ -270,62 +252,78 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
         };
         using K0 = std::integral_constant<int, 0>;
         using K1 = std::integral_constant<int, 1>;
-        stage(0);
-        if (nk > 1) {
-            stage(1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        read_half(smem, K0{});
-        int t = 0;
-        for (; t + 2 < nk; ++t) {                                   // steady state: there is a tile t+2 to request
-            const int slot = t & 1;
-            const char* cur = smem + slot * F_STAGE;
-            const char* nxt = smem + (slot ^ 1) * F_STAGE;
-            read_half(cur, K1{});
-            mfma_half(K0{});
-            slot_reads();
-            mid_tile_barrier();
-            if constexpr (PIPE == 4) { stage(slot); __builtin_amdgcn_sched_barrier(0); }     // DMA pieces as one burst
-            read_half(nxt, K0{});
-            if constexpr (PIPE == 5) stage(slot);
-            mfma_half(K1{});
-            if constexpr (PIPE == 5) {
+        // WB = true: this workgroup also accumulates accb[i] = sum_k A(row, k) (bias gradient of a weight-gradient GEMM)
+        auto main_loop = [&](auto wb_c) {
+            constexpr bool WB = decltype(wb_c)::value;
+            constexpr int NMF = 4 * MF + (WB ? MF : 0);
+            const short8_t ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+            const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
+            auto mfma_half = [&](auto kk_c) {
+                constexpr int KK = decltype(kk_c)::value;
 #pragma unroll
-                for (int n = 0; n < NS1; ++n) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, DSPER, 0);
-                }
+                for (int i = 0; i < MF; ++i) {
 #pragma unroll
-                for (int n = 0; n < NLD; ++n) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                    for (int j = 0; j < 4; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[KK][j], fa[KK][i], acc[j][i], 0, 0, 0);
+                    if constexpr (WB) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[KK][i], accb[i], 0, 0, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, NMF - NS1 - NLD, 0);
+            };
+            auto slot_reads = [&]() {                               // NRD reads behind the first MFMAs, then the remaining MFMAs
+#pragma unroll
+                for (int n = 0; n < NRD; ++n) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
+            };
+            stage(0);
+            if (nk > 1) {
+                stage(1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
             } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            read_half(smem, K0{});
+            int t = 0;
+            for (; t + 2 < nk; ++t) {                               // steady state: there is a tile t+2 to request
+                const int slot = t & 1;
+                const char* cur = smem + slot * F_STAGE;
+                const char* nxt = smem + (slot ^ 1) * F_STAGE;
+                read_half(cur, K1{});
+                mfma_half(K0{});
+                slot_reads();
+                mid_tile_barrier();
+                stage(slot);                                        // DMA pieces as one burst
+                __builtin_amdgcn_sched_barrier(0);
+                read_half(nxt, K0{});
+                mfma_half(K1{});
                 slot_reads();
             }
-        }
-        if (t + 1 < nk) {                                           // second-to-last tile: nothing left to request
-            const char* cur = smem + (t & 1) * F_STAGE;
-            const char* nxt = smem + ((t & 1) ^ 1) * F_STAGE;
-            read_half(cur, K1{});
-            mfma_half(K0{});
-            slot_reads();
-            mid_tile_barrier();
-            read_half(nxt, K0{});
-            mfma_half(K1{});
-            slot_reads();
-            ++t;
-        }
-        {                                                           // last tile
-            const char* cur = smem + (t & 1) * F_STAGE;
-            read_half(cur, K1{});
-            mfma_half(K0{});
-            slot_reads();
-            mfma_half(K1{});
+            if (t + 1 < nk) {                                       // second-to-last tile: nothing left to request
+                const char* cur = smem + (t & 1) * F_STAGE;
+                const char* nxt = smem + ((t & 1) ^ 1) * F_STAGE;
+                read_half(cur, K1{});
+                mfma_half(K0{});
+                slot_reads();
+                mid_tile_barrier();
+                read_half(nxt, K0{});
+                mfma_half(K1{});
+                slot_reads();
+                ++t;
+            }
+            {                                                       // last tile
+                const char* cur = smem + (t & 1) * F_STAGE;
+                read_half(cur, K1{});
+                mfma_half(K0{});
+                slot_reads();
+                mfma_half(K1{});
+            }
+        };
+        if constexpr (BG != 0) {
+            if (bias_wg) main_loop(std::true_type{});
+            else main_loop(std::false_type{});
+        } else {
+            main_loop(std::false_type{});
         }
     } else if (STAGES == 2) {
         stage(0);
@@ -364,6 +362,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
     if (p.dbg == 1 && acc[0][0][0] != 12345.678f) return;
     const vm_gemm_epilogue& e = p.e;
     const float alpha = e.alpha_dev ? e.alpha * (*e.alpha_dev) : e.alpha;
+    if constexpr (BG != 0) {
+        if (bias_wg && wn == 0 && g == 0) {         // one owner per output row (tile column 0, no split): plain read-modify-write
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const int row = m0 + wm * WR + i * 16 + c;
+                if (row < p.M) p.bias_grad[row] += accb[i][0] * alpha;
+            }
+        }
+    }
     float* cs = reinterpret_cast<float*>(smem);     // [RPP][FBN] fp32, 16-B chunks XOR-swizzled by row
     constexpr int RING_BYTES = STAGES * F_STAGE;
     constexpr int LDS_BYTES = RING_BYTES >= WR * FBN * 4 ? RING_BYTES : WR * FBN * 4;   // at least one wave-row of fp32 staging
@@ -437,6 +444,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
         const int64_t off = (int64_t)gm * p.ldc + gn;
         float v[8];
         load8(row, q, v);
+        if (p.dbg == 3) { if (v[0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = v[0]; continue; }      // timing experiment: everything but the stores
         if (p.slabs) {     // split-K: plain partial-slab store, reduced by splitk_reduce_kernel (deterministic, no atomics)
             float* sp = p.slabs + (int64_t)split * p.M * p.ldc + off;
             if (vec) {
@@ -495,6 +503,34 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
         }
     }
     }   // passes
+}
+
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {       // hardware places block b on XCD b % 8; give each XCD a contiguous range
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF, int PIPE>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fast_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // EXPERIMENT (VM_GEMM_STAGGER): the second workgroup of every CU (blocks 256..511 of the first round) starts late, so that its
+    // epilogue (an HBM write burst) falls into the other workgroup's main loop instead of coinciding with its epilogue
+    if (p.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+    gemm_fast_body<LA, LB, WM, WN, STAGES, BKT, MF, PIPE, 0>(p, xcd_remap(blockIdx.x, gridDim.x), smem);
+}
+
+// Several independent GEMMs in ONE launch (the weight gradients of a layer): block -> (problem, tile) through the prefix sums
+// of the per-problem tile counts.  Every problem fills whole tiles of the chip, so none of them needs split-K (no fp32 slabs,
+// no reduce kernel), and the workgroups of tile column 0 also produce the bias gradient (no column-sum kernel).
+template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF, int PIPE>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_grouped_kernel(const GemmGroupArgs ga) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < VM_GEMM_MAX_GROUP; ++i) if (i < ga.n && bid >= ga.tile_start[i]) gi = i;
+    gemm_fast_body<LA, LB, WM, WN, STAGES, BKT, MF, PIPE, 1>(ga.g[gi], bid - ga.tile_start[gi], smem);
 }
 
 template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF, int PIPE = 0>
@@ -562,11 +598,14 @@ int vm_gemm_fast_dispatch(const GemmArgs& a0, int a_layout, int b_layout, int nb
     const int pipe = vm_env().gemm_pipe;
     if (variant == 1) return dispatch_layout<4, 2, 3, 64, 4>(a0, a_layout, b_layout, nblocks, s);
     if (variant == 2) return dispatch_layout<4, 4, 2, 64, 4>(a0, a_layout, b_layout, nblocks, s);
-    // 8 waves x (128 x 64) = 256 x 256 tile, one workgroup per CU, cross-tile register pipeline (8: DMA burst, 9: DMA slotted)
-    if (variant == 8) return dispatch_layout<2, 4, 2, 64, 8, 4>(a0, a_layout, b_layout, nblocks, s);
-    if (variant == 9) return dispatch_layout<2, 4, 2, 64, 8, 5>(a0, a_layout, b_layout, nblocks, s);
-    if (variant == 10) return dispatch_layout<2, 2, 2, 64, 4, 4>(a0, a_layout, b_layout, nblocks, s);   // 128 x 128 tile with the same pipelines
-    if (variant == 11) return dispatch_layout<2, 2, 2, 64, 4, 5>(a0, a_layout, b_layout, nblocks, s);
+    // 8: 8 waves x (128 x 64) = 256 x 256 tile, one workgroup per CU, cross-tile register pipeline.  EXPERIMENT, env only: its main
+    // loop is 1.15x the 128 x 128 one at K = 8192 (1329 vs 1160 TFLOP/s without epilogue) but the LDS-staged epilogue of a 256 x 256
+    // tile with one workgroup per CU costs 2-3x the small tile's (profiles/r02_b_gemm_pipe4_asmdma_ab.txt); row-major A only
+    if (variant == 8) {
+        if (a_layout != 0) { vm_set_error("vm_gemm_bf16: the 256 x 256 tile needs a row-major A"); return VM_EINVAL; }
+        return b_layout == 0 ? launch_fast<0, 0, 2, 4, 2, 64, 8, 4>(a0, nblocks, s) : launch_fast<0, 1, 2, 4, 2, 64, 8, 4>(a0, nblocks, s);
+    }
+    if (variant == 10) return dispatch_layout<2, 2, 2, 64, 4, 4>(a0, a_layout, b_layout, nblocks, s);   // 128 x 128 tile, cross-tile register pipeline
     if (variant == 4 || variant == 12) {  // 160x128 tile (A row-major only): evens out the tile count when 128-row tiles leave a thin last round
         if (a_layout != 0) { vm_set_error("vm_gemm_bf16: 160-row tile needs a row-major A"); return VM_EINVAL; }
         if (variant == 12) return b_layout == 0 ? launch_fast<0, 0, 2, 2, 2, 64, 5, 4>(a0, nblocks, s) : launch_fast<0, 1, 2, 2, 2, 64, 5, 4>(a0, nblocks, s);
@@ -578,6 +617,18 @@ int vm_gemm_fast_dispatch(const GemmArgs& a0, int a_layout, int b_layout, int nb
     return dispatch_layout<2, 2, 2, 64, 4>(a0, a_layout, b_layout, nblocks, s);
 }
 void vm_gemm_variant_tile(int variant, int* bm, int* bn) {
-    *bm = (variant == 1 || variant == 2 || variant == 8 || variant == 9) ? 256 : (variant == 4 || variant == 12) ? 160 : 128;
-    *bn = (variant == 2 || variant == 8 || variant == 9) ? 256 : 128;
+    *bm = (variant == 1 || variant == 2 || variant == 8) ? 256 : (variant == 4 || variant == 12) ? 160 : 128;
+    *bn = (variant == 2 || variant == 8) ? 256 : 128;
+}
+
+
+int vm_gemm_grouped_tn_launch(const GemmGroupArgs& ga, int nblocks, hipStream_t s) {
+    constexpr int LDS = 2 * (128 + 128) * 64 * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<1, 1, 2, 2, 2, 64, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_grouped_kernel<1, 1, 2, 2, 2, 64, 4, 4>), dim3(nblocks), dim3(256), LDS, s, ga);
+    return vm_check_launch("vm_wgrad_grouped");
 }

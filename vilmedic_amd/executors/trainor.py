@@ -69,11 +69,27 @@ class Trainor(object):
             self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
         return bool(flag.item())
 
+    def _zero_grad(self):
+        """gradients of EVERY parameter stay inside the arena's flat buffer (that buffer is what ArenaDDP all-reduces): a
+        torch.optim optimizer's zero_grad(set_to_none=True) would let autograd allocate fresh .grad tensors outside it for the
+        parameters of native torch modules (CNN backbones, adapters), which would then never be averaged across ranks"""
+        arena_of(self.model).zero_grad()
+
+    def _optimizer_step(self, epoch, iteration):
+        if self.clip is not None:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
+        self.optimizer.step()
+        self._zero_grad()
+        self.training_scheduler.iteration_step()
+
     def start(self):
         cfg = self.config
+        early_stop_start = int(cfg.get("early_stop_start") or 0)
+        decay_metric_start = int(cfg.get("decay_metric_start") or 0)
         for epoch in range(int(self.training_scheduler.epoch), int(cfg.epochs) + 1):
             self.model.train()
             losses = []
+            iteration, pending, out = 0, False, {}
             for iteration, batch in enumerate(self.dl, start=1):
                 out = self.model(**batch, epoch=epoch, iteration=iteration)
                 if "loss" not in out:
@@ -81,50 +97,59 @@ class Trainor(object):
                 loss = out["loss"].mean()
                 if not self._all_finite(loss):            # trainor.py:109-112, decided collectively
                     self.logger.warning("NaN/Inf loss: batch skipped on all ranks")
-                    self.optimizer.zero_grad()
+                    self._zero_grad()
+                    pending = False
                     continue
                 step_now = iteration % self.grad_accu == 0
-                if self.ddp is not None and step_now and self.grad_accu == 1:
-                    self.ddp.backward(loss)                      # all-reduce overlapped with the encoder backward
+                # micro-batch gradients are SUMMED, not averaged (the reference calls loss.backward() on the unscaled loss,
+                # trainor.py:114); the cross-rank mean is taken once, on the iteration that steps
+                if self.ddp is not None:
+                    self.ddp.backward(loss, sync=step_now)       # two-phase backward; all-reduce overlapped with the encoder's
                 else:
-                    (loss / self.grad_accu).backward()
-                    if self.ddp is not None and step_now:
-                        self.ddp.finish()
+                    loss.backward()
+                pending = True
                 if step_now:
-                    if self.clip is not None:
-                        torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
-                    self.optimizer.step()
-                    self.optimizer.zero_grad()
-                    self.training_scheduler.iteration_step()
+                    self._optimizer_step(epoch, iteration)
+                    pending = False
                 losses.append(loss.detach())
                 if iteration % 50 == 0 and self.rank == 0:
                     self.logger.info("Epoch {}, iter {}, lr {:.2e}, loss {:.4f} {}".format(
-                        epoch, iteration, self.optimizer.param_groups[0]["lr"], float(torch.stack(losses[-50:]).mean()),
+                        epoch + 1, iteration, self.optimizer.param_groups[0]["lr"], float(torch.stack(losses[-50:]).mean()),
                         out.get("custom_print", "")))
-            training_loss = float(torch.stack(losses).mean()) if losses else float("nan")
+            # last update of the epoch when len(dl) is not a multiple of grad_accu (trainor.py:139-150)
+            if iteration % self.grad_accu != 0 and "loss" in out and pending:
+                if self.ddp is not None:
+                    self.ddp.finish()
+                self._optimizer_step(epoch, iteration)
+            training_loss = float(torch.stack(losses).mean()) if losses else float("inf")
             if self.dist is not None:       # the same number on every rank: it can drive early stopping / lr decay (a per-rank value
                 from ..parallel import mean_over_ranks      # would let ranks leave the loop at different epochs)
                 training_loss = mean_over_ranks(training_loss, self.dist, weight=max(1, len(losses)))
-            self.logger.info("Epoch {} done: training_loss {:.4f}".format(epoch, training_loss))
+            self.logger.info("Epoch {} done: training_loss {:.4f}".format(epoch + 1, training_loss))
             self.training_scheduler.epoch_step()
-            early_stop_score = None
-            if self.evaluator is not None and epoch >= self.eval_start:
+            # evaluation / early stopping / lr decay, with the reference's epoch + 1 bookkeeping (trainor.py:157-203)
+            early_stop_score, decay_metric = None, None
+            do_early_stop = epoch + 1 >= early_stop_start
+            do_lr_decay = epoch + 1 >= decay_metric_start
+            do_eval = epoch + 1 >= self.eval_start
+            metric = cfg.get("early_stop_metric")
+            if metric == "training_loss" and do_early_stop:
+                early_stop_score = training_loss
+            if do_eval and self.evaluator is not None:
                 self.evaluator.epoch = epoch
                 scores = self.evaluator.start()
-                metric = cfg.get("early_stop_metric")
-                if metric == "training_loss":
-                    early_stop_score = training_loss
-                else:
-                    vals = [s[metric] for s in scores if metric in s]
-                    early_stop_score = float(np.mean(vals)) if vals else None
-            elif cfg.get("early_stop_metric") == "training_loss":
-                early_stop_score = training_loss
-            ret = self.training_scheduler.eval_step(decay_metric=training_loss if self.training_scheduler.decay_on_training_loss
-                                                    else early_stop_score, early_stop_score=early_stop_score)
-            if ret["save_state"] and self.rank == 0:
-                self.saver.save({"model": self.model.state_dict(), "training_scheduler": self.training_scheduler.state_dict(),
-                                 "optimizer": self.optimizer.state_dict(), "config": to_container(cfg), "__version__": __version__},
-                                tag=early_stop_score, current_epoch=epoch)
+                if metric != "training_loss" and metric is not None and do_early_stop:
+                    missing = [i for i, sc in enumerate(scores) if metric not in sc]
+                    if missing:              # the reference raises KeyError here (np.mean over s[early_stop_metric]); never save silently nothing
+                        raise KeyError(f"early_stop_metric {metric!r} is not among the validator scores {sorted(scores[missing[0]])}")
+                    early_stop_score = float(np.mean([sc[metric] for sc in scores]))
+            if do_lr_decay:
+                decay_metric = training_loss if self.training_scheduler.decay_on_training_loss else early_stop_score
+            ret = self.training_scheduler.eval_step(decay_metric=decay_metric, early_stop_score=early_stop_score)
             if ret["done_training"]:
                 self.logger.info("Early stopped reached")
                 break
+            if ret["save_state"] and self.rank == 0:
+                self.saver.save({"model": self.model.state_dict(), "training_scheduler": self.training_scheduler.state_dict(),
+                                 "optimizer": self.optimizer.state_dict(), "config": to_container(cfg), "__version__": __version__},
+                                tag=early_stop_score, current_epoch=epoch + 1)

@@ -99,8 +99,9 @@ def _side_stream(device):
 
 
 def join_side():
-    """main stream waits for everything queued on the side stream so far (no host sync)"""
+    """main stream waits for everything queued on the side stream so far (no host sync); queued parameter gradients go first"""
     _side["callback_queued"] = False
+    flush_param_grads()
     if _side["pending"]:
         for dev, st in _side["streams"].items():
             torch.cuda.current_stream(dev).wait_stream(st)
@@ -160,9 +161,11 @@ def _split_k_for(out_tiles, k_tiles):
     return max(1, min(want, max(1, k_tiles // 8)))
 
 
-def wgrad(dY, X, dW, *, ld_dy=None, ld_x=None, alpha_dev=None):
-    """dW[N,K] += dY[M,N]^T @ X[M,K]   (fp32 accumulate, split-K over M)."""
+def wgrad(dY, X, dW, *, ld_dy=None, ld_x=None, alpha_dev=None, n_out=None):
+    """dW[N,K] += dY[M,N]^T @ X[M,K]   (fp32 accumulate, split-K over M): the single-problem form (shapes the grouped launch
+    cannot take: rows % 64 != 0)."""
     M, N = dY.shape
+    N = n_out if n_out is not None else N
     K = X.shape[1]
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     gemm(dY, 1, X, 1, dW, N, K, M, lda=ld_dy or dY.stride(0), ldb=ld_x or X.stride(0), ldc=dW.stride(0),
@@ -174,6 +177,79 @@ def colsum(x, out, rows=None, cols=None, scale_dev=None):
     cols = cols if cols is not None else x.shape[1]
     check(lib().vm_colsum_bf16(ptr(x), x.stride(0), ptr(out), rows, cols, ptr(scale_dev) if scale_dev is not None else None,
                                stream()), "vm_colsum_bf16")
+
+
+# ----------------------------------------------------------------------------- grouped parameter gradients
+# Weight / bias gradients feed only the optimizer, so nothing in a backward pass waits for them.  Instead of launching one
+# split-K GEMM (+ slab reduce) and one column-sum kernel per nn.Linear as its backward node runs, the backward nodes QUEUE
+# (dY, X, dW, db) and the queue is flushed as ONE grouped launch (vm_wgrad_grouped) once it holds enough output tiles to fill
+# the chip without splitting the contraction -- typically the 4-6 linears of one transformer layer -- on the side stream, so it
+# still overlaps the activation-gradient chain.  Flushed at the latest when the backward pass ends, before a gradient
+# all-reduce starts (ArenaDDP) and before the optimizer reads the gradients.
+GROUP_WGRAD = os.environ.get("VM_WGRAD_GROUP", "1") != "0"
+GROUP_TILES = int(os.environ.get("VM_WGRAD_GROUP_TILES", "400"))      # flush threshold in 128 x 128 output tiles (512 resident workgroups)
+_pg = {"items": [], "tiles": 0, "ptrs": set()}
+
+
+def _eligible(dY, X, dW, ld_dy, ld_x):
+    return (dY.shape[0] % 64 == 0 and ld_dy % 8 == 0 and ld_x % 8 == 0 and dW.stride(0) % 8 == 0 and dY.data_ptr() % 16 == 0
+            and X.data_ptr() % 16 == 0 and dW.data_ptr() % 16 == 0 and dW.dtype == torch.float32)
+
+
+def param_grads(dY, X, dW, db=None, *, ld_dy=None, ld_x=None, alpha_dev=None, cols=None):
+    """dW[N,K] += dY[M,N]^T X[M,K]  and  db[N] += colsum(dY)   (either may be None); ``cols``: leading columns of dY that count
+    (the LM head's padded vocabulary).  Queued for the next grouped launch when possible, launched on the side stream otherwise."""
+    if dW is None and db is None:
+        return
+    N = cols if cols is not None else dY.shape[1]
+    ld_dy = ld_dy or dY.stride(0)
+    ld_x = ld_x or (X.stride(0) if X is not None else 0)
+    if GROUP_WGRAD and dW is not None and _eligible(dY, X, dW, ld_dy, ld_x):
+        if dW.data_ptr() in _pg["ptrs"]:            # the same parameter twice in one backward graph: never in one launch (two owners of a tile)
+            flush_param_grads()
+        K = X.shape[1]
+        _pg["items"].append((dY, X, dW, db, ld_dy, ld_x, alpha_dev, N, K))
+        _pg["ptrs"].add(dW.data_ptr())
+        _pg["tiles"] += ((N + 127) // 128) * ((K + 127) // 128)
+        if _pg["tiles"] >= GROUP_TILES:
+            flush_param_grads()
+        else:
+            _ensure_end_of_backward_flush()
+        return
+    with on_side(*(t for t in (dY, X, alpha_dev) if t is not None)):
+        if dW is not None:
+            wgrad(dY, X, dW[:N] if dW.shape[0] != N else dW, ld_dy=ld_dy, ld_x=ld_x, alpha_dev=alpha_dev, n_out=N)
+        if db is not None:
+            colsum(dY, db, rows=dY.shape[0], cols=N, scale_dev=alpha_dev)
+
+
+def flush_param_grads():
+    """launch everything queued by param_grads() as one grouped weight-gradient GEMM (side stream)"""
+    items = _pg["items"]
+    if not items:
+        return
+    _pg["items"], _pg["tiles"], _pg["ptrs"] = [], 0, set()
+    arr = (_lib.WgradProblem * len(items))()
+    tensors = []
+    for q, (dY, X, dW, db, ld_dy, ld_x, alpha_dev, N, K) in zip(arr, items):
+        q.dY, q.ld_dy, q.X, q.ld_x = dY.data_ptr(), ld_dy, X.data_ptr(), ld_x
+        q.dW, q.ld_dw, q.db = dW.data_ptr(), dW.stride(0), (db.data_ptr() if db is not None else None)
+        q.rows, q.n_out, q.k_in = dY.shape[0], N, K
+        q.alpha_dev = alpha_dev.data_ptr() if alpha_dev is not None else None
+        tensors += [t for t in (dY, X, alpha_dev) if t is not None]
+    with on_side(*tensors):
+        check(lib().vm_wgrad_grouped(arr, len(items), stream()), "vm_wgrad_grouped")
+
+
+def _ensure_end_of_backward_flush():
+    """something is queued: make sure it is flushed (and the side stream joined) when the running backward pass ends"""
+    if _side["callback_queued"] or _side["defer"]:
+        return
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(join_side)
+        _side["callback_queued"] = True
+    except RuntimeError:                # not inside a backward pass: do it now
+        join_side()
 
 
 def cast_to_bf16(src, dst=None):
@@ -250,12 +326,7 @@ class LinearFn(torch.autograd.Function):
         M, N = dy2.shape
         K = x2.shape[1]
         dpre = dropout_apply(dy2, dropout_p, seed) if dropout_p > 0 else dy2
-        if wgrad_buf is not None or bgrad_buf is not None:
-            with on_side(dpre, x2):                   # parameter gradients overlap the dgrad chain
-                if wgrad_buf is not None:
-                    wgrad(dpre, x2, wgrad_buf)
-                if bgrad_buf is not None:
-                    colsum(dpre, bgrad_buf)
+        param_grads(dpre, x2, wgrad_buf, bgrad_buf)       # queued: grouped launch on the side stream, overlapping the dgrad chain
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=BF16, device=dy.device)
@@ -294,16 +365,10 @@ class MlpFn(torch.autograd.Function):
         M, K = dy2.shape
         F = w1.shape[0]
         dpre = dropout_apply(dy2, dropout_p, seed) if dropout_p > 0 else dy2
-        if g_w2 is not None:
-            with on_side(dpre, a):
-                wgrad(dpre, a, g_w2)
-                colsum(dpre, g_b2)
+        param_grads(dpre, a, g_w2, g_b2)
         dz = torch.empty(M, F, dtype=BF16, device=dy.device)
         gemm(dpre, 0, w2, 1, dz, M, F, K, mul_gelu_z=z)          # da * gelu'(z) fused in the dgrad epilogue
-        if g_w1 is not None:
-            with on_side(dz, x2):
-                wgrad(dz, x2, g_w1)
-                colsum(dz, g_b1)
+        param_grads(dz, x2, g_w1, g_b1)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=BF16, device=dy.device)
@@ -540,12 +605,7 @@ class CrossKVAllFn(torch.autograd.Function):
                 slot.zero_()
             elif g.data_ptr() != slot.data_ptr():
                 slot.copy_(g)
-        if wgrad_buf is not None or bgrad_buf is not None:
-            with on_side(dkv, e2):
-                if wgrad_buf is not None:
-                    wgrad(dkv, e2, wgrad_buf)
-                if bgrad_buf is not None:
-                    colsum(dkv, bgrad_buf)
+        param_grads(dkv, e2, wgrad_buf, bgrad_buf)
         d_enc = None
         if ctx.needs_input_grad[0]:
             d_enc = torch.empty(M, K, dtype=BF16, device=e2.device)
@@ -626,8 +686,7 @@ class PatchEmbedFn(torch.autograd.Function):
             d_out = d_out.contiguous()
             dpe = torch.empty(B * n, D, dtype=BF16, device=d_out.device)
             check(lib().vm_vit_assemble_bwd(ptr(d_out), ptr(dpe), ptr(g_cls), ptr(g_pos), B, n, D, stream()), "vm_vit_assemble_bwd")
-            wgrad(dpe, cols, g_w.view(D, -1))
-            colsum(dpe, g_b)
+            param_grads(dpe, cols, g_w.view(D, -1), g_b)
         return (None,) * 11
 
 
@@ -683,10 +742,8 @@ class LmHeadLossFn(torch.autograd.Function):
         # into the GEMM / column-sum epilogues through a device pointer -- no host sync, no extra pass over dlogits.
         sc = dloss.detach().to(torch.float32).contiguous()
         M = B * L
-        if g_emb is not None:
-            with on_side(dlogits, h2, sc):
-                wgrad(dlogits, h2, g_emb, alpha_dev=sc)   # dE[V,D] += dlogits^T h (pad columns of dlogits are zero)
-                colsum(dlogits, g_bias, rows=M, cols=V, scale_dev=sc)
+        if g_emb is not None:      # dE[V,D] += dlogits^T h (pad columns of dlogits are zero), d_bias[V] += colsum(dlogits)
+            param_grads(dlogits, h2, g_emb, g_bias, alpha_dev=sc, cols=V)
         dh = None
         if ctx.needs_input_grad[0]:
             dh = torch.empty(M, D, dtype=BF16, device=h2.device)

@@ -29,6 +29,8 @@ class FusedAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        from . import ops
+        ops.join_side()              # queued / side-stream parameter gradients land before the update (no-op when nothing is pending)
         g = self.param_groups[0]
         self.steps += 1
         b1, b2 = g["betas"]

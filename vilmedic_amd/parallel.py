@@ -113,25 +113,37 @@ class ArenaDDP:
             if self.bf16_wire:
                 self._ops.cast_to_f32(self._wire[cs:ce], self.arena.gflat[cs:ce])
 
-    def backward(self, loss):
-        """loss.backward() + gradient averaging, communication overlapped with the encoder's backward when possible."""
+    def backward(self, loss, sync=True):
+        """loss.backward() + gradient averaging, communication overlapped with the encoder's backward when possible.
+        ``sync=False`` (a gradient-accumulation micro-batch that does not step): both backward phases run, nothing is reduced."""
+        self._check_grads_in_arena()
         n = self.arena.numel
         split = getattr(self.model, "_split", None) if self.split_at is not None else None
         if split is None:
             loss.backward()
-            self._wait(self._start(0, n, self.chunks))
+            if sync:
+                self._wait(self._start(0, n, self.chunks))
             return
         feats, leaf = split
+        if not sync:
+            loss.backward()                              # decoder graph (the features were detached) ...
+            if leaf.grad is not None:
+                feats.backward(leaf.grad)                # ... then ALWAYS the encoder graph: the split must never swallow it
+            self._ops.join_side()
+            self.model._split = None
+            return
         ops, dev = self._ops, self.arena.flat.device
         # The collectives are enqueued from the SIDE stream (where the weight-gradient GEMMs run): they are ordered after
         # the gradients they reduce without the main stream ever waiting for the side stream between the two phases.
         ops._side["defer"] = True
         try:
             loss.backward()                              # decoder graph only (features were detached)
+            ops.flush_param_grads()                      # the decoder's queued weight gradients, before their range is reduced
             with ops.side_context(dev):
                 pending = self._start(0, self.split_at, max(1, self.chunks // 2))
             if leaf.grad is not None:
                 feats.backward(leaf.grad)                # encoder graph, overlapping the decoder's all-reduce
+            ops.flush_param_grads()
             with ops.side_context(dev):
                 pending += self._start(self.split_at, n, max(1, self.chunks // 2))
                 self._wait(pending)
@@ -141,7 +153,21 @@ class ArenaDDP:
         self.model._split = None
 
     def finish(self):
+        self._check_grads_in_arena()
         self._wait(self._start(0, self.arena.numel, self.chunks))
+
+    def _check_grads_in_arena(self):
+        """only ``arena.gflat`` is all-reduced: a parameter whose .grad was re-created outside it (optimizer.zero_grad(
+        set_to_none=True) followed by a native-autograd backward) would silently keep per-rank gradients -> fold it back in"""
+        for p, _ in self.arena._layout:
+            g = p.grad
+            if not p.requires_grad or g is p._vm_grad_view:
+                continue
+            if g is None:
+                p.grad = p._vm_grad_view
+            elif g.data_ptr() != p._vm_grad_view.data_ptr():
+                p._vm_grad_view.add_(g.to(p._vm_grad_view.dtype))
+                p.grad = p._vm_grad_view
 
 
 def all_gather_with_grad(x, dist):
