@@ -29,9 +29,10 @@ def report(name, **vals):
     print(f"[parity] {name}: " + " ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in vals.items()), flush=True)
 
 
-@pytest.fixture
-def gemm_variant():
-    """sets VM_GEMM_VARIANT for the duration of a test and restores the cost model afterwards"""
+@pytest.fixture(params=[1, 0], ids=["epi-register", "epi-lds"])
+def gemm_variant(request):
+    """sets VM_GEMM_VARIANT (tile) and VM_GEMM_EPI (1: register-direct epilogue, the default; 0: LDS-staged epilogue) for the
+    duration of a test and restores the defaults afterwards"""
     from vilmedic_amd._lib import lib
 
     def setv(v):
@@ -39,9 +40,11 @@ def gemm_variant():
             os.environ.pop("VM_GEMM_VARIANT", None)
         else:
             os.environ["VM_GEMM_VARIANT"] = str(v)
+        os.environ["VM_GEMM_EPI"] = str(request.param)
         lib().vm_reload_env()
     yield setv
     os.environ.pop("VM_GEMM_VARIANT", None)
+    os.environ.pop("VM_GEMM_EPI", None)
     lib().vm_reload_env()
 
 
@@ -134,19 +137,19 @@ def _run_gemm_case(M, N, K, la, lb, epi, split, seed=0):
     return err.max().item(), (err / (ref.abs() + 1e-2)).max().item()
 
 
-@pytest.mark.parametrize("variant", [None, 0, 4, 1, 2, 8, 10, 12])
+@pytest.mark.parametrize("variant", [None, 0, 4, 1, 8])
 def test_gemm_forward_shapes_every_tile_variant(variant, gemm_variant):
     """forward (row-major x row-major) launches of the step, cost-model choice and every forced tile variant"""
     gemm_variant(variant)
     worst = 0.0
-    cases = FWD[:2] + FWD[6:] if variant in (1, 2) else FWD
+    cases = FWD[:2] + FWD[6:] if variant == 1 else FWD
     for c in cases:
         mx, rel = _run_gemm_case(*c)
         worst = max(worst, rel)
     report(f"gemm fwd variant={variant}", shapes=len(cases), max_rel_err=worst)
 
 
-@pytest.mark.parametrize("variant", [None, 0, 4, 8, 10, 12])
+@pytest.mark.parametrize("variant", [None, 0, 4, 8])
 def test_gemm_dgrad_shapes(variant, gemm_variant):
     gemm_variant(variant)
     worst = 0.0
@@ -156,7 +159,7 @@ def test_gemm_dgrad_shapes(variant, gemm_variant):
     report(f"gemm dgrad variant={variant}", shapes=len(DGRAD), max_rel_err=worst)
 
 
-@pytest.mark.parametrize("variant", [None, 0, 8, 10])
+@pytest.mark.parametrize("variant", [None, 0, 8])
 def test_gemm_wgrad_shapes_splitk(variant, gemm_variant):
     gemm_variant(variant)
     worst = 0.0
@@ -206,10 +209,11 @@ def test_grouped_param_grads_match_fp32_at_layer_shapes():
         k = 3.0 if i == 1 else 1.0
         rw = 0.25 + k * (dY.float().t() @ X.float())
         rb = -1.0 + k * dY.float().sum(0)
-        worst_w = max(worst_w, ((dW - rw).abs() / (1e-2 + rw.abs())).max().item())
-        worst_b = max(worst_b, ((db - rb).abs() / (1e-1 + rb.abs())).max().item())
-    report("grouped wgrad ViT layer", max_rel_err_w=worst_w, max_rel_err_b=worst_b)
-    assert worst_w <= 2e-3 and worst_b <= 2e-3
+        # fp32 accumulation of exact bf16 products over 12608 rows: only the summation order differs from the reference product
+        worst_w = max(worst_w, ((dW - rw).abs().max() / rw.abs().max()).item())
+        worst_b = max(worst_b, ((db - rb).abs().max() / rb.abs().max()).item())
+    report("grouped wgrad ViT layer", max_err_over_max_w=worst_w, max_err_over_max_b=worst_b)
+    assert worst_w <= 2e-5 and worst_b <= 2e-5
     # LM head: rows = 8192, dlogits [8192, 30528] of which 30522 columns count, alpha on the device
     M, V, Vp, D = 8192, 30522, 30528, 768
     dl = _rand_bf16(M, Vp, 60, 0.05)

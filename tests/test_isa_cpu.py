@@ -34,30 +34,59 @@ def _kernel_meta(asm):
     return meta
 
 
-def _hot(name):
-    # gemm_fast_kernel<LA, LB, 2, 2, 2, 64, MF, 1>: 4 waves, 2-stage ring, k-tile 64, pipelined K-tile (the training step's kernels)
-    return re.match(r"_Z16gemm_fast_kernelILi[01]ELi[01]ELi2ELi2ELi2ELi64ELi[45]ELi1EEv8GemmArgs$", name)
+HOT = re.compile(r"_Z(16gemm_fast_kernel|19gemm_grouped_kernel)ILi[01]ELi[01]ELi2ELi[24]ELi2ELi64ELi[458]ELi[14]ELi[01]EEv(8GemmArgs|13GemmGroupArgs)$")
 
 
-def test_hot_gemm_kernels_fit_two_workgroups_per_cu_without_spills(gemm_fast_asm):
-    meta = {k: v for k, v in _kernel_meta(gemm_fast_asm).items() if _hot(k)}
-    assert len(meta) == 6, sorted(meta)                      # 4 layouts of the 128x128 tile + 2 of the 160x128 tile
+def _loop(asm, name):
+    """the basic block of kernel ``name`` with the most MFMAs (its main loop), as a list of (opcode, full line)"""
+    start = asm.index(name + ":")
+    body = asm[start:asm.index(".Lfunc_end", start)]
+    blocks = re.split(r"\n\.LBB\d+_\d+:", body)
+    loop = max(blocks, key=lambda b: b.count("v_mfma_f32_16x16x32_bf16"))
+    return [(l.split()[0], l.strip()) for l in loop.splitlines() if l.strip() and not l.strip().startswith((";", "."))]
+
+
+def test_hot_gemm_kernels_fit_two_waves_per_simd_without_spills(gemm_fast_asm):
+    """every kernel the training step can launch: both epilogues of the 128- / 160-row tiles (row-major: PIPE 1, strided: PIPE 4), the
+    grouped weight-gradient kernel, the 8-wave 256 x 256 tile"""
+    meta = {k: v for k, v in _kernel_meta(gemm_fast_asm).items() if HOT.match(k)}
+    assert len(meta) == 16, sorted(meta)     # (4 layouts x 128 + 2 layouts x 160) x 2 epilogues + 2 grouped + 2 x 256^2
     for name, m in meta.items():
         assert m["vgpr_spill_count"] == 0, (name, m)
+        assert m["sgpr_spill_count"] <= 16, (name, m)        # a few SGPRs parked in VGPR lanes (v_writelane) are harmless; scratch is not
         assert m["vgpr_count"] <= 256, (name, m)             # 512 registers per SIMD lane / 2 resident waves per SIMD
 
 
 def test_pipelined_k_tile_schedule_is_present(gemm_fast_asm):
-    """in the main-loop block of the row-major 128x128 kernel: all MFMAs of a K-tile (32), LDS reads BETWEEN MFMAs (the second
-    k-half's fragments), and no more than two full LDS waits"""
-    start = gemm_fast_asm.index("_Z16gemm_fast_kernelILi0ELi0ELi2ELi2ELi2ELi64ELi4ELi1EEv8GemmArgs:")
-    body = gemm_fast_asm[start:gemm_fast_asm.index(".end_amdhsa_kernel", start)] if ".end_amdhsa_kernel" in gemm_fast_asm[start:] else gemm_fast_asm[start:]
-    blocks = re.split(r"\n\.LBB\d+_\d+:", body)
-    loop = max(blocks, key=lambda b: b.count("v_mfma_f32_16x16x32_bf16") if "ds_read_b128" in b else -1)
-    ops = [l.split()[0] for l in loop.splitlines() if l.strip() and not l.strip().startswith((";", "."))]
-    mfma = [i for i, o in enumerate(ops) if o.startswith("v_mfma")]
+    """row-major 128 x 128 kernel (PIPE 1): all MFMAs of a K-tile (32), LDS reads BETWEEN MFMAs (the second k-half's fragments), and
+    no more than two full LDS waits"""
+    ops = _loop(gemm_fast_asm, "_Z16gemm_fast_kernelILi0ELi0ELi2ELi2ELi2ELi64ELi4ELi1ELi1EEv8GemmArgs")
+    mfma = [i for i, (o, _) in enumerate(ops) if o.startswith("v_mfma")]
     assert len(mfma) == 32, len(mfma)
-    reads_between = [i for i, o in enumerate(ops) if o.startswith("ds_read") and mfma[0] < i < mfma[-1]]
+    reads_between = [i for i, (o, _) in enumerate(ops) if o.startswith("ds_read") and mfma[0] < i < mfma[-1]]
     assert len(reads_between) >= 8, len(reads_between)
-    full_waits = sum(1 for l in loop.splitlines() if "s_waitcnt" in l and "lgkmcnt(0)" in l)
-    assert full_waits <= 2, full_waits
+    assert sum(1 for o, l in ops if o == "s_waitcnt" and "lgkmcnt(0)" in l) <= 2
+
+
+@pytest.mark.parametrize("name,n_mfma", [
+    ("_Z16gemm_fast_kernelILi0ELi1ELi2ELi2ELi2ELi64ELi4ELi4ELi1EEv8GemmArgs", 32),       # dgrad, 128 x 128
+    ("_Z16gemm_fast_kernelILi0ELi1ELi2ELi2ELi2ELi64ELi5ELi4ELi1EEv8GemmArgs", 40),       # dgrad, 160 x 128
+    ("_Z16gemm_fast_kernelILi1ELi1ELi2ELi2ELi2ELi64ELi4ELi4ELi1EEv8GemmArgs", 32),       # wgrad
+    ("_Z19gemm_grouped_kernelILi1ELi1ELi2ELi2ELi2ELi64ELi4ELi4ELi1EEv13GemmGroupArgs", 40),  # grouped wgrad with the bias-gradient MFMAs
+    ("_Z16gemm_fast_kernelILi0ELi0ELi2ELi4ELi2ELi64ELi8ELi4ELi1EEv8GemmArgs", 64),       # 256 x 256
+])
+def test_cross_tile_register_pipeline_keeps_the_dma_in_flight(gemm_fast_asm, name, n_mfma):
+    """PIPE 4 main loops: one barrier per K-tile with the DMA issue right behind it, NO vmcnt wait between the DMA issue and the end
+    of the loop (the builtin LDS-DMA made hipcc put vmcnt(0) in front of the first transpose read: tile t+2 was waited for at once),
+    LDS reads slotted between MFMAs, nothing spilled inside the loop"""
+    ops = _loop(gemm_fast_asm, name)
+    names = [o for o, _ in ops]
+    assert sum(o.startswith("v_mfma") for o in names) == n_mfma
+    assert names.count("s_barrier") == 1
+    assert not any(o.startswith("scratch_") for o in names)
+    bar = names.index("s_barrier")
+    dma = [i for i, o in enumerate(names) if o.startswith("global_load_lds")]
+    assert dma and min(dma) > bar
+    assert not any(o == "s_waitcnt" and "vmcnt" in l for o, l in ops[max(dma):]), [l for o, l in ops[max(dma):] if o == "s_waitcnt"]
+    mf = [i for i, o in enumerate(names) if o.startswith("v_mfma")]
+    assert sum(1 for i, o in enumerate(names) if o.startswith("ds_read") and mf[0] < i < mf[-1]) >= 16

@@ -59,7 +59,10 @@ def load_yaml(path):
         raw = yaml.safe_load(f) or {}
     base = {}
     for inc in raw.pop("includes", []) or []:
-        inc_path = inc if os.path.isabs(inc) or os.path.exists(inc) else os.path.join(os.path.dirname(path), os.path.basename(inc))
+        # bin/utils.py:113-115: the path as written (relative to the working directory), else relative to the including file;
+        # last resort (a config tree used from another working directory): the include's basename next to the including file
+        cands = [inc, os.path.join(os.path.dirname(path), inc), os.path.join(os.path.dirname(path), os.path.basename(inc))]
+        inc_path = next((c for c in cands if os.path.exists(c)), cands[1])
         merge(base, load_yaml(inc_path))
     return merge(base, raw)
 

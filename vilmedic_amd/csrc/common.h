@@ -112,13 +112,11 @@ static inline uint32_t dropout_thresh16(float p) { return (uint32_t)((double)p *
 
 // ---- host-side plumbing
 // diagnostic environment switches, read ONCE (getenv per launch costs host time; vm_reload_env() re-reads them)
-#define VM_GEMM_PIPE_DEFAULT 1
 struct VmEnv {
     int gemm_variant;      // VM_GEMM_VARIANT: force a tile variant (-1: cost model)
     int gemm_debug;        // VM_GEMM_DEBUG: 1 skip the epilogue, 2 one K-tile only (timing breakdowns)
-    int gemm_stagger;      // VM_GEMM_STAGGER: experiment, see gemm_fast_kernel
+    int gemm_epi;          // VM_GEMM_EPI: 1 = register-direct epilogue (default), 0 = LDS-staged epilogue
     int gemm_groupw;       // VM_GEMM_GROUPW: column-group width of the tile order (0: heuristic)
-    int gemm_pipe;         // VM_GEMM_PIPE: 1 = software-pipelined K-tile (default), 0 = compiler-scheduled
     bool gemm_generic;     // VM_GEMM_GENERIC: register-staged fallback kernel only
     bool gemm_no_skinny;   // VM_GEMM_NO_SKINNY: never take the M <= 128 decode-step kernel
     bool attn_tile;        // VM_ATTN_TILE: tile-streaming attention kernels instead of the head-resident ones

@@ -290,7 +290,6 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
                          (!epi->residual || (epi->ldr % 8) == 0) && !vm_env().gemm_generic;
     a.slabs = nullptr;
     a.bias_grad = nullptr;
-    a.stagger = vm_env().gemm_stagger;
     a.dbg = vm_env().gemm_debug;
     // decode-step shapes: few rows -> one workgroup per 16 output columns, K split over its waves (gemm_skinny.hip)
     if (M <= 128 && a_layout == 0 && b_layout == 0 && (K % 32) == 0 && split == 1 && !epi->aux_out && !epi->mul_gelu_z &&
@@ -317,16 +316,8 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
             const int64_t c128 = (t128 + slots - 1) / slots * 128, c160 = (t160 + slots - 1) / slots * 160;
             if (c160 <= c128) variant = 4;   // ties: the larger tile re-reads less of B
         }
-        // strided operands (dgrad: B, wgrad: A and B) run the cross-tile register pipeline with the inline-asm LDS-DMA: the
-        // builtin DMA is followed by a compiler-inserted vmcnt(0) in front of the first transpose read, i.e. the tile just
-        // requested is waited for at once (measured 1.1-1.37x on every strided shape of the step, profiles/r02_b_gemm_pipe4_asmdma_ab.txt)
-        if (force < 0 && (a_layout != 0 || b_layout != 0)) variant = variant == 4 ? 12 : variant == 0 ? 10 : variant;
-        // the 8-wave 256 x 256 kernel keeps both fragment sets of a 128 x 64 wave tile in registers: with a strided A operand
-        // (two transpose reads per fragment, per-fragment swizzled addresses) that spills inside the main loop -> 128 x 128 form
-        if (variant == 8 && a_layout != 0) variant = 10;
-        if (variant == 12 && a_layout != 0) variant = 10;
         int vbm, vbn;
-        vm_gemm_variant_tile(variant, &vbm, &vbn);
+        vm_gemm_variant_tile(variant, a_layout, &vbm, &vbn);
         a.tiles_m = (M + vbm - 1) / vbm;
         a.tiles_n = (N + vbn - 1) / vbn;
         // column-group width of the tile order: wide outputs (N >= 3072) run in groups of 8 tile columns so that an XCD's
@@ -384,7 +375,7 @@ extern "C" int vm_wgrad_grouped(const vm_wgrad_problem* pr, int n, void* stream)
             a.group_w = a.tiles_n;
             a.e = vm_gemm_epilogue{};
             a.e.alpha = 1.0f; a.e.alpha_dev = q.alpha_dev; a.e.out_dtype = VM_F32; a.e.accumulate = 1; a.e.split_k = 1;
-            a.drop_thresh = 0; a.drop_scale = 1.0f; a.dbg = 0; a.slabs = nullptr; a.bias_grad = q.db; a.stagger = 0;
+            a.drop_thresh = 0; a.drop_scale = 1.0f; a.dbg = 0; a.slabs = nullptr; a.bias_grad = q.db;
             ga.tile_start[i] = tiles;
             tiles += a.tiles_m * a.tiles_n;
         }

@@ -13,7 +13,6 @@ struct GemmArgs {
     int dbg;                 // VM_GEMM_DEBUG experiments (0 in production): 1 skip epilogue, 2 single K-tile
     float* slabs;            // split-K partial slabs [split][M][ldc] fp32 (fast path), or null
     float* bias_grad;        // grouped weight-gradient launch: fp32 [M] += alpha * sum_k A(m, k), or null
-    int stagger;             // VM_GEMM_STAGGER experiment: late start of the second workgroup of every CU (units of 1024 cycles)
 };
 
 #define VM_GEMM_MAX_GROUP 8
@@ -26,7 +25,7 @@ int vm_gemm_grouped_tn_launch(const GemmGroupArgs& ga, int nblocks, hipStream_t 
 
 // tuned path (gemm_fast.hip): requires K % 64 == 0
 int vm_gemm_splitk_reduce(const GemmArgs& a, int nsplit, hipStream_t s);
-void vm_gemm_variant_tile(int variant, int* bm, int* bn);
+void vm_gemm_variant_tile(int variant, int a_layout, int* bm, int* bn);
 int vm_gemm_fast_dispatch(const GemmArgs& a, int a_layout, int b_layout, int nblocks, int variant, hipStream_t s);
 // skinny path (gemm_skinny.hip): M <= 128 rows (the decode step), K % 32 == 0, row-major A and B, plain / bias / gelu / residual epilogue
 int vm_gemm_skinny_dispatch(const GemmArgs& a, hipStream_t s);

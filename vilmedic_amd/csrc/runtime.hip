@@ -36,9 +36,8 @@ static void load_env() {
     const char* v;
     g_env.gemm_variant = (v = getenv("VM_GEMM_VARIANT")) ? atoi(v) : -1;
     g_env.gemm_debug = (v = getenv("VM_GEMM_DEBUG")) ? atoi(v) : 0;
-    g_env.gemm_stagger = (v = getenv("VM_GEMM_STAGGER")) ? atoi(v) : 0;
+    g_env.gemm_epi = (v = getenv("VM_GEMM_EPI")) ? atoi(v) : 1;
     g_env.gemm_groupw = (v = getenv("VM_GEMM_GROUPW")) ? atoi(v) : 0;
-    g_env.gemm_pipe = (v = getenv("VM_GEMM_PIPE")) ? atoi(v) : VM_GEMM_PIPE_DEFAULT;
     g_env.gemm_generic = getenv("VM_GEMM_GENERIC") != nullptr;
     g_env.gemm_no_skinny = getenv("VM_GEMM_NO_SKINNY") != nullptr;
     g_env.attn_tile = getenv("VM_ATTN_TILE") != nullptr;
