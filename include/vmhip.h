@@ -159,6 +159,11 @@ int vm_ce_shift_fwd_bwd(const void* logits, int64_t ldl, const int64_t* ids, int
                         float* loss_sum, float* row_logp, void* dlogits, float grad_scale,
                         const float* row_weight, const int32_t* banned, int n_banned, const float* row_min_logit,
                         void* stream);
+/* thr[row] = k-th largest logit of the row among the live columns (c < V, not banned): the TopKLogitsWarper threshold that
+ * vm_ce_shift_fwd_bwd takes as row_min_logit (hf:generation/logits_process.py TopKLogitsWarper as configured by
+ * ref:vilmedic/blocks/rl/SCST.py:142-157).  Exact radix select on the bf16 values; rows with fewer than k live columns keep everything. */
+int vm_topk_threshold_bf16(const void* logits, int64_t ldl, int rows, int V, int k, const int32_t* banned, int n_banned,
+                           float* thr, void* stream);
 /* Generic CE with label smoothing on fp32 logits [R,C] (MVQA head; ref:...LabelSmoothingCrossEntropyLoss.py:38-48) */
 int vm_ce_smooth_fwd_bwd(const float* logits, const int64_t* target, int R, int C, float smoothing,
                          float* loss_sum, float* dlogits, float grad_scale, void* stream);

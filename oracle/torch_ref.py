@@ -610,3 +610,59 @@ def gloria_forward(images, input_ids, attention_mask, state, txt_cfg, visual, id
     g0, g1 = gloria_global_loss(gf, sent, temp3)
     loss = (l0 + l1) * local_loss_weight + (g0 + g1) * global_loss_weight
     return loss, gf, lf, word, sent
+
+
+# --------------------------------------------------------------------------- model-level compositions (round 2)
+# The three functions below are COMPOSITIONS of the pinned pieces above, wired the way the reference's model files wire them;
+# they add no arithmetic of their own (CNN backbones are run, not restated).
+def projection_mlp(x, state, prefix):
+    """nn.Sequential(Linear, ReLU, Linear)  (ref:vilmedic/models/selfsup/conVIRT.py:58-67)."""
+    return linear(F.relu(linear(x, state, prefix + ".0")), state, prefix + ".2")
+
+
+def convirt_forward(images, input_ids, attention_mask, state, txt_cfg, visual, tau, lambda_, fbs):
+    """ConVIRT.forward (ref:vilmedic/models/selfsup/conVIRT.py:75-102): both towers in micro-batches of ``fbs`` (the CNN's
+    BatchNorm sees each micro-batch's statistics in training mode), projections, ConVIRTLoss on the concatenated embeddings.
+    ``visual``: callable images -> [b, C] (the VisualEncoder of the model under test run as a torch module, or an oracle CNN);
+    state keys: ``linguistic.encoder.*``, ``linguistic.pooler.dense.*``, ``lin_proj.{0,2}.*``, ``vis_proj.{0,2}.*``."""
+    enc = {k[len("linguistic.encoder."):]: v for k, v in state.items() if k.startswith("linguistic.encoder.")}
+    bs = images.shape[0]
+    step = min(fbs, bs)
+    ls, vs = [], []
+    for s in range(0, bs, step):
+        h = text_encoder_forward(input_ids[s:s + step], attention_mask[s:s + step], enc, txt_cfg)
+        pooled = bert_pooler(h, state, "linguistic.pooler")
+        ls.append(projection_mlp(pooled, state, "lin_proj"))
+        vs.append(projection_mlp(visual(images[s:s + step]), state, "vis_proj"))
+    linguistics, visuals = torch.cat(ls), torch.cat(vs)
+    loss, loss_l, loss_v = convirt_loss(linguistics, visuals, tau, lambda_)
+    return loss, loss_l, loss_v, linguistics, visuals
+
+
+def mvqa_forward(features, labels, state, cfg, smoothing=0.1):
+    """MVQA.forward behind the CNN (ref:vilmedic/models/mvqa/MVQA.py:40-54): adapter (Linear + LayerNorm) -> BertEncoder without
+    embeddings or mask -> BertPooler -> Classifier -> LabelSmoothingCrossEntropy; ``answer`` = argmax of the class logits.
+    ``features``: the CNN output [B, S, C]; state keys as the model's (``adapter.0.*``, ``adapter.1.*``, ``transformer.layer.*``,
+    ``pooler.dense.*``, ``classifier.classifier.0.*``)."""
+    x = layer_norm(linear(features, state, "adapter.0"), state, "adapter.1", cfg["layer_norm_eps"])
+    x = bert_encoder_forward(x, state, cfg, "transformer.")
+    out = linear(bert_pooler(x, state, "pooler"), state, "classifier.classifier.0")
+    loss = label_smoothing_ce(out, labels, smoothing) if labels is not None else None
+    return loss, out, out.argmax(-1)
+
+
+def scst_forward(sampled_seq, enc, enc_mask, state, cfg, reward_sampling, reward_greedy, scores_weights, pad_token_id, bos_token_id,
+                 top_k=None):
+    """The loss of SCST.forward_sampling for a GIVEN sampled sequence (ref:vilmedic/blocks/rl/SCST.py:142-185): log-softmax of the
+    logits after NoBadWords(pad, bos) and TopKLogitsWarper(top_k) (hf:generation/logits_process.py, in HF's processor order),
+    gathered at the sampled tokens, then scst_loss.  ``sampled_seq`` [B, T] starts with bos; teacher forcing reproduces the
+    per-step distributions of the reference's un-wrapped generate loop because the decoder is causal."""
+    h = decoder_hidden(sampled_seq[:, :-1], None, enc, enc_mask, state, cfg)
+    logits = lm_logits(h, state).float()
+    logits[:, :, [pad_token_id, bos_token_id]] = -float("inf")
+    if top_k:
+        kth = torch.topk(logits, min(top_k, logits.shape[-1]))[0][..., -1:]
+        logits = logits.masked_fill(logits < kth, -float("inf"))
+    sampled = sampled_seq[:, 1:]
+    logp = torch.log_softmax(logits, -1).gather(2, sampled.unsqueeze(-1))
+    return scst_loss(logp, sampled, reward_sampling, reward_greedy, scores_weights, pad_token_id), logp.squeeze(-1)

@@ -120,6 +120,66 @@ extern "C" int vm_ce_shift_fwd_bwd(const void* logits, int64_t ldl, const int64_
     return vm_check_launch("vm_ce_shift_fwd_bwd");
 }
 
+// ------------------------------------------------------------------ top-k threshold of bf16 logits rows
+// thr[row] = k-th largest live logit of the row (HF TopKLogitsWarper keeps scores >= that value; bad-word columns are removed first,
+// hf:generation/logits_process.py NoBadWordsLogitsProcessor -> TopKLogitsWarper, ref:vilmedic/blocks/rl/SCST.py:142-157).  Exact: a bf16
+// has 65536 possible values, so a two-pass radix select over its order-preserving 16-bit key (256-bin histograms in LDS: high byte,
+// then low byte inside the selected bin) finds the k-th value itself -- no fp32 copy of the [rows, V] logits, no sort.
+__device__ __forceinline__ uint32_t bf16_order_key(bf16_t h) { return (h & 0x8000u) ? (uint32_t)(~h & 0xffffu) : (uint32_t)(h | 0x8000u); }
+__global__ __launch_bounds__(256) void topk_threshold_kernel(const bf16_t* __restrict__ logits, int64_t ldl, int V, int k, CeBanned ban,
+                                                             float* __restrict__ thr) {
+    __shared__ uint32_t hist[256];
+    __shared__ int sel[2];       // selected bin, remaining rank inside it
+    const int row = blockIdx.x;
+    const bf16_t* lrow = logits + (int64_t)row * ldl;
+    auto live = [&](int c) { return c < V && !(ban.n > 0 && (c == ban.col[0] || (ban.n > 1 && c == ban.col[1]) || (ban.n > 2 && c == ban.col[2]) || (ban.n > 3 && c == ban.col[3]))); };
+    const int nch = (V + 7) >> 3;
+    int want = k;
+    for (int pass = 0; pass < 2; ++pass) {
+        hist[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t hi_sel = pass ? (uint32_t)sel[0] : 0u;
+        for (int ch = threadIdx.x; ch < nch; ch += 256) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(lrow + ch * 8);
+            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bf16_t h = (bf16_t)((w[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+                if (!live(ch * 8 + j) || (h & 0x7f80u) == 0x7f80u && (h & 0x7fu)) continue;      // dead column / NaN
+                const uint32_t key = bf16_order_key(h);
+                if (pass == 0) atomicAdd(&hist[key >> 8], 1u);
+                else if ((key >> 8) == hi_sel) atomicAdd(&hist[key & 0xffu], 1u);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int acc = 0, b = 255;
+            for (; b > 0; --b) { if (acc + (int)hist[b] >= want) break; acc += (int)hist[b]; }
+            sel[0] = b; sel[1] = want - acc;       // (fewer than k live columns: b = 0, the smallest key -> everything is kept)
+        }
+        __syncthreads();
+        if (pass == 0) want = sel[1];
+        else if (threadIdx.x == 0) {
+            const uint32_t key = (hi_sel << 8) | (uint32_t)sel[0];
+            const bf16_t h = (key & 0x8000u) ? (bf16_t)(key & 0x7fffu) : (bf16_t)(~key & 0xffffu);
+            thr[row] = bf16_to_f32(h);
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int vm_topk_threshold_bf16(const void* logits, int64_t ldl, int rows, int V, int k, const int32_t* banned, int n_banned,
+                                      float* thr, void* stream) {
+    VM_REQUIRE(logits && thr && rows > 0 && V > 0 && k > 0 && ldl >= V && (ldl % 8) == 0, "vm_topk_threshold_bf16: bad arguments");
+    VM_REQUIRE(n_banned >= 0 && n_banned <= 4 && (n_banned == 0 || banned), "vm_topk_threshold_bf16: at most 4 banned columns (HOST array)");
+    CeBanned ban = {n_banned, {0, 0, 0, 0}};
+    for (int i = 0; i < n_banned; ++i) ban.col[i] = banned[i];
+    hipStream_t s = (hipStream_t)stream;
+    VmProfScope prof(VM_FAM_LOSS, 4.0 * rows * (double)ldl, s);
+    hipLaunchKernelGGL(topk_threshold_kernel, dim3(rows), dim3(256), 0, s, (const bf16_t*)logits, ldl, V, k, ban, thr);
+    return vm_check_launch("vm_topk_threshold_bf16");
+}
+
 // ------------------------------------------------------------------ label-smoothing CE on small fp32 logits [R,C]
 // loss_row = eps/C * sum_c(-logp_c) + (1-eps) * (-logp_target)       (reduction 'mean' is applied by the caller)
 __global__ __launch_bounds__(64) void ce_smooth_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, int C,

@@ -3,6 +3,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from ... import ops
 from ...arena import arena_of
 from ...blocks.huggingface.encoder.encoder_model import EncoderModel
 from ...blocks.losses import ConVIRTLoss, InfoNCELoss  # noqa: F401  (eval(proto) namespace)
@@ -25,6 +26,23 @@ def evaluation(models, config, dl, from_training, **kwargs):
     return {"loss": np.ndarray.mean(np.array(losses)), "linguistic": torch.cat(linguistics), "visual": torch.cat(visuals)}
 
 
+class ProjectionMLP(nn.Sequential):
+    """Linear -> ReLU -> Linear (conVIRT.py:58-67), state-dict keys ``0.weight / 0.bias / 2.weight / 2.bias`` as the reference's
+    nn.Sequential; both products run on the bf16 MFMA GEMM (parameters in the model's arena, weight / bias gradients through the
+    grouped weight-gradient launch), the embedding leaves the second GEMM in fp32 straight from the accumulators."""
+
+    def __init__(self, d_in, d_out):
+        super().__init__(nn.Linear(d_in, d_out), nn.ReLU(), nn.Linear(d_out, d_out))
+
+    def forward(self, x, arena):
+        l0, l2 = self[0], self[2]
+        x = x.to(torch.bfloat16).contiguous()
+        h = ops.linear(x, arena.shadow(l0.weight), l0.bias, wgrad_buf=arena.grad(l0.weight), bgrad_buf=arena.grad(l0.bias), anchor=l0.weight)
+        h = torch.relu(h)
+        return ops.linear(h, arena.shadow(l2.weight), l2.bias, wgrad_buf=arena.grad(l2.weight), bgrad_buf=arena.grad(l2.bias),
+                          anchor=l2.weight, out_f32=True)
+
+
 class ConVIRT(nn.Module):
     def __init__(self, encoder, cnn, projection, loss, forward_batch_size=256, **kwargs):
         super().__init__()
@@ -33,8 +51,8 @@ class ConVIRT(nn.Module):
         self.visual = eval(cnn.pop("proto"))(**cnn)
         projection = dict(projection)
         pd = projection["projection_dim"]
-        self.vis_proj = nn.Sequential(nn.Linear(projection["visual_embedding_dim"], pd), nn.ReLU(), nn.Linear(pd, pd))
-        self.lin_proj = nn.Sequential(nn.Linear(projection["textual_embedding_dim"], pd), nn.ReLU(), nn.Linear(pd, pd))
+        self.vis_proj = ProjectionMLP(projection["visual_embedding_dim"], pd)
+        self.lin_proj = ProjectionMLP(projection["textual_embedding_dim"], pd)
         loss = dict(loss)
         self.loss_fn = eval(loss.pop("proto"))(**loss)
         self.fbs = forward_batch_size          # micro-batch of the reference's tower loop; only BatchNorm statistics depend on it
@@ -43,19 +61,20 @@ class ConVIRT(nn.Module):
 
     def forward(self, input_ids, attention_mask, images, **kwargs):
         images, input_ids, attention_mask = images.cuda(), input_ids.cuda(), attention_mask.cuda()
-        arena_of(self).refresh()
+        arena = arena_of(self)
+        arena.refresh()
         # The reference runs both towers in forward_batch_size micro-batches inside ONE autograd graph (conVIRT.py:83-95).  For the
         # text tower (LayerNorm only) that equals a single pass over the batch, which is what runs here.  A CNN image tower in
         # training mode normalises with the statistics of each MICRO-batch, so it keeps the reference's chunks; in eval mode
         # (running statistics) and for BatchNorm-free towers the whole batch goes through at once.
         text = self.linguistic(input_ids=input_ids, attention_mask=attention_mask)
-        linguistics = self.lin_proj(text["pooler_output"].float())
+        linguistics = self.lin_proj(text["pooler_output"], arena)
         bs = images.shape[0]
         if self.training and self._visual_has_bn and self.fbs < bs:
             vis = torch.cat([self.visual(images[i:i + self.fbs]) for i in range(0, bs, self.fbs)])
         else:
             vis = self.visual(images)
-        visuals = self.vis_proj(vis.float() if vis.dim() == 2 else vis[:, 0].float())
+        visuals = self.vis_proj(vis if vis.dim() == 2 else vis[:, 0], arena)
         loss, loss_l, loss_v = self.loss_fn(linguistics, visuals)
         return {"loss": loss, "loss_l": loss_l, "loss_v": loss_v, "linguistic": linguistics, "visual": visuals}
 

@@ -306,11 +306,11 @@ class LinearFn(torch.autograd.Function):
     (several when Q,K,V projections are fused into one GEMM)."""
 
     @staticmethod
-    def forward(ctx, x, w_sh, bias_f32, residual, dropout_p, wgrad_buf, bgrad_buf, anchor):
+    def forward(ctx, x, w_sh, bias_f32, residual, dropout_p, wgrad_buf, bgrad_buf, anchor, out_f32=False):
         x2 = _2d(x)
         M, K = x2.shape
         N = w_sh.shape[0]
-        y = torch.empty(M, N, dtype=BF16, device=x.device)
+        y = torch.empty(M, N, dtype=torch.float32 if out_f32 else BF16, device=x.device)      # fp32: straight from the accumulators
         seed = next_seed() if dropout_p > 0 else 0
         gemm(x2, 0, w_sh, 0, y, M, N, K, bias=bias_f32, dropout_p=dropout_p, dropout_seed=seed,
              residual=_2d(residual) if residual is not None else None)
@@ -323,6 +323,8 @@ class LinearFn(torch.autograd.Function):
         x2, w_sh = ctx.saved_tensors
         dropout_p, seed, wgrad_buf, bgrad_buf, has_res, xshape = ctx.meta
         dy2 = _2d(dy.contiguous())
+        if dy2.dtype != BF16:               # fp32 output (projection heads): the gradient GEMMs take bf16 operands
+            dy2 = dy2.to(BF16)
         M, N = dy2.shape
         K = x2.shape[1]
         dpre = dropout_apply(dy2, dropout_p, seed) if dropout_p > 0 else dy2
@@ -332,11 +334,11 @@ class LinearFn(torch.autograd.Function):
             dx = torch.empty(M, K, dtype=BF16, device=dy.device)
             gemm(dpre, 0, w_sh, 1, dx, M, K, N)
             dx = dx.view(xshape)
-        return dx, None, None, (dy if has_res else None), None, None, None, None
+        return dx, None, None, (dy if has_res else None), None, None, None, None, None
 
 
-def linear(x, w_sh, bias, *, residual=None, dropout_p=0.0, wgrad_buf=None, bgrad_buf=None, anchor=None):
-    return LinearFn.apply(x, w_sh, bias, residual, dropout_p, wgrad_buf, bgrad_buf, anchor)
+def linear(x, w_sh, bias, *, residual=None, dropout_p=0.0, wgrad_buf=None, bgrad_buf=None, anchor=None, out_f32=False):
+    return LinearFn.apply(x, w_sh, bias, residual, dropout_p, wgrad_buf, bgrad_buf, anchor, out_f32)
 
 
 # ----------------------------------------------------------------------------- MLP: FC1 + erf-GELU + FC2 (+dropout) + residual
@@ -704,7 +706,7 @@ class LmHeadLossFn(torch.autograd.Function):
     loss; backward only runs the dgrad / wgrad GEMMs, with dL/dloss folded in through a device scalar."""
 
     @staticmethod
-    def forward(ctx, h, emb_sh, bias, ids, V, g_emb, g_bias, want_logits, row_weight, banned, top_k):
+    def forward(ctx, h, emb_sh, bias, ids, V, g_emb, g_bias, want_logits, row_weight, banned, top_k, need_grad=True):
         B, L, D = h.shape
         Vp = emb_sh.shape[0]
         h2 = _2d(h)
@@ -712,16 +714,16 @@ class LmHeadLossFn(torch.autograd.Function):
         gemm(h2, 0, emb_sh, 0, logits, B * L, V, D, bias=bias)
         loss_sum = torch.zeros(1, dtype=torch.float32, device=h.device)
         inv = 1.0 / (B * (L - 1)) if row_weight is None else 1.0
-        need_grad = h.requires_grad or g_emb is not None
+        # need_grad comes from the caller: grad mode is always off INSIDE an autograd.Function.forward; under no_grad (validation
+        # loss) the gradient half of the fused kernel -- a second full write of the [B*L, Vp] matrix -- is skipped
         dlogits = (torch.empty_like(logits) if want_logits else logits) if need_grad else None
         row_logp = torch.empty(B * L, dtype=torch.float32, device=h.device)
         thr = None
-        if top_k:
-            lv = logits[:, :V].float()
-            if banned:
-                lv[:, list(banned)] = -float("inf")
-            thr = torch.topk(lv, min(top_k, V), dim=-1)[0][:, -1].contiguous()
         ban = (C.c_int32 * 4)(*(list(banned) + [0] * (4 - len(banned)))) if banned else None
+        if top_k:                     # per-row k-th largest live logit: exact radix select on the bf16 logits (no fp32 copy, no sort)
+            thr = torch.empty(B * L, dtype=torch.float32, device=h.device)
+            check(lib().vm_topk_threshold_bf16(ptr(logits), Vp, B * L, V, min(int(top_k), V), ban, len(banned) if banned else 0, ptr(thr),
+                                               stream()), "vm_topk_threshold_bf16")
         check(lib().vm_ce_shift_fwd_bwd(ptr(logits), Vp, ptr(ids), B, L, V, ptr(loss_sum), ptr(row_logp),
                                         ptr(dlogits) if dlogits is not None else None, inv,
                                         ptr(row_weight) if row_weight is not None else None, ban, len(banned) if banned else 0,
@@ -749,12 +751,13 @@ class LmHeadLossFn(torch.autograd.Function):
             dh = torch.empty(M, D, dtype=BF16, device=h2.device)
             gemm(dlogits, 0, emb_sh, 1, dh, M, D, Vp, alpha_dev=sc)
             dh = dh.view(B, L, D)
-        return (dh,) + (None,) * 10
+        return (dh,) + (None,) * 11
 
 
 def lm_head_loss(h, emb_sh, bias, ids, V, g_emb=None, g_bias=None, want_logits=True, row_weight=None, banned=None, top_k=None):
     """-> (loss, logits or None, row_logp [B,L] = log p(ids[b,t+1] | prefix) under the filtered distribution)"""
-    return LmHeadLossFn.apply(h, emb_sh, bias, ids, V, g_emb, g_bias, want_logits, row_weight, banned, top_k)
+    need_grad = torch.is_grad_enabled() and (h.requires_grad or g_emb is not None)
+    return LmHeadLossFn.apply(h, emb_sh, bias, ids, V, g_emb, g_bias, want_logits, row_weight, banned, top_k, need_grad)
 
 
 def lm_logits_f32(h2, emb_sh, bias, V):
