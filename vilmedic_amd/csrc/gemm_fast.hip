@@ -627,21 +627,20 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {       // hardware 
 template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF, int PIPE, int EPI>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fast_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (p.persist_total > 0) {
-        // EXPERIMENT (VM_GEMM_PERSIST): a resident grid (2 workgroups per CU) walks the work items instead of one workgroup per item:
-        // no workgroup teardown / launch between tiles, and the stores of tile i drain while the first DMA of tile i+1 is in flight.
-        // Work item of (iteration k, block b): XCD b & 7 takes the contiguous range [(8 k + xcd) * per, + per) -- same L2 locality as
-        // xcd_remap gives the one-shot grid.  gridDim.x is a multiple of 8.
-        const int per = gridDim.x >> 3;
-        for (int k = 0; k * (int)gridDim.x < p.persist_total; ++k) {
-            const int w = (k * 8 + (int)(blockIdx.x & 7)) * per + (int)(blockIdx.x >> 3);
-            if (w < p.persist_total) gemm_fast_body<LA, LB, WM, WN, STAGES, BKT, MF, PIPE, 0, EPI>(p, w, smem);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // LDS reads of the epilogue staging done (NOT vmcnt: stores keep draining)
-            __builtin_amdgcn_s_barrier();
-        }
-        return;
-    }
-    gemm_fast_body<LA, LB, WM, WN, STAGES, BKT, MF, PIPE, 0, EPI>(p, xcd_remap(blockIdx.x, gridDim.x), smem);
+    // EXPERIMENT (VM_GEMM_PERSIST, persist_total > 0): a resident grid (2 workgroups per CU) walks the work items instead of one
+    // workgroup per item: no workgroup teardown / launch between tiles, and the stores of tile i drain while the first DMA of tile
+    // i+1 is in flight.  Work item of (iteration k, block b): XCD b & 7 takes the contiguous range [(8 k + xcd) * per, + per) -- the
+    // L2 locality xcd_remap gives the one-shot grid.  gridDim.x is then a multiple of 8.
+    const int per = gridDim.x >> 3;
+    int k = 0;
+    do {
+        const int w = p.persist_total > 0 ? (k * 8 + (int)(blockIdx.x & 7)) * per + (int)(blockIdx.x >> 3) : xcd_remap(blockIdx.x, gridDim.x);
+        if (p.persist_total <= 0 || w < p.persist_total) gemm_fast_body<LA, LB, WM, WN, STAGES, BKT, MF, PIPE, 0, EPI>(p, w, smem);
+        if (p.persist_total <= 0) break;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // LDS reads of the epilogue staging done (NOT vmcnt: stores keep draining)
+        __builtin_amdgcn_s_barrier();
+        ++k;
+    } while (k * (int)gridDim.x < p.persist_total);
 }
 
 // Several independent GEMMs in ONE launch (the weight gradients of a layer): block -> (problem, tile) through the prefix sums
