@@ -77,10 +77,12 @@ def test_convirt_forward_vs_oracle(training):
         loss.backward()
         named = dict(model.named_parameters())
         for n in ("lin_proj.0.weight", "vis_proj.2.weight", "vis_proj.2.bias", "linguistic.pooler.dense.weight",
-                  "linguistic.encoder.encoder.layer.1.output.dense.weight", "visual.model.encoder.stages.1.layers.0.layer.0.convolution.weight"):
+                  "linguistic.encoder.encoder.layer.1.output.dense.weight", "visual.model.embedder.embedder.convolution.weight"):
             got, want = named[n].grad.float().cpu(), st[n].grad
-            r["grad_min_cos"] = min(r.get("grad_min_cos", 1.0), _cos(got, want))
-            r["grad_max_rel"] = max(r.get("grad_max_rel", 0.0), _rel(got, want))
+            key = "cnn" if n.startswith("visual.") else "hip"
+            print(f"    grad {n}: cos {_cos(got, want):.5f} rel {_rel(got, want):.3e}", flush=True)
+            r[key + "_grad_min_cos"] = min(r.get(key + "_grad_min_cos", 1.0), _cos(got, want))
+            r[key + "_grad_max_rel"] = max(r.get(key + "_grad_max_rel", 0.0), _rel(got, want))
     print(f"[parity] ConVIRT.forward training={training}: " + " ".join(f"{k}={v:.3e}" for k, v in r.items()), flush=True)
     assert r["loss_err"] <= 5e-3 * max(1.0, abs(r["loss"]))
     assert r["rows_err"] <= 6e-2
