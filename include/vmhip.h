@@ -180,6 +180,18 @@ int vm_lse_cols_f32(const float* S, int64_t ld, float* lse /* [cols] */, int row
 int vm_contrastive_grad(const float* S, int64_t ld, const float* lse_rows, const float* lse_cols, const float* g_rows,
                         const float* g_cols, void* G_bf16, int64_t ldg, int rows, int cols, int diag_offset, void* stream);
 
+/* Fused form (the similarity matrix never reaches HBM): a_hat [R,D], b_hat [C,D] bf16 = the outputs of vm_rownorm_cast.
+ * vm_contrastive_fwd: lse_rows[i] = log sum_j exp(S_ij), lse_cols[j] = log sum_i exp(S_ij), diag[i] = S_{i, i+diag_offset} with
+ *   S = a_hat b_hat^T * inv_tau computed tile by tile on the MFMA and reduced in LDS (ws: vm_contrastive_ws(R, C) bytes of partials).
+ * vm_contrastive_bwd: G (bf16 [R, ldg]) as vm_contrastive_grad, from recomputed tiles.  dA_hat = G b_hat * inv_tau and
+ *   dB_hat = G^T a_hat * inv_tau are two vm_gemm_bf16 calls on G. */
+size_t vm_contrastive_ws(int R, int C);
+int vm_contrastive_fwd(const void* a_hat, const void* b_hat, int R, int C, int D, float inv_tau, int diag_offset,
+                       float* lse_rows, float* lse_cols, float* diag /* [R] or NULL */, void* ws, size_t ws_bytes, void* stream);
+int vm_contrastive_bwd(const void* a_hat, const void* b_hat, int R, int C, int D, float inv_tau, int diag_offset,
+                       const float* lse_rows, const float* lse_cols, const float* g_rows, const float* g_cols,
+                       void* G_bf16, int64_t ldg, void* stream);
+
 /* ------------------------------------------------------------------ element-wise / reductions */
 int vm_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 int vm_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);

@@ -148,6 +148,7 @@ def test_rrg_scst_forward_with_fixed_rollouts_and_top_k_vs_oracle():
                      dl=dl, scores="ROUGEL", top_k=top_k).to(dev())
     vst = R.rand_state(R.vit_shapes(R.VIT_TINY), 31)
     dst = R.rand_state(R.decoder_shapes(R.DEC_TINY), 32, std=0.08)
+    dst["lm_head.bias"][2] += 6.0                # eos is always among the top-k candidates (a row may then legitimately end early)
     sd = {"enc.model." + k: v for k, v in vst.items()}
     sd.update({"dec.decoder." + k: v for k, v in dst.items()})
     sd["dec.decoder.lm_head.decoder.weight"] = dst["bert.embeddings.word_embeddings.weight"]
@@ -165,8 +166,17 @@ def test_rrg_scst_forward_with_fixed_rollouts_and_top_k_vs_oracle():
         lg = O.lm_logits(h, dst).float()[:, -1]
         lg[:, [1, 0]] = -float("inf")
         cand = lg.topk(top_k, dim=-1)[1]
-        seq[:, t] = cand[:, (top_k - 1) if t % 2 else 0]
-    seq[1, 6:] = torch.tensor([2, 1, 1, 1])                     # one row ends early: eos then pads (masked out of the loss)
+        pick = cand[:, (top_k - 1) if t % 2 else 0]
+        if t % 2 == 0:                           # never eos except where placed below
+            pick = torch.where(pick == 2, cand[:, 1], pick)
+        else:
+            pick = torch.where(pick == 2, cand[:, top_k - 2], pick)
+        seq[:, t] = pick
+        if t == 6:
+            assert bool((cand[1] == 2).any()), "fixture: eos must be a top-k candidate"
+            seq[1, 6] = 2                        # one row ends early: eos, then pads (masked out of the loss)
+        if t > 6:
+            seq[1, t] = 1
     greedy = seq.clone()
     greedy[:, 1:] = torch.roll(seq[:, 1:], 1, dims=1)
 
@@ -197,7 +207,7 @@ def test_rrg_scst_forward_with_fixed_rollouts_and_top_k_vs_oracle():
     enc_r, mask_r = O.visual_encode(feats_r, {})
     ref_loss, ref_logp = O.scst_forward(seq, enc_r, mask_r, dst_r, R.DEC_TINY, r_sample, r_greedy, [1.0], 1, 0, top_k=top_k)
     ref_loss.backward()
-    assert torch.isfinite(ref_logp).all(), "fixture: every sampled token must survive the oracle's top-k filter"
+    assert torch.isfinite(ref_logp[seq[:, 1:] > 1]).all(), "fixture: every sampled (non-pad) token must survive the oracle's top-k filter"
     named = dict(model.model.named_parameters())
     g1 = named["dec.decoder.bert.encoder.layer.1.output.dense.weight"].grad.float().cpu()
     g2 = named["enc.model.encoder.layer.0.intermediate.dense.weight"].grad.float().cpu()

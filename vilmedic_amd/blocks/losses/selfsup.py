@@ -8,6 +8,8 @@ two more GEMMs.  When torch.distributed is initialised with world_size > 1 the t
 all-gathered first (RCCL), so every rank sees the GLOBAL batch of negatives (SURVEY §8e -- a capability the reference
 lacks: under DDP it contrasts within the local shard only, conVIRT.py:97-100).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -15,6 +17,7 @@ from ... import ops
 from ..._lib import check, lib, ptr, stream
 
 BF16 = torch.bfloat16
+FUSED = os.environ.get("VM_CONTRASTIVE_FUSED", "1") != "0"     # 0: the round-1 path (S materialised in fp32, three scalar passes) for A/B
 
 
 def _pad8(n):
@@ -40,24 +43,32 @@ class _SimilarityLossFn(torch.autograd.Function):
         L = lib()
         check(L.vm_rownorm_cast(ptr(a32), ptr(ah), ptr(na), R, D, int(normalize), eps, stream()), "vm_rownorm_cast")
         check(L.vm_rownorm_cast(ptr(b32), ptr(bh), ptr(nb), Cn, D, int(normalize), eps, stream()), "vm_rownorm_cast")
-        ldS = (Cn + 3) // 4 * 4
-        S = torch.empty(R, ldS, dtype=torch.float32, device=dev)
-        ops.gemm(ah, 0, bh, 0, S, R, Cn, D, alpha=inv_tau)
         lse_r = torch.empty(R, dtype=torch.float32, device=dev)
         lse_c = torch.empty(Cn, dtype=torch.float32, device=dev)
         diag = torch.empty(R, dtype=torch.float32, device=dev)
-        check(L.vm_lse_rows_f32(ptr(S), ldS, ptr(lse_r), ptr(diag), R, Cn, 0, stream()), "vm_lse_rows_f32")
-        check(L.vm_lse_cols_f32(ptr(S), ldS, ptr(lse_c), R, Cn, stream()), "vm_lse_cols_f32")
+        n = min(R, Cn)
+        if FUSED:       # S tile by tile on the MFMA, reduced in LDS: the [R, C] matrix never reaches HBM
+            ws = torch.empty(L.vm_contrastive_ws(R, Cn), dtype=torch.uint8, device=dev)
+            if n < R:
+                diag.zero_()
+            check(L.vm_contrastive_fwd(ptr(ah), ptr(bh), R, Cn, D, inv_tau, 0, ptr(lse_r), ptr(lse_c), ptr(diag), ptr(ws), ws.numel(), stream()),
+                  "vm_contrastive_fwd")
+            S, ldS = None, 0
+        else:
+            ldS = (Cn + 3) // 4 * 4
+            S = torch.empty(R, ldS, dtype=torch.float32, device=dev)
+            ops.gemm(ah, 0, bh, 0, S, R, Cn, D, alpha=inv_tau)
+            check(L.vm_lse_rows_f32(ptr(S), ldS, ptr(lse_r), ptr(diag), R, Cn, 0, stream()), "vm_lse_rows_f32")
+            check(L.vm_lse_cols_f32(ptr(S), ldS, ptr(lse_c), R, Cn, stream()), "vm_lse_cols_f32")
         ctx.save_for_backward(a32, b32, ah, bh, na, nb, S, lse_r, lse_c)
         ctx.meta = (normalize, inv_tau, eps, R, Cn, D, ldS)
-        n = min(R, Cn)
         return lse_r[:n] - diag[:n], lse_c[:n] - diag[:n]
 
     @staticmethod
     def backward(ctx, g_row, g_col):
         a32, b32, ah, bh, na, nb, S, lse_r, lse_c = ctx.saved_tensors
         normalize, inv_tau, eps, R, Cn, D, ldS = ctx.meta
-        dev = S.device
+        dev = ah.device
         gr = torch.zeros(R, dtype=torch.float32, device=dev)
         gc = torch.zeros(Cn, dtype=torch.float32, device=dev)
         n = min(R, Cn)
@@ -65,8 +76,12 @@ class _SimilarityLossFn(torch.autograd.Function):
         gc[:n] = g_col.float()
         ldg = _pad8(Cn)
         G = torch.zeros(_pad8(R), ldg, dtype=BF16, device=dev)
-        check(lib().vm_contrastive_grad(ptr(S), ldS, ptr(lse_r), ptr(lse_c), ptr(gr), ptr(gc), ptr(G), ldg, R, Cn, 0, stream()),
-              "vm_contrastive_grad")
+        if S is None:   # fused: G from recomputed tiles
+            check(lib().vm_contrastive_bwd(ptr(ah), ptr(bh), R, Cn, D, inv_tau, 0, ptr(lse_r), ptr(lse_c), ptr(gr), ptr(gc), ptr(G), ldg,
+                                           stream()), "vm_contrastive_bwd")
+        else:
+            check(lib().vm_contrastive_grad(ptr(S), ldS, ptr(lse_r), ptr(lse_c), ptr(gr), ptr(gc), ptr(G), ldg, R, Cn, 0, stream()),
+                  "vm_contrastive_grad")
         dah = torch.empty(R, D, dtype=torch.float32, device=dev)
         dbh = torch.empty(Cn, D, dtype=torch.float32, device=dev)
         ops.gemm(G, 0, bh, 1, dah, R, D, ldg, alpha=inv_tau)            # dA^ = G B^ / tau      (contraction over columns)

@@ -290,7 +290,6 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
                          (!epi->residual || (epi->ldr % 8) == 0) && !vm_env().gemm_generic;
     a.slabs = nullptr;
     a.bias_grad = nullptr;
-    a.persist_total = 0;
     a.dbg = vm_env().gemm_debug;
     // decode-step shapes: few rows -> one workgroup per 16 output columns, K split over its waves (gemm_skinny.hip)
     if (M <= 128 && a_layout == 0 && b_layout == 0 && (K % 32) == 0 && split == 1 && !epi->aux_out && !epi->mul_gelu_z &&
@@ -325,8 +324,7 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
         // B working set stays L2-resident (measured +11 % on the N = 30528 LM head, +4 % at N = 3072, neutral below)
         a.group_w = a.tiles_n >= 24 ? 8 : a.tiles_n;
         if (vm_env().gemm_groupw > 0) a.group_w = vm_env().gemm_groupw;
-        int nb = a.tiles_m * a.tiles_n * split;
-        if (vm_env().gemm_persist > 0 && variant != 1 && variant != 8 && nb > 512) { a.persist_total = nb; nb = 512; }
+        const int nb = a.tiles_m * a.tiles_n * split;
         int rc = vm_gemm_fast_dispatch(a, a_layout, b_layout, nb, variant, s);
         if (rc == VM_OK && split > 1) rc = vm_gemm_splitk_reduce(a, split, s);
         return rc;
@@ -377,7 +375,7 @@ extern "C" int vm_wgrad_grouped(const vm_wgrad_problem* pr, int n, void* stream)
             a.group_w = a.tiles_n;
             a.e = vm_gemm_epilogue{};
             a.e.alpha = 1.0f; a.e.alpha_dev = q.alpha_dev; a.e.out_dtype = VM_F32; a.e.accumulate = 1; a.e.split_k = 1;
-            a.drop_thresh = 0; a.drop_scale = 1.0f; a.dbg = 0; a.slabs = nullptr; a.bias_grad = q.db; a.persist_total = 0;
+            a.drop_thresh = 0; a.drop_scale = 1.0f; a.dbg = 0; a.slabs = nullptr; a.bias_grad = q.db;
             ga.tile_start[i] = tiles;
             tiles += a.tiles_m * a.tiles_n;
         }

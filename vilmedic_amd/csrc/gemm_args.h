@@ -13,7 +13,6 @@ struct GemmArgs {
     int dbg;                 // VM_GEMM_DEBUG experiments (0 in production): 1 skip epilogue, 2 single K-tile
     float* slabs;            // split-K partial slabs [split][M][ldc] fp32 (fast path), or null
     float* bias_grad;        // grouped weight-gradient launch: fp32 [M] += alpha * sum_k A(m, k), or null
-    int persist_total;       // VM_GEMM_PERSIST experiment: > 0 = number of work items walked by a resident grid
 };
 
 #define VM_GEMM_MAX_GROUP 8

@@ -627,20 +627,7 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {       // hardware 
 template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF, int PIPE, int EPI>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fast_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // EXPERIMENT (VM_GEMM_PERSIST, persist_total > 0): a resident grid (2 workgroups per CU) walks the work items instead of one
-    // workgroup per item: no workgroup teardown / launch between tiles, and the stores of tile i drain while the first DMA of tile
-    // i+1 is in flight.  Work item of (iteration k, block b): XCD b & 7 takes the contiguous range [(8 k + xcd) * per, + per) -- the
-    // L2 locality xcd_remap gives the one-shot grid.  gridDim.x is then a multiple of 8.
-    const int per = gridDim.x >> 3;
-    int k = 0;
-    do {
-        const int w = p.persist_total > 0 ? (k * 8 + (int)(blockIdx.x & 7)) * per + (int)(blockIdx.x >> 3) : xcd_remap(blockIdx.x, gridDim.x);
-        if (p.persist_total <= 0 || w < p.persist_total) gemm_fast_body<LA, LB, WM, WN, STAGES, BKT, MF, PIPE, 0, EPI>(p, w, smem);
-        if (p.persist_total <= 0) break;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // LDS reads of the epilogue staging done (NOT vmcnt: stores keep draining)
-        __builtin_amdgcn_s_barrier();
-        ++k;
-    } while (k * (int)gridDim.x < p.persist_total);
+    gemm_fast_body<LA, LB, WM, WN, STAGES, BKT, MF, PIPE, 0, EPI>(p, xcd_remap(blockIdx.x, gridDim.x), smem);
 }
 
 // Several independent GEMMs in ONE launch (the weight gradients of a layer): block -> (problem, tile) through the prefix sums
@@ -711,7 +698,8 @@ int vm_gemm_splitk_reduce(const GemmArgs& a, int nsplit, hipStream_t s) {
 // between the MFMAs (profiles/r01_e_gemm_pipe_ab.txt); round 2: k-tile 32 x 3-slot ring with register prefetch 0.72-0.97x, 256 x 128 /
 // 128 x 64 per wave on that ring 0.51-0.98x, s_setprio around the MFMA stream 0.83-1.0x (profiles/r02_a_gemm_candidates_ab.txt); PIPE 4 for
 // row-major operands 0.87-1.05x, DMA pieces slotted one per MFMA = burst (profiles/r02_b_gemm_pipe4_asmdma_ab.txt); late start of the
-// second workgroup of a CU 0.83-1.0x (profiles/r02_c_gemm_stagger_and_epilogue_breakdown.txt); the 16-wave 256 x 256 tile (45 spills).
+// second workgroup of a CU 0.83-1.0x (profiles/r02_c_gemm_stagger_and_epilogue_breakdown.txt); the 16-wave 256 x 256 tile (45 spills);
+// a resident grid of 512 workgroups walking the tiles instead of one workgroup per tile 0.87-1.05x (profiles/r02_e_gemm_persist_ab.txt).
 template <int EPI>
 static int dispatch_epi(const GemmArgs& a0, int a_layout, int b_layout, int nblocks, int variant, hipStream_t s) {
     if (variant == 8 && a_layout == 0)
