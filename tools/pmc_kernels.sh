@@ -10,7 +10,7 @@ mkdir -p $out
 i=0
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  (cd /tmp && rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -o p$i -- "$@" > $out/p$i.log 2>&1)
+  (cd $R && TMPDIR=/tmp rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -o p$i -- "$@" > $out/p$i.log 2>&1)
 done
 python3 - <<PY
 import csv, glob, collections
