@@ -216,3 +216,34 @@ def test_arena_ddp_gradient_accumulation_trains_the_encoder_and_folds_stray_grad
         assert r[rank][0] > 0, "encoder gradient missing after a non-stepping micro-batch"
         torch.testing.assert_close(r[rank][1], r[rank][2], rtol=1e-5, atol=1e-6)
         assert r[rank][3]
+
+
+def _gloria_local_gather(rank, world):
+    """GLoRIA's local loss over the GLOBAL batch: every rank holds 3 (image, caption) pairs, the local feature maps and
+    word embeddings are all-gathered with gradient, the loss is that of the 6-pair batch and each rank's gradients are its slice of the
+    single-process gradients (x world: ArenaDDP then averages parameter gradients over ranks)"""
+    from vilmedic_amd.blocks.losses.selfsup import GLoRIALoss, _maybe_gather
+    g = torch.Generator().manual_seed(21)
+    B, b, D, T = 6, 3, 16, 5
+    img = torch.randn(B, D, 3, 3, generator=g)
+    words = torch.randn(B, D, T, generator=g)
+    lens = [5, 3, 4, 2, 5, 4]
+    crit = GLoRIALoss(temp1=4.0, temp2=5.0, temp3=10.0)
+    li = img[rank * b:(rank + 1) * b].clone().requires_grad_(True)
+    lw = words[rank * b:(rank + 1) * b].clone().requires_grad_(True)
+    (gi, gw), _, w = _maybe_gather(li, lw)
+    assert w == world and gi.shape[0] == B
+    l0, l1, _ = crit._local(gi, gw, lens)
+    (l0 + l1).backward()
+    fi, fw = img.clone().requires_grad_(True), words.clone().requires_grad_(True)
+    r0, r1, _ = crit._local(fi, fw, lens)
+    (r0 + r1).backward()
+    return (float(l0 + l1), float(r0 + r1), li.grad, world * fi.grad[rank * b:(rank + 1) * b], lw.grad, world * fw.grad[rank * b:(rank + 1) * b])
+
+
+def test_gloria_local_loss_contrasts_the_global_batch():
+    r = _run(_gloria_local_gather)
+    for rank in (0, 1):
+        assert r[rank][0] == pytest.approx(r[rank][1], rel=1e-6)
+        torch.testing.assert_close(r[rank][2], r[rank][3], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(r[rank][4], r[rank][5], rtol=1e-5, atol=1e-6)

@@ -240,6 +240,16 @@ class GLoRIALoss(nn.Module):
         self.temp1, self.temp2, self.temp3 = temp1, temp2, temp3
 
     def forward(self, global_features, local_features, word_embeddings, sent_embeddings, sents):
+        # data parallel training: every caption is contrasted with the images of the GLOBAL batch (and vice versa), so the local
+        # feature maps [b, D, 19, 19], the word embeddings [b, D, T] and both global embeddings are all-gathered (RCCL; backward =
+        # sum over ranks + own slice) together with the word lists -- SURVEY §8e "GLoRIA local loss"
+        (global_features, local_features, word_embeddings, sent_embeddings), _, world = _maybe_gather(
+            global_features, local_features, word_embeddings, sent_embeddings)
+        if world > 1:
+            import torch.distributed as dist
+            parts = [None] * world
+            dist.all_gather_object(parts, list(sents))
+            sents = [s_ for p_ in parts for s_ in p_]
         cap_lens = [len([w for w in sent if not w.startswith("[")]) + 1 for sent in sents]
         l0, l1, attn_maps = self._local(local_features.float(), word_embeddings.float(), cap_lens)
         # global: cosine-sim [B,B] * temp3 -> CE both ways == the HIP similarity loss with inv_tau = temp3 (mean over rows)
