@@ -229,6 +229,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("VM_TRAIN_GRAPH", "0")),
+                    help="1: replay the whole step from one captured HIP graph (vilmedic_amd.graph); 0: eager launches")
     args = ap.parse_args()
     if args.cpu_baseline_child:
         cpu_baseline_child()
@@ -265,15 +267,22 @@ def main():
     B, L, V = args.batch, args.seq, DEC_12L["vocab_size"]
     images, ids, am = synthetic_batch(B, L, V, device, seed=rank)
 
-    def step():
-        out = model(input_ids=ids, attention_mask=am, images=images, return_logits=False)
+    def eager_step(input_ids=ids, attention_mask=am, images=images):
+        out = model(input_ids=input_ids, attention_mask=attention_mask, images=images, return_logits=False)
         opt.zero_grad()
+        opt.gate = out["loss"].detach()      # NaN / Inf loss -> the update is skipped on the device (no host read of the loss)
         if ddp is not None:
             ddp.backward(out["loss"])        # two-phase backward: decoder all-reduce overlaps the ViT backward
         else:
             out["loss"].backward()
         opt.step()
         return out["loss"]
+
+    step = eager_step
+    if args.graph and ddp is None:
+        from vilmedic_amd.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(eager_step, dict(input_ids=ids, attention_mask=am, images=images), optimizer=opt, warmup=min(3, max(1, args.warmup - 1)))
+        step = lambda: graphed(input_ids=ids, attention_mask=am, images=images)
 
     for _ in range(args.warmup):
         loss = step()
@@ -313,7 +322,7 @@ def main():
         side = ops.SIDE_STREAM
         ops.SIDE_STREAM = False          # per-launch durations are taken with every kernel alone on the GPU (the timed
         for _ in range(2):               # steps above overlap parameter-gradient kernels with the dgrad chain)
-            step()
+            eager_step()
         torch.cuda.synchronize()
         ops.SIDE_STREAM = side
         if rank == 0:
@@ -354,6 +363,7 @@ def main():
                                    "bf16, 224x224 images, 128-token reports, dropout 0.1, fwd+bwd+Adam",
                        "per_gpu_batch": B, "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}"},
             "model_tflops_per_s": round(step_flops * args.steps / elapsed / 1e12 * world, 1),
+            "launch_mode": "hip-graph replay" if (args.graph and ddp is None) else "eager",
             "final_loss": round(final_loss, 4),
             "roofline": roof, "cpu_baseline": cpu,
         }

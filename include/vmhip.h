@@ -63,6 +63,9 @@ typedef struct {
     int split_k;              /* >=1; >1 requires fp32 output and a plain epilogue (alpha only)  */
     void* workspace;          /* split_k>1: fp32 scratch of >= split_k*M*ldc*4 bytes (partial slabs, */
     size_t workspace_bytes;   /*   reduced deterministically by a second kernel; no atomics)        */
+    const uint64_t* dropout_seed_dev;  /* optional DEVICE counter added to dropout_seed when the kernel runs: a launch replayed
+                                          from a captured HIP graph then draws a fresh mask per replay (the caller bumps the counter
+                                          once per training step, inside the graph) */
 } vm_gemm_epilogue;
 
 int vm_sizeof_gemm_epilogue(void);   /* lets a foreign binding verify its struct layout */
@@ -120,13 +123,14 @@ int vm_layernorm_bwd_reduce(const void* ws, float* dgamma, float* dbeta, int row
 int vm_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                      void* o, int64_t ldo, float* stats, const uint8_t* key_mask,
                      int B, int H, int Lq, int Lk, int dh, float scale, int causal,
-                     float dropout_p, uint64_t dropout_seed, const int32_t* kv_row_index, int64_t kv_index_ld, void* stream);
+                     float dropout_p, uint64_t dropout_seed, const uint64_t* dropout_seed_dev /* see vm_gemm_epilogue; may be NULL */,
+                     const int32_t* kv_row_index, int64_t kv_index_ld, void* stream);
 int vm_attention_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                      const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* stats,
                      const uint8_t* key_mask,
                      void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
                      int B, int H, int Lq, int Lk, int dh, float scale, int causal,
-                     float dropout_p, uint64_t dropout_seed, float* ws_delta /* fp32 [B,H,Lq] */, void* stream);
+                     float dropout_p, uint64_t dropout_seed, const uint64_t* dropout_seed_dev, float* ws_delta /* fp32 [B,H,Lq] */, void* stream);
 
 /* ------------------------------------------------------------------ embeddings
  * hf:...bert_generation.py:394-426: out = word[ids] + pos[past_len + t]   (LayerNorm is a separate call) */
@@ -201,7 +205,7 @@ int vm_colsum_bf16(const void* x, int64_t ldx, float* out /* += [cols] */, int r
                    const float* scale_dev /* optional device scalar */, void* stream);
 int vm_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
 /* out = keep(seed, idx) ? x/(1-p) : 0 with idx = flat element index (the mask vm_gemm_bf16 uses with idx = m*N+n) */
-int vm_dropout_apply_bf16(const void* x, void* out, int64_t n, float p, uint64_t seed, void* stream);
+int vm_dropout_apply_bf16(const void* x, void* out, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 int vm_feature_mask(const void* feats /* bf16 [rows, cols] */, uint8_t* mask, int rows, int cols, void* stream);
 
 /* ------------------------------------------------------------------ optimizer
@@ -210,6 +214,14 @@ int vm_feature_mask(const void* feats /* bf16 [rows, cols] */, uint8_t* mask, in
 int vm_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16 /* or NULL */, int64_t n,
                  float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled_wd,
                  float bias_corr1, float bias_corr2, float grad_scale, void* stream);
+/* The same update with its per-step scalars read from DEVICE memory, so that the launch can sit in a captured HIP graph:
+ * lr_dev (NULL: use lr), step_dev (NULL: use bias_corr1/2; else the 1-based step count t, bias corrections 1 - beta^t computed in the
+ * kernel), gate_dev (NULL: always update; else the update is skipped -- p, m, v, shadow untouched -- unless *gate_dev is finite: the
+ * NaN/Inf-loss guard of ref:vilmedic/executors/trainor.py:109-112 without a host read of the loss). */
+int vm_adam_step_dev(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n,
+                     float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled_wd,
+                     float bias_corr1, float bias_corr2, float grad_scale,
+                     const float* lr_dev, const int64_t* step_dev, const float* gate_dev, void* stream);
 
 /* ------------------------------------------------------------------ decode step helpers
  * hf:generation/utils.py:3384-3389 (fp32 log_softmax), :3113-3119 (top-k over beams*V), :2925 (argmax). */

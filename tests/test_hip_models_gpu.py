@@ -437,3 +437,65 @@ def test_rrs_loss_logits_grads_vs_golden_and_decode_vs_oracle(golden):
                 break
             margin = lp[b, t - 1].max() - lp[b, t - 1, hyp[b, t]]
             assert margin <= 0.25, (b, t, margin)
+
+
+def test_graphed_train_step_follows_the_golden_trajectory_and_redraws_dropout(golden):
+    """vilmedic_amd.graph.GraphedTrainStep: the whole RRG step (forward, autograd backward with the side stream and the grouped
+    weight-gradient launches, fused Adam) replayed from ONE captured HIP graph.  (a) dropout off: step 1 eager, step 2 = capture +
+    first replay, step 3 = replay reproduce the reference's 3-step Adam loss trajectory (fixture G5) -- the device-side step counter
+    drives Adam's bias correction; (b) dropout on, learning rate 0: two replays on the same batch give DIFFERENT losses (the device seed
+    counter advances inside the graph) that are both finite; (c) a NaN loss skips the update on the device (no host read)."""
+    from vilmedic_amd.graph import GraphedTrainStep
+    from vilmedic_amd.models.rrg.RRG import RRG
+    from vilmedic_amd.optim import FusedAdam
+    g = golden("g5_rrg_tiny")
+
+    def make(drop):
+        m = RRG(decoder=dict(proto=None, hidden_dropout_prob=drop, attention_probs_dropout_prob=drop, **g["dec_cfg"]),
+                cnn=dict(proto="VisualEncoder", backbone="vit", permute="no_permute", dropout_out=0.0, **g["vit_cfg"])).to(dev())
+        vst = R.rand_state(R.vit_shapes(g["vit_cfg"]), g["seed"])
+        dst = R.rand_state(R.decoder_shapes(g["dec_cfg"]), g["seed"] + 1)
+        sd = {"enc.model." + k: v for k, v in vst.items()}
+        sd.update({"dec.decoder." + k: v for k, v in dst.items()})
+        sd["dec.decoder.lm_head.decoder.weight"] = dst["bert.embeddings.word_embeddings.weight"]
+        sd["dec.decoder.lm_head.decoder.bias"] = dst["lm_head.bias"]
+        m.load_state_dict(sd, strict=True)
+        return m.train()
+    images = R.make_images(g["B"], g["vit_cfg"]["image_size"], seed=g["seed"]).to(dev())
+    ids, am = R.make_reports(g["B"], g["L"], g["dec_cfg"]["vocab_size"], seed=g["seed"])
+    batch = dict(input_ids=ids.to(dev()), attention_mask=am.to(dev()), images=images)
+
+    def stepper(model, opt):
+        def step(input_ids, attention_mask, images):
+            out = model(input_ids=input_ids, attention_mask=attention_mask, images=images, return_logits=False)
+            opt.zero_grad()
+            opt.gate = out["loss"].detach()
+            out["loss"].backward()
+            opt.step()
+            return out["loss"]
+        return step
+    # (a) golden trajectory through eager -> capture -> replay
+    model = make(0.0)
+    opt = FusedAdam(model, lr=g["lr"])
+    gs = GraphedTrainStep(stepper(model, opt), batch, optimizer=opt, warmup=1)
+    losses = [gs(**batch).item() for _ in range(3)]
+    assert gs.graph is not None and opt.steps == 3
+    for got, ref in zip(losses, g["losses"]):
+        assert abs(got - ref.item()) <= 2e-3 * max(1.0, abs(ref.item())), (losses, g["losses"])
+    # (b) fresh dropout masks per replay
+    model = make(0.3)
+    opt = FusedAdam(model, lr=0.0)
+    gs = GraphedTrainStep(stepper(model, opt), batch, optimizer=opt, warmup=1)
+    ls = [gs(**batch).item() for _ in range(4)]
+    assert all(torch.isfinite(torch.tensor(ls))) and abs(ls[2] - ls[3]) > 1e-4, ls
+    # (c) NaN gate inside the graph
+    model = make(0.0)
+    opt = FusedAdam(model, lr=1e-2)
+    gs = GraphedTrainStep(stepper(model, opt), batch, optimizer=opt, warmup=1)
+    gs(**batch), gs(**batch)
+    from vilmedic_amd.arena import arena_of
+    before = arena_of(model).flat.clone()
+    bad = dict(batch, images=torch.full_like(images, float("nan")))
+    assert not torch.isfinite(gs(**bad)).item()
+    assert torch.equal(arena_of(model).flat, before)                   # update skipped on the device
+    assert torch.isfinite(gs(**batch)).item() and not torch.equal(arena_of(model).flat, before)

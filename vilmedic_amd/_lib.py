@@ -19,7 +19,7 @@ class GemmEpilogue(C.Structure):
         ("bias", C.c_void_p), ("act", C.c_int), ("aux_out", C.c_void_p), ("mul_gelu_z", C.c_void_p),
         ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64), ("residual", C.c_void_p), ("ldr", C.c_int64),
         ("alpha", C.c_float), ("alpha_dev", C.c_void_p), ("out_dtype", C.c_int), ("accumulate", C.c_int), ("split_k", C.c_int),
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("dropout_seed_dev", C.c_void_p),
     ]
 
 
@@ -52,9 +52,9 @@ SIGNATURES = {
     "vm_layernorm_bwd_reduce": (_I, [_P, _P, _P, _I, _I, _P]),
     "vm_image_pipeline_ws": (_SZ, [_I, _I, _I]),
     "vm_image_pipeline_u8": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _SZ, _P]),
-    "vm_attention_fwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _U64, _P, _L, _P]),
+    "vm_attention_fwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _U64, _P, _P, _L, _P]),
     "vm_attention_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _P, _L, _P, _L,
-                              _I, _I, _I, _I, _I, _F, _I, _F, _U64, _P, _P]),
+                              _I, _I, _I, _I, _I, _F, _I, _F, _U64, _P, _P, _P]),
     "vm_embedding_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "vm_embedding_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "vm_im2col_patches": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
@@ -75,9 +75,10 @@ SIGNATURES = {
     "vm_cast_pad_f32_to_bf16": (_I, [_P, _P, _I, _I, _L, _P]),
     "vm_colsum_bf16": (_I, [_P, _L, _P, _I, _I, _P, _P]),
     "vm_add_bf16": (_I, [_P, _P, _P, _L, _P]),
-    "vm_dropout_apply_bf16": (_I, [_P, _P, _L, _F, _U64, _P]),
+    "vm_dropout_apply_bf16": (_I, [_P, _P, _L, _F, _U64, _P, _P]),
     "vm_feature_mask": (_I, [_P, _P, _I, _I, _P]),
     "vm_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _F, _F, _P]),
+    "vm_adam_step_dev": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _F, _F, _P, _P, _P, _P]),
     "vm_logsoftmax_f32": (_I, [_P, _L, _P, _I, _I, _P]),
     "vm_argmax_f32": (_I, [_P, _L, _P, _P, _I, _I, _P]),
     "vm_gemm_f32": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _I, _P, _L, _P]),

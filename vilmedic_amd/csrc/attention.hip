@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, RES ? 4 : ATTN_MIN_BLOCKS) void attn_fwd_kerne
             for (int r = 0; r < 4; ++r) o[f][r] *= alpha;
         if (p.dropout_p > 0.f) {
             const uint64_t base = ((uint64_t)(b * p.H + h) * p.Lq + qrow) * (uint64_t)((p.Lk + 1) & ~1);   // even row pitch
-            const DropKey dk_ = drop_key(p.seed);
+            const DropKey dk_ = drop_key(eff_seed(p.seed, p.seed_dev));
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 bool keep[4];
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256, RES ? 4 : ATTN_MIN_BLOCKS) void attn_bwd_dq_ke
                 val = keep ? val : MASKED_SCORE;
                 const float pr = (key < p.Lk && qok) ? __expf(val - m) * inv_l : 0.f;
                 float dpv = dp[f][r];
-                if (p.dropout_p > 0.f) dpv = dropout_keep(drop_key(p.seed), dbase + key, p.thresh) ? dpv * p.drop_scale : 0.f;
+                if (p.dropout_p > 0.f) dpv = dropout_keep(drop_key(eff_seed(p.seed, p.seed_dev)), dbase + key, p.thresh) ? dpv * p.drop_scale : 0.f;
                 s[f][r] = pr * (dpv - delta);      // dS^T
             }
         }
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256, RES ? 2 : ATTN_MIN_BLOCKS) void attn_bwd_dkv_k
                 const float pr = (qr < p.Lq && kok) ? __expf(val - mr[r]) * ir[r] : 0.f;
                 float dpv = dp[f][r], pd = pr;
                 if (p.dropout_p > 0.f) {
-                    const bool kp_ = dropout_keep(drop_key(p.seed), ((uint64_t)(b * p.H + h) * p.Lq + qr) * (uint64_t)((p.Lk + 1) & ~1) + key, p.thresh);
+                    const bool kp_ = dropout_keep(drop_key(eff_seed(p.seed, p.seed_dev)), ((uint64_t)(b * p.H + h) * p.Lq + qr) * (uint64_t)((p.Lk + 1) & ~1) + key, p.thresh);
                     dpv = kp_ ? dpv * p.drop_scale : 0.f;
                     pd = kp_ ? pr * p.drop_scale : 0.f;
                 }
@@ -463,7 +463,8 @@ static int check_common(const char* fn, int B, int H, int Lq, int Lk, int dh, in
 extern "C" int vm_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                                 void* o, int64_t ldo, float* stats, const uint8_t* key_mask,
                                 int B, int H, int Lq, int Lk, int dh, float scale, int causal,
-                                float dropout_p, uint64_t dropout_seed, const int32_t* kv_row_index, int64_t kv_index_ld, void* stream) {
+                                float dropout_p, uint64_t dropout_seed, const uint64_t* dropout_seed_dev,
+                                const int32_t* kv_row_index, int64_t kv_index_ld, void* stream) {
     VM_REQUIRE(q && k && v && o && stats, "vm_attention_fwd: null pointer");
     int rc = check_common("vm_attention_fwd", B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo);
     if (rc) return rc;
@@ -472,7 +473,7 @@ extern "C" int vm_attention_fwd(const void* q, int64_t ldq, const void* k, int64
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.stats = stats; a.key_mask = key_mask;
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.causal = causal;
     a.kv_index = kv_row_index; a.kv_index_ld = kv_index_ld;
-    a.dropout_p = dropout_p; a.seed = dropout_seed; a.thresh = dropout_thresh16(dropout_p);
+    a.dropout_p = dropout_p; a.seed = dropout_seed; a.seed_dev = dropout_seed_dev; a.thresh = dropout_thresh16(dropout_p);
     a.drop_scale = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_ATTN, 4.0 * B * H * (double)Lq * Lk * dh, s, "fwd_B%d_H%d_Lq%d_Lk%d_c%d_d%d", B, H, Lq, Lk, causal, dropout_p > 0.f);
@@ -493,7 +494,7 @@ extern "C" int vm_attention_bwd(const void* q, int64_t ldq, const void* k, int64
                                 const uint8_t* key_mask,
                                 void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
                                 int B, int H, int Lq, int Lk, int dh, float scale, int causal,
-                                float dropout_p, uint64_t dropout_seed, float* ws_delta, void* stream) {
+                                float dropout_p, uint64_t dropout_seed, const uint64_t* dropout_seed_dev, float* ws_delta, void* stream) {
     VM_REQUIRE(q && k && v && o && d_o && stats && dq && dk && dv && ws_delta, "vm_attention_bwd: null pointer");
     int rc = check_common("vm_attention_bwd", B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo);
     if (rc) return rc;
@@ -504,7 +505,7 @@ extern "C" int vm_attention_bwd(const void* q, int64_t ldq, const void* k, int64
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
     a.stats = const_cast<float*>(stats); a.delta = ws_delta; a.key_mask = key_mask;
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.causal = causal;
-    a.dropout_p = dropout_p; a.seed = dropout_seed; a.thresh = dropout_thresh16(dropout_p);
+    a.dropout_p = dropout_p; a.seed = dropout_seed; a.seed_dev = dropout_seed_dev; a.thresh = dropout_thresh16(dropout_p);
     a.drop_scale = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_ATTN, 14.0 * B * H * (double)Lq * Lk * dh, s, "bwd_B%d_H%d_Lq%d_Lk%d_c%d_d%d", B, H, Lq, Lk, causal, dropout_p > 0.f);

@@ -21,7 +21,7 @@ struct AttnArgs {
     int nslot_k, nslot_q;    // resident variants: LDS tile slots actually allocated (ceil(L/64))
     int ralloc_k, ralloc_q;  // head-resident variants: LDS rows allocated for K/V resp. Q/dO (L rounded up to 4)
     float scale; int causal;
-    float dropout_p; uint64_t seed; uint32_t thresh; float drop_scale;
+    float dropout_p; uint64_t seed; const uint64_t* seed_dev; uint32_t thresh; float drop_scale;
 };
 
 __device__ __forceinline__ bf16x8_t ld_frag_global(const bf16_t* p, const bf16_t* safe, bool ok) {

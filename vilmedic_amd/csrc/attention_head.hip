@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, 3) void attn_head_fwd_kernel(const AttnArgs p)
     const bool has_mask = p.key_mask != nullptr;
     const bool ragged = (p.Lk & 15) != 0;
     const HLane L = hlane_offsets(lane);
-    const DropKey dkey = drop_key(p.seed);
+    const DropKey dkey = drop_key(eff_seed(p.seed, p.seed_dev));
     const uint32_t lk_even = (uint32_t)((p.Lk + 1) & ~1);
     const float c2 = p.scale * LOG2E_F;
     auto load_q = [&](int grp, bf16x8_t (&qf)[2]) {
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256, 3) void attn_head_dq_kernel(const AttnArgs p) 
     const bool has_mask = p.key_mask != nullptr;
     const bool ragged = (p.Lk & 15) != 0;
     const HLane L = hlane_offsets(lane);
-    const DropKey dkey = drop_key(p.seed);
+    const DropKey dkey = drop_key(eff_seed(p.seed, p.seed_dev));
     const uint32_t lk_even = (uint32_t)((p.Lk + 1) & ~1);
     const float c2 = p.scale * LOG2E_F;
     struct Own { bf16x8_t qf[2], dof[2], of[2]; float m, inv_l; };      // of: the forward output rows (for delta = rowsum(dO * O))
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256, 3) void attn_head_dkv_kernel(const AttnArgs p)
         const int rt = min(16 * F_part + 4 * g + (c >> 2), nalloc - 1);
         return rt * HB + (((2 * df + ((c & 3) >> 1)) ^ hswz(rt)) << 4) + (c & 1) * 8;
     };
-    const DropKey dkey = drop_key(p.seed);
+    const DropKey dkey = drop_key(eff_seed(p.seed, p.seed_dev));
     const uint32_t lk_even = (uint32_t)((p.Lk + 1) & ~1);
     const float c2 = p.scale * LOG2E_F;
     struct Own { bf16x8_t kf[2], vf[2]; bool keep; };

@@ -86,6 +86,8 @@ __device__ __forceinline__ uint32_t drop_hash(const DropKey k, uint32_t pair) {
     x ^= x >> 16;
     return x;
 }
+// launch-time seed + optional device counter (HIP-graph replays draw fresh masks; see vm_gemm_epilogue.dropout_seed_dev)
+__device__ __forceinline__ uint64_t eff_seed(uint64_t seed, const uint64_t* dev) { return dev ? seed + *dev : seed; }
 // element idx of the logical index space (pairs are (2k, 2k+1))
 __device__ __forceinline__ bool dropout_keep(const DropKey k, uint64_t idx, uint32_t thresh16) {
     const uint32_t h = drop_hash(k, (uint32_t)(idx >> 1));

@@ -306,8 +306,9 @@ extern "C" int vm_vit_assemble_bwd(const void* d_out, void* d_patches, float* d_
 // ------------------------------------------------------------------ dropout mask re-application (backward of the
 // GEMM-epilogue dropout): out[r,c] = keep(seed, r*cols+c) ? x[r,c]/(1-p) : 0   -- same counter-based mask as gemm.hip
 __global__ __launch_bounds__(256) void dropout_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int64_t n,
-                                                            uint64_t seed, uint32_t thresh, float scale) {
+                                                            uint64_t seed0, const uint64_t* __restrict__ seed_dev, uint32_t thresh, float scale) {
     const int64_t nvec = n >> 3;
+    const uint64_t seed = eff_seed(seed0, seed_dev);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
         float f[8];
         unpack8(*reinterpret_cast<const uint4*>(x + i * 8), f);
@@ -318,10 +319,10 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const bf16_t* __rest
         *reinterpret_cast<uint4*>(out + i * 8) = pack8(f);
     }
 }
-extern "C" int vm_dropout_apply_bf16(const void* x, void* out, int64_t n, float p, uint64_t seed, void* stream) {
+extern "C" int vm_dropout_apply_bf16(const void* x, void* out, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev, void* stream) {
     VM_REQUIRE(x && out && n > 0 && (n % 8) == 0 && p >= 0.f && p < 1.f, "vm_dropout_apply_bf16: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_ELT, 4.0 * n, s);
-    hipLaunchKernelGGL(dropout_apply_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, n, seed, dropout_thresh16(p), 1.0f / (1.0f - p));
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, n, seed, seed_dev, dropout_thresh16(p), 1.0f / (1.0f - p));
     return vm_check_launch("vm_dropout_apply_bf16");
 }

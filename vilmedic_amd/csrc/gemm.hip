@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
         if (e.dropout_p > 0.f) {
             const uint64_t idx = (uint64_t)gm * (uint64_t)p.N + (uint64_t)gn;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = dropout_keep(drop_key(e.dropout_seed), idx + j, p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
+            for (int j = 0; j < 8; ++j) v[j] = dropout_keep(drop_key(eff_seed(e.dropout_seed, e.dropout_seed_dev)), idx + j, p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
         }
         if (e.residual) {
             const bf16_t* rp = reinterpret_cast<const bf16_t*>(e.residual) + (int64_t)gm * e.ldr + gn;

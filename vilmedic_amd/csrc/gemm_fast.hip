@@ -380,7 +380,7 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs& p, const int bid,
         // pair fill whole 128-B lines; the per-element operands (residual, z) are read in exactly that pattern.
         const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(e.mul_gelu_z);
         const bf16_t* rsrc = reinterpret_cast<const bf16_t*>(e.residual);
-        const DropKey dkey = drop_key(e.dropout_seed);
+        const DropKey dkey = drop_key(eff_seed(e.dropout_seed, e.dropout_seed_dev));
         const int colbase = n0 + wn * 64 + 16 * (g & 1) + 8 * (g >> 1);          // + 32 * jp
         const int rowbase = m0 + wm * WR + c;                                    // + 16 * i
         float bias8[2][8];
@@ -518,7 +518,7 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs& p, const int bid,
     const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(e.mul_gelu_z);
     const bf16_t* rsrc = reinterpret_cast<const bf16_t*>(e.residual);
     const bool vec = nvalid == 8;
-    const DropKey dkey = drop_key(e.dropout_seed);
+    const DropKey dkey = drop_key(eff_seed(e.dropout_seed, e.dropout_seed_dev));
 #pragma unroll 1
     for (int ps = 0; ps < NPASS; ++ps) {
     uint4 zq[ITEMS], rq[ITEMS];

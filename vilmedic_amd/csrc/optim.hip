@@ -6,7 +6,14 @@
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, bf16_t* __restrict__ shadow, int64_t n,
                                                    float lr, float b1, float b2, float eps, float wd, int decoupled,
-                                                   float bc1, float bc2, float gscale) {
+                                                   float bc1, float bc2, float gscale, const float* __restrict__ lr_dev,
+                                                   const int64_t* __restrict__ step_dev, const float* __restrict__ gate_dev) {
+    if (gate_dev) {                               // NaN / Inf loss: the whole update is skipped (wave-uniform: one scalar)
+        const float gate = *gate_dev;
+        if (!(fabsf(gate) <= 3.4028234663852886e38f)) return;
+    }
+    if (lr_dev) lr = *lr_dev;
+    if (step_dev) { const float t = (float)(*step_dev); bc1 = 1.0f - powf(b1, t); bc2 = 1.0f - powf(b2, t); }
     const float step = lr / bc1;
     const float inv_sqrt_bc2 = rsqrtf(bc2);
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
@@ -45,12 +52,20 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 extern "C" int vm_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n,
                             float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled_wd,
                             float bias_corr1, float bias_corr2, float grad_scale, void* stream) {
+    return vm_adam_step_dev(p, g, m, v, shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, decoupled_wd, bias_corr1, bias_corr2, grad_scale,
+                            nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int vm_adam_step_dev(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n,
+                                float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled_wd,
+                                float bias_corr1, float bias_corr2, float grad_scale,
+                                const float* lr_dev, const int64_t* step_dev, const float* gate_dev, void* stream) {
     VM_REQUIRE(p && g && m && v && n > 0, "vm_adam_step: bad arguments");
     VM_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0, "vm_adam_step: buffers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_OPT, 30.0 * n, s);
     int64_t blocks = (n + 1023) / 1024; if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, (bf16_t*)shadow_bf16, n, lr, beta1, beta2, eps,
-                       weight_decay, decoupled_wd, bias_corr1, bias_corr2, grad_scale);
+                       weight_decay, decoupled_wd, bias_corr1, bias_corr2, grad_scale, lr_dev, step_dev, gate_dev);
     return vm_check_launch("vm_adam_step");
 }

@@ -52,7 +52,7 @@ def _attn(q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, dh, key_mask=None, kv_index=None
     o = torch.empty(B * Lq, H * dh, dtype=BF16, device=q.device)
     stats = torch.empty(B * H * Lq * 2, dtype=torch.float32, device=q.device)
     check(lib().vm_attention_fwd(ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(o), H * dh, ptr(stats),
-                                 ptr(key_mask) if key_mask is not None else None, B, H, Lq, Lk, dh, dh ** -0.5, 0, 0.0, 0,
+                                 ptr(key_mask) if key_mask is not None else None, B, H, Lq, Lk, dh, dh ** -0.5, 0, 0.0, 0, None,
                                  ptr(kv_index) if kv_index is not None else None, kv_index_ld, stream()), "vm_attention_fwd")
     return o
 

@@ -36,6 +36,24 @@ def next_seed():
     return ((_seed_state["base"] << 32) ^ (_seed_state["counter"] * 0x9E3779B1)) & 0xFFFFFFFFFFFFFFFF
 
 
+# Device-side seed counter: every dropout site passes (launch-time seed, pointer to this counter) and the kernels add the two when
+# they RUN.  Eagerly the counter stays 0 and the host seeds differ per call; in a captured training step (graph.py) the host seeds
+# are frozen into the graph and ``advance_seed_dev()`` -- itself a node of the graph -- makes every replay draw fresh masks, with the
+# forward and backward kernels of one replay still agreeing on them.
+_seed_dev = {}
+
+
+def seed_dev(device):
+    t = _seed_dev.get(device)
+    if t is None:
+        t = _seed_dev[device] = torch.zeros(1, dtype=torch.int64, device=device)
+    return t
+
+
+def advance_seed_dev(device):
+    seed_dev(device).add_(0x2545F4914F6CDD1D)        # odd increment: the 64-bit counter cycles through all values
+
+
 # ----------------------------------------------------------------------------- raw kernel wrappers
 def gemm(A, a_layout, B, b_layout, C_out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, act=0, aux_out=None,
          mul_gelu_z=None, dropout_p=0.0, dropout_seed=0, residual=None, ldr=None, alpha=1.0, alpha_dev=None, accumulate=False,
@@ -47,6 +65,7 @@ def gemm(A, a_layout, B, b_layout, C_out, M, N, K, *, lda=None, ldb=None, ldc=No
     e.mul_gelu_z = ptr(mul_gelu_z).value if mul_gelu_z is not None else None
     e.dropout_p = dropout_p
     e.dropout_seed = dropout_seed
+    e.dropout_seed_dev = seed_dev(C_out.device).data_ptr() if dropout_p > 0 else None
     e.residual = ptr(residual).value if residual is not None else None
     e.ldr = ldr if ldr is not None else (residual.stride(0) if residual is not None else 0)
     e.alpha = alpha
@@ -266,7 +285,7 @@ def cast_to_f32(src, dst=None):
 
 def dropout_apply(x, p, seed):
     out = torch.empty_like(x)
-    check(lib().vm_dropout_apply_bf16(ptr(x), ptr(out), x.numel(), p, seed, stream()), "vm_dropout_apply_bf16")
+    check(lib().vm_dropout_apply_bf16(ptr(x), ptr(out), x.numel(), p, seed, ptr(seed_dev(x.device)), stream()), "vm_dropout_apply_bf16")
     return out
 
 
@@ -457,7 +476,7 @@ class AttentionFn(torch.autograd.Function):
         scale = dh ** -0.5
         check(lib().vm_attention_fwd(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), o.stride(1), ptr(stats),
                                      ptr(key_mask) if key_mask is not None else None, B, H, Lq, Lk, dh, scale, int(causal),
-                                     dropout_p, seed, None, 0, stream()), "vm_attention_fwd")
+                                     dropout_p, seed, ptr(seed_dev(q.device)) if dropout_p > 0 else None, None, 0, stream()), "vm_attention_fwd")
         ctx.save_for_backward(q, k, v, o, stats, key_mask)
         ctx.meta = (H, causal, dropout_p, seed, scale)
         return o
@@ -478,7 +497,7 @@ class AttentionFn(torch.autograd.Function):
         check(lib().vm_attention_bwd(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), o.stride(1),
                                      ptr(d_o), d_o.stride(1), ptr(stats), ptr(key_mask) if key_mask is not None else None,
                                      ptr(dq), dq.stride(1), ptr(dk), dk.stride(1), ptr(dv), dv.stride(1),
-                                     B, H, Lq, Lk, dh, scale, int(causal), dropout_p, seed, ptr(delta), stream()), "vm_attention_bwd")
+                                     B, H, Lq, Lk, dh, scale, int(causal), dropout_p, seed, ptr(seed_dev(q.device)) if dropout_p > 0 else None, ptr(delta), stream()), "vm_attention_bwd")
         return dq, dk, dv, None, None, None, None
 
 
@@ -498,7 +517,7 @@ class PackedSelfAttentionFn(torch.autograd.Function):
         q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
         check(lib().vm_attention_fwd(ptr(q), D3, ptr(k), D3, ptr(v), D3, ptr(o), D, ptr(stats),
                                      ptr(key_mask) if key_mask is not None else None, B, H, L, L, dh, scale, int(causal),
-                                     dropout_p, seed, None, 0, stream()), "vm_attention_fwd")
+                                     dropout_p, seed, ptr(seed_dev(q.device)) if dropout_p > 0 else None, None, 0, stream()), "vm_attention_fwd")
         ctx.save_for_backward(qkv, o, stats, key_mask)
         ctx.meta = (H, causal, dropout_p, seed, scale)
         return o
@@ -517,7 +536,7 @@ class PackedSelfAttentionFn(torch.autograd.Function):
         dq, dk, dv = dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:]
         check(lib().vm_attention_bwd(ptr(q), D3, ptr(k), D3, ptr(v), D3, ptr(o), D, ptr(d_o), D, ptr(stats),
                                      ptr(key_mask) if key_mask is not None else None, ptr(dq), D3, ptr(dk), D3, ptr(dv), D3,
-                                     B, H, L, L, dh, scale, int(causal), dropout_p, seed, ptr(delta), stream()), "vm_attention_bwd")
+                                     B, H, L, L, dh, scale, int(causal), dropout_p, seed, ptr(seed_dev(q.device)) if dropout_p > 0 else None, ptr(delta), stream()), "vm_attention_bwd")
         return dqkv, None, None, None, None
 
 
@@ -541,7 +560,7 @@ class PackedCrossAttentionFn(torch.autograd.Function):
         k, v = kv[..., :D], kv[..., D:]
         check(lib().vm_attention_fwd(ptr(q), D, ptr(k), ldkv, ptr(v), ldkv, ptr(o), D, ptr(stats),
                                      ptr(key_mask) if key_mask is not None else None, B, H, Lq, Lk, dh, scale, 0,
-                                     dropout_p, seed, None, 0, stream()), "vm_attention_fwd")
+                                     dropout_p, seed, ptr(seed_dev(q.device)) if dropout_p > 0 else None, None, 0, stream()), "vm_attention_fwd")
         ctx.save_for_backward(q, kv, o, stats, key_mask)
         ctx.meta = (H, dropout_p, seed, scale, dkv_out)
         return o
@@ -562,7 +581,7 @@ class PackedCrossAttentionFn(torch.autograd.Function):
         dk, dv = dkv[..., :D], dkv[..., D:]
         check(lib().vm_attention_bwd(ptr(q), D, ptr(k), ldkv, ptr(v), ldkv, ptr(o), D, ptr(d_o), D, ptr(stats),
                                      ptr(key_mask) if key_mask is not None else None, ptr(dq), D, ptr(dk), lddkv, ptr(dv), lddkv,
-                                     B, H, Lq, Lk, dh, scale, 0, dropout_p, seed, ptr(delta), stream()), "vm_attention_bwd")
+                                     B, H, Lq, Lk, dh, scale, 0, dropout_p, seed, ptr(seed_dev(q.device)) if dropout_p > 0 else None, ptr(delta), stream()), "vm_attention_bwd")
         return dq, dkv, None, None, None, None
 
 

@@ -19,6 +19,13 @@ class FusedAdam(torch.optim.Optimizer):
         self.v = torch.zeros_like(a.flat)
         self.steps = 0
         self.grad_scale = 1.0
+        # per-step scalars mirrored in device memory, so that step() can be a node of a captured HIP graph (graph.py): the 1-based
+        # step count (bias corrections are computed in the kernel), the learning rate, and an optional gate (a device scalar, normally
+        # the loss: the update is skipped while it is NaN / Inf -- the reference's NaN guard without a host read)
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=a.flat.device)
+        self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=a.flat.device)
+        self._lr_host = float(lr)
+        self.gate = None
         # frozen parameters: their gradient slices stay zero and m=v=0 -> update is exactly 0 (no weight decay applied
         # would still move them, so decay is rejected when something is frozen)
         if weight_decay and any(not p.requires_grad for p in params):
@@ -35,14 +42,23 @@ class FusedAdam(torch.optim.Optimizer):
         self.steps += 1
         b1, b2 = g["betas"]
         a = self.arena
-        check(lib().vm_adam_step(ptr(a.flat), ptr(a.gflat), ptr(self.m), ptr(self.v), ptr(a.shadow_flat), a.numel,
-                                 g["lr"], b1, b2, g["eps"], g["weight_decay"], int(g["decoupled_weight_decay"]),
-                                 1 - b1 ** self.steps, 1 - b2 ** self.steps, self.grad_scale, stream()), "vm_adam_step")
+        if float(g["lr"]) != self._lr_host:          # a scheduler moved the learning rate: refresh the device copy (outside any capture)
+            self.sync_lr()
+        self.step_dev.add_(1)
+        check(lib().vm_adam_step_dev(ptr(a.flat), ptr(a.gflat), ptr(self.m), ptr(self.v), ptr(a.shadow_flat), a.numel,
+                                     g["lr"], b1, b2, g["eps"], g["weight_decay"], int(g["decoupled_weight_decay"]),
+                                     1 - b1 ** self.steps, 1 - b2 ** self.steps, self.grad_scale,
+                                     ptr(self.lr_dev), ptr(self.step_dev), ptr(self.gate) if self.gate is not None else None, stream()),
+              "vm_adam_step_dev")
         a.mark_shadow_fresh()
+
+    def sync_lr(self):
+        self._lr_host = float(self.param_groups[0]["lr"])
+        self.lr_dev.fill_(self._lr_host)
 
     def state_dict(self):
         groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
-        return {"m": self.m, "v": self.v, "steps": self.steps, "param_groups": groups}
+        return {"m": self.m, "v": self.v, "steps": self.steps, "param_groups": groups}      # (step_dev / lr_dev are rebuilt from these)
 
     def load_state_dict(self, sd):
         self.m.copy_(sd["m"])
@@ -50,3 +66,5 @@ class FusedAdam(torch.optim.Optimizer):
         self.steps = sd["steps"]
         for g, saved in zip(self.param_groups, sd.get("param_groups", [])):
             g.update({k: v for k, v in saved.items() if k != "params"})
+        self.step_dev.fill_(int(self.steps))
+        self.sync_lr()
