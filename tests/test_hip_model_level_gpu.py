@@ -144,8 +144,15 @@ def test_rrg_scst_forward_with_fixed_rollouts_and_top_k_vs_oracle():
     ds = SyntheticImSeq(num_samples=4, image_size=32, vocab_size=97, tokenizer_max_len=12)
     dl = torch.utils.data.DataLoader(ds, batch_size=4, collate_fn=ds.get_collate_fn())
     dcfg = dict(R.DEC_TINY, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    import zlib
+
+    def toy_reward(refs, hyps):
+        """deterministic stand-in for a text metric (random-token hypotheses share nothing with the references, so ROUGE-L would make
+        every reward -- and with it the loss -- exactly zero): (corpus score, per-sample scores) like the reference's scorers"""
+        vals = [(zlib.crc32((r + "|" + h).encode()) % 1000) / 1000.0 for r, h in zip(refs, hyps)]
+        return sum(vals) / len(vals), vals
     model = RRG_SCST(decoder=dict(proto=None, **dcfg), cnn=dict(proto="VisualEncoder", backbone="vit", permute="no_permute", **R.VIT_TINY),
-                     dl=dl, scores="ROUGEL", top_k=top_k).to(dev())
+                     dl=dl, scores=[toy_reward], top_k=top_k).to(dev())
     vst = R.rand_state(R.vit_shapes(R.VIT_TINY), 31)
     dst = R.rand_state(R.decoder_shapes(R.DEC_TINY), 32, std=0.08)
     dst["lm_head.bias"][2] += 6.0                # eos is always among the top-k candidates (a row may then legitimately end early)
@@ -216,6 +223,7 @@ def test_rrg_scst_forward_with_fixed_rollouts_and_top_k_vs_oracle():
     r2 = vst_r["encoder.layer.0.intermediate.dense.weight"].grad
     print(f"[parity] RRG_SCST.forward top_k={top_k}: loss {out['loss'].item():.6f} vs {ref_loss.item():.6f}; decoder grad cos {_cos(g1, r1):.5f} rel {_rel(g1, r1):.3e}; "
           f"encoder grad cos {_cos(g2, r2):.5f} rel {_rel(g2, r2):.3e}", flush=True)
+    assert abs(ref_loss.item()) > 1e-3, "fixture: the reward difference must not vanish"
     assert abs(out["loss"].item() - ref_loss.item()) <= 5e-3 * max(1e-1, abs(ref_loss.item()))
     assert _cos(g1, r1) >= 0.99 and _cos(g2, r2) >= 0.99 and _rel(g1, r1) <= 0.15 and _rel(g2, r2) <= 0.15
 

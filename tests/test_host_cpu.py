@@ -326,3 +326,32 @@ def test_train_cli_run_directory_conventions(tmp_path):
     open(tmp_path / "exp1" / "1.68_10_560435.pth", "w").close()
     cfg, seed = cli.prepare(wrap({"name": "exp1", "ckpt_dir": str(tmp_path), "seed": 7, "ckpt": "1.68_10_560435.pth"}))
     assert cfg["ckpt"] == str(tmp_path / "exp1" / "1.68_10_560435.pth") and seed == 560435
+
+
+def test_micro_batch_norm_equals_the_chunked_tower_loop():
+    """blocks/vision/micro_bn.py: a CNN run ONCE over the batch with per-micro-batch BatchNorm statistics == the reference's loop over
+    forward_batch_size chunks (conVIRT.py:83-95) -- outputs, input / parameter gradients and the running statistics after the pass,
+    including a trailing partial micro-batch; state-dict keys are unchanged by the module swap"""
+    import copy
+    import torch.nn as nn
+    from vilmedic_amd.blocks.vision.micro_bn import micro_batches, use_micro_batch_norm
+    torch.manual_seed(0)
+    ref = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.Conv2d(8, 4, 3, padding=1), nn.BatchNorm2d(4))
+    net = use_micro_batch_norm(copy.deepcopy(ref))
+    assert list(net.state_dict()) == list(ref.state_dict())
+    x = torch.randn(14, 3, 6, 6)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    net.train(), ref.train()
+    with micro_batches(4):
+        ya = net(xa)
+    yb = torch.cat([ref(xb[i:i + 4]) for i in range(0, 14, 4)])
+    torch.testing.assert_close(ya, yb, rtol=1e-5, atol=1e-5)
+    ya.square().sum().backward()
+    yb.square().sum().backward()
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-4, atol=1e-4)
+    for (n, a), (_, b) in zip(net.named_parameters(), ref.named_parameters()):
+        torch.testing.assert_close(a.grad, b.grad, rtol=1e-4, atol=2e-4, msg=n)
+    for (n, a), (_, b) in zip(net.named_buffers(), ref.named_buffers()):
+        torch.testing.assert_close(a.float(), b.float(), rtol=1e-6, atol=1e-6, msg=n)
+    net.eval(), ref.eval()
+    torch.testing.assert_close(net(x), ref(x), rtol=1e-6, atol=1e-6)

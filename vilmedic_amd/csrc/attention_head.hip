@@ -105,6 +105,13 @@ __device__ __forceinline__ void mask_scores(float4_t& s, bool plain, const uint8
 
 // =============================================================================== forward
 // K/V rows are allocated up to Lk rounded to 16 (zero-filled past Lk), so every fragment a group attends to is in range.
+// NG = owner groups a wave works on AT ONCE.  The kernel is latency-, not throughput-bound (rocprofv3 PMC, profiles/r02_f_attention_pmc.txt:
+// waves wait 48 % of their cycles, the SIMD's VALU is busy 23 % per wave, 23 VALU instructions per MFMA): with one group per wave the
+// chain  S = K Q^T (MFMA) -> max / exp / sum (VALU, cross-lane) -> P V (MFMA)  is strictly serial and only the 3 waves of a SIMD
+// overlap.  With NG = 2 the clean-tile path issues the MFMAs and the softmax of two INDEPENDENT 16-query groups in one basic block,
+// so one group's VALU work covers the other's MFMA latency.  (Used for the non-causal calls -- ViT self-attention and cross-
+// attention, where both groups of a pair see the same key tiles; causal groups have different diagonals and keep NG = 1.)
+template <int NG>
 __global__ __launch_bounds__(256, 3) void attn_head_fwd_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nalloc = p.ralloc_k;
@@ -130,8 +137,9 @@ __global__ __launch_bounds__(256, 3) void attn_head_fwd_kernel(const AttnArgs p)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) qf[kk] = ld_frag_global(qp + kk * 32 + g * 8, p.q, qrow < p.Lq && grp < ngroups);
     };
-    bf16x8_t qn[2];
-    load_q(wave, qn);
+    bf16x8_t qn[NG][2];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) load_q(wave + 4 * i, qn[i]);
     __syncthreads();
     // bit F of unmasked = every key of 16-key fragment F is attendable (key mask byte != 0; bytes past Lk are 1): decided at
     // run time, so a mask that is all ones (real images, unpadded reports) costs nothing
@@ -145,131 +153,161 @@ __global__ __launch_bounds__(256, 3) void attn_head_fwd_kernel(const AttnArgs p)
             for (int f = 0; f < 4; ++f) unmasked |= (((ok >> (16 * f)) & 0xffffull) == 0xffffull ? 1u : 0u) << (4 * q4 + f);
         }
     }
-    for (int grp = wave; grp < ngroups; grp += 4) {
-        const int q0 = qc0 + grp * 16, qrow = q0 + c;
-        const bool qok = qrow < p.Lq;
-        const bf16x8_t qf[2] = {qn[0], qn[1]};
-        load_q(grp + 4, qn);                       // prefetch the next group's queries behind this group's math
-        float4_t o[4];
+    for (int grp0 = wave; grp0 < ngroups; grp0 += 4 * NG) {
+        bf16x8_t qf[NG][2];
+        float4_t o[NG][4];
+        float m[NG], l[NG];
+        int qrow[NG], diag[NG], nfr[NG];
+        uint32_t dbase[NG];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) o[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
-        float m = -INFINITY, l = 0.f;
-        const int diag = q0 >> 4;                                              // fragment holding the causal diagonal
-        const int nfr = p.causal ? min(kfr_all, diag + 1) : kfr_all;           // 16-key fragments this group attends to
-        const uint32_t dbase = (uint32_t)(((uint64_t)(b * p.H + h) * p.Lq + qrow) * lk_even >> 1);   // pair index of key 0
-        for (int kt = 0; kt * 4 < nfr; ++kt) {
-            const int nf = min(4, nfr - 4 * kt);
+        for (int i = 0; i < NG; ++i) {
+            const int q0 = qc0 + (grp0 + 4 * i) * 16;
+            qrow[i] = q0 + c;
+            qf[i][0] = qn[i][0]; qf[i][1] = qn[i][1];
+            load_q(grp0 + 4 * NG + 4 * i, qn[i]);      // prefetch the next iteration's queries behind this iteration's math
+#pragma unroll
+            for (int f = 0; f < 4; ++f) o[i][f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            m[i] = -INFINITY; l[i] = 0.f;
+            diag[i] = q0 >> 4;                                                          // fragment holding the causal diagonal
+            nfr[i] = grp0 + 4 * i >= ngroups ? 0 : (p.causal ? min(kfr_all, diag[i] + 1) : kfr_all);   // 16-key fragments the group attends to
+            dbase[i] = (uint32_t)(((uint64_t)(b * p.H + h) * p.Lq + qrow[i]) * lk_even >> 1);         // pair index of key 0
+        }
+        int nfr_max = nfr[0];
+#pragma unroll
+        for (int i = 1; i < NG; ++i) nfr_max = max(nfr_max, nfr[i]);
+        for (int kt = 0; kt * 4 < nfr_max; ++kt) {
             const char* skt = sk + kt * 8192;
             const char* svt = sv + kt * 8192;
-            // "clean" tile (the common case): 4 full fragments, no key mask, not touching the causal diagonal or the ragged
-            // tail.  Scores stay unscaled; exp(s*scale - m) is one fma + one v_exp_f32 (base 2) per element.
-            if (nf == 4 && ((unmasked >> (4 * kt)) & 0xfu) == 0xfu && !(p.causal && 4 * kt + 3 >= diag) && !(ragged && 4 * kt + 3 >= kfr_all - 1)) {
+            // "clean" tile (the common case): 4 full fragments, no key mask, not touching a causal diagonal or the ragged tail -- for
+            // EVERY group of the iteration.  Scores stay unscaled; exp(s*scale - m) is one fma + one v_exp_f32 (base 2) per element.
+            bool clean = ((unmasked >> (4 * kt)) & 0xfu) == 0xfu && !(ragged && 4 * kt + 3 >= kfr_all - 1);
+#pragma unroll
+            for (int i = 0; i < NG; ++i) clean = clean && nfr[i] - 4 * kt >= 4 && !(p.causal && 4 * kt + 3 >= diag[i]);
+            if (clean) {
+                float4_t s[NG][4];
+#pragma unroll
+                for (int i = 0; i < NG; ++i)
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        s[i][f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk)
+                            s[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_b128(skt + f * 2048 + L.row[kk]), qf[i][kk], s[i][f], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int i = 0; i < NG; ++i) {
+                    const float mt = col_max(fmaxf(fmaxf(max4(s[i][0]), max4(s[i][1])), fmaxf(max4(s[i][2]), max4(s[i][3])))) * p.scale;
+                    const float m_new = fmaxf(m[i], mt);
+                    const float alpha = __expf(m[i] - m_new);
+                    const float nm = -m_new * LOG2E_F;
+                    float ls = 0.f;
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(s[i][f][r], c2, nm)); s[i][f][r] = e; ls += e; }
+                    l[i] = l[i] * alpha + col_sum(ls);
+                    m[i] = m_new;
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[i][f][r] *= alpha;
+                    if (p.dropout_p > 0.f) {
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) {
+                            const uint32_t pr0 = dbase[i] + (uint32_t)(8 * (4 * kt + f) + 2 * g);
+                            const uint32_t h0 = drop_hash(dkey, pr0), h1 = drop_hash(dkey, pr0 + 1);
+                            s[i][f][0] = (h0 & 0xffffu) >= p.thresh ? s[i][f][0] * p.drop_scale : 0.f;
+                            s[i][f][1] = (h0 >> 16) >= p.thresh ? s[i][f][1] * p.drop_scale : 0.f;
+                            s[i][f][2] = (h1 & 0xffffu) >= p.thresh ? s[i][f][2] * p.drop_scale : 0.f;
+                            s[i][f][3] = (h1 >> 16) >= p.thresh ? s[i][f][3] * p.drop_scale : 0.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int df = 0; df < 4; ++df) {
+                        const bf16x8_t vt = tr_pair(svt, st, L.tr[df]);        // one transposed V fragment feeds every group
+#pragma unroll
+                        for (int i = 0; i < NG; ++i) {
+                            const bf16x8_t pb = st == 0 ? pack_b_operand(s[i][0], s[i][1]) : pack_b_operand(s[i][2], s[i][3]);
+                            o[i][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pb, o[i][df], 0, 0, 0);
+                        }
+                    }
+                continue;
+            }
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                if (4 * kt >= nfr[i]) continue;
+                const int nf = min(4, nfr[i] - 4 * kt);
                 float4_t s[4];
+                float mt = -INFINITY;
 #pragma unroll
                 for (int f = 0; f < 4; ++f) {
-                    s[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                    if (f < nf) {
+                        const int F = 4 * kt + f;
+                        s[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int kk = 0; kk < 2; ++kk)
-                        s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_b128(skt + f * 2048 + L.row[kk]), qf[kk], s[f], 0, 0, 0);
+                        for (int kk = 0; kk < 2; ++kk)
+                            s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_b128(skt + f * 2048 + L.row[kk]), qf[i][kk], s[f], 0, 0, 0);
+                        const bool plain = ((unmasked >> F) & 1u) && !(p.causal && F == diag[i]) && !(ragged && F == kfr_all - 1);
+                        mask_scores(s[f], plain, smask, 16 * F + 4 * g, qrow[i], p);
+                        mt = fmaxf(fmaxf(mt, fmaxf(s[f][0], s[f][1])), fmaxf(s[f][2], s[f][3]));
+                    } else {
+                        s[f] = (float4_t){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    }
                 }
-                const float mt = col_max(fmaxf(fmaxf(max4(s[0]), max4(s[1])), fmaxf(max4(s[2]), max4(s[3])))) * p.scale;
-                const float m_new = fmaxf(m, mt);
-                const float alpha = __expf(m - m_new);
-                const float nm = -m_new * LOG2E_F;
+                mt = col_max(mt);
+                const float m_new = fmaxf(m[i], mt);
+                const float alpha = __expf(m[i] - m_new);
                 float ls = 0.f;
 #pragma unroll
                 for (int f = 0; f < 4; ++f)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(s[f][r], c2, nm)); s[f][r] = e; ls += e; }
-                l = l * alpha + col_sum(ls);
-                m = m_new;
+                    for (int r = 0; r < 4; ++r) { const float e = __expf(s[f][r] - m_new); s[f][r] = e; ls += e; }
+                l[i] = l[i] * alpha + col_sum(ls);
+                m[i] = m_new;
 #pragma unroll
                 for (int f = 0; f < 4; ++f)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[f][r] *= alpha;
+                    for (int r = 0; r < 4; ++r) o[i][f][r] *= alpha;
                 if (p.dropout_p > 0.f) {
 #pragma unroll
                     for (int f = 0; f < 4; ++f) {
-                        const uint32_t pr0 = dbase + (uint32_t)(8 * (4 * kt + f) + 2 * g);
-                        const uint32_t h0 = drop_hash(dkey, pr0), h1 = drop_hash(dkey, pr0 + 1);
-                        s[f][0] = (h0 & 0xffffu) >= p.thresh ? s[f][0] * p.drop_scale : 0.f;
-                        s[f][1] = (h0 >> 16) >= p.thresh ? s[f][1] * p.drop_scale : 0.f;
-                        s[f][2] = (h1 & 0xffffu) >= p.thresh ? s[f][2] * p.drop_scale : 0.f;
-                        s[f][3] = (h1 >> 16) >= p.thresh ? s[f][3] * p.drop_scale : 0.f;
+                        if (f < nf) {
+                            const uint32_t pr0 = dbase[i] + (uint32_t)(8 * (4 * kt + f) + 2 * g);
+                            const uint32_t h0 = drop_hash(dkey, pr0), h1 = drop_hash(dkey, pr0 + 1);
+                            s[f][0] = (h0 & 0xffffu) >= p.thresh ? s[f][0] * p.drop_scale : 0.f;
+                            s[f][1] = (h0 >> 16) >= p.thresh ? s[f][1] * p.drop_scale : 0.f;
+                            s[f][2] = (h1 & 0xffffu) >= p.thresh ? s[f][2] * p.drop_scale : 0.f;
+                            s[f][3] = (h1 >> 16) >= p.thresh ? s[f][3] * p.drop_scale : 0.f;
+                        }
                     }
                 }
                 const bf16x8_t pb[2] = {pack_b_operand(s[0], s[1]), pack_b_operand(s[2], s[3])};
 #pragma unroll
-                for (int st = 0; st < 2; ++st)
+                for (int st = 0; st < 2; ++st) {
+                    if (2 * st < nf) {
+                        const bool hi_ok = 2 * st + 1 < nf;            // the odd fragment may lie past the allocation
 #pragma unroll
-                    for (int df = 0; df < 4; ++df)
-                        o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(svt, st, L.tr[df]), pb[st], o[df], 0, 0, 0);
-                continue;
-            }
-            float4_t s[4];
-            float mt = -INFINITY;
-#pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                if (f < nf) {
-                    const int F = 4 * kt + f;
-                    s[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk)
-                        s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_b128(skt + f * 2048 + L.row[kk]), qf[kk], s[f], 0, 0, 0);
-                    const bool plain = ((unmasked >> F) & 1u) && !(p.causal && F == diag) && !(ragged && F == kfr_all - 1);
-                    mask_scores(s[f], plain, smask, 16 * F + 4 * g, qrow, p);
-                    mt = fmaxf(fmaxf(mt, fmaxf(s[f][0], s[f][1])), fmaxf(s[f][2], s[f][3]));
-                } else {
-                    s[f] = (float4_t){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                }
-            }
-            mt = col_max(mt);
-            const float m_new = fmaxf(m, mt);
-            const float alpha = __expf(m - m_new);
-            float ls = 0.f;
-#pragma unroll
-            for (int f = 0; f < 4; ++f)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const float e = __expf(s[f][r] - m_new); s[f][r] = e; ls += e; }
-            l = l * alpha + col_sum(ls);
-            m = m_new;
-#pragma unroll
-            for (int f = 0; f < 4; ++f)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[f][r] *= alpha;
-            if (p.dropout_p > 0.f) {
-#pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    if (f < nf) {
-                        const uint32_t pr0 = dbase + (uint32_t)(8 * (4 * kt + f) + 2 * g);
-                        const uint32_t h0 = drop_hash(dkey, pr0), h1 = drop_hash(dkey, pr0 + 1);
-                        s[f][0] = (h0 & 0xffffu) >= p.thresh ? s[f][0] * p.drop_scale : 0.f;
-                        s[f][1] = (h0 >> 16) >= p.thresh ? s[f][1] * p.drop_scale : 0.f;
-                        s[f][2] = (h1 & 0xffffu) >= p.thresh ? s[f][2] * p.drop_scale : 0.f;
-                        s[f][3] = (h1 >> 16) >= p.thresh ? s[f][3] * p.drop_scale : 0.f;
-                    }
-                }
-            }
-            const bf16x8_t pb[2] = {pack_b_operand(s[0], s[1]), pack_b_operand(s[2], s[3])};
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                if (2 * st < nf) {
-                    const bool hi_ok = 2 * st + 1 < nf;            // the odd fragment may lie past the allocation
-#pragma unroll
-                    for (int df = 0; df < 4; ++df) {
-                        const v4s lo = lds_tr(svt + (2 * st) * 2048 + L.tr[df]);
-                        v4s hi = (v4s){0, 0, 0, 0};
-                        if (hi_ok) hi = lds_tr(svt + (2 * st + 1) * 2048 + L.tr[df]);
-                        o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_tr(lo, hi), pb[st], o[df], 0, 0, 0);
+                        for (int df = 0; df < 4; ++df) {
+                            const v4s lo = lds_tr(svt + (2 * st) * 2048 + L.tr[df]);
+                            v4s hi = (v4s){0, 0, 0, 0};
+                            if (hi_ok) hi = lds_tr(svt + (2 * st + 1) * 2048 + L.tr[df]);
+                            o[i][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_tr(lo, hi), pb[st], o[i][df], 0, 0, 0);
+                        }
                     }
                 }
             }
         }
-        if (qok) {
-            hstore_t_acc(p.out + (int64_t)(b * p.Lq + qrow) * p.ldo + h * 64, o, 1.0f / l, lane);
-            if (g == 0) {
-                float* st = p.stats + ((int64_t)(b * p.H + h) * p.Lq + qrow) * 2;
-                st[0] = m; st[1] = l;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            if (grp0 + 4 * i < ngroups && qrow[i] < p.Lq) {
+                hstore_t_acc(p.out + (int64_t)(b * p.Lq + qrow[i]) * p.ldo + h * 64, o[i], 1.0f / l[i], lane);
+                if (g == 0) {
+                    float* st = p.stats + ((int64_t)(b * p.H + h) * p.Lq + qrow[i]) * 2;
+                    st[0] = m[i]; st[1] = l[i];
+                }
             }
         }
     }
@@ -633,7 +671,11 @@ static void launch_head(K kernel, dim3 grid, size_t lds, hipStream_t s, const At
 int vm_attn_head_fwd(const AttnArgs& a0, hipStream_t s) {
     AttnArgs a = a0;
     a.ralloc_k = (a.Lk + 15) / 16 * 16;
-    launch_head(attn_head_fwd_kernel, dim3((a.Lq + HCHUNK - 1) / HCHUNK, a.H, a.B), (size_t)2 * a.ralloc_k * HB + 256, s, a);
+    const dim3 grid((a.Lq + HCHUNK - 1) / HCHUNK, a.H, a.B);
+    const size_t lds = (size_t)2 * a.ralloc_k * HB + 256;
+    // two owner groups in flight per wave where every group of a pair sees the same key tiles (non-causal) and a wave has >= 2 groups
+    if (!a.causal && a.Lq > 64 && vm_env().attn_ng != 1) launch_head(attn_head_fwd_kernel<2>, grid, lds, s, a);
+    else launch_head(attn_head_fwd_kernel<1>, grid, lds, s, a);
     return vm_check_launch("vm_attention_fwd(head)");
 }
 

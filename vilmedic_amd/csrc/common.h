@@ -121,6 +121,7 @@ struct VmEnv {
     int gemm_groupw;       // VM_GEMM_GROUPW: column-group width of the tile order (0: heuristic)
     bool gemm_generic;     // VM_GEMM_GENERIC: register-staged fallback kernel only
     bool gemm_no_skinny;   // VM_GEMM_NO_SKINNY: never take the M <= 128 decode-step kernel
+    int attn_ng;           // VM_ATTN_NG=1: one owner group per wave in the head-resident attention forward (A/B switch)
     bool attn_tile;        // VM_ATTN_TILE: tile-streaming attention kernels instead of the head-resident ones
     bool attn_stream;      // VM_ATTN_STREAM: streaming (non-resident) tile kernels
 };

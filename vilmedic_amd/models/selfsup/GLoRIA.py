@@ -17,6 +17,7 @@ from ...arena import arena_of
 from ...blocks.huggingface.encoder.encoder_model import EncoderModel
 from ...blocks.losses import GLoRIALoss, cosine_similarity, gloria_attention_fn  # noqa: F401
 from ...blocks.vision import *  # noqa: F401,F403
+from ...blocks.vision.micro_bn import micro_batches, use_micro_batch_norm
 from ...nn import Affine
 from ..utils import get_n_params
 
@@ -92,6 +93,7 @@ class GLoRIA(nn.Module):
         def hook(module, inp, out):
             self.activation["local_features"] = out
         self.visual.model[6].register_forward_hook(hook)          # output of layer3 (GLoRIA.py:77)
+        use_micro_batch_norm(self.visual)
         self.eval_func = evaluation
         self.fbs = forward_batch_size
 
@@ -113,18 +115,15 @@ class GLoRIA(nn.Module):
         arena = arena_of(self)
         arena.refresh()
         bs = images.shape[0]
-        global_features, local_features, hidden_states = [], [], []
-        # the towers are chunked exactly like the reference (GLoRIA.py:92-105): BatchNorm statistics are per chunk
-        for i in chunks(range(bs), min(self.fbs, bs)):
-            i = list(i)
-            images_ = images[i].cuda()
-            global_features.append(self._embed_global(self.visual(self.up_sample(images_)), arena))
-            local_features.append(self._embed_local(self.activation["local_features"], arena))
-            out = self.linguistic(input_ids[i].cuda(), attention_mask[i].cuda(), output_hidden_states=True)
-            hidden_states.append(torch.stack([h.float() for h in out["hidden_states"]]))
-        global_features = torch.cat(global_features)
-        local_features = torch.cat(local_features)
-        hidden_states = torch.cat(hidden_states, dim=1)
+        # The reference chunks both towers by forward_batch_size (GLoRIA.py:92-105); only the CNN's BatchNorm statistics depend on
+        # that.  Here every tower runs ONCE over the batch and the BatchNorm layers group their statistics per micro-batch
+        # (blocks/vision/micro_bn.py) -- the same values from batch / fbs times fewer launches.
+        images_ = images.cuda()
+        with micro_batches(self.fbs if (self.training and self.fbs < bs) else 0):
+            global_features = self._embed_global(self.visual(self.up_sample(images_)), arena)
+        local_features = self._embed_local(self.activation["local_features"], arena)
+        out = self.linguistic(input_ids.cuda(), attention_mask.cuda(), output_hidden_states=True)
+        hidden_states = torch.stack([h.float() for h in out["hidden_states"]])
         embeddings, sents = self.aggregate_tokens(hidden_states[-self.last_n_layers:], input_ids)
         sent_embeddings = torch.sum(torch.mean(embeddings, dim=2), dim=1)
         word_embeddings = torch.sum(embeddings, dim=1).permute(0, 2, 1)

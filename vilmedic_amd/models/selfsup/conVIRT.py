@@ -8,6 +8,7 @@ from ...arena import arena_of
 from ...blocks.huggingface.encoder.encoder_model import EncoderModel
 from ...blocks.losses import ConVIRTLoss, InfoNCELoss  # noqa: F401  (eval(proto) namespace)
 from ...blocks.vision import *  # noqa: F401,F403
+from ...blocks.vision.micro_bn import micro_batches, use_micro_batch_norm
 from ..utils import get_n_params
 
 
@@ -57,6 +58,7 @@ class ConVIRT(nn.Module):
         self.loss_fn = eval(loss.pop("proto"))(**loss)
         self.fbs = forward_batch_size          # micro-batch of the reference's tower loop; only BatchNorm statistics depend on it
         self._visual_has_bn = any(isinstance(m, nn.modules.batchnorm._BatchNorm) for m in self.visual.modules())
+        use_micro_batch_norm(self.visual)       # BatchNorm layers that can take their statistics per micro-batch at full batch
         self.eval_func = evaluation
 
     def forward(self, input_ids, attention_mask, images, **kwargs):
@@ -65,14 +67,12 @@ class ConVIRT(nn.Module):
         arena.refresh()
         # The reference runs both towers in forward_batch_size micro-batches inside ONE autograd graph (conVIRT.py:83-95).  For the
         # text tower (LayerNorm only) that equals a single pass over the batch, which is what runs here.  A CNN image tower in
-        # training mode normalises with the statistics of each MICRO-batch, so it keeps the reference's chunks; in eval mode
-        # (running statistics) and for BatchNorm-free towers the whole batch goes through at once.
+        # training mode normalises with the statistics of each MICRO-batch: it also runs ONCE over the batch, with its BatchNorm
+        # layers grouping the statistics per micro-batch (blocks/vision/micro_bn.py: same values, 1 pass instead of batch / fbs).
         text = self.linguistic(input_ids=input_ids, attention_mask=attention_mask)
         linguistics = self.lin_proj(text["pooler_output"], arena)
         bs = images.shape[0]
-        if self.training and self._visual_has_bn and self.fbs < bs:
-            vis = torch.cat([self.visual(images[i:i + self.fbs]) for i in range(0, bs, self.fbs)])
-        else:
+        with micro_batches(self.fbs if (self.training and self._visual_has_bn and self.fbs < bs) else 0):
             vis = self.visual(images)
         visuals = self.vis_proj(vis if vis.dim() == 2 else vis[:, 0], arena)
         loss, loss_l, loss_v = self.loss_fn(linguistics, visuals)
