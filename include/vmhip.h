@@ -110,6 +110,15 @@ int vm_layernorm_bwd_fused(const void* dy, const void* dy2, const void* dres, co
 int vm_layernorm_bwd_partial(const void* dy, const void* dy2, const void* dres, const void* x, const float* gamma,
                              const float* mean, const float* rstd, void* dx, int rows, int cols, void* ws, void* stream);
 int vm_layernorm_bwd_reduce(const void* ws, float* dgamma, float* dbeta, int rows, int cols, void* stream);
+/* the reduce of up to any number of LayerNorm backward launches in ONE launch (their partials wait in their workspaces): the
+   training step queues its 62 LayerNorms and reduces them together when the backward pass ends -- one problem alone is latency-bound */
+typedef struct {
+    const void* ws;                     /* workspace a vm_layernorm_bwd_partial(rows, cols) launch filled */
+    float* dgamma;                      /* fp32 [cols], accumulated; no two problems of one call may share it */
+    float* dbeta;
+    int rows, cols;
+} vm_ln_reduce_problem;
+int vm_layernorm_bwd_reduce_batched(const vm_ln_reduce_problem* problems, int n, void* stream);
 
 /* ------------------------------------------------------------------ attention (self / causal / cross)
  * softmax(Q K^T * scale + mask) V with optional dropout on the probabilities.

@@ -28,6 +28,10 @@ class WgradProblem(C.Structure):
                 ("db", C.c_void_p), ("rows", C.c_int), ("n_out", C.c_int), ("k_in", C.c_int), ("alpha_dev", C.c_void_p)]
 
 
+class LnReduceProblem(C.Structure):
+    _fields_ = [("ws", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int)]
+
+
 _lib = None
 
 _P, _I, _L, _F, _U64, _SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
@@ -50,6 +54,7 @@ SIGNATURES = {
     "vm_layernorm_bwd_fused": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "vm_layernorm_bwd_partial": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "vm_layernorm_bwd_reduce": (_I, [_P, _P, _P, _I, _I, _P]),
+    "vm_layernorm_bwd_reduce_batched": (_I, [_P, _I, _P]),
     "vm_image_pipeline_ws": (_SZ, [_I, _I, _I]),
     "vm_image_pipeline_u8": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _SZ, _P]),
     "vm_attention_fwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _U64, _P, _P, _L, _P]),

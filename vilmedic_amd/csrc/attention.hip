@@ -235,8 +235,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs p, int D
                  + __uint_as_float(a.y << 16) * __uint_as_float(d.y << 16) + __uint_as_float(a.y & 0xffff0000u) * __uint_as_float(d.y & 0xffff0000u);
         }
     }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    acc += dpp_f32<0xB1>(acc);  acc += dpp_f32<0x4E>(acc);      // sum over the row of 16 lanes: DPP steps of wave_sum (common.h)
+    acc += dpp_f32<0x141>(acc); acc += dpp_f32<0x140>(acc);
     if (gid < total && sub == 0) p.delta[gid] = acc;
 }
 

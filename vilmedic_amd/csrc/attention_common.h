@@ -35,8 +35,22 @@ __device__ __forceinline__ bf16x8_t pack_b_operand(const float4_t& a, const floa
     u.z = pack_bf16x2(b[0], b[1]); u.w = pack_bf16x2(b[2], b[3]);
     return __builtin_bit_cast(bf16x8_t, u);
 }
-__device__ __forceinline__ float col_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
-__device__ __forceinline__ float col_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+// reductions over the 4 lanes (c, g = 0..3) that share an MFMA output column: lane ^ 16 and lane ^ 32.  v_permlane16_swap /
+// v_permlane32_swap of a register WITH ITSELF leave {the even rows | lower half} replicated in one result and {the odd rows | upper
+// half} in the other, so one swap + one VALU op is an xor-16 (xor-32) butterfly step -- no ds_bpermute round trip through the LDS
+// pipeline on the serial  S -> max -> exp -> P V  chain of the attention kernels.
+__device__ __forceinline__ float col_max(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float col_sum(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 
 // predicated 16-B load: out-of-range lanes re-read a valid address (``safe``) and zero the result, so the
 // compiler keeps a plain global_load (a select between the pointer and a stack zero becomes a flat load)

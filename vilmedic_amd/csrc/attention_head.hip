@@ -105,12 +105,12 @@ __device__ __forceinline__ void mask_scores(float4_t& s, bool plain, const uint8
 
 // =============================================================================== forward
 // K/V rows are allocated up to Lk rounded to 16 (zero-filled past Lk), so every fragment a group attends to is in range.
-// NG = owner groups a wave works on AT ONCE.  The kernel is latency-, not throughput-bound (rocprofv3 PMC, profiles/r02_f_attention_pmc.txt:
-// waves wait 48 % of their cycles, the SIMD's VALU is busy 23 % per wave, 23 VALU instructions per MFMA): with one group per wave the
-// chain  S = K Q^T (MFMA) -> max / exp / sum (VALU, cross-lane) -> P V (MFMA)  is strictly serial and only the 3 waves of a SIMD
-// overlap.  With NG = 2 the clean-tile path issues the MFMAs and the softmax of two INDEPENDENT 16-query groups in one basic block,
-// so one group's VALU work covers the other's MFMA latency.  (Used for the non-causal calls -- ViT self-attention and cross-
-// attention, where both groups of a pair see the same key tiles; causal groups have different diagonals and keep NG = 1.)
+// NG = owner groups (16 queries each) a wave works on at once; the code below is written over NG and instantiated with NG = 1.
+// The kernel is latency-, not throughput-bound (rocprofv3 PMC, profiles/r02_f_attention_pmc.txt: waves wait 48 % of their cycles,
+// VALU busy 23 % per wave, 23 VALU instructions per MFMA): the chain  S = K Q^T (MFMA) -> max / exp / sum (VALU, cross-lane) -> P V
+// (MFMA)  is serial per group.  NG = 2 (two independent groups interleaved in one basic block, 166 VGPRs, no spills) was measured on
+// the three production shapes and gave nothing (ViT 48.9 vs 46.4 us, cross 28.8 vs 28.5 us, same file): the 3 resident waves per
+// SIMD already overlap as much as the LDS-read / cross-lane latency allows, so the instantiation and its switch were removed.
 template <int NG>
 __global__ __launch_bounds__(256, 3) void attn_head_fwd_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -674,8 +674,7 @@ int vm_attn_head_fwd(const AttnArgs& a0, hipStream_t s) {
     const dim3 grid((a.Lq + HCHUNK - 1) / HCHUNK, a.H, a.B);
     const size_t lds = (size_t)2 * a.ralloc_k * HB + 256;
     // two owner groups in flight per wave where every group of a pair sees the same key tiles (non-causal) and a wave has >= 2 groups
-    if (!a.causal && a.Lq > 64 && vm_env().attn_ng != 1) launch_head(attn_head_fwd_kernel<2>, grid, lds, s, a);
-    else launch_head(attn_head_fwd_kernel<1>, grid, lds, s, a);
+    launch_head(attn_head_fwd_kernel<1>, grid, lds, s, a);
     return vm_check_launch("vm_attention_fwd(head)");
 }
 

@@ -35,16 +35,25 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
     return v;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// wave64 all-lanes reductions without the LDS pipeline (``__shfl_xor`` compiles to ds_bpermute_b32: six dependent LDS round trips per
+// reduction): four DPP steps inside each row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror -- after the quad steps
+// a mirror read fetches the other quad's / half-row's total), then v_permlane16_swap / v_permlane32_swap of the register with itself
+// across the rows (see col_max in attention_common.h).  Eight VALU instructions, every lane ends with the total.
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
+#define VM_WAVE_REDUCE(OP)                                                                                         \
+    v = OP(v, dpp_f32<0xB1>(v));  /* quad_perm [1,0,3,2] */                                                        \
+    v = OP(v, dpp_f32<0x4E>(v));  /* quad_perm [2,3,0,1] */                                                        \
+    v = OP(v, dpp_f32<0x141>(v)); /* row_half_mirror */                                                            \
+    v = OP(v, dpp_f32<0x140>(v)); /* row_mirror */                                                                 \
+    { auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);             \
+      v = OP(__uint_as_float(a[0]), __uint_as_float(a[1])); }                                                      \
+    { auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);             \
+      v = OP(__uint_as_float(b[0]), __uint_as_float(b[1])); }
+__device__ __forceinline__ float vm_addf(float a, float b) { return a + b; }
+__device__ __forceinline__ float wave_sum(float v) { VM_WAVE_REDUCE(vm_addf) return v; }
+__device__ __forceinline__ float wave_max(float v) { VM_WAVE_REDUCE(fmaxf) return v; }
 
 // erf-GELU and its derivative (hf:activations.py "gelu" -> nn.functional.gelu, the exact erf form).
 // erf is evaluated with Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of every consumer):
@@ -121,7 +130,6 @@ struct VmEnv {
     int gemm_groupw;       // VM_GEMM_GROUPW: column-group width of the tile order (0: heuristic)
     bool gemm_generic;     // VM_GEMM_GENERIC: register-staged fallback kernel only
     bool gemm_no_skinny;   // VM_GEMM_NO_SKINNY: never take the M <= 128 decode-step kernel
-    int attn_ng;           // VM_ATTN_NG=1: one owner group per wave in the head-resident attention forward (A/B switch)
     bool attn_tile;        // VM_ATTN_TILE: tile-streaming attention kernels instead of the head-resident ones
     bool attn_stream;      // VM_ATTN_STREAM: streaming (non-resident) tile kernels
 };

@@ -187,23 +187,49 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __res
         }
     }
 }
+// backward of word + position embedding.  One block per (position t, column half): it walks the B rows of that position,
+//   d_pos[t]      += sum_b d_out[b, t]       in registers -- every (t, column) has exactly one owner thread: no atomics, deterministic
+//                                            (the previous kernel issued B-way contended atomics per element: 64 adds on each address);
+//   d_word[id[b,t]] += d_out[b, t]           hardware fp32 atomics, one wave instruction = 64 lanes x 2 consecutive columns (512 B
+//                                            contiguous), contended only where a token id repeats.
+// The token id is block-uniform (scalar load).  Rows are read once, 4 in flight per thread.
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ d_out,
                                                             float* __restrict__ d_word, float* __restrict__ d_pos,
-                                                            int rows, int L, int D, int padding_idx) {
-    const int lane = threadIdx.x & 63;
-    const int nch = D >> 3;
-    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
-        const int64_t id = ids[row];
-        const int t = row % L;
-        for (int ch = lane; ch < nch; ch += 64) {
-            float f[8];
-            unpack8(*reinterpret_cast<const uint4*>(d_out + (int64_t)row * D + ch * 8), f);
+                                                            int B, int L, int D, int padding_idx) {
+    const int t = blockIdx.x;
+    const int half = D >> 1;                                   // column PAIRS per row
+    const int per = (half + gridDim.y - 1) / gridDim.y;
+    const int p_lo = blockIdx.y * per, p_hi = min(half, p_lo + per);
+    for (int cp = p_lo + threadIdx.x; cp < p_hi; cp += 256) {
+        float a0 = 0.f, a1 = 0.f;
+        int b = 0;
+        for (; b + 4 <= B; b += 4) {
+            uint32_t v[4]; int64_t id[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (id != padding_idx) atomicAdd(d_word + id * D + ch * 8 + j, f[j]);
-                atomicAdd(d_pos + (int64_t)t * D + ch * 8 + j, f[j]);
+            for (int u = 0; u < 4; ++u) {
+                const int64_t row = (int64_t)(b + u) * L + t;
+                id[u] = ids[row];
+                v[u] = *reinterpret_cast<const uint32_t*>(d_out + row * D + 2 * cp);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float lo = __uint_as_float(v[u] << 16), hi = __uint_as_float(v[u] & 0xffff0000u);
+                a0 += lo; a1 += hi;
+                if (id[u] != padding_idx) { atomicAdd(d_word + id[u] * D + 2 * cp, lo); atomicAdd(d_word + id[u] * D + 2 * cp + 1, hi); }
             }
         }
+        for (; b < B; ++b) {
+            const int64_t row = (int64_t)b * L + t;
+            const int64_t id = ids[row];
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(d_out + row * D + 2 * cp);
+            const float lo = __uint_as_float(v << 16), hi = __uint_as_float(v & 0xffff0000u);
+            a0 += lo; a1 += hi;
+            if (id != padding_idx) { atomicAdd(d_word + id * D + 2 * cp, lo); atomicAdd(d_word + id * D + 2 * cp + 1, hi); }
+        }
+        float2* dp = reinterpret_cast<float2*>(d_pos + (int64_t)t * D + 2 * cp);
+        float2 cur = *dp;
+        cur.x += a0; cur.y += a1;
+        *dp = cur;
     }
 }
 extern "C" int vm_embedding_fwd(const int64_t* ids, const float* word, const float* pos, void* out, int B, int L, int D, int past_len, void* stream) {
@@ -217,7 +243,8 @@ extern "C" int vm_embedding_bwd(const int64_t* ids, const void* d_out, float* d_
     VM_REQUIRE(ids && d_out && d_word && d_pos && B > 0 && L > 0 && D > 0 && (D % 8) == 0, "vm_embedding_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_ELT, 10.0 * B * L * (double)D, s);
-    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid_for(B * L, 4)), dim3(256), 0, s, ids, (const bf16_t*)d_out, d_word, d_pos, B * L, L, D, padding_idx);
+    const int ysplit = (D / 2 + 255) / 256 > 1 ? 2 : 1;       // D = 768: 2 blocks x 192 column pairs per position
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(L, ysplit), dim3(256), 0, s, ids, (const bf16_t*)d_out, d_word, d_pos, B, L, D, padding_idx);
     return vm_check_launch("vm_embedding_bwd");
 }
 

@@ -170,33 +170,43 @@ __global__ __launch_bounds__(256, NCH <= 2 ? 3 : 1) void ln_bwd_kernel(const bf1
         wg[i] = red[i] + red[2 * cols + i] + red[4 * cols + i] + red[6 * cols + i];
 }
 
-// grid (ceil(cols/32), 2): blockIdx.y selects dgamma / dbeta; 32 columns x 8 slab-groups per block, 8 loads in flight
-__global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ ws, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int nslabs, int cols) {
-    __shared__ float part[8][33];
+// dgamma / dbeta += sum over the slabs a backward launch left in its workspace, for a BATCH of LayerNorms in one launch
+// (vm_layernorm_bwd_reduce_batched): grid (ceil(max cols / 32), 2, n problems); blockIdx.y selects dgamma / dbeta; 32 columns x 32
+// slab groups per block (1024 threads), up to 8 independent loads in flight per thread.  One problem alone is latency-bound (48 blocks,
+// each thread walking its slabs in dependent round trips: 13.8 us per LayerNorm in profiles/r01_e_kernel_stats_overlapped.csv,
+// 62 launches per step); the 62 problems of a training step together put ~3000 blocks in flight and run at HBM speed.
+#define LN_RED_MAX 64
+struct LnRedProblem { const float* ws; float* dgamma; float* dbeta; int nslabs; int cols; };
+struct LnRedBatch { int n; LnRedProblem p[LN_RED_MAX]; };
+
+__global__ __launch_bounds__(1024) void ln_bwd_reduce(const LnRedBatch batch) {
+    __shared__ float part[32][33];
+    const LnRedProblem& q = batch.p[blockIdx.z];
+    const int cols = q.cols, nslabs = q.nslabs;
+    if ((int)blockIdx.x * 32 >= cols) return;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + tx;
     float a = 0.f;
     if (c < cols) {
-        const float* base = ws + blockIdx.y * cols + c;
+        const float* base = q.ws + blockIdx.y * cols + c;
         const int64_t stride = 2 * (int64_t)cols;
         int w = ty;
-        for (; w + 56 < nslabs; w += 64) {
+        for (; w + 224 < nslabs; w += 256) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = base[(int64_t)(w + 8 * u) * stride];
+            for (int u = 0; u < 8; ++u) v[u] = base[(int64_t)(w + 32 * u) * stride];
 #pragma unroll
             for (int u = 0; u < 8; ++u) a += v[u];
         }
-        for (; w < nslabs; w += 8) a += base[(int64_t)w * stride];
+        for (; w < nslabs; w += 32) a += base[(int64_t)w * stride];
     }
     part[ty][tx] = a;
     __syncthreads();
     if (ty == 0 && c < cols) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += part[k][tx];
-        if (blockIdx.y == 0) dgamma[c] += t; else dbeta[c] += t;
+        for (int k = 0; k < 32; ++k) t += part[k][tx];
+        if (blockIdx.y == 0) q.dgamma[c] += t; else q.dbeta[c] += t;
     }
 }
 
@@ -209,7 +219,8 @@ static int ln_grid(int rows, int cap) {
     return blocks;
 }
 #define LN_FWD_CAP 16384
-#define LN_BWD_CAP 1024
+static int ln_bwd_cap() { static const int v = getenv("VM_LN_BWD_CAP") ? atoi(getenv("VM_LN_BWD_CAP")) : 1024; return v; }   // TUNING KNOB (temporary)
+#define LN_BWD_CAP ln_bwd_cap()
 
 extern "C" int vm_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                 int rows, int cols, float eps, void* stream) {
@@ -244,12 +255,28 @@ extern "C" int vm_layernorm_bwd_fused(const void* dy, const void* dy2, const voi
     return vm_layernorm_bwd_reduce(ws, dgamma, dbeta, rows, cols, stream);
 }
 
-extern "C" int vm_layernorm_bwd_reduce(const void* ws, float* dgamma, float* dbeta, int rows, int cols, void* stream) {
-    VM_REQUIRE(ws && dgamma && dbeta && rows > 0 && cols > 0, "vm_layernorm_bwd_reduce: bad arguments");
+extern "C" int vm_layernorm_bwd_reduce_batched(const vm_ln_reduce_problem* problems, int n, void* stream) {
+    VM_REQUIRE(problems && n > 0, "vm_layernorm_bwd_reduce_batched: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_LN, 0.0, s);
-    hipLaunchKernelGGL(ln_bwd_reduce, dim3((cols + 31) / 32, 2), dim3(256), 0, s, (const float*)ws, dgamma, dbeta, ln_grid(rows, LN_BWD_CAP), cols);
-    return vm_check_launch("vm_layernorm_bwd_reduce");
+    for (int i0 = 0; i0 < n; i0 += LN_RED_MAX) {
+        LnRedBatch b;
+        b.n = n - i0 < LN_RED_MAX ? n - i0 : LN_RED_MAX;
+        int max_cols = 0;
+        for (int i = 0; i < b.n; ++i) {
+            const vm_ln_reduce_problem& q = problems[i0 + i];
+            VM_REQUIRE(q.ws && q.dgamma && q.dbeta && q.rows > 0 && q.cols > 0, "vm_layernorm_bwd_reduce_batched: bad problem %d", i0 + i);
+            b.p[i] = LnRedProblem{(const float*)q.ws, q.dgamma, q.dbeta, ln_grid(q.rows, LN_BWD_CAP), q.cols};
+            if (q.cols > max_cols) max_cols = q.cols;
+        }
+        hipLaunchKernelGGL(ln_bwd_reduce, dim3((max_cols + 31) / 32, 2, b.n), dim3(1024), 0, s, b);
+    }
+    return vm_check_launch("vm_layernorm_bwd_reduce_batched");
+}
+
+extern "C" int vm_layernorm_bwd_reduce(const void* ws, float* dgamma, float* dbeta, int rows, int cols, void* stream) {
+    const vm_ln_reduce_problem q{ws, dgamma, dbeta, rows, cols};
+    return vm_layernorm_bwd_reduce_batched(&q, 1, stream);
 }
 
 extern "C" int vm_layernorm_bwd_partial(const void* dy, const void* dy2, const void* dres, const void* x, const float* gamma,

@@ -40,7 +40,6 @@ static void load_env() {
     g_env.gemm_groupw = (v = getenv("VM_GEMM_GROUPW")) ? atoi(v) : 0;
     g_env.gemm_generic = getenv("VM_GEMM_GENERIC") != nullptr;
     g_env.gemm_no_skinny = getenv("VM_GEMM_NO_SKINNY") != nullptr;
-    g_env.attn_ng = (v = getenv("VM_ATTN_NG")) ? atoi(v) : 2;
     g_env.attn_tile = getenv("VM_ATTN_TILE") != nullptr;
     g_env.attn_stream = getenv("VM_ATTN_STREAM") != nullptr;
     g_env_loaded = true;

@@ -242,8 +242,25 @@ def param_grads(dY, X, dW, db=None, *, ld_dy=None, ld_x=None, alpha_dev=None, co
             colsum(dY, db, rows=dY.shape[0], cols=N, scale_dev=alpha_dev)
 
 
+_lnq = {"items": [], "ptrs": set()}
+
+
+def flush_ln_reduce():
+    """dgamma / dbeta of every LayerNorm backward queued so far: one batched reduce launch on the side stream"""
+    items = _lnq["items"]
+    if not items:
+        return
+    _lnq["items"], _lnq["ptrs"] = [], set()
+    arr = (_lib.LnReduceProblem * len(items))()
+    for q, (ws, gg, gb, rows, cols) in zip(arr, items):
+        q.ws, q.dgamma, q.dbeta, q.rows, q.cols = ws.data_ptr(), gg.data_ptr(), gb.data_ptr(), rows, cols
+    with on_side(*(it[0] for it in items)):
+        check(lib().vm_layernorm_bwd_reduce_batched(arr, len(items), stream()), "vm_layernorm_bwd_reduce_batched")
+
+
 def flush_param_grads():
-    """launch everything queued by param_grads() as one grouped weight-gradient GEMM (side stream)"""
+    """launch everything queued by param_grads() as one grouped weight-gradient GEMM, and the queued LayerNorm reduces (side stream)"""
+    flush_ln_reduce()
     items = _pg["items"]
     if not items:
         return
@@ -452,8 +469,13 @@ class LayerNormFn(torch.autograd.Function):
                                              ptr(_2d(dres.contiguous())) if dres is not None else None,
                                              ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), rows, cols, ptr(ws), stream()),
               "vm_layernorm_bwd")
-        with on_side(ws):          # the dgamma / dbeta reduction only feeds the optimizer: off the dgrad chain
-            check(lib().vm_layernorm_bwd_reduce(ptr(ws), ptr(g_gamma), ptr(g_beta), rows, cols, stream()), "vm_layernorm_bwd_reduce")
+        # the dgamma / dbeta reduction only feeds the optimizer: queued, and reduced together with the step's other LayerNorms in one
+        # launch when the parameter-gradient queue is flushed (flush_param_grads)
+        if g_gamma.data_ptr() in _lnq["ptrs"] or len(_lnq["items"]) >= 64:
+            flush_ln_reduce()
+        _lnq["items"].append((ws, g_gamma, g_beta, rows, cols))
+        _lnq["ptrs"].add(g_gamma.data_ptr())
+        _ensure_end_of_backward_flush()
         return dx.view(xshape), None, None, None, None, None, None
 
 
