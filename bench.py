@@ -267,20 +267,15 @@ def main():
     B, L, V = args.batch, args.seq, DEC_12L["vocab_size"]
     images, ids, am = synthetic_batch(B, L, V, device, seed=rank)
 
-    from vilmedic_amd.parallel import SplitStep
-    split = SplitStep(model) if (ddp is None and os.environ.get("VM_SPLIT_STEP", "1") != "0") else None
-
     def eager_step(input_ids=ids, attention_mask=am, images=images):
         out = model(input_ids=input_ids, attention_mask=attention_mask, images=images, return_logits=False)
         opt.zero_grad()
         opt.gate = out["loss"].detach()      # NaN / Inf loss -> the update is skipped on the device (no host read of the loss)
-        if ddp is not None:                  # two-phase backward: the decoder's all-reduce and Adam overlap the ViT backward
-            ddp.backward(out["loss"], opt=opt)
-        elif split is not None:              # the same without collectives: the decoder's Adam overlaps the ViT backward
-            split.backward_and_step(out["loss"], opt)
+        if ddp is not None:
+            ddp.backward(out["loss"])        # two-phase backward: decoder all-reduce overlaps the ViT backward
         else:
             out["loss"].backward()
-            opt.step()
+        opt.step()
         return out["loss"]
 
     step = eager_step

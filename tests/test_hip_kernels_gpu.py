@@ -216,6 +216,48 @@ def test_embedding_and_ce():
     assert torch.count_nonzero(dl[:, V:]) == 0
 
 
+@pytest.mark.parametrize("V,Vp,banned,thr", [(30522, 30528, 0, False),      # the production row: fast path + the chunk that touches V
+                                              (30522, 30528, 2, True),       # banned columns + top-k threshold: general path
+                                              (40003, 40008, 0, False),      # > 32768 columns: the streaming variant
+                                              (40003, 40008, 1, True)])
+def test_ce_shift_wide_rows_and_filtered_rows_vs_torch(V, Vp, banned, thr):
+    """vm_ce_shift_fwd_bwd against torch cross_entropy on the same bf16 logits: register-resident rows (<= 32768 columns) and the
+    streaming variant for wider vocabularies, each with and without the SCST filters (banned columns and a per-row top-k threshold,
+    below which logits are removed from the distribution); loss sum, per-row log-probability and gradient (bf16 output: rtol 1e-2)."""
+    from vilmedic_amd._lib import lib, ptr, stream, check
+    import ctypes
+    B, L = 2, 6
+    g = torch.Generator().manual_seed(V + banned)
+    ids = torch.randint(5, V, (B, L), generator=g).to(dev())
+    logits = torch.zeros(B * L, Vp, dtype=BF, device=dev())
+    logits[:, :V] = (torch.randn(B * L, V, generator=g) * 2.0).to(BF).to(dev())
+    ban = [0, 3][:banned]
+    thr_t = None
+    lf = logits[:, :V].float()
+    if banned:
+        lf[:, ban] = float("-inf")
+    if thr:
+        thr_t = torch.topk(lf, 50, dim=-1).values[:, -1].contiguous()
+        lf = torch.where(lf < thr_t[:, None], torch.full_like(lf, float("-inf")), lf)
+        # the label must survive the filter (SCST only scores tokens it sampled from the filtered distribution)
+        best = lf.argmax(-1).view(B, L)
+        ids[:, 1:] = best[:, :-1]
+    lf = lf.view(B, L, V).requires_grad_(True)
+    loss_sum, row_logp, dl = torch.zeros(1, device=dev()), torch.empty(B * L, device=dev()), torch.empty_like(logits)
+    barr = (ctypes.c_int32 * max(1, banned))(*ban) if banned else None
+    check(lib().vm_ce_shift_fwd_bwd(ptr(logits), Vp, ptr(ids), B, L, V, ptr(loss_sum), ptr(row_logp), ptr(dl), 1.0 / (B * (L - 1)), None,
+                                    barr, banned, ptr(thr_t) if thr_t is not None else None, stream()))
+    logp = torch.log_softmax(lf[:, :-1], -1).gather(-1, ids[:, 1:, None])[..., 0]
+    ref = -logp.mean()
+    ref.backward()
+    torch.testing.assert_close(loss_sum[0] / (B * (L - 1)), ref.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(row_logp.view(B, L)[:, :-1], logp.detach(), rtol=1e-5, atol=1e-5)
+    assert torch.count_nonzero(row_logp.view(B, L)[:, -1]) == 0
+    gref = torch.nan_to_num(lf.grad, nan=0.0)
+    torch.testing.assert_close(dl[:, :V].float().view(B, L, V), gref, rtol=1e-2, atol=1e-6)
+    assert torch.count_nonzero(dl[:, V:]) == 0
+
+
 def test_adam_matches_torch():
     from vilmedic_amd._lib import lib, ptr, stream, check
     n = 10007

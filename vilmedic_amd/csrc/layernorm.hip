@@ -160,8 +160,12 @@ __global__ __launch_bounds__(256, NCH <= 2 ? 3 : 1) void ln_bwd_kernel(const bf1
     for (int c = 0; c < NCH; ++c) {
         const int ch = lane + 64 * c;
         if (ch < nchunks) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { mine[ch * 8 + j] = dg[c][j]; mine[cols + ch * 8 + j] = db[c][j]; }
+            // 16-B LDS stores: scalar stores at this 32-B lane stride were 16-way bank conflicts (1.4 M conflict cycles per launch,
+            // rocprofv3 PMC profiles/r02_g_layernorm_pmc.txt)
+            *reinterpret_cast<float4*>(mine + ch * 8) = make_float4(dg[c][0], dg[c][1], dg[c][2], dg[c][3]);
+            *reinterpret_cast<float4*>(mine + ch * 8 + 4) = make_float4(dg[c][4], dg[c][5], dg[c][6], dg[c][7]);
+            *reinterpret_cast<float4*>(mine + cols + ch * 8) = make_float4(db[c][0], db[c][1], db[c][2], db[c][3]);
+            *reinterpret_cast<float4*>(mine + cols + ch * 8 + 4) = make_float4(db[c][4], db[c][5], db[c][6], db[c][7]);
         }
     }
     __syncthreads();
@@ -219,8 +223,9 @@ static int ln_grid(int rows, int cap) {
     return blocks;
 }
 #define LN_FWD_CAP 16384
-static int ln_bwd_cap() { static const int v = getenv("VM_LN_BWD_CAP") ? atoi(getenv("VM_LN_BWD_CAP")) : 1024; return v; }   // TUNING KNOB (temporary)
-#define LN_BWD_CAP ln_bwd_cap()
+// backward grid: 512 workgroups (2 per CU) -- tools/ln_bench.py sweep (profiles/r02_h_layernorm_sweep.txt): 19.4 / 15.1 us for the
+// ViT / decoder shapes against 22.2 / 16.5 us at 1024 (whose second round of workgroups is a third full), and half the slabs to reduce
+#define LN_BWD_CAP 512
 
 extern "C" int vm_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                 int rows, int cols, float eps, void* stream) {

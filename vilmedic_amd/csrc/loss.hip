@@ -22,10 +22,66 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* sh) {
 }
 
 // ------------------------------------------------------------------ shifted causal-LM CE on bf16 logits
-// row = (b,t); label = ids[b,t+1]; rows t == L-1 carry no loss.  The row is kept in registers (<= NCH 16-B
-// chunks per thread) so logits are read from HBM once; dlogits may alias logits.
-#define CE_NCH 16   // 256 threads * 16 chunks * 8 = 32768 columns max
+// row = (b,t); label = ids[b,t+1]; rows t == L-1 carry no loss.  One workgroup per row; dlogits may alias logits.
+// RESIDENT (ldl <= 32768): the row is kept in registers (<= CE_NCH 16-B chunks per thread), so the logits are read from HBM once;
+// otherwise the three passes (max, sum of exponentials, gradient) stream the row from memory again (a 60-130 KB row stays in L2).
+// The kernel is VALU-bound before it is HBM-bound (119 elements per lane, three passes), so the per-element work of the common case
+// -- no banned columns, no top-k threshold, chunk entirely below V -- is 1 unpack + 1 max / 1 unpack + 1 fma + v_exp + 1 add /
+// 1 unpack + 1 fma + v_exp + 1 mul + pack; the label column is handled once per row by the thread that owns its chunk, not by a compare
+// per element.  Chunks that touch V, banned columns or a threshold take the general path.
+#define CE_NCH 16   // 256 threads * 16 chunks * 8 = 32768 columns resident
+#define CE_LOG2E 1.4426950408889634f
 struct CeBanned { int n; int col[4]; };
+struct CeRow {
+    int V; CeBanned ban; float thr; bool plain_row;        // plain_row: no banned column, no threshold (block-uniform)
+    __device__ __forceinline__ bool live(int c, float f) const {
+        return c < V && f >= thr && !(ban.n > 0 && (c == ban.col[0] || (ban.n > 1 && c == ban.col[1]) || (ban.n > 2 && c == ban.col[2]) || (ban.n > 3 && c == ban.col[3])));
+    }
+    __device__ __forceinline__ bool plain(int ch) const { return plain_row && ch * 8 + 8 <= V; }
+    __device__ __forceinline__ float chunk_max(const uint4 raw, int ch, float mx) const {
+        float f[8];
+        unpack8(raw, f);
+        if (plain(ch)) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mx = fmaxf(mx, f[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (live(ch * 8 + j, f[j])) mx = fmaxf(mx, f[j]);
+        }
+        return mx;
+    }
+    // nm = -max * log2(e): exp(f - max) = exp2(f * log2(e) + nm)
+    __device__ __forceinline__ float chunk_sumexp(const uint4 raw, int ch, float nm, float se) const {
+        float f[8];
+        unpack8(raw, f);
+        if (plain(ch)) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) se += __builtin_amdgcn_exp2f(fmaf(f[j], CE_LOG2E, nm));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (live(ch * 8 + j, f[j])) se += __builtin_amdgcn_exp2f(fmaf(f[j], CE_LOG2E, nm));
+        }
+        return se;
+    }
+    __device__ __forceinline__ uint4 chunk_grad(const uint4 raw, int ch, float nm, float inv, int label, float gs) const {
+        float f[8];
+        unpack8(raw, f);
+        if (plain(ch)) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = __builtin_amdgcn_exp2f(fmaf(f[j], CE_LOG2E, nm)) * inv;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = live(ch * 8 + j, f[j]) ? __builtin_amdgcn_exp2f(fmaf(f[j], CE_LOG2E, nm)) * inv : 0.f;
+        }
+        if (ch == (label >> 3)) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (j == (label & 7)) f[j] -= gs;
+        }
+        return pack8(f);
+    }
+};
+
+template <bool RESIDENT>
 __global__ __launch_bounds__(256) void ce_shift_kernel(const bf16_t* __restrict__ logits, int64_t ldl, const int64_t* __restrict__ ids,
                                                        int L, int V, float* __restrict__ loss_sum, float* __restrict__ row_logp,
                                                        bf16_t* __restrict__ dlogits, float grad_scale,
@@ -43,39 +99,44 @@ __global__ __launch_bounds__(256) void ce_shift_kernel(const bf16_t* __restrict_
     }
     const bf16_t* lrow = logits + (int64_t)row * ldl;
     const int label = (int)ids[(int64_t)b * L + t + 1];
-    uint4 raw[CE_NCH];
+    CeRow R;
+    R.V = V; R.ban = ban; R.thr = row_min_logit ? row_min_logit[row] : -INFINITY;
+    R.plain_row = ban.n == 0 && !row_min_logit;
+    uint4 raw[RESIDENT ? CE_NCH : 1];
     float mx = -INFINITY;
-    const float thr = row_min_logit ? row_min_logit[row] : -INFINITY;
-    auto live = [&](int c) { return c < V && !(ban.n > 0 && (c == ban.col[0] || (ban.n > 1 && c == ban.col[1]) || (ban.n > 2 && c == ban.col[2]) || (ban.n > 3 && c == ban.col[3]))); };
+    if (RESIDENT) {
 #pragma unroll
-    for (int i = 0; i < CE_NCH; ++i) {
-        const int ch = threadIdx.x + 256 * i;
-        raw[i] = make_uint4(0, 0, 0, 0);
-        if (ch < nch) {
-            raw[i] = *reinterpret_cast<const uint4*>(lrow + ch * 8);
-            float f[8];
-            unpack8(raw[i], f);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) if (live(ch * 8 + j) && f[j] >= thr) mx = fmaxf(mx, f[j]);
+        for (int i = 0; i < CE_NCH; ++i) {
+            const int ch = threadIdx.x + 256 * i;
+            raw[i] = make_uint4(0, 0, 0, 0);
+            if (ch < nch) raw[i] = *reinterpret_cast<const uint4*>(lrow + ch * 8);
         }
+#pragma unroll
+        for (int i = 0; i < CE_NCH; ++i) {
+            const int ch = threadIdx.x + 256 * i;
+            if (ch < nch) mx = R.chunk_max(raw[i], ch, mx);
+        }
+    } else {
+        for (int ch = threadIdx.x; ch < nch; ch += 256) mx = R.chunk_max(*reinterpret_cast<const uint4*>(lrow + ch * 8), ch, mx);
     }
     mx = block_reduce_max(mx, sh);
-    float se = 0.f, lab = 0.f;
+    const float nm = -mx * CE_LOG2E;
+    float se = 0.f;
+    if (RESIDENT) {
 #pragma unroll
-    for (int i = 0; i < CE_NCH; ++i) {
-        const int ch = threadIdx.x + 256 * i;
-        if (ch < nch) {
-            float f[8];
-            unpack8(raw[i], f);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int c = ch * 8 + j;
-                if (live(c) && f[j] >= thr) { se += __expf(f[j] - mx); if (c == label) lab = f[j]; }
-            }
+        for (int i = 0; i < CE_NCH; ++i) {
+            const int ch = threadIdx.x + 256 * i;
+            if (ch < nch) se = R.chunk_sumexp(raw[i], ch, nm, se);
         }
+    } else {
+        for (int ch = threadIdx.x; ch < nch; ch += 256) se = R.chunk_sumexp(*reinterpret_cast<const uint4*>(lrow + ch * 8), ch, nm, se);
     }
     se = block_reduce_sum(se, sh);
-    lab = block_reduce_sum(lab, sh);
+    // the label's logit, read by every thread from the row (one 2-byte load that hits the cache the row just came through); a banned or
+    // thresholded-out label contributes lab = 0 like the per-element form did (reference: its log-probability is -inf there and SCST
+    // never scores such a token)
+    const float labv = bf16_to_f32(lrow[label]);
+    const float lab = R.live(label, labv) ? labv : 0.f;
     const float lse = mx + __logf(se);
     if (threadIdx.x == 0) {
         atomicAdd(loss_sum, w * (lse - lab));
@@ -84,21 +145,15 @@ __global__ __launch_bounds__(256) void ce_shift_kernel(const bf16_t* __restrict_
     if (drow) {
         const float gs = grad_scale * w;
         const float inv = gs / se;
+        if (RESIDENT) {
 #pragma unroll
-        for (int i = 0; i < CE_NCH; ++i) {
-            const int ch = threadIdx.x + 256 * i;
-            if (ch < nch) {
-                float f[8];
-                unpack8(raw[i], f);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int c = ch * 8 + j;
-                    float g = (live(c) && f[j] >= thr) ? __expf(f[j] - mx) * inv : 0.f;
-                    if (c == label) g -= gs;
-                    f[j] = g;
-                }
-                *reinterpret_cast<uint4*>(drow + ch * 8) = pack8(f);
+            for (int i = 0; i < CE_NCH; ++i) {
+                const int ch = threadIdx.x + 256 * i;
+                if (ch < nch) *reinterpret_cast<uint4*>(drow + ch * 8) = R.chunk_grad(raw[i], ch, nm, inv, label, gs);
             }
+        } else {
+            for (int ch = threadIdx.x; ch < nch; ch += 256)
+                *reinterpret_cast<uint4*>(drow + ch * 8) = R.chunk_grad(*reinterpret_cast<const uint4*>(lrow + ch * 8), ch, nm, inv, label, gs);
         }
     }
 }
@@ -109,14 +164,17 @@ extern "C" int vm_ce_shift_fwd_bwd(const void* logits, int64_t ldl, const int64_
                                    void* stream) {
     VM_REQUIRE(logits && ids && loss_sum, "vm_ce_shift_fwd_bwd: null pointer");
     VM_REQUIRE(B > 0 && L > 1 && V > 0 && ldl >= V && (ldl % 8) == 0, "vm_ce_shift_fwd_bwd: bad shape");
-    VM_REQUIRE(ldl <= 256 * CE_NCH * 8, "vm_ce_shift_fwd_bwd: vocabulary %d too large (max %d)", V, 256 * CE_NCH * 8);
     VM_REQUIRE(n_banned >= 0 && n_banned <= 4 && (n_banned == 0 || banned), "vm_ce_shift_fwd_bwd: at most 4 banned columns (HOST array)");
     CeBanned ban = {n_banned, {0, 0, 0, 0}};
     for (int i = 0; i < n_banned; ++i) ban.col[i] = banned[i];
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_LOSS, 4.0 * B * L * (double)ldl, s);
-    hipLaunchKernelGGL(ce_shift_kernel, dim3(B * L), dim3(256), 0, s, (const bf16_t*)logits, ldl, ids, L, V, loss_sum, row_logp, (bf16_t*)dlogits,
-                       grad_scale, row_weight, ban, row_min_logit);
+    if (ldl <= 256 * CE_NCH * 8)
+        hipLaunchKernelGGL(ce_shift_kernel<true>, dim3(B * L), dim3(256), 0, s, (const bf16_t*)logits, ldl, ids, L, V, loss_sum, row_logp, (bf16_t*)dlogits,
+                           grad_scale, row_weight, ban, row_min_logit);
+    else        // wider vocabularies (> 32768 columns): the passes stream the row instead of holding it in registers
+        hipLaunchKernelGGL(ce_shift_kernel<false>, dim3(B * L), dim3(256), 0, s, (const bf16_t*)logits, ldl, ids, L, V, loss_sum, row_logp, (bf16_t*)dlogits,
+                           grad_scale, row_weight, ban, row_min_logit);
     return vm_check_launch("vm_ce_shift_fwd_bwd");
 }
 

@@ -38,29 +38,15 @@ class FusedAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         from . import ops
         ops.join_side()              # queued / side-stream parameter gradients land before the update (no-op when nothing is pending)
-        self.begin_step()
-        self.step_range(0, self.arena.numel)
-
-    @torch.no_grad()
-    def begin_step(self):
-        """advance the step count (host + device) once per optimizer step; step_range() then updates any part of the arena"""
         g = self.param_groups[0]
         self.steps += 1
+        b1, b2 = g["betas"]
+        a = self.arena
         if float(g["lr"]) != self._lr_host:          # a scheduler moved the learning rate: refresh the device copy (outside any capture)
             self.sync_lr()
         self.step_dev.add_(1)
-
-    @torch.no_grad()
-    def step_range(self, lo, hi):
-        """Adam on arena elements [lo, hi) (64-element aligned), on the CURRENT stream: callers that know a range's gradients are final
-        (the decoder's, while the encoder's backward still runs) update it early -- parallel.SplitStep / ArenaDDP.backward(opt=...)."""
-        g = self.param_groups[0]
-        b1, b2 = g["betas"]
-        a = self.arena
-        if lo % 4 or (hi - lo) <= 0:
-            raise ValueError("FusedAdam.step_range: range must start on a multiple of 4 elements and be non-empty")
-        check(lib().vm_adam_step_dev(ptr(a.flat[lo:hi]), ptr(a.gflat[lo:hi]), ptr(self.m[lo:hi]), ptr(self.v[lo:hi]), ptr(a.shadow_flat[lo:hi]),
-                                     hi - lo, g["lr"], b1, b2, g["eps"], g["weight_decay"], int(g["decoupled_weight_decay"]),
+        check(lib().vm_adam_step_dev(ptr(a.flat), ptr(a.gflat), ptr(self.m), ptr(self.v), ptr(a.shadow_flat), a.numel,
+                                     g["lr"], b1, b2, g["eps"], g["weight_decay"], int(g["decoupled_weight_decay"]),
                                      1 - b1 ** self.steps, 1 - b2 ** self.steps, self.grad_scale,
                                      ptr(self.lr_dev), ptr(self.step_dev), ptr(self.gate) if self.gate is not None else None, stream()),
               "vm_adam_step_dev")

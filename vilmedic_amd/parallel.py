@@ -113,12 +113,9 @@ class ArenaDDP:
             if self.bf16_wire:
                 self._ops.cast_to_f32(self._wire[cs:ce], self.arena.gflat[cs:ce])
 
-    def backward(self, loss, sync=True, opt=None):
+    def backward(self, loss, sync=True):
         """loss.backward() + gradient averaging, communication overlapped with the encoder's backward when possible.
-        ``sync=False`` (a gradient-accumulation micro-batch that does not step): both backward phases run, nothing is reduced.
-        ``opt`` (a FusedAdam, with sync): the optimizer update of each arena range is launched right behind that range's all-reduce on
-        the side stream -- the decoder's parameters are updated while the encoder's backward still runs; the caller must NOT call
-        opt.step() afterwards."""
+        ``sync=False`` (a gradient-accumulation micro-batch that does not step): both backward phases run, nothing is reduced."""
         self._check_grads_in_arena()
         n = self.arena.numel
         split = getattr(self.model, "_split", None) if self.split_at is not None else None
@@ -126,8 +123,6 @@ class ArenaDDP:
             loss.backward()
             if sync:
                 self._wait(self._start(0, n, self.chunks))
-                if opt is not None:
-                    opt.step()
             return
         feats, leaf = split
         if not sync:
@@ -144,22 +139,14 @@ class ArenaDDP:
         try:
             loss.backward()                              # decoder graph only (features were detached)
             ops.flush_param_grads()                      # the decoder's queued weight gradients, before their range is reduced
-            if opt is not None:
-                opt.begin_step()
             with ops.side_context(dev):
                 pending = self._start(0, self.split_at, max(1, self.chunks // 2))
-                if opt is not None:                      # decoder update behind its all-reduce, while the encoder's backward runs
-                    self._wait(pending)
-                    pending = []
-                    opt.step_range(0, self.split_at)
             if leaf.grad is not None:
-                feats.backward(leaf.grad)                # encoder graph, overlapping the decoder's all-reduce (and update)
+                feats.backward(leaf.grad)                # encoder graph, overlapping the decoder's all-reduce
             ops.flush_param_grads()
             with ops.side_context(dev):
                 pending += self._start(self.split_at, n, max(1, self.chunks // 2))
                 self._wait(pending)
-                if opt is not None:
-                    opt.step_range(self.split_at, n)
         finally:
             ops._side["defer"] = False
         ops.join_side()                                  # the optimizer (main stream) waits for the averaged gradients
@@ -181,53 +168,6 @@ class ArenaDDP:
             elif g.data_ptr() != p._vm_grad_view.data_ptr():
                 p._vm_grad_view.add_(g.to(p._vm_grad_view.dtype))
                 p.grad = p._vm_grad_view
-
-
-class SplitStep:
-    """Single-process form of ArenaDDP's two-phase step (no collectives): for a model with the encoder / decoder split protocol
-    (RRG), ``backward_and_step(loss, opt)`` runs the decoder's backward, launches the decoder range's fused Adam on the SIDE stream
-    (behind the decoder's grouped weight gradients) and runs the encoder's backward meanwhile on the main stream; the encoder range
-    follows.  The optimizer's 1.4 ms HBM pass (30 B / parameter over 223 M parameters) is hidden behind the ViT backward for the
-    decoder's 61 % of the arena."""
-
-    def __init__(self, model):
-        from . import ops
-        from .arena import arena_of
-        self.model, self._ops = model, ops
-        self.arena = arena_of(model)
-        self.split_at = None
-        if hasattr(model, "enc") and hasattr(model, "dec") and hasattr(model, "split_backward"):
-            enc_offs = [p._vm_off for p in model.enc.parameters()]
-            dec_offs = [p._vm_off + p.numel() for p in model.dec.parameters()]
-            if enc_offs and dec_offs and min(enc_offs) >= max(dec_offs):
-                self.split_at = min(enc_offs)
-                model.split_backward = True
-
-    def backward_and_step(self, loss, opt):
-        ops, n = self._ops, self.arena.numel
-        split = getattr(self.model, "_split", None) if self.split_at is not None else None
-        if split is None:
-            loss.backward()
-            opt.step()
-            return
-        feats, leaf = split
-        dev = self.arena.flat.device
-        ops._side["defer"] = True
-        try:
-            loss.backward()
-            ops.flush_param_grads()
-            opt.begin_step()
-            with ops.side_context(dev):
-                opt.step_range(0, self.split_at)
-            if leaf.grad is not None:
-                feats.backward(leaf.grad)
-            ops.flush_param_grads()
-            with ops.side_context(dev):
-                opt.step_range(self.split_at, n)
-        finally:
-            ops._side["defer"] = False
-        ops.join_side()
-        self.model._split = None
 
 
 def all_gather_with_grad(x, dist):
