@@ -205,6 +205,31 @@ int vm_contrastive_bwd(const void* a_hat, const void* b_hat, int R, int C, int D
                        const float* lse_rows, const float* lse_cols, const float* g_rows, const float* g_cols,
                        void* G_bf16, int64_t ldg, void* stream);
 
+/* ------------------------------------------------------------------ GLoRIA local (word x image-region) loss
+ * ref:vilmedic/blocks/losses/selfsup/GLoRIALoss.py:14-51 (gloria_attention_fn), :78-129 (local_loss): every (caption i, image j) pair of
+ * the batch at once, fp32 throughout (see csrc/gloria.hip for the math).  Layouts (B captions = B images, Tp / Pp = words / regions
+ * padded to multiples of 16, cap_lens int32 [B] on the device):
+ *   S     fp32 [B*Tp, ldS >= B*Pp]   S[(i Tp + t), j Pp + p] = <word t of caption i, region p of image j>  (one vm_gemm_f32)
+ *   a2    fp32 [B img][B*Tp][Pp]     attention of word (i, t) over the regions of image j; rows t >= cap_lens[i] and columns >= P zero
+ *   dot   fp32 [B*Tp][B]             sum_p a2 S = <word, attention-weighted context>
+ *   colstat fp32 [B cap][B img][2][Pp]  per-region (max, 1 / sum exp) over the caption's words, kept for the backward pass
+ *   x     fp32 [B img][B*Tp][ldx]    context vectors x = a2 C^T (one vm_gemm_f32 per image)
+ *   sims  fp32 [B img][B cap] = temp3 log sum_t exp(temp2 cos(word, x)), simsT its transpose (the two cross-entropy inputs)
+ * Backward: vm_gloria_cos_bwd turns d sims (+ d simsT) into d x [B img][B*Tp][ldx] and the first half of d words (dW1 [B*Tp][ldx]);
+ * vm_gloria_attn_bwd turns da2 (= d x C per image, overwritten as scratch) into d S (layout of S). */
+int vm_transpose_f32(const float* src, int64_t src_batch_stride, int64_t ld_src, float* dst, int64_t dst_batch_stride, int64_t ld_dst,
+                     int batch, int rows, int cols, int dst_rows /* >= cols */, int dst_cols /* >= rows */, void* stream);   /* dst[b][c][r] = src[b][r][c], zero padded */
+int vm_row_norm_f32(const float* x, int64_t ldx, float* out /* [rows] */, int rows, int cols, void* stream);
+int vm_gloria_attn_fwd(const float* S, int64_t ldS, const int32_t* cap_lens, int B, int Tp, int P, int Pp, float temp1,
+                       float* a2, float* dot, float* colstat, void* stream);
+int vm_gloria_cos_fwd(const float* x, int64_t ldx, const float* word_norm /* [B*Tp] */, const float* dot, const int32_t* cap_lens, int B, int Tp, int D,
+                      float temp2, float temp3, float eps, float* sims, float* simsT, float* cosv /* [B*Tp][B] */, float* nxv /* [B*Tp][B] */, void* stream);
+int vm_gloria_cos_bwd(const float* dsims, const float* dsimsT, const float* sims, const float* cosv, const float* nxv, const float* word_norm,
+                      const float* x, const float* Wt /* [B*Tp][ldx] */, int64_t ldx, const int32_t* cap_lens, int B, int Tp, int D, float temp2, float temp3,
+                      float eps, float* dx, float* dW1, void* stream);
+int vm_gloria_attn_bwd(const float* S, int64_t ldS, const float* colstat, float* da2 /* in: d x C; scratch */, const int32_t* cap_lens,
+                       int B, int Tp, int P, int Pp, float temp1, float* dS /* layout of S */, void* stream);
+
 /* ------------------------------------------------------------------ element-wise / reductions */
 int vm_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 int vm_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);

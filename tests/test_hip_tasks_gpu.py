@@ -61,9 +61,44 @@ def test_gloria_loss_vs_golden(golden):
     loss, attn = GLoRIALoss(1.0, 1.0, 4.0, 5.0, 10.0)(glob, loc, words, sent, sents)
     loss.backward()
     assert abs(loss.item() - g["loss"].item()) <= 2e-2
-    assert rel(loc.grad.cpu(), g["g_loc"]) <= 1e-3 and rel(words.grad.cpu(), g["g_words"]) <= 1e-3     # local part: fp32 torch ops
+    assert rel(loc.grad.cpu(), g["g_loc"]) <= 1e-3 and rel(words.grad.cpu(), g["g_words"]) <= 1e-3     # local part: fp32 HIP kernels (csrc/gloria.hip)
     assert rel(glob.grad.cpu(), g["g_glob"]) <= 3e-2 and rel(sent.grad.cpu(), g["g_sent"]) <= 3e-2     # global part: bf16 GEMM
     torch.testing.assert_close(attn[0].cpu(), g["attn0"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,D,T,hw,seed", [(6, 32, 9, 5, 99), (5, 40, 21, 7, 3), (8, 768, 33, 19, 4)])
+def test_gloria_local_loss_kernels_vs_oracle(golden, B, D, T, hw, seed):
+    """csrc/gloria.hip (every caption x image pair at once, fp32, ragged caption lengths masked in the kernels) against the oracle's
+    restatement of the reference's per-caption loop (ref:GLoRIALoss.py:78-129), forward and backward: the G6 fixture shape (whose
+    gradients / first attention map are the reference's own), a shape with D, T, P all off the 16-multiples the GEMMs are padded to, and
+    the production feature size (D = 768, 19 x 19 regions).  Caption lengths include 1 and T."""
+    from oracle import torch_ref as O
+    from vilmedic_amd.blocks.losses import GLoRIALoss
+    gen = torch.Generator().manual_seed(seed)
+    if seed == 99:
+        torch.randn(B, D, generator=gen)                       # the fixture draws the global features first
+    loc = torch.randn(B, D, hw, hw, generator=gen)
+    words = torch.randn(B, D, T, generator=gen)
+    if D >= 256:                                               # unit-variance features of width 768 saturate both softmaxes: scale to O(1) scores
+        loc, words = loc * D ** -0.25, words * D ** -0.25
+    lens = golden("g6_losses")["gloria"]["cap_lens"] if seed == 99 else ([T, 1, 2, max(1, T - 3)] + [max(1, T // 2)] * B)[:B]
+    crit = GLoRIALoss(1.0, 1.0, 4.0, 5.0, 10.0)
+    dl, dw = loc.to(dev()).requires_grad_(True), words.to(dev()).requires_grad_(True)
+    l0, l1, maps = crit._local(dl, dw, lens)
+    (l0 + 2.0 * l1).backward()
+    rl, rw = loc.clone().requires_grad_(True), words.clone().requires_grad_(True)
+    r0, r1 = O.gloria_local_loss(rl, rw, lens, 4.0, 5.0, 10.0)
+    (r0 + 2.0 * r1).backward()
+    torch.testing.assert_close(torch.stack([l0, l1]).detach().cpu(), torch.stack([r0, r1]).detach(), rtol=2e-5, atol=2e-5)
+    e_loc, e_w = rel(dl.grad.cpu(), rl.grad), rel(dw.grad.cpu(), rw.grad)
+    print(f"[parity] gloria local B={B} D={D} T={T} P={hw * hw}: loss {l0.item():.6f}/{l1.item():.6f} vs {r0.item():.6f}/{r1.item():.6f}  "
+          f"grad rel-l2 loc {e_loc:.2e} words {e_w:.2e}")
+    assert e_loc <= 1e-4 and e_w <= 1e-4
+    assert [m.shape for m in maps] == [(1, n, hw, hw) for n in lens]
+    assert torch.count_nonzero(dw.grad[1, :, lens[1]:]) == 0             # words past the caption's length get no gradient
+    if seed == 99:
+        g = golden("g6_losses")["gloria"]
+        torch.testing.assert_close(maps[0].cpu(), g["attn0"], rtol=1e-4, atol=1e-6)
 
 
 def test_mvqa_core_and_text_encoder_vs_golden(golden):

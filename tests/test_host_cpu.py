@@ -170,33 +170,6 @@ def test_every_shipped_yaml_parses_and_constructs(rel):
     assert executor_view(cfg, "validator").batch_size > 0
 
 
-def test_gloria_all_pairs_local_loss_matches_reference_fixture(golden):
-    """GLoRIALoss._local (one product for every caption x image pair, ragged caption lengths masked; plain torch, runs on any
-    device) against the reference's per-caption loop: the G6 fixture's gradients w.r.t. the local features / word embeddings
-    (both come only from the local term) and its first attention map, plus the oracle's local loss on ragged lengths."""
-    from oracle import torch_ref as O
-    from vilmedic_amd.blocks.losses import GLoRIALoss
-    g = golden("g6_losses")["gloria"]
-    B, D, T, hw = g["B"], g["D"], g["T"], g["hw"]
-    gen = torch.Generator().manual_seed(99)
-    torch.randn(B, D, generator=gen)
-    loc = torch.randn(B, D, hw, hw, generator=gen).requires_grad_(True)
-    words = torch.randn(B, D, T, generator=gen).requires_grad_(True)
-    crit = GLoRIALoss(1.0, 1.0, 4.0, 5.0, 10.0)
-    l0, l1, attn = crit._local(loc, words, g["cap_lens"])
-    (l0 + l1).backward()
-    torch.testing.assert_close(loc.grad, g["g_loc"], rtol=1e-3, atol=1e-6)
-    torch.testing.assert_close(words.grad, g["g_words"], rtol=1e-3, atol=1e-6)
-    torch.testing.assert_close(attn[0], g["attn0"], rtol=1e-4, atol=1e-6)
-    r0, r1 = O.gloria_local_loss(loc.detach(), words.detach(), g["cap_lens"], 4.0, 5.0, 10.0)
-    torch.testing.assert_close(torch.stack([l0, l1]).detach(), torch.stack([r0, r1]), rtol=1e-5, atol=1e-5)
-    lens = [T, 2, 1, max(1, T - 3)] + [3] * (B - 4)
-    a0, a1, maps = crit._local(loc.detach(), words.detach(), lens[:B])
-    r0, r1 = O.gloria_local_loss(loc.detach(), words.detach(), lens[:B], 4.0, 5.0, 10.0)
-    torch.testing.assert_close(torch.stack([a0, a1]), torch.stack([r0, r1]), rtol=1e-5, atol=1e-5)
-    assert [m.shape[1] for m in maps] == lens[:B]
-
-
 def test_data_parallel_training_shards_have_equal_batch_counts():
     """create_data_loader under WORLD_SIZE > 1: every rank iterates the same number of training batches (an extra batch on one rank
     would hang its gradient all-reduce); validation keeps every sample"""

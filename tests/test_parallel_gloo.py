@@ -220,23 +220,24 @@ def test_arena_ddp_gradient_accumulation_trains_the_encoder_and_folds_stray_grad
 
 def _gloria_local_gather(rank, world):
     """GLoRIA's local loss over the GLOBAL batch: every rank holds 3 (image, caption) pairs, the local feature maps and
-    word embeddings are all-gathered with gradient, the loss is that of the 6-pair batch and each rank's gradients are its slice of the
-    single-process gradients (x world: ArenaDDP then averages parameter gradients over ranks)"""
-    from vilmedic_amd.blocks.losses.selfsup import GLoRIALoss, _maybe_gather
+    word embeddings are all-gathered with gradient (the product's _maybe_gather, as GLoRIALoss.forward calls it), the loss is that of
+    the 6-pair batch and each rank's gradients are its slice of the single-process gradients (x world: ArenaDDP then averages parameter
+    gradients over ranks).  The loss itself is evaluated by the oracle here (the product's local loss is HIP-only)."""
+    from oracle import torch_ref as O
+    from vilmedic_amd.blocks.losses.selfsup import _maybe_gather
     g = torch.Generator().manual_seed(21)
     B, b, D, T = 6, 3, 16, 5
     img = torch.randn(B, D, 3, 3, generator=g)
     words = torch.randn(B, D, T, generator=g)
     lens = [5, 3, 4, 2, 5, 4]
-    crit = GLoRIALoss(temp1=4.0, temp2=5.0, temp3=10.0)
     li = img[rank * b:(rank + 1) * b].clone().requires_grad_(True)
     lw = words[rank * b:(rank + 1) * b].clone().requires_grad_(True)
     (gi, gw), _, w = _maybe_gather(li, lw)
     assert w == world and gi.shape[0] == B
-    l0, l1, _ = crit._local(gi, gw, lens)
+    l0, l1 = O.gloria_local_loss(gi, gw, lens, 4.0, 5.0, 10.0)
     (l0 + l1).backward()
     fi, fw = img.clone().requires_grad_(True), words.clone().requires_grad_(True)
-    r0, r1, _ = crit._local(fi, fw, lens)
+    r0, r1 = O.gloria_local_loss(fi, fw, lens, 4.0, 5.0, 10.0)
     (r0 + r1).backward()
     return (float(l0 + l1), float(r0 + r1), li.grad, world * fi.grad[rank * b:(rank + 1) * b], lw.grad, world * fw.grad[rank * b:(rank + 1) * b])
 

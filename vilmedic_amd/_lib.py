@@ -67,6 +67,12 @@ SIGNATURES = {
     "vm_vit_assemble_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "vm_ce_shift_fwd_bwd": (_I, [_P, _L, _P, _I, _I, _I, _P, _P, _P, _F, _P, C.POINTER(C.c_int32), _I, _P, _P]),
     "vm_topk_threshold_bf16": (_I, [_P, _L, _I, _I, _I, C.POINTER(C.c_int32), _I, _P, _P]),
+    "vm_transpose_f32": (_I, [_P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _P]),
+    "vm_row_norm_f32": (_I, [_P, _L, _P, _I, _I, _P]),
+    "vm_gloria_attn_fwd": (_I, [_P, _L, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P]),
+    "vm_gloria_cos_fwd": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P]),
+    "vm_gloria_cos_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P]),
+    "vm_gloria_attn_bwd": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P]),
     "vm_ce_smooth_fwd_bwd": (_I, [_P, _P, _I, _I, _F, _P, _P, _F, _P]),
     "vm_rownorm_cast": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
     "vm_lse_rows_f32": (_I, [_P, _L, _P, _P, _I, _I, _I, _P]),

@@ -233,6 +233,123 @@ def gloria_attention_fn(query, context, temp1):
     return torch.bmm(ctx, attn.transpose(1, 2)), attn.view(B, -1, ih, iw)
 
 
+def _pad16(n):
+    return (n + 15) // 16 * 16
+
+
+def _transpose(src, sbs, lds, dst, dbs, ldd, batch, rows, cols, drows, dcols):
+    check(lib().vm_transpose_f32(ptr(src), sbs, lds, ptr(dst), dbs, ldd, batch, rows, cols, drows, dcols, stream()), "vm_transpose_f32")
+
+
+def _gemm_f32(A, W, C, M, N, K, residual=None):
+    """C[M,N] = A[M,K] W[N,K]^T (+ residual), fp32 on the exact f32 MFMA (vm_gemm_f32); leading dimensions from the tensors"""
+    check(lib().vm_gemm_f32(ptr(A), A.stride(0), ptr(W), W.stride(0), ptr(C), C.stride(0), M, N, K, None, 0,
+                            ptr(residual) if residual is not None else None, residual.stride(0) if residual is not None else 0, stream()),
+          "vm_gemm_f32")
+
+
+class _GloriaLocalFn(torch.autograd.Function):
+    """(local image features [B,D,ih,iw], word embeddings [B,D,T], caption lengths) -> (loss0, loss1, a2) with
+    loss0 = CE(sims, arange), loss1 = CE(sims^T, arange), sims [B img, B cap] the word-region matching score of every pair and
+    a2 [B img, B*Tp, Pp] the attention of every word over every image's regions (csrc/gloria.hip; layouts in include/vmhip.h)."""
+
+    @staticmethod
+    def forward(ctx, img, words, lens, temp1, temp2, temp3):
+        dev = img.device
+        B, D, ih, iw = img.shape
+        P, T = ih * iw, words.shape[2]
+        Tmax = int(lens.max())
+        if Tmax > T or int(lens.min()) < 1:
+            raise ValueError("GLoRIA local loss: caption lengths must be in 1..T")
+        Tp, Pp, Dp = _pad16(Tmax), _pad16(P), _pad16(D)
+        f32 = dict(dtype=torch.float32, device=dev)
+        L = lib()
+        ctx3 = img.detach().float().reshape(B, D, P).contiguous()
+        w3 = words.detach().float().contiguous()
+        lens_dev = lens.to(dev)
+        # operand layouts for the NT GEMMs (both operands contraction-contiguous), zero padded to multiples of 16
+        Ct = torch.empty(B, Pp, Dp, **f32)                      # regions x features
+        _transpose(ctx3, D * P, P, Ct, Pp * Dp, Dp, B, D, P, Pp, Dp)
+        Cn = torch.zeros(B, Dp, Pp, **f32)                      # features x regions
+        Cn[:, :D, :P] = ctx3
+        Wt = torch.empty(B, Tp, Dp, **f32)                      # words x features (rows >= Tmax zero, rows >= cap_lens[i] masked in the kernels)
+        _transpose(w3, D * T, T, Wt, Tp * Dp, Dp, B, D, Tmax, Tp, Dp)
+        nw = torch.empty(B * Tp, **f32)
+        check(L.vm_row_norm_f32(ptr(Wt), Dp, ptr(nw), B * Tp, Dp, stream()), "vm_row_norm_f32")
+        S = torch.empty(B * Tp, B * Pp, **f32)
+        _gemm_f32(Wt.view(B * Tp, Dp), Ct.view(B * Pp, Dp), S, B * Tp, B * Pp, Dp)
+        a2 = torch.empty(B, B * Tp, Pp, **f32)
+        dot = torch.empty(B * Tp, B, **f32)
+        colstat = torch.empty(B, B, 2, Pp, **f32)
+        check(L.vm_gloria_attn_fwd(ptr(S), S.stride(0), ptr(lens_dev), B, Tp, P, Pp, temp1, ptr(a2), ptr(dot), ptr(colstat), stream()),
+              "vm_gloria_attn_fwd")
+        x = torch.empty(B, B * Tp, Dp, **f32)
+        for j in range(B):                                      # x_j = a2_j C_j^T
+            _gemm_f32(a2[j], Cn[j], x[j], B * Tp, Dp, Pp)
+        sims, simsT = torch.empty(B, B, **f32), torch.empty(B, B, **f32)
+        cosv, nxv = torch.empty(B * Tp, B, **f32), torch.empty(B * Tp, B, **f32)
+        check(L.vm_gloria_cos_fwd(ptr(x), Dp, ptr(nw), ptr(dot), ptr(lens_dev), B, Tp, Dp, temp2, temp3, 1e-8, ptr(sims), ptr(simsT), ptr(cosv),
+                                  ptr(nxv), stream()), "vm_gloria_cos_fwd")
+        labels = torch.arange(B, device=dev)
+        losses = torch.zeros(2, **f32)
+        dsims, dsimsT = torch.empty_like(sims), torch.empty_like(simsT)
+        check(L.vm_ce_smooth_fwd_bwd(ptr(sims), ptr(labels), B, B, 0.0, ptr(losses[0:1]), ptr(dsims), 1.0 / B, stream()), "vm_ce_smooth_fwd_bwd")
+        check(L.vm_ce_smooth_fwd_bwd(ptr(simsT), ptr(labels), B, B, 0.0, ptr(losses[1:2]), ptr(dsimsT), 1.0 / B, stream()), "vm_ce_smooth_fwd_bwd")
+        losses = losses / B
+        ctx.save_for_backward(S, a2, x, Wt, Ct, Cn, colstat, cosv, nxv, nw, sims, dsims, dsimsT, lens_dev)
+        ctx.meta = (B, D, P, T, Tmax, Tp, Pp, Dp, ih, iw, temp1, temp2, temp3)
+        ctx.mark_non_differentiable(a2)
+        return losses[0], losses[1], a2
+
+    @staticmethod
+    def backward(ctx, g0, g1, _ga2):
+        S, a2, x, Wt, Ct, Cn, colstat, cosv, nxv, nw, sims, dsims, dsimsT, lens_dev = ctx.saved_tensors
+        B, D, P, T, Tmax, Tp, Pp, Dp, ih, iw, temp1, temp2, temp3 = ctx.meta
+        dev = S.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        L = lib()
+        g0 = g0 if g0 is not None else torch.zeros((), **f32)
+        g1 = g1 if g1 is not None else torch.zeros((), **f32)
+        ds, dsT = (dsims * g0).contiguous(), (dsimsT * g1).contiguous()
+        dx = torch.empty(B, B * Tp, Dp, **f32)
+        dW = torch.empty(B * Tp, Dp, **f32)
+        check(L.vm_gloria_cos_bwd(ptr(ds), ptr(dsT), ptr(sims), ptr(cosv), ptr(nxv), ptr(nw), ptr(x), ptr(Wt), Dp, ptr(lens_dev), B, Tp, Dp,
+                                  temp2, temp3, 1e-8, ptr(dx), ptr(dW), stream()), "vm_gloria_cos_bwd")
+        # through x_j = a2_j C_j^T:  d a2_j = d x_j C_j ,  d C_j = d x_j^T a2_j
+        da2 = torch.empty(B, B * Tp, Pp, **f32)
+        dxT = torch.empty(B, Dp, B * Tp, **f32)
+        a2T = torch.empty(B, Pp, B * Tp, **f32)
+        _transpose(dx, B * Tp * Dp, Dp, dxT, Dp * B * Tp, B * Tp, B, B * Tp, Dp, Dp, B * Tp)
+        _transpose(a2, B * Tp * Pp, Pp, a2T, Pp * B * Tp, B * Tp, B, B * Tp, Pp, Pp, B * Tp)
+        dCn = torch.empty(B, Dp, Pp, **f32)
+        for j in range(B):
+            _gemm_f32(dx[j], Ct[j], da2[j], B * Tp, Pp, Dp)
+            _gemm_f32(dxT[j], a2T[j], dCn[j], Dp, Pp, B * Tp)
+        del dxT, a2T
+        dS = torch.empty_like(S)
+        check(L.vm_gloria_attn_bwd(ptr(S), S.stride(0), ptr(colstat), ptr(da2), ptr(lens_dev), B, Tp, P, Pp, temp1, ptr(dS), stream()),
+              "vm_gloria_attn_bwd")
+        # through S = Wt Ct^T:  d Wt += d S Ct ,  d Ct = d S^T Wt
+        CtT = torch.empty(Dp, B * Pp, **f32)
+        _transpose(Ct, 0, Dp, CtT, 0, B * Pp, 1, B * Pp, Dp, Dp, B * Pp)
+        _gemm_f32(dS, CtT, dW, B * Tp, Dp, B * Pp, residual=dW)
+        dST = torch.empty(B * Pp, B * Tp, **f32)
+        _transpose(dS, 0, dS.stride(0), dST, 0, B * Tp, 1, B * Tp, B * Pp, B * Pp, B * Tp)
+        WtT = torch.empty(Dp, B * Tp, **f32)
+        _transpose(Wt, 0, Dp, WtT, 0, B * Tp, 1, B * Tp, Dp, Dp, B * Tp)
+        dCt = torch.empty(B, Pp, Dp, **f32)
+        _gemm_f32(dST, WtT, dCt.view(B * Pp, Dp), B * Pp, Dp, B * Tp)
+        # back to the callers' layouts
+        dCt_n = torch.empty(B, Dp, Pp, **f32)
+        _transpose(dCt, Pp * Dp, Dp, dCt_n, Dp * Pp, Pp, B, Pp, Dp, Dp, Pp)
+        d_img = (dCn + dCt_n)[:, :D, :P].reshape(B, D, ih, iw)
+        dWn = torch.empty(B, Dp, Tp, **f32)
+        _transpose(dW, Tp * Dp, Dp, dWn, Dp * Tp, Tp, B, Tp, Dp, Dp, Tp)
+        d_words = torch.zeros(B, D, T, **f32)
+        d_words[:, :, :Tmax] = dWn[:, :D, :Tmax]
+        return d_img, d_words, None, None, None, None
+
+
 class GLoRIALoss(nn.Module):
     def __init__(self, local_loss_weight=1.0, global_loss_weight=1.0, temp1=4.0, temp2=5.0, temp3=10.0):
         super().__init__()
@@ -258,32 +375,12 @@ class GLoRIALoss(nn.Module):
         return loss, attn_maps
 
     def _local(self, img, words, cap_lens):
-        """ref: GLoRIALoss.py:78-129.  The reference loops over captions, repeating each caption B times and attending the whole
-        image batch (two bmm's with the feature dimension and a [B,D,T] weighted context per caption).  Here every
-        (caption i, image j) pair is handled at once from ONE product, S[i,t,j,p] = <word_it, ctx_jp>:
-          a1 = softmax over the caption's words t (ragged lengths masked), a2 = softmax over pixels p of temp1 * a1,
-          <word_it, wctx_ijt> = sum_p a2 * S          (wctx = ctx_j a2 is never formed),
-          |wctx_ijt|^2 = a2^T (ctx_j^T ctx_j) a2      (one [P,P] Gram matrix per image),
-        so the feature dimension is contracted once, nothing is repeated, and captions of any length share the launch."""
-        B, D = img.shape[0], img.shape[1]
-        ih, iw = img.shape[2], img.shape[3]
-        P = ih * iw
-        T = int(max(cap_lens))
-        ctx = img.reshape(B, D, P)
-        w = words[:, :, :T]                                                        # [B,D,T]
-        lens = torch.tensor(cap_lens, device=img.device)
-        valid = torch.arange(T, device=img.device)[None, :] < lens[:, None]        # [B,T]
-        S = (w.transpose(1, 2).reshape(B * T, D) @ ctx.permute(1, 0, 2).reshape(D, B * P)).view(B, T, B, P)
-        a1 = torch.softmax(S.masked_fill(~valid[:, :, None, None], float("-inf")), dim=1)
-        a2 = torch.softmax(a1 * self.temp1, dim=3)                                 # [B(cap),T,B(img),P]
-        dot = (a2 * S).sum(3)                                                      # [B,T,B]
-        gram = torch.bmm(ctx.transpose(1, 2), ctx)                                 # [B(img),P,P]
-        a2j = a2.permute(2, 0, 1, 3).reshape(B, B * T, P)                          # image-major
-        wn2 = (torch.bmm(a2j, gram) * a2j).sum(2).view(B, B, T).permute(1, 2, 0)   # |wctx|^2 as [B(cap),T,B(img)]
-        wnorm = w.norm(dim=1)                                                      # [B,T]
-        cos = dot / (wnorm[:, :, None] * wn2.clamp_min(1e-30).sqrt()).clamp(min=1e-8)
-        row = torch.log((torch.exp(cos * self.temp2) * valid[:, :, None]).sum(1))  # [B(cap),B(img)]
-        sims = row.t() * self.temp3                                                # [B(img),B(cap)]
-        labels = torch.arange(B, device=img.device)
-        att_maps = [a2[i, :cap_lens[i], i].reshape(1, cap_lens[i], ih, iw) for i in range(B)]
-        return nn.functional.cross_entropy(sims, labels), nn.functional.cross_entropy(sims.t(), labels), att_maps
+        """ref: GLoRIALoss.py:78-129.  The reference loops over captions, repeating each caption B times and attending the whole image
+        batch (two bmm's and two softmaxes per caption).  Here every (caption i, image j) pair is handled at once by the kernels of
+        csrc/gloria.hip (forward and backward, fp32): -> (loss0, loss1, attention maps of the matched pairs)."""
+        lens = torch.as_tensor(list(cap_lens), dtype=torch.int32)
+        l0, l1, a2 = _GloriaLocalFn.apply(img, words, lens, float(self.temp1), float(self.temp2), float(self.temp3))
+        B, ih, iw = img.shape[0], img.shape[2], img.shape[3]
+        Tp = a2.shape[1] // B
+        att_maps = [a2[i, i * Tp:i * Tp + int(cap_lens[i]), :ih * iw].reshape(1, int(cap_lens[i]), ih, iw) for i in range(B)]
+        return l0, l1, att_maps
