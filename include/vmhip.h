@@ -89,6 +89,18 @@ typedef struct {
     const float* alpha_dev;
 } vm_wgrad_problem;
 int vm_wgrad_grouped(const vm_wgrad_problem* problems, int n, void* stream);
+/* n independent products C_i[M_i,N_i] (+)= A_i B_i of ONE operand layout (vm_gemm_bf16's a_layout / b_layout; NT, NN or TN) with the plain
+ * epilogue, 8 problems per launch: small same-shape products (the per-image contractions of the GLoRIA local loss: 72 tiles each) fill
+ * the chip together.  Returns VM_EUNSUPPORTED unless K % 64 == 0, leading dimensions % 8 == 0 and 16-byte pointers (callers then loop
+ * over vm_gemm_bf16). */
+typedef struct {
+    const void* A; int64_t lda;
+    const void* B; int64_t ldb;
+    void* C; int64_t ldc;
+    int M, N, K;
+} vm_gemm_problem;
+int vm_gemm_grouped(const vm_gemm_problem* problems, int n, int a_layout, int b_layout, int out_dtype /* VM_BF16 / VM_F32 */, int accumulate,
+                    void* stream);
 
 /* ------------------------------------------------------------------ LayerNorm
  * hf:...bert_generation.py:49,55 (post-LN, eps from YAML), hf:models/vit/modeling_vit.py:261-262,348 (pre-LN).
@@ -220,6 +232,12 @@ int vm_contrastive_bwd(const void* a_hat, const void* b_hat, int R, int C, int D
 int vm_transpose_f32(const float* src, int64_t src_batch_stride, int64_t ld_src, float* dst, int64_t dst_batch_stride, int64_t ld_dst,
                      int batch, int rows, int cols, int dst_rows /* >= cols */, int dst_cols /* >= rows */, void* stream);   /* dst[b][c][r] = src[b][r][c], zero padded */
 int vm_row_norm_f32(const float* x, int64_t ldx, float* out /* [rows] */, int rows, int cols, void* stream);
+/* fp32 [rows, cols] -> the three bf16 parts of a "bf16 x 3" GEMM operand (a = hi + lo; A side (hi, hi, lo), B side (hi, lo, hi)), laid out
+   along the contraction axis in blocks of ``block``: along_rows = 0 -> dst [rows, 3 cols] (columns [3 b block, 3 (b+1) block) = the parts of
+   source columns [b block, (b+1) block)); along_rows = 1 -> dst [3 rows, cols] likewise over the rows.  vm_gemm_bf16 with the contraction
+   3 x as long and fp32 output then gives the product to ~2^-16 relative. */
+int vm_split3_bf16(const float* src, int64_t ld_src, int rows, int cols, void* dst_bf16, int64_t ld_dst, int role /* 0 = A, 1 = B */,
+                   int along_rows, int block, void* stream);
 int vm_gloria_attn_fwd(const float* S, int64_t ldS, const int32_t* cap_lens, int B, int Tp, int P, int Pp, float temp1,
                        float* a2, float* dot, float* colstat, void* stream);
 int vm_gloria_cos_fwd(const float* x, int64_t ldx, const float* word_norm /* [B*Tp] */, const float* dot, const int32_t* cap_lens, int B, int Tp, int D,

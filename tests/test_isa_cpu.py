@@ -34,7 +34,7 @@ def _kernel_meta(asm):
     return meta
 
 
-HOT = re.compile(r"_Z(16gemm_fast_kernel|19gemm_grouped_kernel)ILi[01]ELi[01]ELi2ELi[24]ELi2ELi64ELi[458]ELi[14]ELi[01]EEv(8GemmArgs|13GemmGroupArgs)$")
+HOT = re.compile(r"_Z(16gemm_fast_kernel|19gemm_grouped_kernel)ILi[01]ELi[01]ELi2ELi[24]ELi2ELi64ELi[458]ELi[14]ELi[01]E(Li[01]E)?Ev(8GemmArgs|13GemmGroupArgs)$")
 
 
 def _loop(asm, name):
@@ -50,7 +50,7 @@ def test_hot_gemm_kernels_fit_two_waves_per_simd_without_spills(gemm_fast_asm):
     """every kernel the training step can launch: both epilogues of the 128- / 160-row tiles (row-major: PIPE 1, strided: PIPE 4), the
     grouped weight-gradient kernel, the 8-wave 256 x 256 tile"""
     meta = {k: v for k, v in _kernel_meta(gemm_fast_asm).items() if HOT.match(k)}
-    assert len(meta) == 16, sorted(meta)     # (4 layouts x 128 + 2 layouts x 160) x 2 epilogues + 2 grouped + 2 x 256^2
+    assert len(meta) == 18, sorted(meta)     # (4 layouts x 128 + 2 layouts x 160) x 2 epilogues + 4 grouped (TN x 2 epilogues, NT, NN) + 2 x 256^2
     for name, m in meta.items():
         assert m["vgpr_spill_count"] == 0, (name, m)
         assert m["sgpr_spill_count"] <= 16, (name, m)        # a few SGPRs parked in VGPR lanes (v_writelane) are harmless; scratch is not
@@ -72,7 +72,8 @@ def test_pipelined_k_tile_schedule_is_present(gemm_fast_asm):
     ("_Z16gemm_fast_kernelILi0ELi1ELi2ELi2ELi2ELi64ELi4ELi4ELi1EEv8GemmArgs", 32),       # dgrad, 128 x 128
     ("_Z16gemm_fast_kernelILi0ELi1ELi2ELi2ELi2ELi64ELi5ELi4ELi1EEv8GemmArgs", 40),       # dgrad, 160 x 128
     ("_Z16gemm_fast_kernelILi1ELi1ELi2ELi2ELi2ELi64ELi4ELi4ELi1EEv8GemmArgs", 32),       # wgrad
-    ("_Z19gemm_grouped_kernelILi1ELi1ELi2ELi2ELi2ELi64ELi4ELi4ELi1EEv13GemmGroupArgs", 40),  # grouped wgrad with the bias-gradient MFMAs
+    ("_Z19gemm_grouped_kernelILi1ELi1ELi2ELi2ELi2ELi64ELi4ELi4ELi1ELi1EEv13GemmGroupArgs", 40),  # grouped wgrad with the bias-gradient MFMAs
+    ("_Z19gemm_grouped_kernelILi0ELi1ELi2ELi2ELi2ELi64ELi4ELi4ELi0ELi0EEv13GemmGroupArgs", 32),  # grouped NN (per-image products)
     ("_Z16gemm_fast_kernelILi0ELi0ELi2ELi4ELi2ELi64ELi8ELi4ELi1EEv8GemmArgs", 64),       # 256 x 256
 ])
 def test_cross_tile_register_pipeline_keeps_the_dma_in_flight(gemm_fast_asm, name, n_mfma):

@@ -28,6 +28,11 @@ class WgradProblem(C.Structure):
                 ("db", C.c_void_p), ("rows", C.c_int), ("n_out", C.c_int), ("k_in", C.c_int), ("alpha_dev", C.c_void_p)]
 
 
+class GemmProblem(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64), ("C", C.c_void_p), ("ldc", C.c_int64),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int)]
+
+
 class LnReduceProblem(C.Structure):
     _fields_ = [("ws", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int)]
 
@@ -48,6 +53,7 @@ SIGNATURES = {
     "vm_prof_dump": (_I, [C.c_char_p]),
     "vm_gemm_bf16": (_I, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, C.POINTER(GemmEpilogue), _P]),
     "vm_wgrad_grouped": (_I, [C.POINTER(WgradProblem), _I, _P]),
+    "vm_gemm_grouped": (_I, [_P, _I, _I, _I, _I, _I, _P]),
     "vm_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "vm_layernorm_bwd_ws": (_SZ, [_I, _I]),
     "vm_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
@@ -69,6 +75,7 @@ SIGNATURES = {
     "vm_topk_threshold_bf16": (_I, [_P, _L, _I, _I, _I, C.POINTER(C.c_int32), _I, _P, _P]),
     "vm_transpose_f32": (_I, [_P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _P]),
     "vm_row_norm_f32": (_I, [_P, _L, _P, _I, _I, _P]),
+    "vm_split3_bf16": (_I, [_P, _L, _I, _I, _P, _L, _I, _I, _I, _P]),
     "vm_gloria_attn_fwd": (_I, [_P, _L, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P]),
     "vm_gloria_cos_fwd": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P]),
     "vm_gloria_cos_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P]),

@@ -237,21 +237,35 @@ def _pad16(n):
     return (n + 15) // 16 * 16
 
 
+def _pad_k(n):
+    """contraction lengths: a multiple of 64 keeps the GEMM on the LDS-DMA kernels (K % 64 == 0, also after the x 3 of the split
+    operands); tiny test shapes stay at multiples of 16 (register-staged kernel)"""
+    return (n + 63) // 64 * 64 if n >= 64 else _pad16(n)
+
+
 def _transpose(src, sbs, lds, dst, dbs, ldd, batch, rows, cols, drows, dcols):
     check(lib().vm_transpose_f32(ptr(src), sbs, lds, ptr(dst), dbs, ldd, batch, rows, cols, drows, dcols, stream()), "vm_transpose_f32")
 
 
-def _gemm_f32(A, W, C, M, N, K, residual=None):
-    """C[M,N] = A[M,K] W[N,K]^T (+ residual), fp32 on the exact f32 MFMA (vm_gemm_f32); leading dimensions from the tensors"""
-    check(lib().vm_gemm_f32(ptr(A), A.stride(0), ptr(W), W.stride(0), ptr(C), C.stride(0), M, N, K, None, 0,
-                            ptr(residual) if residual is not None else None, residual.stride(0) if residual is not None else 0, stream()),
-          "vm_gemm_f32")
+def _split3(src2d, role, along_rows, block):
+    """fp32 [rows, cols] -> the (hi, hi, lo) / (hi, lo, hi) bf16 parts of a "bf16 x 3" GEMM operand (vm_split3_bf16), laid out along the
+    contraction axis: [rows, 3 cols] (along_rows = 0) or [3 rows, cols]"""
+    rows, cols = src2d.shape
+    dst = torch.empty((3 * rows, cols) if along_rows else (rows, 3 * cols), dtype=BF16, device=src2d.device)
+    check(lib().vm_split3_bf16(ptr(src2d), src2d.stride(0), rows, cols, ptr(dst), dst.stride(0), role, int(along_rows), block, stream()),
+          "vm_split3_bf16")
+    return dst
+
+
+_A, _B = 0, 1       # operand roles of vm_split3_bf16
 
 
 class _GloriaLocalFn(torch.autograd.Function):
     """(local image features [B,D,ih,iw], word embeddings [B,D,T], caption lengths) -> (loss0, loss1, a2) with
     loss0 = CE(sims, arange), loss1 = CE(sims^T, arange), sims [B img, B cap] the word-region matching score of every pair and
-    a2 [B img, B*Tp, Pp] the attention of every word over every image's regions (csrc/gloria.hip; layouts in include/vmhip.h)."""
+    a2 [B img, B*Tp, Pp] the attention of every word over every image's regions (csrc/gloria.hip; layouts in include/vmhip.h).
+    The six contractions (S, the context vectors and their four gradient products) run on the bf16 MFMA GEMM with "bf16 x 3" split
+    operands and fp32 output; everything between them is fp32."""
 
     @staticmethod
     def forward(ctx, img, words, lens, temp1, temp2, temp3):
@@ -261,31 +275,35 @@ class _GloriaLocalFn(torch.autograd.Function):
         Tmax = int(lens.max())
         if Tmax > T or int(lens.min()) < 1:
             raise ValueError("GLoRIA local loss: caption lengths must be in 1..T")
-        Tp, Pp, Dp = _pad16(Tmax), _pad16(P), _pad16(D)
+        Tp, Pp, Dp = _pad16(Tmax), _pad_k(P), _pad_k(D)
+        while B * Tp >= 64 and (B * Tp) % 64:                   # B * Tp is a contraction length too (the gradients w.r.t. the features)
+            Tp += 16
         f32 = dict(dtype=torch.float32, device=dev)
         L = lib()
         ctx3 = img.detach().float().reshape(B, D, P).contiguous()
         w3 = words.detach().float().contiguous()
         lens_dev = lens.to(dev)
-        # operand layouts for the NT GEMMs (both operands contraction-contiguous), zero padded to multiples of 16
-        Ct = torch.empty(B, Pp, Dp, **f32)                      # regions x features
+        Ct = torch.empty(B * Pp, Dp, **f32)                     # (image, region) x features, zero padded to multiples of 16
         _transpose(ctx3, D * P, P, Ct, Pp * Dp, Dp, B, D, P, Pp, Dp)
-        Cn = torch.zeros(B, Dp, Pp, **f32)                      # features x regions
-        Cn[:, :D, :P] = ctx3
-        Wt = torch.empty(B, Tp, Dp, **f32)                      # words x features (rows >= Tmax zero, rows >= cap_lens[i] masked in the kernels)
+        Wt = torch.empty(B * Tp, Dp, **f32)                     # (caption, word) x features (rows >= cap_lens[i] are masked in the kernels)
         _transpose(w3, D * T, T, Wt, Tp * Dp, Dp, B, D, Tmax, Tp, Dp)
         nw = torch.empty(B * Tp, **f32)
         check(L.vm_row_norm_f32(ptr(Wt), Dp, ptr(nw), B * Tp, Dp, stream()), "vm_row_norm_f32")
+        # S[(i,t), (j,p)] = <word, region>
+        Ct_B = _split3(Ct, _B, False, Dp)                       # [B*Pp, 3 Dp]
         S = torch.empty(B * Tp, B * Pp, **f32)
-        _gemm_f32(Wt.view(B * Tp, Dp), Ct.view(B * Pp, Dp), S, B * Tp, B * Pp, Dp)
+        ops.gemm(_split3(Wt, _A, False, Dp), 0, Ct_B, 0, S, B * Tp, B * Pp, 3 * Dp)
         a2 = torch.empty(B, B * Tp, Pp, **f32)
         dot = torch.empty(B * Tp, B, **f32)
         colstat = torch.empty(B, B, 2, Pp, **f32)
         check(L.vm_gloria_attn_fwd(ptr(S), S.stride(0), ptr(lens_dev), B, Tp, P, Pp, temp1, ptr(a2), ptr(dot), ptr(colstat), stream()),
               "vm_gloria_attn_fwd")
+        # x_j = a2_j C_j  (contraction over the regions of image j)
+        a2_A = _split3(a2.view(B * B * Tp, Pp), _A, False, Pp).view(B, B * Tp, 3 * Pp)
+        Ct_Bs = _split3(Ct, _B, True, Pp).view(B, 3 * Pp, Dp)  # per image: [3 Pp, Dp]
         x = torch.empty(B, B * Tp, Dp, **f32)
-        for j in range(B):                                      # x_j = a2_j C_j^T
-            _gemm_f32(a2[j], Cn[j], x[j], B * Tp, Dp, Pp)
+        ops.gemm_grouped([(a2_A[j], Ct_Bs[j], x[j], B * Tp, Dp, 3 * Pp) for j in range(B)], 0, 1)
+        del a2_A
         sims, simsT = torch.empty(B, B, **f32), torch.empty(B, B, **f32)
         cosv, nxv = torch.empty(B * Tp, B, **f32), torch.empty(B * Tp, B, **f32)
         check(L.vm_gloria_cos_fwd(ptr(x), Dp, ptr(nw), ptr(dot), ptr(lens_dev), B, Tp, Dp, temp2, temp3, 1e-8, ptr(sims), ptr(simsT), ptr(cosv),
@@ -296,14 +314,14 @@ class _GloriaLocalFn(torch.autograd.Function):
         check(L.vm_ce_smooth_fwd_bwd(ptr(sims), ptr(labels), B, B, 0.0, ptr(losses[0:1]), ptr(dsims), 1.0 / B, stream()), "vm_ce_smooth_fwd_bwd")
         check(L.vm_ce_smooth_fwd_bwd(ptr(simsT), ptr(labels), B, B, 0.0, ptr(losses[1:2]), ptr(dsimsT), 1.0 / B, stream()), "vm_ce_smooth_fwd_bwd")
         losses = losses / B
-        ctx.save_for_backward(S, a2, x, Wt, Ct, Cn, colstat, cosv, nxv, nw, sims, dsims, dsimsT, lens_dev)
+        ctx.save_for_backward(S, a2, x, Wt, Ct, Ct_B, Ct_Bs, colstat, cosv, nxv, nw, sims, dsims, dsimsT, lens_dev)
         ctx.meta = (B, D, P, T, Tmax, Tp, Pp, Dp, ih, iw, temp1, temp2, temp3)
         ctx.mark_non_differentiable(a2)
         return losses[0], losses[1], a2
 
     @staticmethod
     def backward(ctx, g0, g1, _ga2):
-        S, a2, x, Wt, Ct, Cn, colstat, cosv, nxv, nw, sims, dsims, dsimsT, lens_dev = ctx.saved_tensors
+        S, a2, x, Wt, Ct, Ct_B, Ct_Bs, colstat, cosv, nxv, nw, sims, dsims, dsimsT, lens_dev = ctx.saved_tensors
         B, D, P, T, Tmax, Tp, Pp, Dp, ih, iw, temp1, temp2, temp3 = ctx.meta
         dev = S.device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -315,34 +333,27 @@ class _GloriaLocalFn(torch.autograd.Function):
         dW = torch.empty(B * Tp, Dp, **f32)
         check(L.vm_gloria_cos_bwd(ptr(ds), ptr(dsT), ptr(sims), ptr(cosv), ptr(nxv), ptr(nw), ptr(x), ptr(Wt), Dp, ptr(lens_dev), B, Tp, Dp,
                                   temp2, temp3, 1e-8, ptr(dx), ptr(dW), stream()), "vm_gloria_cos_bwd")
-        # through x_j = a2_j C_j^T:  d a2_j = d x_j C_j ,  d C_j = d x_j^T a2_j
+        # through x_j = a2_j C_j:  d a2_j = d x_j C_j^T  (contraction over the features),  d C_j = a2_j^T d x_j  (over the B*Tp word rows)
+        dx2 = dx.view(B * B * Tp, Dp)
+        dx_A = _split3(dx2, _A, False, Dp).view(B, B * Tp, 3 * Dp)
         da2 = torch.empty(B, B * Tp, Pp, **f32)
-        dxT = torch.empty(B, Dp, B * Tp, **f32)
-        a2T = torch.empty(B, Pp, B * Tp, **f32)
-        _transpose(dx, B * Tp * Dp, Dp, dxT, Dp * B * Tp, B * Tp, B, B * Tp, Dp, Dp, B * Tp)
-        _transpose(a2, B * Tp * Pp, Pp, a2T, Pp * B * Tp, B * Tp, B, B * Tp, Pp, Pp, B * Tp)
-        dCn = torch.empty(B, Dp, Pp, **f32)
-        for j in range(B):
-            _gemm_f32(dx[j], Ct[j], da2[j], B * Tp, Pp, Dp)
-            _gemm_f32(dxT[j], a2T[j], dCn[j], Dp, Pp, B * Tp)
-        del dxT, a2T
+        ops.gemm_grouped([(dx_A[j], Ct_B[j * Pp:(j + 1) * Pp], da2[j], B * Tp, Pp, 3 * Dp) for j in range(B)], 0, 0)
+        del dx_A
+        a2_As = _split3(a2.view(B * B * Tp, Pp), _A, True, B * Tp).view(B, 3 * B * Tp, Pp)
+        dx_Bs = _split3(dx2, _B, True, B * Tp).view(B, 3 * B * Tp, Dp)
+        dCt = torch.empty(B, Pp, Dp, **f32)
+        ops.gemm_grouped([(a2_As[j], dx_Bs[j], dCt[j], Pp, Dp, 3 * B * Tp) for j in range(B)], 1, 1)
+        del a2_As, dx_Bs, dx2, dx
         dS = torch.empty_like(S)
         check(L.vm_gloria_attn_bwd(ptr(S), S.stride(0), ptr(colstat), ptr(da2), ptr(lens_dev), B, Tp, P, Pp, temp1, ptr(dS), stream()),
               "vm_gloria_attn_bwd")
-        # through S = Wt Ct^T:  d Wt += d S Ct ,  d Ct = d S^T Wt
-        CtT = torch.empty(Dp, B * Pp, **f32)
-        _transpose(Ct, 0, Dp, CtT, 0, B * Pp, 1, B * Pp, Dp, Dp, B * Pp)
-        _gemm_f32(dS, CtT, dW, B * Tp, Dp, B * Pp, residual=dW)
-        dST = torch.empty(B * Pp, B * Tp, **f32)
-        _transpose(dS, 0, dS.stride(0), dST, 0, B * Tp, 1, B * Tp, B * Pp, B * Pp, B * Tp)
-        WtT = torch.empty(Dp, B * Tp, **f32)
-        _transpose(Wt, 0, Dp, WtT, 0, B * Tp, 1, B * Tp, Dp, Dp, B * Tp)
-        dCt = torch.empty(B, Pp, Dp, **f32)
-        _gemm_f32(dST, WtT, dCt.view(B * Pp, Dp), B * Pp, Dp, B * Tp)
+        # through S = Wt Ct^T:  d Wt += d S Ct  (over all regions),  d Ct += d S^T Wt  (over all word rows)
+        ops.gemm(_split3(dS, _A, False, B * Pp), 0, _split3(Ct, _B, True, B * Pp), 1, dW, B * Tp, Dp, 3 * B * Pp, accumulate=True)
+        ops.gemm(_split3(dS, _A, True, B * Tp), 1, _split3(Wt, _B, True, B * Tp), 1, dCt.view(B * Pp, Dp), B * Pp, Dp, 3 * B * Tp, accumulate=True)
         # back to the callers' layouts
-        dCt_n = torch.empty(B, Dp, Pp, **f32)
-        _transpose(dCt, Pp * Dp, Dp, dCt_n, Dp * Pp, Pp, B, Pp, Dp, Dp, Pp)
-        d_img = (dCn + dCt_n)[:, :D, :P].reshape(B, D, ih, iw)
+        dCn = torch.empty(B, Dp, Pp, **f32)
+        _transpose(dCt, Pp * Dp, Dp, dCn, Dp * Pp, Pp, B, Pp, Dp, Dp, Pp)
+        d_img = dCn[:, :D, :P].reshape(B, D, ih, iw)
         dWn = torch.empty(B, Dp, Tp, **f32)
         _transpose(dW, Tp * Dp, Dp, dWn, Dp * Tp, Tp, B, Tp, Dp, Dp, Tp)
         d_words = torch.zeros(B, D, T, **f32)

@@ -380,7 +380,53 @@ extern "C" int vm_wgrad_grouped(const vm_wgrad_problem* pr, int n, void* stream)
             tiles += a.tiles_m * a.tiles_n;
         }
         for (int i = ga.n; i <= VM_GEMM_MAX_GROUP; ++i) ga.tile_start[i] = tiles;
-        const int rc = vm_gemm_grouped_tn_launch(ga, tiles, s);
+        const int rc = vm_gemm_grouped_launch(ga, tiles, 1, 1, s);
+        if (rc != VM_OK) return rc;
+    }
+    return VM_OK;
+}
+
+// ------------------------------------------------------------------ independent GEMMs of one layout in one launch
+// C_i[M_i, N_i] (+)= A_i . B_i with a plain epilogue, up to VM_GEMM_MAX_GROUP problems per launch (block -> problem through the
+// prefix sums of the tile counts): 48 per-image products of 72 tiles each (the GLoRIA local loss) fill the chip as 6 launches of
+// 576 tiles instead of 48 launches at 28 % occupancy.
+extern "C" int vm_gemm_grouped(const vm_gemm_problem* pr, int n, int a_layout, int b_layout, int out_dtype, int accumulate, void* stream) {
+    VM_REQUIRE(pr && n > 0, "vm_gemm_grouped: no problems");
+    VM_REQUIRE((out_dtype == VM_F32 || out_dtype == VM_BF16) && (a_layout == 0 || a_layout == 1) && (b_layout == 0 || b_layout == 1), "vm_gemm_grouped: bad flags");
+    hipStream_t s = (hipStream_t)stream;
+    double work = 0;
+    for (int i = 0; i < n; ++i) {
+        const vm_gemm_problem& q = pr[i];
+        VM_REQUIRE(q.A && q.B && q.C && q.M > 0 && q.N > 0 && q.K > 0, "vm_gemm_grouped: bad problem %d", i);
+        if ((q.K % 64) != 0 || (q.lda % 8) != 0 || (q.ldb % 8) != 0 || (q.ldc % 8) != 0 || ((uintptr_t)q.A % 16) != 0 || ((uintptr_t)q.B % 16) != 0 ||
+            ((uintptr_t)q.C % 16) != 0 || (a_layout == 1 && b_layout == 0)) {
+            vm_set_error("vm_gemm_grouped: problem %d is not eligible (K %% 64, leading dims %% 8, 16-byte pointers, layouts NT / NN / TN)", i);
+            return VM_EUNSUPPORTED;
+        }
+        work += 2.0 * q.M * (double)q.N * q.K;
+    }
+    VmProfScope prof(VM_FAM_GEMM, work, s, "grouped_l%d%d_n%d_M%d_N%d_K%d", a_layout, b_layout, n, pr[0].M, pr[0].N, pr[0].K);
+    for (int base = 0; base < n; base += VM_GEMM_MAX_GROUP) {
+        GemmGroupArgs ga = {};
+        ga.n = n - base < VM_GEMM_MAX_GROUP ? n - base : VM_GEMM_MAX_GROUP;
+        int tiles = 0;
+        for (int i = 0; i < ga.n; ++i) {
+            const vm_gemm_problem& q = pr[base + i];
+            GemmArgs& a = ga.g[i];
+            a.A = (const bf16_t*)q.A; a.B = (const bf16_t*)q.B; a.C = q.C;
+            a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc;
+            a.M = q.M; a.N = q.N; a.K = q.K;
+            a.tiles_m = (a.M + 127) / 128; a.tiles_n = (a.N + 127) / 128;
+            a.ktiles = a.K / 64; a.ktiles_per_split = a.ktiles;
+            a.group_w = a.tiles_n;
+            a.e = vm_gemm_epilogue{};
+            a.e.alpha = 1.0f; a.e.out_dtype = out_dtype; a.e.accumulate = accumulate ? 1 : 0; a.e.split_k = 1;
+            a.drop_thresh = 0; a.drop_scale = 1.0f; a.dbg = 0; a.slabs = nullptr; a.bias_grad = nullptr;
+            ga.tile_start[i] = tiles;
+            tiles += a.tiles_m * a.tiles_n;
+        }
+        for (int i = ga.n; i <= VM_GEMM_MAX_GROUP; ++i) ga.tile_start[i] = tiles;
+        const int rc = vm_gemm_grouped_launch(ga, tiles, a_layout, b_layout, s);
         if (rc != VM_OK) return rc;
     }
     return VM_OK;

@@ -21,7 +21,7 @@ struct GemmGroupArgs {
     int tile_start[VM_GEMM_MAX_GROUP + 1];
     GemmArgs g[VM_GEMM_MAX_GROUP];
 };
-int vm_gemm_grouped_tn_launch(const GemmGroupArgs& ga, int nblocks, hipStream_t s);
+int vm_gemm_grouped_launch(const GemmGroupArgs& ga, int nblocks, int a_layout, int b_layout, hipStream_t s);
 
 // tuned path (gemm_fast.hip): requires K % 64 == 0
 int vm_gemm_splitk_reduce(const GemmArgs& a, int nsplit, hipStream_t s);

@@ -633,14 +633,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fas
 // Several independent GEMMs in ONE launch (the weight gradients of a layer): block -> (problem, tile) through the prefix sums
 // of the per-problem tile counts.  Every problem fills whole tiles of the chip, so none of them needs split-K (no fp32 slabs,
 // no reduce kernel), and the workgroups of tile column 0 also produce the bias gradient (no column-sum kernel).
-template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF, int PIPE, int EPI>
+template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF, int PIPE, int EPI, int BG>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_grouped_kernel(const GemmGroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     int gi = 0;
 #pragma unroll
     for (int i = 1; i < VM_GEMM_MAX_GROUP; ++i) if (i < ga.n && bid >= ga.tile_start[i]) gi = i;
-    gemm_fast_body<LA, LB, WM, WN, STAGES, BKT, MF, PIPE, 1, EPI>(ga.g[gi], bid - ga.tile_start[gi], smem);
+    gemm_fast_body<LA, LB, WM, WN, STAGES, BKT, MF, PIPE, BG, EPI>(ga.g[gi], bid - ga.tile_start[gi], smem);
 }
 
 template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF, int PIPE, int EPI>
@@ -731,15 +731,25 @@ void vm_gemm_variant_tile(int variant, int a_layout, int* bm, int* bn) {
 }
 
 
-int vm_gemm_grouped_tn_launch(const GemmGroupArgs& ga, int nblocks, hipStream_t s) {
+template <int LA, int LB, int PIPE, int EPI, int BG>
+static int launch_grouped(const GemmGroupArgs& ga, int nblocks, hipStream_t s) {
     constexpr int LDS = 2 * (128 + 128) * 64 * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<1, 1, 2, 2, 2, 64, 4, 4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<1, 1, 2, 2, 2, 64, 4, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<LA, LB, 2, 2, 2, 64, 4, PIPE, EPI, BG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    if (vm_env().gemm_epi == 0) hipLaunchKernelGGL((gemm_grouped_kernel<1, 1, 2, 2, 2, 64, 4, 4, 0>), dim3(nblocks), dim3(256), LDS, s, ga);
-    else hipLaunchKernelGGL((gemm_grouped_kernel<1, 1, 2, 2, 2, 64, 4, 4, 1>), dim3(nblocks), dim3(256), LDS, s, ga);
-    return vm_check_launch("vm_wgrad_grouped");
+    hipLaunchKernelGGL((gemm_grouped_kernel<LA, LB, 2, 2, 2, 64, 4, PIPE, EPI, BG>), dim3(nblocks), dim3(256), LDS, s, ga);
+    return vm_check_launch("vm_gemm_grouped");
+}
+
+// 128 x 128 tiles.  TN (both operands contraction-major): the weight-gradient form, with the bias-gradient MFMAs compiled in (BG);
+// NT / NN: independent problems of one layout in one launch (vm_gemm_grouped: the per-image products of the GLoRIA local loss).
+int vm_gemm_grouped_launch(const GemmGroupArgs& ga, int nblocks, int a_layout, int b_layout, hipStream_t s) {
+    if (a_layout == 1 && b_layout == 1)
+        return vm_env().gemm_epi == 0 ? launch_grouped<1, 1, 4, 0, 1>(ga, nblocks, s) : launch_grouped<1, 1, 4, 1, 1>(ga, nblocks, s);
+    if (a_layout == 0 && b_layout == 0) return launch_grouped<0, 0, 1, 0, 0>(ga, nblocks, s);
+    if (a_layout == 0 && b_layout == 1) return launch_grouped<0, 1, 4, 0, 0>(ga, nblocks, s);
+    vm_set_error("vm_gemm_grouped: layout (a=%d, b=%d) has no grouped kernel", a_layout, b_layout);
+    return VM_EUNSUPPORTED;
 }

@@ -3,11 +3,11 @@
 // over captions in Python, repeats each caption B times and runs two torch.bmm + two softmax + a cosine per caption).
 //
 // Per pair, with W = the caption's word embeddings [T_i, D] and C = the image's region features [D, P]:
-//     S[t,p]  = <W_t, C_p>                                   (one fp32 GEMM for all pairs: vm_gemm_f32, exact f32 MFMA)
+//     S[t,p]  = <W_t, C_p>                                   (one GEMM for all pairs; "bf16 x 3" operands, see vm_split3_bf16)
 //     a1[t,p] = softmax over the caption's words t of S[.,p]            \
 //     a2[t,p] = softmax over the regions p of temp1 * a1[t,.]            > gloria_attn_fwd_kernel (this file)
 //     dot[t]  = sum_p a2[t,p] S[t,p] = <W_t, x_t>                       /
-//     x_t     = sum_p a2[t,p] C_p    (attention-weighted context)        (vm_gemm_f32 per image)
+//     x_t     = sum_p a2[t,p] C_p    (attention-weighted context)        (one GEMM per image)
 //     cos[t]  = dot[t] / max(|W_t| |x_t|, eps);  sims[j,i] = temp3 * log sum_t exp(temp2 cos[t])      gloria_cos_fwd_kernel
 // followed by a cross-entropy over sims and sims^T (vm_ce_smooth_fwd_bwd, smoothing 0).  The backward pass mirrors it:
 // gloria_cos_bwd_kernel (d cos -> d dot, d x, the first half of d W), two GEMMs per image, gloria_attn_bwd_kernel (both softmax
@@ -52,6 +52,52 @@ extern "C" int vm_transpose_f32(const float* src, int64_t src_batch_stride, int6
     hipLaunchKernelGGL(transpose_f32_kernel, dim3((dst_cols + 31) / 32, (dst_rows + 31) / 32, batch), dim3(256), 0, s, src, src_batch_stride, ld_src,
                        dst, dst_batch_stride, ld_dst, rows, cols, dst_rows, dst_cols);
     return vm_check_launch("vm_transpose_f32");
+}
+
+// ------------------------------------------------------------------ fp32 -> three bf16 operand parts ("bf16 x 3" products)
+// The contractions of this loss need fp32-grade accuracy (see the header) but are 0.5 TFLOP per step at B = 48: on the f32 MFMA
+// (1/16 of the bf16 rate) they would dominate the GLoRIA step.  Instead every fp32 operand is split a = hi + lo with hi = bf16(a),
+// lo = bf16(a - hi) (a - hi is exact in fp32), and a . b ~= hi_a hi_b + hi_a lo_b + lo_a hi_b (the dropped lo_a lo_b term is 2^-18 of
+// the product, the parts themselves carry 16 mantissa bits): ONE bf16 MFMA GEMM (vm_gemm_bf16, fp32 accumulate and output) with the
+// contraction three times as long, A-side parts (hi, hi, lo), B-side parts (hi, lo, hi).  This kernel lays the parts out next to each
+// other along the contraction axis: along the columns (cat: [rows, 3 cols], operands stored contraction-contiguous) or along the
+// rows (stack: [3 rows, cols], operands stored contraction-major), in blocks of ``block`` (the contraction length of one GEMM call,
+// so that per-image sub-matrices stay contiguous: block b occupies [3 b block, 3 (b+1) block)).
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, int64_t ld_src, int rows, int cols, bf16_t* __restrict__ dst,
+                                                     int64_t ld_dst, int role, int along_rows, int block) {
+    const int c4n = cols >> 2;
+    const int64_t total = (int64_t)rows * c4n;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int r = (int)(idx / c4n), c = (int)(idx % c4n) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)r * ld_src + c);
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        float hi[4], lo[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { hi[k] = bf16_to_f32(f32_to_bf16(f[k])); lo[k] = f[k] - hi[k]; }
+        uint2 H, Lw;
+        H.x = pack_bf16x2(hi[0], hi[1]); H.y = pack_bf16x2(hi[2], hi[3]);
+        Lw.x = pack_bf16x2(lo[0], lo[1]); Lw.y = pack_bf16x2(lo[2], lo[3]);
+        const uint2 part1 = role == 0 ? H : Lw, part2 = role == 0 ? Lw : H;       // A: (hi, hi, lo)   B: (hi, lo, hi)
+        int64_t o0, step;
+        if (along_rows) { o0 = ((int64_t)(r / block) * 3 * block + (r % block)) * ld_dst + c; step = (int64_t)block * ld_dst; }
+        else { o0 = (int64_t)r * ld_dst + (int64_t)(c / block) * 3 * block + (c % block); step = block; }
+        *reinterpret_cast<uint2*>(dst + o0) = H;
+        *reinterpret_cast<uint2*>(dst + o0 + step) = part1;
+        *reinterpret_cast<uint2*>(dst + o0 + 2 * step) = part2;
+    }
+}
+extern "C" int vm_split3_bf16(const float* src, int64_t ld_src, int rows, int cols, void* dst, int64_t ld_dst, int role, int along_rows, int block,
+                              void* stream) {
+    VM_REQUIRE(src && dst && rows > 0 && cols > 0 && (cols % 4) == 0 && (ld_src % 4) == 0 && (ld_dst % 4) == 0 && block > 0,
+               "vm_split3_bf16: bad arguments");
+    VM_REQUIRE((role == 0 || role == 1) && (along_rows ? rows % block == 0 : (cols % block == 0 && block % 4 == 0)),
+               "vm_split3_bf16: the split axis must be a multiple of block=%d (rows=%d cols=%d)", block, rows, cols);
+    hipStream_t s = (hipStream_t)stream;
+    VmProfScope prof(VM_FAM_ELT, 10.0 * rows * (double)cols, s);
+    const int64_t total = (int64_t)rows * (cols / 4);
+    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256), 0, s, src, ld_src, rows, cols,
+                       (bf16_t*)dst, ld_dst, role, along_rows, block);
+    return vm_check_launch("vm_split3_bf16");
 }
 
 // ------------------------------------------------------------------ |row| of an fp32 matrix (one wave per row)

@@ -85,6 +85,23 @@ def gemm(A, a_layout, B, b_layout, C_out, M, N, K, *, lda=None, ldb=None, ldc=No
     return C_out
 
 
+def gemm_grouped(problems, a_layout, b_layout, accumulate=False):
+    """[(A, B, C_out, M, N, K), ...] independent products of one layout, 8 per launch (vm_gemm_grouped); shapes the grouped kernels
+    cannot take (K % 64, alignment) run as single vm_gemm_bf16 launches instead"""
+    arr = (_lib.GemmProblem * len(problems))()
+    ok = True
+    for q, (A, B, Cm, M, N, K) in zip(arr, problems):
+        q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K = A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), Cm.data_ptr(), Cm.stride(0), M, N, K
+        ok = ok and K % 64 == 0 and A.stride(0) % 8 == 0 and B.stride(0) % 8 == 0 and Cm.stride(0) % 8 == 0 and not (a_layout == 1 and b_layout == 0) \
+            and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0 and Cm.data_ptr() % 16 == 0
+    if ok:
+        out = VM_F32 if problems[0][2].dtype == torch.float32 else VM_BF16
+        check(lib().vm_gemm_grouped(arr, len(problems), a_layout, b_layout, out, int(accumulate), stream()), "vm_gemm_grouped")
+    else:
+        for A, B, Cm, M, N, K in problems:
+            gemm(A, a_layout, B, b_layout, Cm, M, N, K, accumulate=accumulate)
+
+
 _ws_cache = {}
 
 
