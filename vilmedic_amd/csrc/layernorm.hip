@@ -223,7 +223,7 @@ static int ln_grid(int rows, int cap) {
     return blocks;
 }
 #define LN_FWD_CAP 16384
-// backward grid: 512 workgroups (2 per CU) -- tools/ln_bench.py sweep (profiles/r02_h_layernorm_sweep.txt): 19.4 / 15.1 us for the
+// backward grid: 512 workgroups (2 per CU) -- tools/ln_bench.py sweep (profiles/r02_h_layernorm_sweep_and_stream_experiments.txt): 19.4 / 15.1 us for the
 // ViT / decoder shapes against 22.2 / 16.5 us at 1024 (whose second round of workgroups is a third full), and half the slabs to reduce
 #define LN_BWD_CAP 512
 
