@@ -251,7 +251,7 @@ def main():
 
     # The model, its arena and the optimizer state are allocated BEFORE the RCCL communicator exists: on this stack
     # (ROCm 7.0 / RCCL 2.26, dmabuf IPC) device memory allocated after init_process_group made every step 5.6 ms slower
-    # (tools/dbg/init_order.py: 35.65 vs 30.02 ms/step on one GPU with a 1-rank group).
+    # (measured in round 1: 35.65 vs 30.02 ms/step on one GPU with a 1-rank group).
     model = build_model(device)
     model.train()
     ops.manual_seed(1234 + rank)

@@ -198,17 +198,11 @@ int vm_ce_smooth_fwd_bwd(const float* logits, const int64_t* target, int R, int 
  * the pieces around it.  Row i pairs with column i + diag_offset (local rows of a rank vs all gathered columns). */
 int vm_rownorm_cast(const float* x /* [rows,D] */, void* out_bf16, float* norms /* [rows] or NULL */, int rows, int D,
                     int normalize /* 1: x/max(|x|,eps) (ConVIRT cosine)  0: plain cast (InfoNCE) */, float eps, void* stream);
-int vm_lse_rows_f32(const float* S, int64_t ld, float* lse /* [rows] */, float* diag /* [rows] or NULL */, int rows, int cols,
-                    int diag_offset, void* stream);
-int vm_lse_cols_f32(const float* S, int64_t ld, float* lse /* [cols] */, int rows, int cols, void* stream);
-/* G[i,j] = g_rows[i] softmax_row(S)[i,j] + g_cols[j] softmax_col(S)[i,j] - [j == i+diag_offset] (g_rows[i] + g_cols[j])  (bf16) */
-int vm_contrastive_grad(const float* S, int64_t ld, const float* lse_rows, const float* lse_cols, const float* g_rows,
-                        const float* g_cols, void* G_bf16, int64_t ldg, int rows, int cols, int diag_offset, void* stream);
-
-/* Fused form (the similarity matrix never reaches HBM): a_hat [R,D], b_hat [C,D] bf16 = the outputs of vm_rownorm_cast.
+/* The similarity matrix never reaches HBM: a_hat [R,D], b_hat [C,D] bf16 = the outputs of vm_rownorm_cast.
  * vm_contrastive_fwd: lse_rows[i] = log sum_j exp(S_ij), lse_cols[j] = log sum_i exp(S_ij), diag[i] = S_{i, i+diag_offset} with
  *   S = a_hat b_hat^T * inv_tau computed tile by tile on the MFMA and reduced in LDS (ws: vm_contrastive_ws(R, C) bytes of partials).
- * vm_contrastive_bwd: G (bf16 [R, ldg]) as vm_contrastive_grad, from recomputed tiles.  dA_hat = G b_hat * inv_tau and
+ * vm_contrastive_bwd: G[i,j] = g_rows[i] softmax_row(S)[i,j] + g_cols[j] softmax_col(S)[i,j] - [j == i+diag_offset] (g_rows[i] + g_cols[j])
+ *   (bf16 [R, ldg]) from recomputed tiles.  dA_hat = G b_hat * inv_tau and
  *   dB_hat = G^T a_hat * inv_tau are two vm_gemm_bf16 calls on G. */
 size_t vm_contrastive_ws(int R, int C);
 int vm_contrastive_fwd(const void* a_hat, const void* b_hat, int R, int C, int D, float inv_tau, int diag_offset,

@@ -82,9 +82,6 @@ SIGNATURES = {
     "vm_gloria_attn_bwd": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P]),
     "vm_ce_smooth_fwd_bwd": (_I, [_P, _P, _I, _I, _F, _P, _P, _F, _P]),
     "vm_rownorm_cast": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
-    "vm_lse_rows_f32": (_I, [_P, _L, _P, _P, _I, _I, _I, _P]),
-    "vm_lse_cols_f32": (_I, [_P, _L, _P, _I, _I, _P]),
-    "vm_contrastive_grad": (_I, [_P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "vm_contrastive_ws": (_SZ, [_I, _I]),
     "vm_contrastive_fwd": (_I, [_P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P, _SZ, _P]),
     "vm_contrastive_bwd": (_I, [_P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _L, _P]),

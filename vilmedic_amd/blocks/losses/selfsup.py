@@ -2,14 +2,12 @@
 
 ref: vilmedic/blocks/losses/selfsup/ConVIRTLoss.py:5-38, InfoNCELoss.py:5-24, GLoRIALoss.py:5-170.
 
-The [B,B] similarity is one bf16 MFMA GEMM with fp32 output (alpha = 1/tau); row / column log-sum-exp, the diagonal
-and the gradient matrix G are produced by the kernels in csrc/contrastive.hip; dA = G B / tau and dB = G^T A / tau are
-two more GEMMs.  When torch.distributed is initialised with world_size > 1 the text / image embeddings are
+The [B,B] similarity S = n(a) n(b)^T / tau is computed tile by tile on the MFMA and never reaches HBM: row / column
+log-sum-exp and the diagonal in the forward pass, the gradient matrix G from recomputed tiles in the backward pass
+(csrc/contrastive.hip); dA = G B / tau and dB = G^T A / tau are two GEMMs.  When torch.distributed is initialised with world_size > 1 the text / image embeddings are
 all-gathered first (RCCL), so every rank sees the GLOBAL batch of negatives (SURVEY §8e -- a capability the reference
 lacks: under DDP it contrasts within the local shard only, conVIRT.py:97-100).
 """
-import os
-
 import torch
 import torch.nn as nn
 
@@ -17,7 +15,6 @@ from ... import ops
 from ..._lib import check, lib, ptr, stream
 
 BF16 = torch.bfloat16
-FUSED = os.environ.get("VM_CONTRASTIVE_FUSED", "1") != "0"     # 0: the round-1 path (S materialised in fp32, three scalar passes) for A/B
 
 
 def _pad8(n):
@@ -47,27 +44,20 @@ class _SimilarityLossFn(torch.autograd.Function):
         lse_c = torch.empty(Cn, dtype=torch.float32, device=dev)
         diag = torch.empty(R, dtype=torch.float32, device=dev)
         n = min(R, Cn)
-        if FUSED:       # S tile by tile on the MFMA, reduced in LDS: the [R, C] matrix never reaches HBM
-            ws = torch.empty(L.vm_contrastive_ws(R, Cn), dtype=torch.uint8, device=dev)
-            if n < R:
-                diag.zero_()
-            check(L.vm_contrastive_fwd(ptr(ah), ptr(bh), R, Cn, D, inv_tau, 0, ptr(lse_r), ptr(lse_c), ptr(diag), ptr(ws), ws.numel(), stream()),
-                  "vm_contrastive_fwd")
-            S, ldS = None, 0
-        else:
-            ldS = (Cn + 3) // 4 * 4
-            S = torch.empty(R, ldS, dtype=torch.float32, device=dev)
-            ops.gemm(ah, 0, bh, 0, S, R, Cn, D, alpha=inv_tau)
-            check(L.vm_lse_rows_f32(ptr(S), ldS, ptr(lse_r), ptr(diag), R, Cn, 0, stream()), "vm_lse_rows_f32")
-            check(L.vm_lse_cols_f32(ptr(S), ldS, ptr(lse_c), R, Cn, stream()), "vm_lse_cols_f32")
-        ctx.save_for_backward(a32, b32, ah, bh, na, nb, S, lse_r, lse_c)
-        ctx.meta = (normalize, inv_tau, eps, R, Cn, D, ldS)
+        # S tile by tile on the MFMA, reduced in LDS: the [R, C] matrix never reaches HBM
+        ws = torch.empty(L.vm_contrastive_ws(R, Cn), dtype=torch.uint8, device=dev)
+        if n < R:
+            diag.zero_()
+        check(L.vm_contrastive_fwd(ptr(ah), ptr(bh), R, Cn, D, inv_tau, 0, ptr(lse_r), ptr(lse_c), ptr(diag), ptr(ws), ws.numel(), stream()),
+              "vm_contrastive_fwd")
+        ctx.save_for_backward(a32, b32, ah, bh, na, nb, lse_r, lse_c)
+        ctx.meta = (normalize, inv_tau, eps, R, Cn, D)
         return lse_r[:n] - diag[:n], lse_c[:n] - diag[:n]
 
     @staticmethod
     def backward(ctx, g_row, g_col):
-        a32, b32, ah, bh, na, nb, S, lse_r, lse_c = ctx.saved_tensors
-        normalize, inv_tau, eps, R, Cn, D, ldS = ctx.meta
+        a32, b32, ah, bh, na, nb, lse_r, lse_c = ctx.saved_tensors
+        normalize, inv_tau, eps, R, Cn, D = ctx.meta
         dev = ah.device
         gr = torch.zeros(R, dtype=torch.float32, device=dev)
         gc = torch.zeros(Cn, dtype=torch.float32, device=dev)
@@ -76,12 +66,8 @@ class _SimilarityLossFn(torch.autograd.Function):
         gc[:n] = g_col.float()
         ldg = _pad8(Cn)
         G = torch.zeros(_pad8(R), ldg, dtype=BF16, device=dev)
-        if S is None:   # fused: G from recomputed tiles
-            check(lib().vm_contrastive_bwd(ptr(ah), ptr(bh), R, Cn, D, inv_tau, 0, ptr(lse_r), ptr(lse_c), ptr(gr), ptr(gc), ptr(G), ldg,
-                                           stream()), "vm_contrastive_bwd")
-        else:
-            check(lib().vm_contrastive_grad(ptr(S), ldS, ptr(lse_r), ptr(lse_c), ptr(gr), ptr(gc), ptr(G), ldg, R, Cn, 0, stream()),
-                  "vm_contrastive_grad")
+        check(lib().vm_contrastive_bwd(ptr(ah), ptr(bh), R, Cn, D, inv_tau, 0, ptr(lse_r), ptr(lse_c), ptr(gr), ptr(gc), ptr(G), ldg,
+                                       stream()), "vm_contrastive_bwd")          # G from recomputed tiles
         dah = torch.empty(R, D, dtype=torch.float32, device=dev)
         dbh = torch.empty(Cn, D, dtype=torch.float32, device=dev)
         ops.gemm(G, 0, bh, 1, dah, R, D, ldg, alpha=inv_tau)            # dA^ = G B^ / tau      (contraction over columns)

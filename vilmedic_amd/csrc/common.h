@@ -126,7 +126,6 @@ static inline uint32_t dropout_thresh16(float p) { return (uint32_t)((double)p *
 struct VmEnv {
     int gemm_variant;      // VM_GEMM_VARIANT: force a tile variant (-1: cost model)
     int gemm_debug;        // VM_GEMM_DEBUG: 1 skip the epilogue, 2 one K-tile only (timing breakdowns)
-    int gemm_epi;          // VM_GEMM_EPI: 0 = LDS-staged epilogue (default), 1 = register-direct epilogue (measured 0.88-1.06x: profiles/r02_d_*)
     int gemm_groupw;       // VM_GEMM_GROUPW: column-group width of the tile order (0: heuristic)
     bool gemm_generic;     // VM_GEMM_GENERIC: register-staged fallback kernel only
     bool gemm_no_skinny;   // VM_GEMM_NO_SKINNY: never take the M <= 128 decode-step kernel

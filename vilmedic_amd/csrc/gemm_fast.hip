@@ -78,7 +78,7 @@ __device__ __forceinline__ void glds16_asm(const bf16_t* src, char* lds_dst) {
 //                      BG   = 1: the workgroups of tile column 0 also produce the bias gradient sum_k A(m, k) (one extra MFMA per A
 //                             fragment against an all-ones B fragment) -- the grouped weight-gradient launch
 // ``bid`` = logical work item (XCD-remapped by the caller): split * tiles + tile
-template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF, int PIPE, int BG, int EPI>
+template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF, int PIPE, int BG>
 __device__ __forceinline__ void gemm_fast_body(const GemmArgs& p, const int bid, char* smem) {
     constexpr int WR = MF * 16;                     // rows per wave (MF 16-row A fragments; 4 or 5)
     constexpr int FBM = WM * WR, FBN = WN * 64, NW = WM * WN, NT = NW * 64;
@@ -371,120 +371,6 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs& p, const int bid,
             }
         }
     }
-    if constexpr (EPI == 1) {
-        // ---- register-direct epilogue (no LDS staging, no workgroup barriers: every wave finishes on its own).
-        // In the D^T layout lane (c, g) holds, for n-fragment j, the 4 columns 16 j + 4 g .. + 3 of row c.  One v_permlane16_swap
-        // per register between the fragments of a pair (j0, j0 + 1) turns that into 8 CONSECUTIVE columns per lane:
-        //   16-lane row g of the wave ends with fragment j0 + (g & 1), columns 8 (g >> 1) .. + 7
-        // so a lane owns one 16-B bf16 piece, a store instruction covers 16 rows x 64 B, and the two instructions of a fragment
-        // pair fill whole 128-B lines; the per-element operands (residual, z) are read in exactly that pattern.
-        const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(e.mul_gelu_z);
-        const bf16_t* rsrc = reinterpret_cast<const bf16_t*>(e.residual);
-        const DropKey dkey = drop_key(eff_seed(e.dropout_seed, e.dropout_seed_dev));
-        const int colbase = n0 + wn * 64 + 16 * (g & 1) + 8 * (g >> 1);          // + 32 * jp
-        const int rowbase = m0 + wm * WR + c;                                    // + 16 * i
-        float bias8[2][8];
-#pragma unroll
-        for (int jp = 0; jp < 2; ++jp)
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int col = colbase + 32 * jp + r;
-                bias8[jp][r] = (e.bias && col < p.N) ? e.bias[col] : 0.f;
-            }
-        // per-element operands are requested a group of PFG row-fragments ahead of their use (the whole wave tile for the 4- / 5-
-        // fragment tiles; two at a time for the 8-fragment tile, whose 128 accumulator registers leave no room for more)
-        constexpr int PFG = MF <= 5 ? MF : 2;
-        static_assert(MF % PFG == 0, "operand prefetch groups");
-#pragma unroll
-        for (int i0 = 0; i0 < MF; i0 += PFG) {
-        uint4 zq[PFG][2], rq[PFG][2];
-#pragma unroll
-        for (int ii = 0; ii < PFG; ++ii)
-#pragma unroll
-            for (int jp = 0; jp < 2; ++jp) {
-                const int gm = min(rowbase + 16 * (i0 + ii), p.M - 1);
-                const int gn = min(colbase + 32 * jp, ((p.N - 1) >> 3) << 3);
-                if (zsrc) zq[ii][jp] = *reinterpret_cast<const uint4*>(zsrc + (int64_t)gm * p.ldc + gn);
-                if (rsrc) rq[ii][jp] = *reinterpret_cast<const uint4*>(rsrc + (int64_t)gm * e.ldr + gn);
-            }
-#pragma unroll
-        for (int ii = 0; ii < PFG; ++ii)
-#pragma unroll
-            for (int jp = 0; jp < 2; ++jp) {
-                const int i = i0 + ii;
-                float v[8];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * jp][i][r]), __float_as_uint(acc[2 * jp + 1][i][r]), false, false);
-                    v[r] = __uint_as_float(sw[0]) * alpha;
-                    v[4 + r] = __uint_as_float(sw[1]) * alpha;
-                }
-                const int gm = rowbase + 16 * i, gn = colbase + 32 * jp;
-                if (gm >= p.M || gn >= p.N) continue;
-                const int nvalid = min(8, p.N - gn);
-                const bool vec = nvalid == 8;
-                const int64_t off = (int64_t)gm * p.ldc + gn;
-                if (p.dbg == 3) { if (v[0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = v[0]; continue; }
-                if (p.slabs) {
-                    float* sp = p.slabs + (int64_t)split * p.M * p.ldc + off;
-                    if (vec) {
-                        *reinterpret_cast<float4*>(sp) = make_float4(v[0], v[1], v[2], v[3]);
-                        *reinterpret_cast<float4*>(sp + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                    } else for (int r = 0; r < nvalid; ++r) sp[r] = v[r];
-                    continue;
-                }
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] += bias8[jp][r];
-                if (e.aux_out) {
-                    bf16_t* z = reinterpret_cast<bf16_t*>(e.aux_out) + off;
-                    if (vec) st16(z, pack8(v));
-                    else for (int r = 0; r < nvalid; ++r) z[r] = f32_to_bf16(v[r]);
-                }
-                if (e.act == 1) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
-                }
-                if (zsrc) {
-                    float zf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (vec) unpack8(zq[ii][jp], zf);
-                    else for (int r = 0; r < nvalid; ++r) zf[r] = bf16_to_f32(zsrc[off + r]);
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] *= gelu_grad_f(zf[r]);
-                }
-                if (e.dropout_p > 0.f) {
-                    bool keep[8];
-                    dropout_keep_n<8>(dkey, (uint64_t)gm * (uint64_t)p.N + (uint64_t)gn, p.drop_thresh, keep);
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] = keep[r] ? v[r] * p.drop_scale : 0.f;
-                }
-                if (rsrc) {
-                    float rf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (vec) unpack8(rq[ii][jp], rf);
-                    else for (int r = 0; r < nvalid; ++r) rf[r] = bf16_to_f32(rsrc[(int64_t)gm * e.ldr + gn + r]);
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] += rf[r];
-                }
-                if (e.out_dtype == VM_BF16) {
-                    bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + off;
-                    if (vec) st16(cp, pack8(v));
-                    else for (int r = 0; r < nvalid; ++r) cp[r] = f32_to_bf16(v[r]);
-                } else {
-                    float* cp = reinterpret_cast<float*>(p.C) + off;
-                    if (e.accumulate) {
-                        if (vec) {
-                            const float4 o0 = *reinterpret_cast<float4*>(cp), o1 = *reinterpret_cast<float4*>(cp + 4);
-                            *reinterpret_cast<float4*>(cp) = make_float4(o0.x + v[0], o0.y + v[1], o0.z + v[2], o0.w + v[3]);
-                            *reinterpret_cast<float4*>(cp + 4) = make_float4(o1.x + v[4], o1.y + v[5], o1.z + v[6], o1.w + v[7]);
-                        } else for (int r = 0; r < nvalid; ++r) cp[r] += v[r];
-                    } else if (vec) {
-                        *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-                        *reinterpret_cast<float4*>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                    } else for (int r = 0; r < nvalid; ++r) cp[r] = v[r];
-                }
-            }
-        }   // operand prefetch groups
-        return;
-    }
     float* cs = reinterpret_cast<float*>(smem);     // [RPP][FBN] fp32, 16-B chunks XOR-swizzled by row
     constexpr int RING_BYTES = STAGES * F_STAGE;
     constexpr int LDS_BYTES = RING_BYTES >= WR * FBN * 4 ? RING_BYTES : WR * FBN * 4;   // at least one wave-row of fp32 staging
@@ -624,35 +510,35 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {       // hardware 
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
 
-template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF, int PIPE, int EPI>
+template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF, int PIPE>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_fast_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_fast_body<LA, LB, WM, WN, STAGES, BKT, MF, PIPE, 0, EPI>(p, xcd_remap(blockIdx.x, gridDim.x), smem);
+    gemm_fast_body<LA, LB, WM, WN, STAGES, BKT, MF, PIPE, 0>(p, xcd_remap(blockIdx.x, gridDim.x), smem);
 }
 
 // Several independent GEMMs in ONE launch (the weight gradients of a layer): block -> (problem, tile) through the prefix sums
 // of the per-problem tile counts.  Every problem fills whole tiles of the chip, so none of them needs split-K (no fp32 slabs,
 // no reduce kernel), and the workgroups of tile column 0 also produce the bias gradient (no column-sum kernel).
-template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF, int PIPE, int EPI, int BG>
+template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF, int PIPE, int BG>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? 2 : 1) void gemm_grouped_kernel(const GemmGroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     int gi = 0;
 #pragma unroll
     for (int i = 1; i < VM_GEMM_MAX_GROUP; ++i) if (i < ga.n && bid >= ga.tile_start[i]) gi = i;
-    gemm_fast_body<LA, LB, WM, WN, STAGES, BKT, MF, PIPE, BG, EPI>(ga.g[gi], bid - ga.tile_start[gi], smem);
+    gemm_fast_body<LA, LB, WM, WN, STAGES, BKT, MF, PIPE, BG>(ga.g[gi], bid - ga.tile_start[gi], smem);
 }
 
-template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF, int PIPE, int EPI>
+template <int LA, int LB, int WM, int WN, int STAGES, int BKT, int MF, int PIPE>
 static int launch_fast(const GemmArgs& a, int nblocks, hipStream_t s) {
     constexpr int RING = STAGES * (WM * MF * 16 + WN * 64) * BKT * 2, STAGE_MIN = MF * 16 * WN * 64 * 4;
-    constexpr int LDS = (EPI == 1 || RING >= STAGE_MIN) ? RING : STAGE_MIN;
+    constexpr int LDS = RING >= STAGE_MIN ? RING : STAGE_MIN;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<LA, LB, WM, WN, STAGES, BKT, MF, PIPE, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<LA, LB, WM, WN, STAGES, BKT, MF, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_fast_kernel<LA, LB, WM, WN, STAGES, BKT, MF, PIPE, EPI>), dim3(nblocks), dim3(WM * WN * 64), LDS, s, a);
+    hipLaunchKernelGGL((gemm_fast_kernel<LA, LB, WM, WN, STAGES, BKT, MF, PIPE>), dim3(nblocks), dim3(WM * WN * 64), LDS, s, a);
     return vm_check_launch("vm_gemm_bf16(fast)");
 }
 
@@ -691,7 +577,7 @@ int vm_gemm_splitk_reduce(const GemmArgs& a, int nsplit, hipStream_t s) {
 
 // Tile variants (the host's cost model picks 0 or 4 per launch; VM_GEMM_VARIANT forces one):
 //   0: 128 x 128, 4 waves of 64 x 64, two workgroups per CU      4: 160 x 128 (5 A fragments per wave), row-major A only
-//   1: 256 x 128, 8 waves, 3-stage ring (huge square problems)   8: 256 x 256, 8 waves of 128 x 64, one workgroup per CU (EXPERIMENT)
+//   1: 256 x 128, 8 waves, 3-stage ring (huge square problems)
 // Main loop per operand layout: row-major x row-major runs the software-pipelined K-tile (PIPE 1); every launch with a strided
 // operand (dgrad, wgrad) runs the cross-tile register pipeline with the inline-asm LDS-DMA (PIPE 4, see glds16_asm).
 // Measured and dropped -- round 1: 128 x 128 with k-tile 32 x 4-stage ring, 256 x 128 with 128 x 64 per wave, DMA pieces issued from
@@ -699,57 +585,51 @@ int vm_gemm_splitk_reduce(const GemmArgs& a, int nsplit, hipStream_t s) {
 // 128 x 64 per wave on that ring 0.51-0.98x, s_setprio around the MFMA stream 0.83-1.0x (profiles/r02_a_gemm_candidates_ab.txt); PIPE 4 for
 // row-major operands 0.87-1.05x, DMA pieces slotted one per MFMA = burst (profiles/r02_b_gemm_pipe4_asmdma_ab.txt); late start of the
 // second workgroup of a CU 0.83-1.0x (profiles/r02_c_gemm_stagger_and_epilogue_breakdown.txt); the 16-wave 256 x 256 tile (45 spills);
-// a resident grid of 512 workgroups walking the tiles instead of one workgroup per tile 0.87-1.05x (profiles/r02_e_gemm_persist_ab.txt).
-template <int EPI>
-static int dispatch_epi(const GemmArgs& a0, int a_layout, int b_layout, int nblocks, int variant, hipStream_t s) {
-    if (variant == 8 && a_layout == 0)
-        return b_layout == 0 ? launch_fast<0, 0, 2, 4, 2, 64, 8, 4, 1>(a0, nblocks, s) : launch_fast<0, 1, 2, 4, 2, 64, 8, 4, 1>(a0, nblocks, s);
-    if (variant == 4 && a_layout == 0)
-        return b_layout == 0 ? launch_fast<0, 0, 2, 2, 2, 64, 5, 1, EPI>(a0, nblocks, s) : launch_fast<0, 1, 2, 2, 2, 64, 5, 4, EPI>(a0, nblocks, s);
-    if (a_layout == 0 && b_layout == 0) return launch_fast<0, 0, 2, 2, 2, 64, 4, 1, EPI>(a0, nblocks, s);
-    if (a_layout == 0 && b_layout == 1) return launch_fast<0, 1, 2, 2, 2, 64, 4, 4, EPI>(a0, nblocks, s);
-    if (a_layout == 1 && b_layout == 0) return launch_fast<1, 0, 2, 2, 2, 64, 4, 4, EPI>(a0, nblocks, s);
-    return launch_fast<1, 1, 2, 2, 2, 64, 4, 4, EPI>(a0, nblocks, s);
-}
-
+// a resident grid of 512 workgroups walking the tiles instead of one workgroup per tile 0.87-1.05x (profiles/r02_e_gemm_persist_ab.txt);
+// a register-direct epilogue (v_permlane16_swap to 8 consecutive columns per lane, no LDS staging, no barriers) 0.88-1.06x and the 8-wave
+// 256 x 256 tile (128 x 64 per wave, one workgroup per CU) 0.80-1.02x (profiles/r02_d_gemm_register_epilogue_ab.txt); forced column-group
+// widths of the tile order 0.85-1.03x (profiles/r02_k_gemm_groupw_ab.txt).  None of that code is kept.
 int vm_gemm_fast_dispatch(const GemmArgs& a0, int a_layout, int b_layout, int nblocks, int variant, hipStream_t s) {
     if (variant == 1) {
-        if (a_layout == 0 && b_layout == 0) return launch_fast<0, 0, 4, 2, 3, 64, 4, 0, 0>(a0, nblocks, s);
-        if (a_layout == 0 && b_layout == 1) return launch_fast<0, 1, 4, 2, 3, 64, 4, 0, 0>(a0, nblocks, s);
-        if (a_layout == 1 && b_layout == 0) return launch_fast<1, 0, 4, 2, 3, 64, 4, 0, 0>(a0, nblocks, s);
-        return launch_fast<1, 1, 4, 2, 3, 64, 4, 0, 0>(a0, nblocks, s);
+        if (a_layout == 0 && b_layout == 0) return launch_fast<0, 0, 4, 2, 3, 64, 4, 0>(a0, nblocks, s);
+        if (a_layout == 0 && b_layout == 1) return launch_fast<0, 1, 4, 2, 3, 64, 4, 0>(a0, nblocks, s);
+        if (a_layout == 1 && b_layout == 0) return launch_fast<1, 0, 4, 2, 3, 64, 4, 0>(a0, nblocks, s);
+        return launch_fast<1, 1, 4, 2, 3, 64, 4, 0>(a0, nblocks, s);
     }
-    return vm_env().gemm_epi == 0 ? dispatch_epi<0>(a0, a_layout, b_layout, nblocks, variant, s)
-                                  : dispatch_epi<1>(a0, a_layout, b_layout, nblocks, variant, s);
+    if (variant == 4 && a_layout == 0)
+        return b_layout == 0 ? launch_fast<0, 0, 2, 2, 2, 64, 5, 1>(a0, nblocks, s) : launch_fast<0, 1, 2, 2, 2, 64, 5, 4>(a0, nblocks, s);
+    if (a_layout == 0 && b_layout == 0) return launch_fast<0, 0, 2, 2, 2, 64, 4, 1>(a0, nblocks, s);
+    if (a_layout == 0 && b_layout == 1) return launch_fast<0, 1, 2, 2, 2, 64, 4, 4>(a0, nblocks, s);
+    if (a_layout == 1 && b_layout == 0) return launch_fast<1, 0, 2, 2, 2, 64, 4, 4>(a0, nblocks, s);
+    return launch_fast<1, 1, 2, 2, 2, 64, 4, 4>(a0, nblocks, s);
 }
+
 // the tile a variant runs for these layouts (strided A falls back to the 128-row tile)
 void vm_gemm_variant_tile(int variant, int a_layout, int* bm, int* bn) {
     if (variant == 1) { *bm = 256; *bn = 128; return; }
-    if (variant == 8 && a_layout == 0) { *bm = 256; *bn = 256; return; }
     *bm = (variant == 4 && a_layout == 0) ? 160 : 128;
     *bn = 128;
 }
 
 
-template <int LA, int LB, int PIPE, int EPI, int BG>
+template <int LA, int LB, int PIPE, int BG>
 static int launch_grouped(const GemmGroupArgs& ga, int nblocks, hipStream_t s) {
     constexpr int LDS = 2 * (128 + 128) * 64 * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<LA, LB, 2, 2, 2, 64, 4, PIPE, EPI, BG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<LA, LB, 2, 2, 2, 64, 4, PIPE, BG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_grouped_kernel<LA, LB, 2, 2, 2, 64, 4, PIPE, EPI, BG>), dim3(nblocks), dim3(256), LDS, s, ga);
+    hipLaunchKernelGGL((gemm_grouped_kernel<LA, LB, 2, 2, 2, 64, 4, PIPE, BG>), dim3(nblocks), dim3(256), LDS, s, ga);
     return vm_check_launch("vm_gemm_grouped");
 }
 
 // 128 x 128 tiles.  TN (both operands contraction-major): the weight-gradient form, with the bias-gradient MFMAs compiled in (BG);
 // NT / NN: independent problems of one layout in one launch (vm_gemm_grouped: the per-image products of the GLoRIA local loss).
 int vm_gemm_grouped_launch(const GemmGroupArgs& ga, int nblocks, int a_layout, int b_layout, hipStream_t s) {
-    if (a_layout == 1 && b_layout == 1)
-        return vm_env().gemm_epi == 0 ? launch_grouped<1, 1, 4, 0, 1>(ga, nblocks, s) : launch_grouped<1, 1, 4, 1, 1>(ga, nblocks, s);
-    if (a_layout == 0 && b_layout == 0) return launch_grouped<0, 0, 1, 0, 0>(ga, nblocks, s);
-    if (a_layout == 0 && b_layout == 1) return launch_grouped<0, 1, 4, 0, 0>(ga, nblocks, s);
+    if (a_layout == 1 && b_layout == 1) return launch_grouped<1, 1, 4, 1>(ga, nblocks, s);
+    if (a_layout == 0 && b_layout == 0) return launch_grouped<0, 0, 1, 0>(ga, nblocks, s);
+    if (a_layout == 0 && b_layout == 1) return launch_grouped<0, 1, 4, 0>(ga, nblocks, s);
     vm_set_error("vm_gemm_grouped: layout (a=%d, b=%d) has no grouped kernel", a_layout, b_layout);
     return VM_EUNSUPPORTED;
 }

@@ -36,7 +36,6 @@ static void load_env() {
     const char* v;
     g_env.gemm_variant = (v = getenv("VM_GEMM_VARIANT")) ? atoi(v) : -1;
     g_env.gemm_debug = (v = getenv("VM_GEMM_DEBUG")) ? atoi(v) : 0;
-    g_env.gemm_epi = (v = getenv("VM_GEMM_EPI")) ? atoi(v) : 0;
     g_env.gemm_groupw = (v = getenv("VM_GEMM_GROUPW")) ? atoi(v) : 0;
     g_env.gemm_generic = getenv("VM_GEMM_GENERIC") != nullptr;
     g_env.gemm_no_skinny = getenv("VM_GEMM_NO_SKINNY") != nullptr;

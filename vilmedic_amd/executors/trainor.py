@@ -44,7 +44,7 @@ class Trainor(object):
         self.model = create_model(config, self.dl, self.logger, from_training=True, state_dict=self.state)
         self.optimizer = create_optimizer(config, self.logger, self.model, state_dict=self.state)
         # The RCCL communicator is created AFTER the model, its arena and the optimizer state exist: device memory allocated
-        # after init_process_group was measurably slower on this stack (tools/dbg/init_order.py, +5.6 ms per RRG step).
+        # after init_process_group was measurably slower on this stack (measured in round 1: +5.6 ms per RRG step).
         self.ddp = None
         if self.world > 1:
             import torch.distributed as dist
