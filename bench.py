@@ -48,7 +48,7 @@ def flops_per_pair_fwd(S=197, L=128, d=768, V=30522, layers=12):
 def dominant_shape_roofline(dump_path):
     """the single largest forward GEMM shape (QKV projection of the ViT, 12608 x 2304 x 768, bias epilogue): achieved rate from
     this run's per-launch HIP events, HBM-side traffic per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2
-    gfx950 correction + WRITE_SIZE, profiles/r01_c_pmc_gemm_12608x2304x768.txt)."""
+    gfx950 correction + WRITE_SIZE, profiles/r02_n_pmc_gemm.txt)."""
     tag, M, N, K = "M12608_N2304_K768_l00", 12608, 2304, 768
     ms = n = 0.0
     try:
@@ -62,9 +62,10 @@ def dominant_shape_roofline(dump_path):
         return None
     traffic = None
     try:
-        for line in open(os.path.join(ROOT, "profiles", "r01_c_pmc_gemm_12608x2304x768.txt")):
+        for line in open(os.path.join(ROOT, "profiles", "r02_n_pmc_gemm.txt")):
             if "traffic per launch" in line:
                 traffic = float(line.split("traffic per launch =")[1].split("MB")[0]) * 1e6
+                break                       # the first entry of the file is this shape
     except (OSError, ValueError, IndexError):
         pass
     dur = ms / n * 1e-3
@@ -337,8 +338,8 @@ def main():
             roof = {"bound": "mfma", "kernel": "gemm_fast_kernel<LA,LB,...> (every instantiation: fwd + dgrad + wgrad launches of vm_gemm_bf16, "
                                              "split-K reduce included)", "achieved": round(ach, 1),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                    "traffic_note": "family of 33 shapes; PMC pass for the dominant shape (12608x2304x768: 168.7 MB per launch at the fabric vs "
-                                    "81.0 MB algorithmic) in profiles/r01_c_pmc_gemm_12608x2304x768.txt",
+                    "traffic_note": "family of 33 shapes; PMC passes for the dominant shapes (12608x2304x768 forward: 144.6 MB per launch at the fabric "
+                                    "vs 81.0 MB algorithmic; its dgrad: 118.1 MB) in profiles/r02_n_pmc_gemm.txt",
                     "launches_per_step": gn // 2, "avg_launch_ms": round(gms / max(gn, 1), 4),
                     "family_ms_per_step": {k: round(v[0] / 2, 3) for k, v in fam.items()}}
             dump = os.environ.get("VM_PROF_DUMP") or os.path.join(tempfile.gettempdir(), f"vm_prof_{os.getpid()}.txt")

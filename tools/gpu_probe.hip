@@ -220,6 +220,10 @@ static void bench_ab(int M, int N, int K, int la, int lb, int flags, int split) 
 }
 
 int main(int argc, char** argv) {
+    if (argc >= 8 && !strcmp(argv[1], "one")) {     // gpu_probe.bin one M N K la lb split     (production kernel only: rocprofv3 --pmc workload)
+        bench_gemm(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]));
+        return 0;
+    }
     if (argc >= 8 && !strcmp(argv[1], "bench")) {   // gpu_probe.bin bench M N K la lb split   (for rocprofv3 --pmc runs)
         for (int dbg = 0; dbg < 4; ++dbg) {
             char b[4]; snprintf(b, 4, "%d", dbg); setenv("VM_GEMM_DEBUG", b, 1); vm_reload_env();
