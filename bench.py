@@ -335,10 +335,10 @@ def main():
                 fam[name] = (ms.value, work.value, n.value)
             gms, gwork, gn = fam["gemm"]
             ach = gwork / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
-            roof = {"bound": "mfma", "kernel": "gemm_fast_kernel<LA,LB,...> (every instantiation: fwd + dgrad + wgrad launches of vm_gemm_bf16, "
-                                             "split-K reduce included)", "achieved": round(ach, 1),
+            roof = {"bound": "mfma", "kernel": "gemm_fast_kernel<LA,LB,...> + gemm_grouped_kernel (every forward / dgrad launch of vm_gemm_bf16 and the "
+                                             "grouped weight + bias gradient launches of vm_wgrad_grouped)", "achieved": round(ach, 1),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                    "traffic_note": "family of 33 shapes; PMC passes for the dominant shapes (12608x2304x768 forward: 144.6 MB per launch at the fabric "
+                    "traffic_note": "family of ~30 shapes; PMC passes for the dominant shapes (12608x2304x768 forward: 144.6 MB per launch at the fabric "
                                     "vs 81.0 MB algorithmic; its dgrad: 118.1 MB) in profiles/r02_n_pmc_gemm.txt",
                     "launches_per_step": gn // 2, "avg_launch_ms": round(gms / max(gn, 1), 4),
                     "family_ms_per_step": {k: round(v[0] / 2, 3) for k, v in fam.items()}}
