@@ -11,9 +11,10 @@
 // Replaces (in fp32 mode) hf:models/bert_generation/modeling_bert_generation.py:45-231,264-358,394-426,590-610 as reached
 // from ref:vilmedic/blocks/huggingface/decoder/evaluation.py:73-78 (generate) -- same call sites as the bf16 step.
 #include "common.h"
+#include "gemm_args.h"
 
 // ------------------------------------------------------------------ C[M,N] = epi(A[M,K] . W[N,K]^T), all fp32
-// One workgroup owns 16 output columns for a block of 16*MF rows; its 4 waves split the contraction four ways (operands go
+// One workgroup owns 16 output columns for a block of 16*MF rows; its 8 waves split the contraction eight ways (operands go
 // straight from global / L2 into MFMA fragments, W is streamed exactly once per row block), partial accumulators meet in LDS.
 // A lane loads 4 consecutive k of its row (16 B): MFMA sub-step j contracts k = k0 + 4g + j, g = lane / 16 -- any bijection
 // of the contraction index works as long as both operands use the same one.
@@ -26,14 +27,19 @@ struct GemmF32Args {
 
 __device__ __forceinline__ float gelu_erf_f32(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
+#define F32_NW 8       // waves per workgroup (the contraction is split 8 ways)
+// k-steps of operand fragments in flight per wave (register ring, see gemm_skinny.hip): 4 for <= 64 rows, fewer for the taller blocks
+// (16 fragments x 4 steps would be 256 registers of operands alone)
+#define F32_D (MF <= 4 ? 4 : MF <= 8 ? 2 : 1)
+
 template <int MF>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args p) {
-    extern __shared__ __attribute__((aligned(16))) float red[];          // [4 waves][MF][64 lanes][4]
+__global__ __launch_bounds__(F32_NW * 64) void gemm_f32_kernel(const GemmF32Args p) {
+    extern __shared__ __attribute__((aligned(16))) float red[];          // [F32_NW waves][MF][64 lanes][4]
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (16 * MF);
     const int ksteps = p.K >> 4;                                          // 16-deep steps (4 MFMAs each)
-    const int per = (ksteps + 3) >> 2;
+    const int per = (ksteps + F32_NW - 1) / F32_NW;
     const int ks0 = wave * per, ks1 = min(ksteps, ks0 + per);
     const float* wrow = p.W + (int64_t)min(n0 + c, p.N - 1) * p.ldw + g * 4;
     const float* arow[MF];
@@ -42,25 +48,29 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args p) {
     float4_t acc[MF];
 #pragma unroll
     for (int i = 0; i < MF; ++i) acc[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
-    float4 wf, af[MF], wn, an[MF];
+    constexpr int D = F32_D;
+    float4 wq[D], aq[D][MF];
     auto load = [&](int ks, float4& w_, float4 (&a_)[MF]) {
         w_ = *reinterpret_cast<const float4*>(wrow + ks * 16);
 #pragma unroll
         for (int i = 0; i < MF; ++i) a_[i] = *reinterpret_cast<const float4*>(arow[i] + ks * 16);
     };
-    if (ks0 < ks1) load(ks0, wf, af);
-    for (int ks = ks0; ks < ks1; ++ks) {
-        if (ks + 1 < ks1) load(ks + 1, wn, an);
 #pragma unroll
-        for (int i = 0; i < MF; ++i) {
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.x, af[i].x, acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.y, af[i].y, acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.z, af[i].z, acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.w, af[i].w, acc[i], 0, 0, 0);
+    for (int d = 0; d < D; ++d) if (ks0 + d < ks1) load(ks0 + d, wq[d], aq[d]);
+    for (int ks = ks0; ks < ks1; ks += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (ks + d < ks1) {
+#pragma unroll
+                for (int i = 0; i < MF; ++i) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[d].x, aq[d][i].x, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[d].y, aq[d][i].y, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[d].z, aq[d][i].z, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[d].w, aq[d][i].w, acc[i], 0, 0, 0);
+                }
+                if (ks + d + D < ks1) load(ks + d + D, wq[d], aq[d]);
+            }
         }
-        wf = wn;
-#pragma unroll
-        for (int i = 0; i < MF; ++i) af[i] = an[i];
     }
     // D^T layout: lane (c, g) of fragment i holds row m0 + 16 i + c, columns n0 + 4 g .. + 3
     float4_t* mine = reinterpret_cast<float4_t*>(red) + (wave * MF) * 64 + lane;
@@ -68,11 +78,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args p) {
     for (int i = 0; i < MF; ++i) mine[i * 64] = acc[i];
     __syncthreads();
     const int gn = n0 + 4 * g;
-    for (int i = wave; i < MF; i += 4) {
+    for (int i = wave; i < MF; i += F32_NW) {
         const int gm = m0 + 16 * i + c;
         float4_t s = reinterpret_cast<const float4_t*>(red)[(0 * MF + i) * 64 + lane];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {                                      // fixed order: deterministic
+        for (int w = 1; w < F32_NW; ++w) {                                 // fixed order: deterministic
             const float4_t t = reinterpret_cast<const float4_t*>(red)[(w * MF + i) * 64 + lane];
             s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
         }
@@ -90,8 +100,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args p) {
 
 template <int MF>
 static int launch_gemm_f32(const GemmF32Args& a, hipStream_t s) {
-    const size_t lds = (size_t)4 * MF * 64 * sizeof(float4_t);
-    hipLaunchKernelGGL((gemm_f32_kernel<MF>), dim3((a.N + 15) / 16, (a.M + 16 * MF - 1) / (16 * MF)), dim3(256), lds, s, a);
+    const size_t lds = (size_t)F32_NW * MF * 64 * sizeof(float4_t);
+    static bool attr_set = false;
+    if (!attr_set && lds > 65536) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<MF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_f32_kernel<MF>), dim3((a.N + 15) / 16, (a.M + 16 * MF - 1) / (16 * MF)), dim3(F32_NW * 64), lds, s, a);
     return vm_check_launch("vm_gemm_f32");
 }
 
@@ -105,12 +120,13 @@ extern "C" int vm_gemm_f32(const float* A, int64_t lda, const float* W, int64_t 
     GemmF32Args a = {A, W, C, bias, residual, lda, ldw, ldc, ldr, M, N, K, act};
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_DECODE, 2.0 * M * (double)N * K, s, "f32_M%d_N%d_K%d", M, N, K);
-    const int mf = (M + 15) / 16;
-    if (mf <= 1) return launch_gemm_f32<1>(a, s);
-    if (mf <= 2) return launch_gemm_f32<2>(a, s);
-    if (mf <= 4) return launch_gemm_f32<4>(a, s);
-    if (mf <= 8) return launch_gemm_f32<8>(a, s);
-    return launch_gemm_f32<16>(a, s);          // 256 rows per workgroup (64 KiB of LDS for the cross-wave reduction); more rows -> grid.y
+    switch (vm_skinny_rows_per_wg(M, N, 16)) {         // rows per workgroup: at least one workgroup per CU (gemm_skinny.hip)
+        case 1: return launch_gemm_f32<1>(a, s);
+        case 2: return launch_gemm_f32<2>(a, s);
+        case 4: return launch_gemm_f32<4>(a, s);
+        case 8: return launch_gemm_f32<8>(a, s);
+        default: return launch_gemm_f32<16>(a, s);
+    }
 }
 
 // ------------------------------------------------------------------ LayerNorm, fp32 in / out (one wave per row)

@@ -292,7 +292,7 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
     a.bias_grad = nullptr;
     a.dbg = vm_env().gemm_debug;
     // decode-step shapes: few rows -> one workgroup per 16 output columns, K split over its waves (gemm_skinny.hip)
-    if (M <= 128 && a_layout == 0 && b_layout == 0 && (K % 32) == 0 && split == 1 && !epi->aux_out && !epi->mul_gelu_z &&
+    if (M <= 256 && a_layout == 0 && b_layout == 0 && (K % 32) == 0 && split == 1 && !epi->aux_out && !epi->mul_gelu_z &&
         epi->dropout_p == 0.f && (!epi->residual || (epi->ldr % 4) == 0) && !vm_env().gemm_no_skinny && !vm_env().gemm_generic && a.dbg == 0 &&
         vm_env().gemm_variant < 0)
         return vm_gemm_skinny_dispatch(a, s);
