@@ -184,18 +184,22 @@ struct AttnF32Args {
 };
 
 __global__ __launch_bounds__(64) void attn_decode_f32_kernel(const AttnF32Args p) {
-    extern __shared__ float sc[];                                          // [Lk] scores, then probabilities; [dh] query after them
+    extern __shared__ float sc[];                 // [Lk8] scores, then probabilities (zero past Lk); [Lk8] key-row numbers; [dh] query
     const int lane = threadIdx.x;
     const int r = blockIdx.x / p.H, h = blockIdx.x - r * p.H;
     const int kvb = r / p.q_per_kv;
-    float* qs = sc + p.Lk;
+    const int Lk8 = (p.Lk + 7) & ~7;
+    int* ro = reinterpret_cast<int*>(sc + Lk8);
+    float* qs = sc + 2 * Lk8;
     const float* qr = p.q + (int64_t)r * p.ldq + h * p.dh;
     for (int d = lane; d < p.dh; d += 64) qs[d] = qr[d];
     __syncthreads();
-    auto krow = [&](int j) -> int64_t { return p.kv_index ? (int64_t)p.kv_index[(int64_t)r * p.kv_index_ld + j] : (int64_t)kvb * p.Lk + j; };
     float mx = -INFINITY;
-    for (int j = lane; j < p.Lk; j += 64) {
-        const float* kr = p.k + krow(j) * p.ldk + h * p.dh;
+    for (int j = lane; j < Lk8; j += 64) {
+        if (j >= p.Lk) { sc[j] = -INFINITY; ro[j] = 0; continue; }
+        const int row = p.kv_index ? p.kv_index[(int64_t)r * p.kv_index_ld + j] : kvb * p.Lk + j;
+        ro[j] = row;                                                       // the P.V pass reads it from LDS: no dependent index load there
+        const float* kr = p.k + (int64_t)row * p.ldk + h * p.dh;
         float s = 0.f;
         for (int d = 0; d < p.dh; d += 4) {
             const float4 kk = *reinterpret_cast<const float4*>(kr + d);
@@ -208,17 +212,25 @@ __global__ __launch_bounds__(64) void attn_decode_f32_kernel(const AttnF32Args p
     }
     mx = wave_max(mx);
     float se = 0.f;
-    for (int j = lane; j < p.Lk; j += 64) { const float e = expf(sc[j] - mx); sc[j] = e; se += e; }
+    for (int j = lane; j < Lk8; j += 64) { const float e = j < p.Lk ? expf(sc[j] - mx) : 0.f; sc[j] = e; se += e; }
     se = wave_sum(se);
     __syncthreads();
     const float inv = 1.0f / se;
+    // P.V with the lanes over the head dimension: 8 keys' V values requested before the 8 multiply-adds (the serial form paid one
+    // L2 round trip per key: 197 in a row for cross-attention); the accumulation order over the keys is unchanged
     for (int d = lane; d < p.dh; d += 64) {
+        const float* vb = p.v + h * p.dh + d;
         float acc = 0.f;
-        for (int j = 0; j < p.Lk; ++j) acc = fmaf(sc[j], p.v[krow(j) * p.ldv + h * p.dh + d], acc);
+        for (int j0 = 0; j0 < Lk8; j0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = vb[(int64_t)ro[j0 + u] * p.ldv];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(sc[j0 + u], v[u], acc);
+        }
         p.o[(int64_t)r * p.ldo + h * p.dh + d] = acc * inv;
     }
 }
-
 extern "C" int vm_attention_decode_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                                        float* o, int64_t ldo, const uint8_t* key_mask, const int32_t* kv_row_index, int64_t kv_index_ld,
                                        int rows, int H, int Lk, int dh, int q_per_kv, float scale, void* stream) {
@@ -228,6 +240,6 @@ extern "C" int vm_attention_decode_f32(const float* q, int64_t ldq, const float*
     AttnF32Args a = {q, k, v, o, key_mask, kv_row_index, ldq, ldk, ldv, ldo, kv_index_ld, rows, H, Lk, dh, q_per_kv, scale};
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_DECODE, 4.0 * rows * H * (double)Lk * dh, s, "attn_f32_r%d_H%d_Lk%d", rows, H, Lk);
-    hipLaunchKernelGGL(attn_decode_f32_kernel, dim3((unsigned)(rows * H)), dim3(64), (size_t)(Lk + dh) * sizeof(float), s, a);
+    hipLaunchKernelGGL(attn_decode_f32_kernel, dim3((unsigned)(rows * H)), dim3(64), (size_t)(2 * ((Lk + 7) & ~7) + dh) * sizeof(float), s, a);
     return vm_check_launch("vm_attention_decode_f32");
 }
