@@ -128,7 +128,7 @@ struct VmEnv {
     int gemm_debug;        // VM_GEMM_DEBUG: 1 skip the epilogue, 2 one K-tile only (timing breakdowns)
     int gemm_groupw;       // VM_GEMM_GROUPW: column-group width of the tile order (0: heuristic)
     bool gemm_generic;     // VM_GEMM_GENERIC: register-staged fallback kernel only
-    bool gemm_no_skinny;   // VM_GEMM_NO_SKINNY: never take the M <= 128 decode-step kernel
+    bool gemm_no_skinny;   // VM_GEMM_NO_SKINNY: never take the M <= 256 decode-step kernel
     bool attn_tile;        // VM_ATTN_TILE: tile-streaming attention kernels instead of the head-resident ones
     bool attn_stream;      // VM_ATTN_STREAM: streaming (non-resident) tile kernels
 };

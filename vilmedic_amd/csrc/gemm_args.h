@@ -27,6 +27,6 @@ int vm_gemm_grouped_launch(const GemmGroupArgs& ga, int nblocks, int a_layout, i
 int vm_gemm_splitk_reduce(const GemmArgs& a, int nsplit, hipStream_t s);
 void vm_gemm_variant_tile(int variant, int a_layout, int* bm, int* bn);
 int vm_gemm_fast_dispatch(const GemmArgs& a, int a_layout, int b_layout, int nblocks, int variant, hipStream_t s);
-// skinny path (gemm_skinny.hip): M <= 128 rows (the decode step), K % 32 == 0, row-major A and B, plain / bias / gelu / residual epilogue
+// skinny path (gemm_skinny.hip): M <= 256 rows (the decode step), K % 32 == 0, row-major A and B, plain / bias / gelu / residual epilogue
 int vm_skinny_rows_per_wg(int M, int N, int max_mf);
 int vm_gemm_skinny_dispatch(const GemmArgs& a, hipStream_t s);
