@@ -121,6 +121,12 @@ int vm_layernorm_bwd_fused(const void* dy, const void* dy2, const void* dres, co
    _partial writes dx and the per-workgroup dgamma/dbeta partials to ws; _reduce accumulates them into dgamma/dbeta */
 int vm_layernorm_bwd_partial(const void* dy, const void* dy2, const void* dres, const void* x, const float* gamma,
                              const float* mean, const float* rstd, void* dx, int rows, int cols, void* ws, void* stream);
+/* _partial that also writes dx_dropped = keep(seed, row * cols + col) ? dx / (1 - p) : 0 (bf16, same shape as dx): the gradient the
+   linear that produced x needs when x = dropout(linear(..)) + residual -- the mask of that linear's vm_gemm_bf16 epilogue (dropout_seed /
+   dropout_seed_dev as there) -- instead of a separate vm_dropout_apply_bf16 pass over dx.  dx_dropped may be NULL (= _partial). */
+int vm_layernorm_bwd_partial_dropout(const void* dy, const void* dy2, const void* dres, const void* x, const float* gamma,
+                                     const float* mean, const float* rstd, void* dx, void* dx_dropped, float dropout_p, uint64_t dropout_seed,
+                                     const uint64_t* dropout_seed_dev, int rows, int cols, void* ws, void* stream);
 int vm_layernorm_bwd_reduce(const void* ws, float* dgamma, float* dbeta, int rows, int cols, void* stream);
 /* the reduce of up to any number of LayerNorm backward launches in ONE launch (their partials wait in their workspaces): the
    training step queues its 62 LayerNorms and reduces them together when the backward pass ends -- one problem alone is latency-bound */

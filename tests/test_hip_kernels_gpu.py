@@ -258,6 +258,30 @@ def test_ce_shift_wide_rows_and_filtered_rows_vs_torch(V, Vp, banned, thr):
     assert torch.count_nonzero(dl[:, V:]) == 0
 
 
+def test_layernorm_backward_writes_the_dropout_masked_gradient():
+    """vm_layernorm_bwd_partial_dropout: dx is unchanged and dx_dropped == vm_dropout_apply_bf16(dx) with the same (seed, element index)
+    mask -- up to one bf16 rounding, because the fused kernel masks the fp32 value before it is rounded -- and the mask is the one the
+    GEMM epilogue draws (zeros at exactly the same positions)."""
+    from vilmedic_amd._lib import lib, ptr, stream, check
+    rows, cols, p, seed = 300, 768, 0.25, 0x1234ABCD5678
+    g = torch.Generator().manual_seed(5)
+    x, dy, dy2, dres = ((torch.randn(rows, cols, generator=g)).to(BF).to(dev()) for _ in range(4))
+    gamma = (torch.rand(cols, generator=g) + 0.5).to(dev())
+    mean, rstd = x.float().mean(1), (x.float().var(1, unbiased=False) + 1e-12).rsqrt()
+    ws = torch.empty(lib().vm_layernorm_bwd_ws(rows, cols) // 4, device=dev())
+    dx0, dx1, dxd = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    check(lib().vm_layernorm_bwd_partial(ptr(dy), ptr(dy2), ptr(dres), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx0), rows, cols, ptr(ws), stream()))
+    check(lib().vm_layernorm_bwd_partial_dropout(ptr(dy), ptr(dy2), ptr(dres), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx1), ptr(dxd), p, seed,
+                                                 None, rows, cols, ptr(ws), stream()))
+    assert torch.equal(dx0, dx1)
+    ref = torch.empty_like(x)
+    check(lib().vm_dropout_apply_bf16(ptr(dx0), ptr(ref), dx0.numel(), p, seed, None, stream()))
+    assert torch.equal(dxd == 0, ref == 0) or ((dxd == 0) != (ref == 0)).sum() <= (dx0 == 0).sum()      # identical mask
+    torch.testing.assert_close(dxd.float(), ref.float(), rtol=2 ** -7, atol=1e-6)
+    kept = (ref != 0).float().mean().item()
+    assert abs(kept - (1 - p)) < 0.01, kept
+
+
 def test_adam_matches_torch():
     from vilmedic_amd._lib import lib, ptr, stream, check
     n = 10007

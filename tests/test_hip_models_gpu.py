@@ -277,6 +277,50 @@ def test_two_phase_backward_equals_single_backward(golden):
     assert min(p._vm_off for p in m2.enc.parameters()) >= max(p._vm_off + p.numel() for p in m2.dec.parameters())
 
 
+def test_dropout_mask_fused_into_layernorm_backward_equals_the_separate_pass(golden):
+    """With dropout on, the gradient of  y = dropout(linear(x)) + residual  is masked either by vm_dropout_apply_bf16 in the linear's
+    backward or (default) by the LayerNorm backward kernel that produced it (vm_layernorm_bwd_partial_dropout -> ops._masked_grad).
+    Same seeds, same model, both ways: loss identical, every parameter gradient equal up to the single bf16 rounding the fused form
+    skips, and the fused run must actually have used the fused path (no dropout_apply launch)."""
+    from vilmedic_amd import ops
+    from vilmedic_amd.arena import arena_of
+    from vilmedic_amd.models.rrg.RRG import RRG
+    g = golden("g5_rrg_tiny")
+    torch.manual_seed(0)
+    m = RRG(decoder=dict(proto=None, hidden_dropout_prob=0.2, attention_probs_dropout_prob=0.1, **g["dec_cfg"]),
+            cnn=dict(proto="VisualEncoder", backbone="vit", permute="no_permute", dropout_out=0.0, **g["vit_cfg"])).to(dev()).train()
+    images = R.make_images(4, g["vit_cfg"]["image_size"], seed=3).to(dev())
+    ids, am = R.make_reports(4, 20, g["dec_cfg"]["vocab_size"], seed=3)
+    ids, am = ids.to(dev()), am.to(dev())
+    arena = arena_of(m)
+    calls = {"n": 0}
+    real = ops.dropout_apply
+
+    def counting(x, p, seed):
+        calls["n"] += 1
+        return real(x, p, seed)
+    out = {}
+    try:
+        ops.dropout_apply = counting
+        for fuse in (True, False):
+            ops.FUSE_LN_DROPOUT = fuse
+            ops.manual_seed(77)
+            arena.zero_grad()
+            calls["n"] = 0
+            loss = m(input_ids=ids, attention_mask=am, images=images)["loss"]
+            loss.backward()
+            torch.cuda.synchronize()
+            out[fuse] = (loss.item(), arena.gflat.clone(), calls["n"])
+    finally:
+        ops.dropout_apply = real
+        ops.FUSE_LN_DROPOUT = True
+    assert out[True][0] == out[False][0]
+    assert out[False][2] > 0 and out[True][2] < out[False][2], (out[True][2], out[False][2])      # the fused run skipped the separate passes
+    err = rel_l2(out[True][1], out[False][1])
+    print(f"[parity] fused LN-backward dropout mask vs separate pass: grad rel-l2 {err:.2e}, dropout_apply launches {out[True][2]} vs {out[False][2]}")
+    assert err < 5e-3, err
+
+
 def _rrg_hf_pair(vit_cfg, dec_cfg, seed):
     from vilmedic_amd.models import RRG_HF
     m = RRG_HF(vision=dict(proto_model="vit", proto_config="vit", proto_config_args=dict(vit_cfg)),

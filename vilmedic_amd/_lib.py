@@ -59,6 +59,7 @@ SIGNATURES = {
     "vm_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "vm_layernorm_bwd_fused": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "vm_layernorm_bwd_partial": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "vm_layernorm_bwd_partial_dropout": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _P, _I, _I, _P, _P]),
     "vm_layernorm_bwd_reduce": (_I, [_P, _P, _P, _I, _I, _P]),
     "vm_layernorm_bwd_reduce_batched": (_I, [_P, _I, _P]),
     "vm_image_pipeline_ws": (_SZ, [_I, _I, _I]),

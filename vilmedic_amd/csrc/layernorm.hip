@@ -69,12 +69,15 @@ __global__ __launch_bounds__(256, NCH <= 2 ? 3 : 1) void ln_bwd_kernel(const bf1
                                                      const bf16_t* __restrict__ dres, const bf16_t* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, bf16_t* __restrict__ dx,
-                                                     float* __restrict__ ws, int rows, int cols) {
+                                                     float* __restrict__ ws, int rows, int cols, bf16_t* __restrict__ dx_drop,
+                                                     uint64_t drop_seed, const uint64_t* __restrict__ drop_seed_dev, uint32_t drop_thresh,
+                                                     float drop_scale) {
     const int lane = threadIdx.x & 63;
     const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 4;
     const int nchunks = cols >> 3;
     float dg[NCH][8], db[NCH][8], g[NCH][8];
+    const DropKey dkey = drop_key(dx_drop ? eff_seed(drop_seed, drop_seed_dev) : 0);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int ch = lane + 64 * c;
@@ -149,6 +152,13 @@ __global__ __launch_bounds__(256, NCH <= 2 ? 3 : 1) void ln_bwd_kernel(const bf1
                     for (int j = 0; j < 8; ++j) o[j] += r8[j];
                 }
                 *reinterpret_cast<uint4*>(dx + (int64_t)row * cols + ch * 8) = pack8(o);
+                if (dx_drop) {       // the masked copy the producing linear's backward needs (mask of its forward epilogue: index row * cols + col)
+                    bool keep[8];
+                    dropout_keep_n<8>(dkey, (uint64_t)row * (uint64_t)cols + (uint64_t)(ch * 8), drop_thresh, keep);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = keep[j] ? o[j] * drop_scale : 0.f;
+                    *reinterpret_cast<uint4*>(dx_drop + (int64_t)row * cols + ch * 8) = pack8(o);
+                }
             }
         }
         if (PREFETCH) cur = nxt;
@@ -286,20 +296,31 @@ extern "C" int vm_layernorm_bwd_reduce(const void* ws, float* dgamma, float* dbe
 
 extern "C" int vm_layernorm_bwd_partial(const void* dy, const void* dy2, const void* dres, const void* x, const float* gamma,
                                         const float* mean, const float* rstd, void* dx, int rows, int cols, void* ws, void* stream) {
+    return vm_layernorm_bwd_partial_dropout(dy, dy2, dres, x, gamma, mean, rstd, dx, nullptr, 0.f, 0, nullptr, rows, cols, ws, stream);
+}
+
+extern "C" int vm_layernorm_bwd_partial_dropout(const void* dy, const void* dy2, const void* dres, const void* x, const float* gamma,
+                                                const float* mean, const float* rstd, void* dx, void* dx_dropped, float dropout_p,
+                                                uint64_t dropout_seed, const uint64_t* dropout_seed_dev, int rows, int cols, void* ws,
+                                                void* stream) {
     VM_REQUIRE(dy && x && gamma && mean && rstd && dx && ws, "vm_layernorm_bwd: null pointer");
     VM_REQUIRE(rows > 0 && cols > 0 && (cols % 8) == 0 && cols <= 64 * 8 * LN_MAX_CHUNKS, "vm_layernorm_bwd: cols=%d must be a multiple of 8 and <= 2048", cols);
+    VM_REQUIRE(!dx_dropped || (dropout_p > 0.f && dropout_p < 1.f), "vm_layernorm_bwd_partial_dropout: dropout_p must be in (0, 1)");
     hipStream_t s = (hipStream_t)stream;
-    VmProfScope prof(VM_FAM_LN, 6.0 * rows * (double)cols, s);
+    VmProfScope prof(VM_FAM_LN, (dx_dropped ? 8.0 : 6.0) * rows * (double)cols, s);
     const int nch = (cols / 8 + 63) / 64;
     const int grid = ln_grid(rows, LN_BWD_CAP);
     const bf16_t* dyp = (const bf16_t*)dy; const bf16_t* xp = (const bf16_t*)x; bf16_t* dxp = (bf16_t*)dx;
     const bf16_t* dy2p = (const bf16_t*)dy2; const bf16_t* drp = (const bf16_t*)dres;
+    bf16_t* ddp = (bf16_t*)dx_dropped;
+    const uint32_t th = dx_dropped ? dropout_thresh16(dropout_p) : 0u;
+    const float sc = dx_dropped ? 1.0f / (1.0f - dropout_p) : 1.0f;
     float* wsp = (float*)ws;
     const size_t red_bytes = (size_t)4 * 2 * cols * sizeof(float);
     switch (nch) {
-        case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(grid), dim3(256), red_bytes, s, dyp, dy2p, drp, xp, gamma, mean, rstd, dxp, wsp, rows, cols); break;
-        case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(grid), dim3(256), red_bytes, s, dyp, dy2p, drp, xp, gamma, mean, rstd, dxp, wsp, rows, cols); break;
-        default: hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(grid), dim3(256), red_bytes, s, dyp, dy2p, drp, xp, gamma, mean, rstd, dxp, wsp, rows, cols); break;
+        case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(grid), dim3(256), red_bytes, s, dyp, dy2p, drp, xp, gamma, mean, rstd, dxp, wsp, rows, cols, ddp, dropout_seed, dropout_seed_dev, th, sc); break;
+        case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(grid), dim3(256), red_bytes, s, dyp, dy2p, drp, xp, gamma, mean, rstd, dxp, wsp, rows, cols, ddp, dropout_seed, dropout_seed_dev, th, sc); break;
+        default: hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(grid), dim3(256), red_bytes, s, dyp, dy2p, drp, xp, gamma, mean, rstd, dxp, wsp, rows, cols, ddp, dropout_seed, dropout_seed_dev, th, sc); break;
     }
     return vm_check_launch("vm_layernorm_bwd");
 }

@@ -359,12 +359,11 @@ class LinearFn(torch.autograd.Function):
     (several when Q,K,V projections are fused into one GEMM)."""
 
     @staticmethod
-    def forward(ctx, x, w_sh, bias_f32, residual, dropout_p, wgrad_buf, bgrad_buf, anchor, out_f32=False):
+    def forward(ctx, x, w_sh, bias_f32, residual, dropout_p, wgrad_buf, bgrad_buf, anchor, out_f32=False, seed=0):
         x2 = _2d(x)
         M, K = x2.shape
         N = w_sh.shape[0]
         y = torch.empty(M, N, dtype=torch.float32 if out_f32 else BF16, device=x.device)      # fp32: straight from the accumulators
-        seed = next_seed() if dropout_p > 0 else 0
         gemm(x2, 0, w_sh, 0, y, M, N, K, bias=bias_f32, dropout_p=dropout_p, dropout_seed=seed,
              residual=_2d(residual) if residual is not None else None)
         ctx.save_for_backward(x2, w_sh)
@@ -380,24 +379,41 @@ class LinearFn(torch.autograd.Function):
             dy2 = dy2.to(BF16)
         M, N = dy2.shape
         K = x2.shape[1]
-        dpre = dropout_apply(dy2, dropout_p, seed) if dropout_p > 0 else dy2
+        dpre = _masked_grad(dy2, dropout_p, seed) if dropout_p > 0 else dy2
         param_grads(dpre, x2, wgrad_buf, bgrad_buf)       # queued: grouped launch on the side stream, overlapping the dgrad chain
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=BF16, device=dy.device)
             gemm(dpre, 0, w_sh, 1, dx, M, K, N)
             dx = dx.view(xshape)
-        return dx, None, None, (dy if has_res else None), None, None, None, None, None
+        return dx, None, None, (dy if has_res else None), None, None, None, None, None, None
 
 
 def linear(x, w_sh, bias, *, residual=None, dropout_p=0.0, wgrad_buf=None, bgrad_buf=None, anchor=None, out_f32=False):
-    return LinearFn.apply(x, w_sh, bias, residual, dropout_p, wgrad_buf, bgrad_buf, anchor, out_f32)
+    seed = next_seed() if dropout_p > 0 else 0
+    y = LinearFn.apply(x, w_sh, bias, residual, dropout_p, wgrad_buf, bgrad_buf, anchor, out_f32, seed)
+    if dropout_p > 0:
+        y._vm_drop = (dropout_p, seed)         # read by layer_norm(): its backward then also writes the masked gradient (_masked_grad)
+    return y
+
+
+# The gradient of y = dropout(linear(x)) + residual arrives from the LayerNorm backward that consumed y; that kernel can write the masked
+# copy  keep ? dy / (1 - p) : 0  next to dy (vm_layernorm_bwd_partial_dropout), which saves one pass over dy per linear.  LayerNormFn
+# registers the masked tensor under the address of the dy it returns; the linear's backward picks it up when exactly that tensor arrives.
+_masked = {}
+
+
+def _masked_grad(dy2, dropout_p, seed):
+    hit = _masked.pop(dy2.data_ptr(), None)
+    if hit is not None and hit[1] == (dropout_p, seed) and hit[0].shape == dy2.shape:
+        return hit[0]
+    return dropout_apply(dy2, dropout_p, seed)
 
 
 # ----------------------------------------------------------------------------- MLP: FC1 + erf-GELU + FC2 (+dropout) + residual
 class MlpFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, residual, dropout_p, g_w1, g_b1, g_w2, g_b2, anchor):
+    def forward(ctx, x, w1, b1, w2, b2, residual, dropout_p, g_w1, g_b1, g_w2, g_b2, anchor, seed=0):
         x2 = _2d(x)
         M, K = x2.shape
         F = w1.shape[0]
@@ -405,7 +421,6 @@ class MlpFn(torch.autograd.Function):
         a = torch.empty(M, F, dtype=BF16, device=x.device)
         gemm(x2, 0, w1, 0, a, M, F, K, bias=b1, act=1, aux_out=z)
         y = torch.empty(M, K, dtype=BF16, device=x.device)
-        seed = next_seed() if dropout_p > 0 else 0
         gemm(a, 0, w2, 0, y, M, K, F, bias=b2, dropout_p=dropout_p, dropout_seed=seed,
              residual=_2d(residual) if residual is not None else None)
         ctx.save_for_backward(x2, z, a, w1, w2)
@@ -419,7 +434,7 @@ class MlpFn(torch.autograd.Function):
         dy2 = _2d(dy.contiguous())
         M, K = dy2.shape
         F = w1.shape[0]
-        dpre = dropout_apply(dy2, dropout_p, seed) if dropout_p > 0 else dy2
+        dpre = _masked_grad(dy2, dropout_p, seed) if dropout_p > 0 else dy2
         param_grads(dpre, a, g_w2, g_b2)
         dz = torch.empty(M, F, dtype=BF16, device=dy.device)
         gemm(dpre, 0, w2, 1, dz, M, F, K, mul_gelu_z=z)          # da * gelu'(z) fused in the dgrad epilogue
@@ -429,11 +444,15 @@ class MlpFn(torch.autograd.Function):
             dx = torch.empty(M, K, dtype=BF16, device=dy.device)
             gemm(dz, 0, w1, 1, dx, M, K, F)
             dx = dx.view(xshape)
-        return dx, None, None, None, None, (dy if has_res else None), None, None, None, None, None, None
+        return dx, None, None, None, None, (dy if has_res else None), None, None, None, None, None, None, None
 
 
 def mlp(x, w1, b1, w2, b2, *, residual=None, dropout_p=0.0, grads=(None, None, None, None), anchor=None):
-    return MlpFn.apply(x, w1, b1, w2, b2, residual, dropout_p, *grads, anchor)
+    seed = next_seed() if dropout_p > 0 else 0
+    y = MlpFn.apply(x, w1, b1, w2, b2, residual, dropout_p, *grads, anchor, seed)
+    if dropout_p > 0:
+        y._vm_drop = (dropout_p, seed)
+    return y
 
 
 # ----------------------------------------------------------------------------- LayerNorm
@@ -446,7 +465,7 @@ class LayerNormFn(torch.autograd.Function):
                  backward gets two gradients of y that are summed in fp32 inside the kernel."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, g_gamma, g_beta, fork):
+    def forward(ctx, x, gamma, beta, eps, g_gamma, g_beta, fork, drop=None):
         x2 = _2d(x)
         rows, cols = x2.shape
         y = torch.empty_like(x2)
@@ -455,7 +474,7 @@ class LayerNormFn(torch.autograd.Function):
         check(lib().vm_layernorm_fwd(ptr(x2), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows, cols, eps, stream()),
               "vm_layernorm_fwd")
         ctx.save_for_backward(x2, gamma, mean, rstd)
-        ctx.meta = (g_gamma, g_beta, x.shape, fork)
+        ctx.meta = (g_gamma, g_beta, x.shape, fork, drop)
         ctx.set_materialize_grads(False)
         y = y.view(x.shape)
         if fork == "in":
@@ -467,7 +486,7 @@ class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, d2=None):
         x2, gamma, mean, rstd = ctx.saved_tensors
-        g_gamma, g_beta, xshape, fork = ctx.meta
+        g_gamma, g_beta, xshape, fork, drop = ctx.meta
         rows, cols = x2.shape
         dres = None
         if fork == "in":
@@ -475,17 +494,24 @@ class LayerNormFn(torch.autograd.Function):
         if dy is None and d2 is not None:
             dy, d2 = d2, None
         if dy is None:                      # the normalised output was not used: only the pass-through gradient
-            return dres, None, None, None, None, None, None
+            return dres, None, None, None, None, None, None, None
         dy2 = _2d(dy.contiguous())
         dx = torch.empty_like(x2)
         ws = torch.empty(lib().vm_layernorm_bwd_ws(rows, cols) // 4, dtype=torch.float32, device=dy.device)
         if g_gamma is None:   # frozen affine: still need dx; send the param grads to scratch
             g_gamma = torch.zeros(cols, dtype=torch.float32, device=dy.device)
             g_beta = torch.zeros(cols, dtype=torch.float32, device=dy.device)
-        check(lib().vm_layernorm_bwd_partial(ptr(dy2), ptr(_2d(d2.contiguous())) if d2 is not None else None,
-                                             ptr(_2d(dres.contiguous())) if dres is not None else None,
-                                             ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), rows, cols, ptr(ws), stream()),
+        dxd = torch.empty_like(x2) if drop is not None else None       # masked copy for the linear that produced x (see _masked_grad)
+        check(lib().vm_layernorm_bwd_partial_dropout(ptr(dy2), ptr(_2d(d2.contiguous())) if d2 is not None else None,
+                                                     ptr(_2d(dres.contiguous())) if dres is not None else None,
+                                                     ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dxd) if dxd is not None else None,
+                                                     drop[0] if drop else 0.0, drop[1] if drop else 0,
+                                                     ptr(seed_dev(dy.device)) if drop else None, rows, cols, ptr(ws), stream()),
               "vm_layernorm_bwd")
+        if dxd is not None:
+            if len(_masked) > 8:
+                _masked.clear()
+            _masked[dx.data_ptr()] = (dxd, drop)
         # the dgamma / dbeta reduction only feeds the optimizer: queued, and reduced together with the step's other LayerNorms in one
         # launch when the parameter-gradient queue is flushed (flush_param_grads)
         if g_gamma.data_ptr() in _lnq["ptrs"] or len(_lnq["items"]) >= 64:
@@ -493,11 +519,14 @@ class LayerNormFn(torch.autograd.Function):
         _lnq["items"].append((ws, g_gamma, g_beta, rows, cols))
         _lnq["ptrs"].add(g_gamma.data_ptr())
         _ensure_end_of_backward_flush()
-        return dx.view(xshape), None, None, None, None, None, None
+        return dx.view(xshape), None, None, None, None, None, None, None
+
+
+FUSE_LN_DROPOUT = os.environ.get("VM_LN_DROPOUT_FUSE", "1") != "0"     # 0: separate vm_dropout_apply_bf16 pass in the linear's backward (A/B, tests)
 
 
 def layer_norm(x, gamma, beta, eps, g_gamma=None, g_beta=None, fork=None):
-    return LayerNormFn.apply(x, gamma, beta, eps, g_gamma, g_beta, fork)
+    return LayerNormFn.apply(x, gamma, beta, eps, g_gamma, g_beta, fork, getattr(x, "_vm_drop", None) if FUSE_LN_DROPOUT else None)
 
 
 # ----------------------------------------------------------------------------- attention
