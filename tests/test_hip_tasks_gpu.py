@@ -1,4 +1,6 @@
 """GPU parity of the task-level pieces: contrastive / CE losses, MVQA core, text encoder, SCST loss, Trainor loop."""
+import os
+
 import pytest
 import torch
 
@@ -327,3 +329,64 @@ def test_vicreg_loss_vs_golden(golden):
         cov = VICREGLoss.covariance_loss(a.detach(), b.detach()).item()
         assert abs(cov - case["cov"].item()) <= 5e-3 * case["cov"].item(), (cov, case["cov"].item())
         assert rel(a.grad.cpu(), case["g1"]) <= 1e-2 and rel(b.grad.cpu(), case["g2"]) <= 1e-2
+
+
+def test_zoo_checkpoint_round_trip_generates_the_same_reports(tmp_path):
+    """SURVEY §8(f) rank 4 on the GPU: a model trained here -> the reference's checkpoint wire format (old DataParallel prefix and
+    pre-1.3.2 encoder names, ref:vilmedic/executors/utils.py:26-34) -> a zoo directory -> AutoModel.from_pretrained -> the loaded model
+    gives the same loss and the same greedy / beam-2 reports on raw inputs (image FILES through the device pipeline, raw sentences through
+    the tokenizer) as the model it was saved from.  (Published zoo checkpoints cannot be fetched here.)"""
+    import copy
+    import types
+    import yaml
+    from test_datasets import _make_corpus
+    from test_zoo import _model_cfg
+    from vilmedic_amd import models as M
+    from vilmedic_amd.datasets import ImSeq
+    from vilmedic_amd.optim import FusedAdam
+    from vilmedic_amd.zoo import AutoModel
+    root, zoo = str(tmp_path / "data"), str(tmp_path / "zoo" / "rrg-tiny")
+    os.makedirs(root), os.makedirs(zoo)
+    _make_corpus(root)
+    seq = dict(root=root, file="report.tok", tokenizer=None, tokenizer_max_len=12, processing="r2gen_clean_report", source="tgt")
+    image = dict(root=root, file="image.tok", image_path=root, resize=40, crop=32, ext=".png")
+    train = ImSeq(seq=seq, image=image, split="train", ckpt_dir=zoo)
+    cfg = _model_cfg()
+    mc = copy.deepcopy(cfg)
+    torch.manual_seed(0)
+    model = getattr(M, mc.pop("proto"))(**mc, dl=types.SimpleNamespace(dataset=train)).to(dev())
+    files = [os.path.join(root, "img", f"validate_{i}.png") for i in range(3)]
+    sents = ["The heart is normal. 2. No effusion.", "clear lungs", "small effusion the heart is enlarged"]
+    # a few optimizer steps so that the weights are not the initialisation
+    model.train()
+    opt = FusedAdam(model, lr=1e-3)
+    for _ in range(3):
+        batch = {k: (v.to(dev()) if torch.is_tensor(v) else v) for k, v in train.inference(seq=sents, image=files).items()}
+        opt.zero_grad()
+        model(**batch)["loss"].backward()
+        opt.step()
+    model.eval()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    old = {"module." + k.replace("enc.model.", "enc.0.cnn."): v.clone() for k, v in sd.items()}
+    torch.save({"model": old, "__version__": "1.2.9"}, os.path.join(zoo, "0.5_3_0.pth"))
+    yaml.safe_dump({"name": "rrg_tiny", "model": cfg,
+                    "dataset": {"proto": "ImSeq",
+                                "seq": {"vocab_file": "vocab.tgt", "tokenizer_max_len": 12, "processing": "r2gen_clean_report", "source": "tgt"},
+                                "image": {"resize": 40, "crop": 32, "ext": ".png"}}}, open(os.path.join(zoo, "config.yml"), "w"))
+    loaded, dataset = AutoModel.from_pretrained(zoo)
+    loaded = loaded.to(dev()).eval()
+    # raw inputs through the LOADED dataset (evaluation transform: resize to the crop size, no random crop / flip; the training dataset
+    # above draws augmentations) -- token ids must be those of the training tokenizer
+    b2 = {k: (v.to(dev()) if torch.is_tensor(v) else v) for k, v in dataset.inference(seq=sents, image=files).items()}
+    assert torch.equal(b2["input_ids"].cpu(), train.seq.inference(sents)["input_ids"]) and b2["images"].shape == (3, 3, 32, 32)
+    b1 = b2
+    with torch.no_grad():
+        l1, l2 = model(**b1)["loss"].item(), loaded(**b2)["loss"].item()
+        assert abs(l1 - l2) <= 1e-5 * abs(l1), (l1, l2)           # (the CE kernel sums the rows' losses with atomics: order-dependent last bits)
+        for beams in (1, 2):                       # greedy and beam-2 reports through the models' own encode + generate
+            outs = []
+            for m, b in ((model, b1), (loaded, b2)):
+                hs, hmask = m.encode(images=b["images"])
+                outs.append(m.dec.generate(encoder_hidden_states=hs, encoder_attention_mask=hmask, num_beams=beams, max_length=12).cpu())
+            assert torch.equal(outs[0], outs[1]), (beams, outs)
+    assert outs[0].shape[0] == 3 and outs[0].shape[1] <= 12
