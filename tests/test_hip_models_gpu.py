@@ -280,7 +280,7 @@ def test_two_phase_backward_equals_single_backward(golden):
 def test_dropout_mask_fused_into_layernorm_backward_equals_the_separate_pass(golden):
     """With dropout on, the gradient of  y = dropout(linear(x)) + residual  is masked either by vm_dropout_apply_bf16 in the linear's
     backward or (default) by the LayerNorm backward kernel that produced it (vm_layernorm_bwd_partial_dropout -> ops._masked_grad).
-    Same seeds, same model, both ways: loss identical, every parameter gradient equal up to the single bf16 rounding the fused form
+    Same seeds, same model, both ways: same loss, every parameter gradient equal up to the single bf16 rounding the fused form
     skips, and the fused run must actually have used the fused path (no dropout_apply launch)."""
     from vilmedic_amd import ops
     from vilmedic_amd.arena import arena_of
@@ -314,7 +314,7 @@ def test_dropout_mask_fused_into_layernorm_backward_equals_the_separate_pass(gol
     finally:
         ops.dropout_apply = real
         ops.FUSE_LN_DROPOUT = True
-    assert out[True][0] == out[False][0]
+    assert abs(out[True][0] - out[False][0]) <= 1e-6 * abs(out[False][0])        # same forward; the CE kernel's atomic loss sum is order-dependent in the last bits
     assert out[False][2] > 0 and out[True][2] < out[False][2], (out[True][2], out[False][2])      # the fused run skipped the separate passes
     err = rel_l2(out[True][1], out[False][1])
     print(f"[parity] fused LN-backward dropout mask vs separate pass: grad rel-l2 {err:.2e}, dropout_apply launches {out[True][2]} vs {out[False][2]}")
