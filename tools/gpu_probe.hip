@@ -170,9 +170,9 @@ static int test_ln(int rows, int cols) {
     return bad != 0;
 }
 
-// A/B of VM_GEMM_PIPE on one shape with one set of (rotating) buffers: pipe 0,1,0,1
+// A/B of one integer switch of the library on one shape with one set of (rotating) buffers: A, B, A, B
 static int g_pipe_a = 0, g_pipe_b = 1;
-static const char* g_ab_env = "VM_GEMM_PIPE";     // the switch bench_ab toggles (VM_GEMM_PIPE, VM_GEMM_VARIANT, ...)
+static const char* g_ab_env = "VM_GEMM_VARIANT";  // the switch bench_ab toggles (VM_GEMM_VARIANT, VM_GEMM_GROUPW, ...)
 static void bench_ab(int M, int N, int K, int la, int lb, int flags, int split) {
     const int rot = 4;
     int64_t lda = la == 0 ? K : M, ldb = lb == 0 ? K : N;
@@ -232,13 +232,10 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
-    // gpu_probe.bin pipe [A B]        A/B of two VM_GEMM_PIPE settings (default 0 1) on the training step's shapes
     // gpu_probe.bin ab ENV A B        the same for any integer switch of the library, e.g.  ab VM_GEMM_VARIANT 0 7
-    if (argc >= 2 && (!strcmp(argv[1], "pipe") || (!strcmp(argv[1], "ab") && argc >= 5))) {
+    if (argc >= 5 && !strcmp(argv[1], "ab")) {
         int fails = 0;
-        const bool generic = !strcmp(argv[1], "ab");
-        if (generic) { g_ab_env = argv[2]; g_pipe_a = atoi(argv[3]); g_pipe_b = atoi(argv[4]); }
-        else if (argc >= 4) { g_pipe_a = atoi(argv[2]); g_pipe_b = atoi(argv[3]); }
+        g_ab_env = argv[2]; g_pipe_a = atoi(argv[3]); g_pipe_b = atoi(argv[4]);
         printf("A = %s=%d (pipe0 columns), B = %s=%d (pipe1 columns)\n", g_ab_env, g_pipe_a, g_ab_env, g_pipe_b);
         { char pb[4]; snprintf(pb, 4, "%d", g_pipe_b); setenv(g_ab_env, pb, 1); }
         const bool variant_ab = !strcmp(g_ab_env, "VM_GEMM_VARIANT");
