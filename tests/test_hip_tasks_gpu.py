@@ -227,6 +227,43 @@ def test_trainor_runs_and_checkpoints(tmp_path):
     assert {"model", "training_scheduler", "optimizer", "config", "__version__"} <= set(sd)
 
 
+def _tiny_rrg_cfg(tmp_path, extra):
+    from vilmedic_amd.config import get_config
+    return get_config(os.path.join(os.path.dirname(__file__), "..", "config", "RRG", "rrg-vit-synthetic.yml"),
+                      ["dataset.num_samples=16", "dataset.image_size=32", "dataset.vocab_size=97", "dataset.tokenizer_max_len=16",
+                       "model.decoder.hidden_size=128", "model.decoder.num_attention_heads=2", "model.decoder.intermediate_size=256",
+                       "model.decoder.num_hidden_layers=1", "model.decoder.max_position_embeddings=64",
+                       "model.cnn.image_size=32", "model.cnn.patch_size=8", "model.cnn.hidden_size=128", "model.cnn.num_attention_heads=2",
+                       "model.cnn.intermediate_size=256", "model.cnn.num_hidden_layers=1",
+                       "trainor.batch_size=4", "validator.batch_size=4", "validator.beam_width=1", f"ckpt_dir={tmp_path}",
+                       "trainor.optim_params.lr=0.003"] + extra)
+
+
+def test_trainor_keeps_the_reference_loop_semantics(tmp_path):
+    """ref:vilmedic/executors/trainor.py:95-203: (a) with grad_accu = 3 and 4 iterations per epoch the optimizer steps at
+    iteration 3 AND once more on the left-over micro-batch at the end of the epoch (:139-150) -> 2 steps per epoch; (b) evaluation starts
+    when epoch + 1 >= eval_start and the checkpoint carries epoch + 1 in its name; (c) an early_stop_metric the validator does not
+    produce raises KeyError instead of silently never saving."""
+    from vilmedic_amd.config import executor_view
+    from vilmedic_amd.executors import Trainor
+    cfg = _tiny_rrg_cfg(tmp_path / "a", ["trainor.epochs=1", "trainor.grad_accu=3", "trainor.eval_start=2", "trainor.early_stop_metric=ROUGEL"])
+    os.makedirs(tmp_path / "a")
+    t = executor_view(cfg, "trainor")
+    t["validator_view"] = executor_view(cfg, "validator")
+    tr = Trainor(t, seed=0)
+    assert len(tr.dl) == 4
+    tr.start()                                          # epochs 0 and 1 (range(0, epochs + 1) as in the reference)
+    assert tr.optimizer.steps == 2 * 2, tr.optimizer.steps             # (a): iteration 3 + the left-over update, per epoch
+    ckpts = sorted(f for f in os.listdir(tmp_path / "a") if f.endswith(".pth"))
+    assert len(ckpts) == 1 and ckpts[0].split("_")[-2] == "2", ckpts   # (b): only epoch index 1 was evaluated, named epoch + 1 = 2
+    os.makedirs(tmp_path / "b")
+    cfg = _tiny_rrg_cfg(tmp_path / "b", ["trainor.epochs=0", "trainor.eval_start=0", "trainor.early_stop_metric=no_such_metric"])
+    t = executor_view(cfg, "trainor")
+    t["validator_view"] = executor_view(cfg, "validator")
+    with pytest.raises(KeyError, match="no_such_metric"):
+        Trainor(t, seed=0).start()                      # (c)
+
+
 def test_gloria_model_vs_oracle():
     """GLoRIA: CNN tower (MIOpen) + text tower, HIP embedders, on-device word-piece merge, GLoRIALoss --
     against the oracle composition on the CPU (same CNN module class in fp32)."""
