@@ -54,6 +54,7 @@ def test_arena_ddp_step_equals_single_process_step(nccl, bf16_wire):
     assert ddp.split_at is not None and m2.split_backward
     ddp.backward(m2(input_ids=ids, attention_mask=am, images=images)["loss"])
     torch.cuda.synchronize()
+    assert ddp.mark_starts == len(ddp._marks) >= 1, (ddp.mark_starts, ddp._marks)      # the encoder's rear buckets started from backward marks
     g1, g2 = arena_of(m1).gflat, arena_of(m2).gflat
     assert g1.abs().sum().item() > 0
     err = _rel(g2, g1)

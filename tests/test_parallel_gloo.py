@@ -180,6 +180,68 @@ def test_arena_ddp_two_phase_backward_equals_single_process_gradient():
         torch.testing.assert_close(r[rank][1], r[rank][2], rtol=1e-5, atol=1e-6)
 
 
+class _TwoPhaseLayers(_TwoPhase):
+    """as _TwoPhase with a three-layer encoder that carries backward marks in front of layers 1 and 2 (what nn.ViTModel does)"""
+
+    def __init__(self):
+        super().__init__()
+        self.enc = torch.nn.ModuleList([torch.nn.Linear(10, 16), torch.nn.Linear(16, 16), torch.nn.Linear(16, 12)])
+
+    def forward(self, x, y):
+        from vilmedic_amd import ops
+        h = x
+        for i, layer in enumerate(self.enc):
+            if i:
+                h = ops.backward_mark(h, ("enc_layer", i))
+            h = torch.tanh(layer(h))
+        feats = h
+        if self.split_backward and torch.is_grad_enabled():
+            leaf = feats.detach().requires_grad_(True)
+            self._split = (feats, leaf)
+            feats = leaf
+        return torch.nn.functional.mse_loss(self.dec(feats), y)
+
+
+def _arena_ddp_buckets(rank, world):
+    """the encoder range reduced in three buckets, back to front, each started from the backward mark in front of its first layer while
+    the layers before it are still being differentiated: two rear buckets from marks + the front bucket at the end"""
+    from vilmedic_amd import ops
+    from vilmedic_amd.parallel import ArenaDDP
+    torch.manual_seed(7)
+    model = _TwoPhaseLayers()
+    arena = _FakeArena(model)
+    model.__dict__["_vm_arena_cache"] = arena
+    model.ddp_marks = {("enc_layer", i): model.enc[i].weight._vm_off for i in (1, 2)}
+    try:
+        ddp = ArenaDDP(model, dist, chunks=2, bf16_wire=False, enc_buckets=3)
+        assert len(ddp._marks) == 2 and ops._bwd_mark["cb"] is not None
+        g = torch.Generator().manual_seed(13)
+        X, Y = torch.randn(8, 10, generator=g), torch.randn(8, 3, generator=g)
+        outs = []
+        for step in range(2):                              # twice: the bucket state must reset between steps
+            arena.gflat.zero_()
+            before = ddp.mark_starts
+            ddp.backward(model(X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]))
+            outs.append((ddp.mark_starts - before, arena.gflat.clone()))
+        ref = _TwoPhaseLayers()
+        ref.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+        cb, ops._bwd_mark["cb"] = ops._bwd_mark["cb"], None     # the single-process reference runs without marks
+        ref(X, Y).backward()
+        ops._bwd_mark["cb"] = cb
+        return outs, torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    finally:
+        ops._bwd_mark["cb"] = None
+
+
+def test_arena_ddp_encoder_buckets_start_from_backward_marks():
+    r = _run(_arena_ddp_buckets)
+    for rank in (0, 1):
+        outs, ref = r[rank]
+        for fired, gflat in outs:
+            assert fired == 2, fired
+            torch.testing.assert_close(gflat, ref, rtol=1e-5, atol=1e-6)
+
+
 def _arena_ddp_grad_accu(rank, world):
     """two micro-batches per optimizer step: the first backward must NOT reduce but MUST run both phases (with the split
     enabled and a plain loss.backward() the encoder received no gradient at all); between them an optimizer drops .grad

@@ -166,7 +166,9 @@ class ViTModel(nn.Module):
                             e.cls_token.view(-1), e.position_embeddings.view(-1, cfg.hidden_size), cfg.patch_size,
                             grads=(arena.grad(proj.weight), arena.grad(proj.bias), _flat(arena.grad(e.cls_token)),
                                    _flat2(arena.grad(e.position_embeddings), cfg.hidden_size)))
-        for layer in self.encoder.layer:
+        for i, layer in enumerate(self.encoder.layer):
+            if i:
+                x = ops.backward_mark(x, ("enc_layer", i))      # data parallel: the gradients of layers >= i can be reduced from here on
             x = layer(x, arena)
         return _ln(arena, x, self.layernorm, cfg.layer_norm_eps)
 

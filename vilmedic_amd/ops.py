@@ -215,6 +215,33 @@ def colsum(x, out, rows=None, cols=None, scale_dev=None):
                                stream()), "vm_colsum_bf16")
 
 
+# ----------------------------------------------------------------------------- backward marks
+# An identity op whose backward tells a registered listener "the backward pass has just passed this point".  Models put marks between
+# their layers (nn.ViTModel: in front of every encoder layer); ArenaDDP listens and starts the gradient all-reduce of the layers behind
+# a mark while the layers in front of it are still being differentiated.  Without a listener no mark is inserted (single-GPU runs).
+_bwd_mark = {"cb": None}
+
+
+class _BackwardMark(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, tag):
+        ctx.tag = tag
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        cb = _bwd_mark["cb"]
+        if cb is not None:
+            cb(ctx.tag)
+        return g, None
+
+
+def backward_mark(x, tag):
+    if _bwd_mark["cb"] is None or not torch.is_grad_enabled() or not x.requires_grad:
+        return x
+    return _BackwardMark.apply(x, tag)
+
+
 # ----------------------------------------------------------------------------- grouped parameter gradients
 # Weight / bias gradients feed only the optimizer, so nothing in a backward pass waits for them.  Instead of launching one
 # split-K GEMM (+ slab reduce) and one column-sum kernel per nn.Linear as its backward node runs, the backward nodes QUEUE

@@ -69,11 +69,14 @@ class ArenaDDP:
     ``backward(loss)`` overlaps communication with compute when the model exposes an encoder/decoder split (RRG): the
     decoder consumes a DETACHED copy of the image features, so ``loss.backward()`` runs exactly the decoder's graph; the
     decoder's arena range (parameters are laid out [dec | enc]) is then all-reduced asynchronously on RCCL's stream
-    while the encoder's backward (``features.backward(d_features)``) runs on the compute stream; the encoder range
-    follows.  Explicit two-phase backward -- correct by construction, no reliance on autograd's scheduling order.
+    while the encoder's backward (``features.backward(d_features)``) runs on the compute stream.  The encoder range itself
+    is reduced in ``enc_buckets`` pieces, back to front: the encoder's layers carry backward marks (ops.backward_mark), and when
+    the backward pass crosses the mark in front of layer i the gradients of layers >= i (which lie BEHIND it in the arena) are
+    complete and their all-reduce starts while layers < i are still being differentiated; only the front bucket is exposed.
+    Every rank issues the same collectives in the same order (the marks fire in program order).
     ``finish()`` (no overlap) remains for callers that ran ``loss.backward()`` themselves."""
 
-    def __init__(self, model, dist, chunks=4, bf16_wire=True, wire=None):
+    def __init__(self, model, dist, chunks=4, bf16_wire=True, wire=None, enc_buckets=3):
         from . import ops
         from .arena import arena_of
         self.dist = dist
@@ -92,9 +95,50 @@ class ArenaDDP:
             if enc_offs and dec_offs and min(enc_offs) >= max(dec_offs):
                 self.split_at = min(enc_offs)
                 model.split_backward = True
+        # encoder buckets: {mark tag: arena offset where that layer's parameters start}; models may provide ``ddp_marks`` themselves
+        self._marks, self._live, self.mark_starts = {}, None, 0
+        if self.split_at is not None and enc_buckets > 1:
+            marks = getattr(model, "ddp_marks", None) or self._layer_marks(model)
+            offs = sorted(o for o in marks.values() if self.split_at < o < self.arena.numel)
+            if offs:
+                want = [self.split_at + (self.arena.numel - self.split_at) * k // enc_buckets for k in range(1, enc_buckets)]
+                chosen = {min(offs, key=lambda o: abs(o - w)) for w in want}
+                self._marks = {t: o for t, o in marks.items() if o in chosen}
+                ops._bwd_mark["cb"] = self._on_mark
         # ``wire``: optional pre-allocated bf16 staging buffer (callers allocate it before init_process_group, see bench.py)
         self._wire = (wire if wire is not None else
                       torch.empty(self.arena.numel, dtype=torch.bfloat16, device=self.arena.flat.device)) if bf16_wire else None
+
+    @staticmethod
+    def _layer_marks(model):
+        """("enc_layer", i) -> arena offset of layer i's first parameter, for encoders with an ``encoder.layer`` list whose layers lie
+        in the arena in order (nn.ViTModel); {} otherwise"""
+        enc = getattr(getattr(model, "enc", None), "model", None)
+        layers = getattr(getattr(enc, "encoder", None), "layer", None)
+        if layers is None:
+            return {}
+        spans = []
+        for layer in layers:
+            offs = [(p._vm_off, p._vm_off + p.numel()) for p in layer.parameters()]
+            if not offs:
+                return {}
+            spans.append((min(o for o, _ in offs), max(e for _, e in offs)))
+        if any(spans[i][1] > spans[i + 1][0] for i in range(len(spans) - 1)):      # not laid out layer after layer
+            return {}
+        return {("enc_layer", i): spans[i][0] for i in range(1, len(spans))}
+
+    def _on_mark(self, tag):
+        """backward has just crossed the mark in front of an encoder layer: reduce everything behind it that is not reduced yet"""
+        st = self._live
+        off = self._marks.get(tag)
+        if st is None or off is None or off >= st["hi"]:
+            return
+        ops = self._ops
+        ops.flush_param_grads()                          # the queued weight / LayerNorm gradients of the layers behind the mark
+        with ops.side_context(self.arena.flat.device):
+            st["pending"] += self._start(off, st["hi"], 1)
+        st["hi"] = off
+        self.mark_starts += 1
 
     # ---- asynchronous all-reduce of gflat[s:e] in `chunks` pieces; returns the pending work items
     def _start(self, s, e, chunks):
@@ -141,13 +185,16 @@ class ArenaDDP:
             ops.flush_param_grads()                      # the decoder's queued weight gradients, before their range is reduced
             with ops.side_context(dev):
                 pending = self._start(0, self.split_at, max(1, self.chunks // 2))
+            self._live = {"hi": n, "pending": pending}   # the encoder's backward marks start the buckets behind them (_on_mark)
             if leaf.grad is not None:
-                feats.backward(leaf.grad)                # encoder graph, overlapping the decoder's all-reduce
+                feats.backward(leaf.grad)                # encoder graph, overlapping the decoder's (and its own rear buckets') all-reduce
+            hi, self._live = self._live["hi"], None
             ops.flush_param_grads()
             with ops.side_context(dev):
-                pending += self._start(self.split_at, n, max(1, self.chunks // 2))
+                pending += self._start(self.split_at, hi, 1 if hi < n else max(1, self.chunks // 2))
                 self._wait(pending)
         finally:
+            self._live = None
             ops._side["defer"] = False
         ops.join_side()                                  # the optimizer (main stream) waits for the averaged gradients
         self.model._split = None
