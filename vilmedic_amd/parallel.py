@@ -76,7 +76,7 @@ class ArenaDDP:
     Every rank issues the same collectives in the same order (the marks fire in program order).
     ``finish()`` (no overlap) remains for callers that ran ``loss.backward()`` themselves."""
 
-    def __init__(self, model, dist, chunks=4, bf16_wire=True, wire=None, enc_buckets=3):
+    def __init__(self, model, dist, chunks=4, bf16_wire=True, wire=None, enc_buckets=4):
         from . import ops
         from .arena import arena_of
         self.dist = dist
