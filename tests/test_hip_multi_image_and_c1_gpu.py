@@ -1,15 +1,12 @@
-"""GPU parity cases written at the end of round 1 AFTER the GPU budget was spent: they have not run on an MI355X yet.  Their CPU
-halves are green (oracle pinned: tests/test_oracle_golden.py::test_g16_multi_image_encode, test_hf_resnet_oracle_matches_transformers,
-tests/test_host_cpu.py::test_c1_model_state_dict_drives_the_oracle).  They are marked xfail(strict=False) so that an unexpected
-mismatch cannot turn the validated suite red, and the file sorts last so that nothing runs after them; once seen green on the GPU
-they move into test_hip_models_gpu.py without the mark.  No new kernel is involved: both go through paths the validated tests
-already exercise (VisualEncoder.encode, ops.linear, the decoder)."""
+"""GPU parity of the multi-image VisualEncoder.encode path (fixture G16) and of the BASELINE configs[0] model (HF ResNet-18 encoder +
+2-layer decoder) against the oracle.  Written at the end of round 1, green on the MI355X in every round-2 run (profiles/r02_*_pytest_gpu.txt),
+now regular tests.  No new kernel is involved: both go through VisualEncoder.encode, ops.linear and the decoder."""
 import pytest
 import torch
 
 import golden_recipes as R
 
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="not yet run on a GPU (written after the round's GPU budget was spent)")]
+pytestmark = pytest.mark.gpu
 
 
 def dev():
