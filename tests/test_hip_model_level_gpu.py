@@ -195,12 +195,14 @@ def test_rrg_scst_forward_with_fixed_rollouts_and_top_k_vs_oracle():
     dec = model.model.dec.decoder
     calls = []
 
-    def fake_generate(input_ids=None, do_sample=False, **kw):
-        calls.append(bool(do_sample))
+    def fake_generate(input_ids=None, do_sample=False, greedy_rows=None, encoder_hidden_states=None, **kw):
+        calls.append((bool(do_sample), greedy_rows, tuple(encoder_hidden_states.shape[:1])))
+        if greedy_rows:                              # the paired rollout: greedy rows first, sampled rows behind them
+            return _Gen(torch.cat([greedy, seq]).to(dev()))
         return _Gen((seq if do_sample else greedy).to(dev()))
     dec.generate = fake_generate
     out = model(**batch)
-    assert calls == [False, True]
+    assert calls == [(True, B, (2 * B,))]            # ONE decode loop of 2B rows serves the baseline and the sampled rollout
     out["loss"].backward()
     # oracle side: rewards by the same scorer on the same strings, loss by scst_forward
     tok = ds.tokenizer

@@ -248,6 +248,30 @@ def test_bf16_decode_step_stays_within_margin_of_fp32_oracle(golden):
     assert worst <= 0.25
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_paired_rollout_greedy_rows_equal_a_separate_greedy_decode(golden, dtype):
+    """generation.sample(greedy_rows=B) -- SCST's two rollouts in ONE decode loop of 2B rows (blocks/rl/SCST.forward_rollouts): the first B
+    rows must emit exactly the tokens of a separate greedy generate() on the same encoder states (rows are independent of their batch
+    mates in every kernel of the step), the other B rows sample from the bad-word + top-k filtered distribution (never a banned token
+    before their eos) on THEIR encoder states."""
+    from vilmedic_amd.generation import trim_to_last_eos
+    g, cfg, dec, st, enc, start, common = _g7_setup(golden)
+    enc_d, mask_d = enc.to(dev()).to(BF), g["enc_mask"].to(dev())
+    alone = dec.generate(input_ids=start, encoder_hidden_states=enc_d, encoder_attention_mask=mask_d, decode_dtype=dtype, **common)
+    B = enc_d.shape[0]
+    enc2 = torch.cat([enc_d, enc_d.flip(0)])                          # the sampled rows run on different encoder states
+    mask2 = torch.cat([mask_d, mask_d.flip(0)])
+    both = dec.generate(input_ids=torch.zeros(2 * B, 1, dtype=torch.long, device=dev()), encoder_hidden_states=enc2, encoder_attention_mask=mask2,
+                        do_sample=True, greedy_rows=B, top_k=5, bad_words_ids=[[1], [0]], decode_dtype=dtype,
+                        generator=torch.Generator(device=dev()).manual_seed(3), **common)
+    greedy = trim_to_last_eos(both[:B], 2)
+    n = min(greedy.shape[1], alone.shape[1])
+    assert torch.equal(greedy[:, :n], alone[:, :n]) and (greedy[:, n:] == 1).all() and (alone[:, n:] == 1).all()
+    sampled = both[B:, 1:]
+    ended = torch.cumsum((sampled == 2).int(), 1) - (sampled == 2).int() > 0          # positions after a row's eos hold pads
+    assert not (((sampled == 0) | (sampled == 1)) & ~ended).any()
+
+
 def test_two_phase_backward_equals_single_backward(golden):
     """ArenaDDP's overlap trick (decoder consumes detached features; encoder backward runs as a second phase) yields the
     same gradients as one loss.backward()."""

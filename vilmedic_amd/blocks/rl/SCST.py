@@ -84,11 +84,6 @@ class SCST(nn.Module):
     def forward_sampling(self, input_ids, attention_mask, encoder_hidden_states, encoder_attention_mask, reward_greedy):
         assert torch.is_grad_enabled()
         dev = encoder_hidden_states.device
-        nll_loss = None
-        if self.use_nll:
-            nll_loss = self.decoder(input_ids=input_ids.to(dev), attention_mask=attention_mask.to(dev),
-                                    encoder_hidden_states=encoder_hidden_states, encoder_attention_mask=encoder_attention_mask,
-                                    labels=input_ids.to(dev), return_logits=False)["loss"]
         banned = [self.pad_token_id, self.bos_token_id]
         with torch.no_grad():
             out = self.decoder.generate(input_ids=torch.full((input_ids.shape[0], 1), self.bos_token_id, dtype=torch.long, device=dev),
@@ -96,7 +91,39 @@ class SCST(nn.Module):
                                         bad_words_ids=[[b] for b in banned], return_dict_in_generate=True, decode_dtype=self.decode_dtype,
                                         encoder_hidden_states=encoder_hidden_states.detach(),
                                         encoder_attention_mask=encoder_attention_mask.detach())
-        seq = out.sequences                       # [B, T] with bos at 0
+        return self._policy_gradient(out.sequences, input_ids, attention_mask, encoder_hidden_states, encoder_attention_mask, reward_greedy)
+
+    def forward_rollouts(self, input_ids, attention_mask, greedy_encoder, sampling_encoder):
+        """Both rollouts of a step in ONE decode loop (a decode step is launch-latency-bound: 2B rows cost about what B rows cost, so
+        the greedy baseline rides along with the sampled rollout): rows [0, B) decode greedily on ``greedy_encoder`` = (features,
+        mask) of the eval-mode encoder pass, rows [B, 2B) sample on ``sampling_encoder`` = those of the train-mode pass -- exactly the
+        inputs forward_greedy / forward_sampling get (ref:vilmedic/models/rrg/RRG_SCST.py:53-75) -- then the rewards and the
+        policy-gradient loss.  -> (forward_sampling's return tuple, reward_greedy)"""
+        assert torch.is_grad_enabled()
+        from ...generation import trim_to_last_eos
+        (enc_g, mask_g), (enc_s, mask_s) = greedy_encoder, sampling_encoder
+        dev, B = enc_s.device, input_ids.shape[0]
+        banned = [self.pad_token_id, self.bos_token_id]
+        with torch.no_grad():
+            out = self.decoder.generate(input_ids=torch.full((2 * B, 1), self.bos_token_id, dtype=torch.long, device=dev),
+                                        max_length=self.max_length, num_beams=1, do_sample=True, greedy_rows=B, top_k=self.top_k,
+                                        bad_words_ids=[[b] for b in banned], return_dict_in_generate=True, decode_dtype=self.decode_dtype,
+                                        encoder_hidden_states=torch.cat([enc_g.detach(), enc_s.detach()]),
+                                        encoder_attention_mask=torch.cat([mask_g.detach(), mask_s.detach()]))
+        greedy = trim_to_last_eos(out.sequences[:B], self.eos_token_id)
+        sampled = trim_to_last_eos(out.sequences[B:], self.eos_token_id)
+        reward_greedy, _, _ = self.get_reward(greedy.detach(), input_ids)
+        return self._policy_gradient(sampled, input_ids, attention_mask, enc_s, mask_s, reward_greedy), reward_greedy
+
+    def _policy_gradient(self, seq, input_ids, attention_mask, encoder_hidden_states, encoder_attention_mask, reward_greedy):
+        """seq [B, T] with bos at 0 = the sampled rollout -> SCST loss through one teacher-forced pass (ref:...SCST.py:14-45,159-185)"""
+        dev = encoder_hidden_states.device
+        nll_loss = None
+        if self.use_nll:
+            nll_loss = self.decoder(input_ids=input_ids.to(dev), attention_mask=attention_mask.to(dev),
+                                    encoder_hidden_states=encoder_hidden_states, encoder_attention_mask=encoder_attention_mask,
+                                    labels=input_ids.to(dev), return_logits=False)["loss"]
+        banned = [self.pad_token_id, self.bos_token_id]
         sampled_ids = seq[:, 1:].contiguous()
         reward_sampling, hyp_list, _ = self.get_reward(sampled_ids, input_ids)
         weights = self.scores_weights[-len(self.scorers):]

@@ -316,9 +316,20 @@ def _process(logits, bad_ids, top_k):
 
 
 @torch.no_grad()
+def trim_to_last_eos(seq, eos_token_id):
+    """HF's stopping point for a finished batch: generation ends right after the step at which its last row emitted eos"""
+    is_eos = seq[:, 1:] == eos_token_id
+    if seq.shape[1] > 1 and bool(is_eos.any(dim=1).all()):
+        return seq[:, :int((is_eos.float().argmax(dim=1) + 1).max()) + 1]
+    return seq
+
+
 def sample(decoder, input_ids, enc, enc_mask, *, max_length, eos_token_id, pad_token_id, do_sample=False, top_k=None,
-           bad_words_ids=None, output_scores=False, generator=None, decode_dtype=None):
-    """HF ``_sample``: greedy (argmax) or multinomial sampling, 1 sequence per batch row."""
+           bad_words_ids=None, output_scores=False, generator=None, decode_dtype=None, greedy_rows=None):
+    """HF ``_sample``: greedy (argmax) or multinomial sampling, 1 sequence per batch row.  ``greedy_rows`` = n (with do_sample):
+    the first n rows decode greedily on the RAW logits, the others sample from the processed ones -- two rollouts in one pass of
+    launch-latency-bound decode steps (SCST: baseline + sampled rollout); callers split the rows and trim each part
+    (trim_to_last_eos)."""
     B = input_ids.shape[0]
     st, decoder, enc0 = _decode_state(decoder, enc, enc_mask, 1, max_length, decode_dtype)
     dev = enc0.device
@@ -330,13 +341,20 @@ def sample(decoder, input_ids, enc, enc_mask, *, max_length, eos_token_id, pad_t
     cur = 1
     while cur < max_length:
         logits = st.step(seq[:, cur - 1], cur - 1)
-        if do_sample or bad or output_scores:
-            logits = _process(logits.clone(), bad, top_k)
-        if do_sample:
-            probs = torch.softmax(logits, dim=-1)
-            nxt = torch.multinomial(probs, 1, generator=generator).squeeze(1)
+        if do_sample and greedy_rows:
+            g = int(greedy_rows)
+            nxt = torch.empty(B, dtype=torch.long, device=dev)
+            nxt[:g] = argmax_f32(logits[:g].contiguous())
+            probs = torch.softmax(_process(logits[g:].clone(), bad, top_k), dim=-1)
+            nxt[g:] = torch.multinomial(probs, 1, generator=generator).squeeze(1)
         else:
-            nxt = argmax_f32(logits.contiguous())
+            if do_sample or bad or output_scores:
+                logits = _process(logits.clone(), bad, top_k)
+            if do_sample:
+                probs = torch.softmax(logits, dim=-1)
+                nxt = torch.multinomial(probs, 1, generator=generator).squeeze(1)
+            else:
+                nxt = argmax_f32(logits.contiguous())
         if output_scores:
             scores.append(logits)
         nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad_token_id))
@@ -451,5 +469,5 @@ def generate(decoder, input_ids=None, encoder_hidden_states=None, encoder_attent
         out = sample(decoder, input_ids, encoder_hidden_states, encoder_attention_mask, max_length=max_length, eos_token_id=eos,
                      pad_token_id=pad, do_sample=bool(args.get("do_sample")), top_k=args.get("top_k"),
                      bad_words_ids=args.get("bad_words_ids"), output_scores=bool(args.get("output_scores")),
-                     generator=args.get("generator"), decode_dtype=args.get("decode_dtype"))
+                     generator=args.get("generator"), decode_dtype=args.get("decode_dtype"), greedy_rows=args.get("greedy_rows"))
     return out if ret_dict else out.sequences

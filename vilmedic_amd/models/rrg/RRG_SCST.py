@@ -39,16 +39,15 @@ class RRG_SCST(nn.Module):
         self.eval_func = evaluation
 
     def forward(self, input_ids, attention_mask, images, images_mask=None, encoder_outputs=None, **kwargs):
-        with torch.no_grad():                                   # 1. greedy baseline
+        with torch.no_grad():                                   # 1. the greedy baseline's encoder pass (eval mode, as the reference)
             self.model.eval()
-            enc, enc_mask = self.model.encode(images.cuda(), images_mask, **kwargs)
-            reward_greedy, _, _ = self.scst.forward_greedy(input_ids=input_ids, encoder_hidden_states=enc,
-                                                           encoder_attention_mask=enc_mask)
-        self.model.train()                                      # 2. sampling rollout + policy gradient
+            enc_g = self.model.encode(images.cuda(), images_mask, **kwargs)
+        self.model.train()                                      # 2. the sampling rollout's encoder pass (train mode, differentiated)
         enc, enc_mask = self.model.encode(images.cuda(), images_mask, **kwargs)
-        loss, delta_reward, _, reward_sampling, _ = self.scst.forward_sampling(
-            input_ids=input_ids, attention_mask=attention_mask, encoder_hidden_states=enc, encoder_attention_mask=enc_mask,
-            reward_greedy=reward_greedy)
+        # 3. both rollouts in one decode loop (greedy rows on the eval features, sampled rows on the train features), rewards, policy
+        #    gradient -- the reference's forward_greedy + forward_sampling (RRG_SCST.py:53-75) without a second 128-step decode
+        (loss, delta_reward, _, reward_sampling, _), _ = self.scst.forward_rollouts(
+            input_ids=input_ids, attention_mask=attention_mask, greedy_encoder=enc_g, sampling_encoder=(enc, enc_mask))
         return {"loss": loss,
                 "custom_print": "reward_sampling {}, delta_reward: {}".format(torch.mean(torch.tensor(reward_sampling)),
                                                                               float(delta_reward))}
