@@ -130,6 +130,21 @@ def test_mvqa_forward_vs_oracle_answer_bit_exact():
     assert err <= 5e-2 + 1e-2 * ref_out.abs().max().item()
     assert abs(out["loss"].item() - ref_loss.item()) <= 5e-3 * max(1.0, abs(ref_loss.item()))
     assert gap > 2 * err, "fixture too weak: a top-2 gap is within the logit error"
+    # the reference's use_amp switch (fp16 autocast there) = bf16 channels-last convolutions in the CNN tower here (Trainor sets it from
+    # ``use_amp``; default off = fp32 convolutions as the reference's default): the CNN features move by bf16 rounding, the answers must not
+    from vilmedic_amd.blocks.vision import visual_encoder as VE
+    try:
+        VE.CNN_AMP = True
+        with torch.no_grad():
+            feats_amp = model.cnn(images).float()
+            out_amp = model(images=images, labels=labels.to(dev()), from_training=True)
+    finally:
+        VE.CNN_AMP = False
+    ferr = ((feats_amp - feats).norm() / feats.norm()).item()
+    print(f"[parity] MVQA with the CNN tower under bf16 autocast: CNN feature rel-l2 {ferr:.2e}, loss {out_amp['loss'].item():.5f}", flush=True)
+    # (a randomly initialised 169-layer DenseNet amplifies the bf16 rounding of its convolutions: ~8 % here -- which is why the switch is
+    # opt-in; the class logits move by less than their top-2 gap)
+    assert 0 < ferr < 0.15 and torch.equal(out_amp["answer"].cpu(), ref_answer)
 
 
 def test_rrg_scst_forward_with_fixed_rollouts_and_top_k_vs_oracle():

@@ -5,6 +5,8 @@ ViT backbones run on the hand-written HIP path (vilmedic_amd.nn.ViTModel).  CNN 
 executed by MIOpen through PyTorch-ROCm (not in the north-star kernel list)."""
 import json
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -23,6 +25,8 @@ def get_network(backbone, output_layer, pretrained, **kwargs):
         raise NotImplementedError(f"backbone {backbone!r} is outside the MI355X hot path (SURVEY §8a)")
     return _cnn.build(backbone, output_layer, pretrained, **kwargs)
 
+
+CNN_AMP = os.environ.get("VM_CNN_AMP", "") == "bf16"
 
 class VisualEncoder(nn.Module):
     def __init__(self, backbone, permute, dropout_out=0.0, freeze=False, output_layer=None, pretrained=True,
@@ -89,7 +93,14 @@ class VisualEncoder(nn.Module):
         if isinstance(self.model, ViTModel):
             out = self.model(images)
             return self._dropout_out(out)
-        out = self.model(images)
+        # CNN backbones are torch modules on MIOpen.  VM_CNN_AMP=bf16: channels-last bf16 convolutions under autocast with
+        # fp32 master weights and fp32 BatchNorm statistics -- the counterpart of the reference's use_amp (fp16 autocast) training mode
+        if CNN_AMP:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = self.model(images.contiguous(memory_format=torch.channels_last))
+            out = out.float()
+        else:
+            out = self.model(images)
         out = self._dropout_out(out)
         if self.permute == "no_permute":
             pass

@@ -35,6 +35,9 @@ class Trainor(object):
         torch.manual_seed(seed + self.rank)
         np.random.seed(seed + self.rank)
         ops.manual_seed(seed + self.rank)
+        if config.get("use_amp"):             # the reference's fp16-autocast switch (trainor.py:49,104): here the transformer path is bf16 anyway,
+            from ..blocks.vision import visual_encoder      # and the MIOpen-backed CNN towers run bf16 channels-last convolutions under autocast
+            visual_encoder.CNN_AMP = True
         self.state = None
         if config.get("ckpt") is not None:
             self.state = torch.load(config.ckpt, map_location="cpu")
