@@ -274,3 +274,30 @@ def test_g16_multi_image_encode(golden):
     S = feats.shape[1] // N
     assert not mask[0, 2 * S:].any() and mask[0, :2 * S].all() and not mask[1, S:2 * S].any()
     close(feats[0, 2 * S], st["visual_projection.bias"])
+
+
+def test_g18_model_level_compositions_vs_the_reference_classes(golden):
+    """G18: the reference's own ``MVQA`` and ``ConVIRT`` class bodies (lifted by AST in tools/make_golden.py, stand-in CNNs) pin the
+    oracle's model-level compositions: adapter + LayerNorm -> encoder -> pooler -> classifier -> label-smoothing CE with the arg-max
+    answers (MVQA.py:40-54), and both towers in ``forward_batch_size`` micro-batches (training-mode BatchNorm statistics per micro-batch)
+    -> projection heads -> ConVIRTLoss (conVIRT.py:75-102)."""
+    g = golden("g18_model_compositions")
+    m = g["mvqa"]
+    loss, out, answer = O.mvqa_forward(m["features"], m["labels"], m["state"], dict(m["cfg"], hidden_act="gelu"))
+    torch.testing.assert_close(out, m["output"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(loss, m["loss"], rtol=1e-5, atol=1e-5)
+    assert torch.equal(answer, m["answer"])
+    c = g["convirt"]
+    ids, am = R.make_reports(c["B"], c["L"], c["cfg"]["vocab_size"], seed=185)
+    st = R.rand_state(R.text_encoder_shapes(c["cfg"]), c["encoder_seed"])
+    assert R.state_checksum(st) == c["encoder_checksum"]
+    state = dict(c["state"], **{"linguistic.encoder." + k: v for k, v in st.items()})
+
+    def visual(x):                                     # the fixture's stand-in CNN: flatten -> Linear -> training-mode BatchNorm1d
+        y = x.flatten(1) @ c["visual_fc_w"].t() + c["visual_fc_b"]
+        return (y - y.mean(0)) / torch.sqrt(y.var(0, unbiased=False) + 1e-5)
+    loss, loss_l, loss_v, lin, vis = O.convirt_forward(c["images"], ids, am, state, c["cfg"], visual, c["tau"], c["lambda_"], c["fbs"])
+    torch.testing.assert_close(vis, c["visual"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(lin, c["linguistic"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(torch.stack([loss_l, loss_v]), torch.stack([c["loss_l"], c["loss_v"]]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(loss, c["loss"], rtol=1e-4, atol=1e-5)

@@ -505,8 +505,102 @@ def gen_rrs():
                               dec_grads={n: dn[n].grad.clone() for n in dec_grads}))
 
 
+# ------------------------------------------------------------------ G18: the reference's MVQA and ConVIRT classes themselves
+def _lift(rel, names, ns):
+    """compile the named top-level classes / functions of a reference file into ``ns`` (the file itself star-imports the
+    ``vilmedic`` package, which cannot be imported here: omegaconf / torchvision are absent)"""
+    import ast
+    tree = ast.parse(open(REF + rel).read())
+    body = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in names]
+    assert len(body) == len(names), [n.name for n in body]
+    exec(compile(ast.Module(body=body, type_ignores=[]), rel, "exec"), ns)
+    return ns
+
+
+class _Identity(torch.nn.Module):
+    """stand-in for the CNN of MVQA: the fixture feeds the CNN OUTPUT [B, S, C] as ``images``"""
+
+    def forward(self, x):
+        return x
+
+
+class _StubVisual(torch.nn.Module):
+    """stand-in for ConVIRT's VisualEncoder: flatten -> Linear -> BatchNorm1d, so the forward_batch_size micro-batching is visible in
+    the result (training-mode batch statistics per micro-batch)"""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.fc = torch.nn.Linear(in_dim, out_dim)
+        self.bn = torch.nn.BatchNorm1d(out_dim)
+
+    def forward(self, x):
+        return self.bn(self.fc(x.flatten(1)))
+
+
+def gen_model_compositions():
+    """G18: ``MVQA.forward`` (models/mvqa/MVQA.py:13-54) and ``ConVIRT.forward`` (models/selfsup/conVIRT.py:47-102) run from the
+    reference's own class bodies (lifted by AST) on the reference's own blocks (EncoderModel, ConVIRTLoss, Classifier,
+    LabelSmoothingCrossEntropy) with stand-in CNNs -- pins oracle.mvqa_forward / oracle.convirt_forward, i.e. the model-level
+    composition (adapter + LayerNorm, micro-batched towers, projection heads, loss wiring), not only the pieces."""
+    from transformers.models.bert.modeling_bert import BertEncoder, BertPooler
+    from transformers.models.bert_generation import BertGenerationConfig
+    out = {}
+    # ---- MVQA
+    ns = _lift("models/mvqa/MVQA.py", ["MVQA"], dict(torch=torch, nn=torch.nn, BertEncoder=BertEncoder, BertPooler=BertPooler,
+                                                      BertGenerationConfig=BertGenerationConfig, Classifier=cl.Classifier,
+                                                      LabelSmoothingCrossEntropy=ll.LabelSmoothingCrossEntropy, evaluation=None,
+                                                      get_n_params=lambda m: 0, _Identity=_Identity))
+    cfg, B, S, Cin, NC = R.MVQA_TINY, 5, 7, 24, 11
+    torch.manual_seed(181)
+    tcfg = AttrDict(hidden_act="gelu", attention_probs_dropout_prob=0.0, hidden_dropout_prob=0.0, **cfg)
+    m = ns["MVQA"](cnn=dict(proto="_Identity"), classifier=dict(proto="Classifier", input_size=cfg["hidden_size"], num_classes=NC, dropout=0.0),
+                   adapter=dict(input_size=Cin, output_size=cfg["hidden_size"]), transformer=tcfg,
+                   loss=dict(proto="LabelSmoothingCrossEntropy")).eval()
+    m.transformer.config._attn_implementation = "eager"
+    g = torch.Generator().manual_seed(182)
+    feats, labels = torch.randn(B, S, Cin, generator=g), torch.randint(0, NC, (B,), generator=g)
+    with torch.no_grad():
+        o = m(images=feats, labels=labels, from_training=True)
+    out["mvqa"] = dict(cfg=dict(cfg), features=feats, labels=labels, state={k: v.clone() for k, v in m.state_dict().items()},
+                       loss=o["loss"].clone(), output=o["output"].clone(), answer=o["answer"].clone())
+    # ---- ConVIRT
+    class _EncoderModelItems(em.EncoderModel):
+        """the reference reads ``linguistic['pooler_output']`` (conVIRT.py:91), which only exists as an ITEM for hub encoders that return
+        it natively; its own EncoderModel(proto=None) attaches the pooled output as an attribute (encoder_model.py:58-60) -> expose both"""
+
+        def forward(self, *a, **k):
+            o = super().forward(*a, **k)
+            return {"last_hidden_state": o.last_hidden_state, "pooler_output": o.pooler_output}
+
+    ns = _lift("models/selfsup/conVIRT.py", ["chunks", "ConVIRT"], dict(torch=torch, nn=torch.nn, EncoderModel=_EncoderModelItems,
+                                                                        ConVIRTLoss=lc.ConVIRTLoss, InfoNCELoss=li.InfoNCELoss,
+                                                                        evaluation=None, get_n_params=lambda m: 0, _StubVisual=_StubVisual))
+    tcfg, B, L, C, Pd, fbs = R.TXT_TINY, 6, 12, 20, 16, 4
+    torch.manual_seed(183)
+    m = ns["ConVIRT"](encoder=AttrDict(proto=None, add_pooling_layer=True, hidden_act="gelu", attention_probs_dropout_prob=0.0,
+                                       hidden_dropout_prob=0.0, **tcfg),
+                      cnn=dict(proto="_StubVisual", in_dim=3 * 4 * 4, out_dim=C),
+                      projection=AttrDict(visual_embedding_dim=C, textual_embedding_dim=tcfg["hidden_size"], projection_dim=Pd),
+                      loss=dict(proto="ConVIRTLoss", tau=0.1, lambda_=0.75), forward_batch_size=fbs)
+    m.linguistic.encoder.config._attn_implementation = "eager"
+    st = R.rand_state(R.text_encoder_shapes(tcfg), 184)
+    load_into(m.linguistic.encoder, st)
+    m.train()                                              # BatchNorm batch statistics per micro-batch of ``fbs`` (6 = 4 + 2 rows)
+    ids, am = R.make_reports(B, L, tcfg["vocab_size"], seed=185)
+    images = torch.randn(B, 3, 4, 4, generator=torch.Generator().manual_seed(186))
+    o = m(input_ids=ids, attention_mask=am, images=images)
+    # the text encoder's weights are a recipe (R.rand_state(R.text_encoder_shapes(cfg), encoder_seed)); only the small heads are stored
+    state = {k: v.detach().clone() for k, v in m.state_dict().items() if not k.startswith(("linguistic.encoder.", "visual."))}
+    out["convirt"] = dict(cfg=dict(tcfg), B=B, L=L, fbs=fbs, tau=0.1, lambda_=0.75, images=images, state=state, encoder_seed=184,
+                          encoder_checksum=R.state_checksum(st),
+                          visual_fc_w=m.visual.fc.weight.detach().clone(), visual_fc_b=m.visual.fc.bias.detach().clone(),
+                          loss=o["loss"].detach().clone(), loss_l=o["loss_l"].detach().clone(), loss_v=o["loss_v"].detach().clone(),
+                          linguistic=o["linguistic"].detach().clone(), visual=o["visual"].detach().clone())
+    save("g18_model_compositions", out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs", "vicreg", "bleu", "vit_multi", "schedulers"]
+    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs", "vicreg", "bleu", "vit_multi", "schedulers", "model_compositions"]
     for w in which:
         globals()["gen_" + w]()
