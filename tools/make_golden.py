@@ -599,8 +599,74 @@ def gen_model_compositions():
     save("g18_model_compositions", out)
 
 
+# ------------------------------------------------------------------ G19: SCST.forward_sampling itself
+def gen_scst_sampling():
+    """G19: ``SCST.forward_sampling`` (blocks/rl/SCST.py:142-185) lifted out of its class and run on the reference's DecoderModel with
+    HF ``generate`` (do_sample, top_k, bad_words_ids, output_scores -- the un-wrapped, differentiable call): the sampled sequence, the
+    gathered log-probabilities of the processed scores, the loss and a decoder gradient.  Pins oracle.scst_forward, which takes that
+    sampled sequence as input.  Stand-ins: fixed per-sample rewards instead of text scorers (``get_reward``), and the HF 5.x cache
+    object the cross-attention expects (as in G7)."""
+    import ast
+    import inspect
+    from transformers.cache_utils import DynamicCache, EncoderDecoderCache
+    tree = ast.parse(open(REF + "blocks/rl/SCST.py").read())
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "scst_loss"]
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "SCST"][0]
+    fns += [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "forward_sampling"]
+    ns = {"torch": torch, "F": torch.nn.functional, "inspect": inspect}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "SCST.py", "exec"), ns)
+    cfg, B, S, T, top_k = R.DEC_TINY, 4, 6, 24, 6
+    recipe = dict(std=0.3, emb_std=0.2, eos_bias=7.0, qk_std=0.15, pos_std=0.3)
+    # the reference passes forced_eos_token_id=True, which HF turns into a BOOLEAN index tensor that fails the moment a row reaches
+    # max_length - 1 (SCST.py:163; transformers ForcedEOSTokenLogitsProcessor): the call only works while every sampled row ends early.
+    # A random decoder often falls into a repeating token, so the first seed whose sampled rows all end before max_length is taken.
+    for seed in range(91, 131):
+        dec, st = build_ref_decoder(cfg, seed, **recipe)
+        hf = dec.decoder
+        hf.train()                                          # dropout probabilities are 0 in the recipe: train() only matters for autograd
+        g = torch.Generator().manual_seed(seed + 1)
+        enc = torch.randn(B, S, cfg["hidden_size"], generator=g).requires_grad_(True)
+        enc_mask = torch.ones(B, S, dtype=torch.bool)
+        enc_mask[1, 4:] = False
+        rs, rg = [torch.rand(B, generator=g).tolist()], [torch.rand(B, generator=g).tolist()]
+        raw = inspect.unwrap(hf.generate)
+
+        def _generate(self, hf=hf, raw=raw, **kw):
+            return raw(hf, past_key_values=EncoderDecoderCache(DynamicCache(config=hf.config), DynamicCache(config=hf.config)), **kw)
+        torch.manual_seed(seed + 2)
+        with torch.no_grad():
+            probe = _generate(None, input_ids=torch.zeros(B, 1, dtype=torch.long), max_length=T, num_beams=1, encoder_hidden_states=enc.detach(),
+                              encoder_attention_mask=enc_mask, bad_words_ids=[[1], [0]], top_k=top_k, do_sample=True, use_cache=True)
+        lens = (probe != 1).sum(1)
+        if probe.shape[1] < T - 1 and int(lens.min()) >= 3 and len(set(lens.tolist())) > 1:
+            break
+    else:
+        raise RuntimeError("no seed gives sampled rows that all end before max_length")
+    print("G19 seed", seed, "sampled lengths", lens.tolist())
+    standin = types.SimpleNamespace(
+        decoder=types.SimpleNamespace(generate=torch.no_grad()(_generate)), use_nll=False, max_length=T, bos_token_id=0, pad_token_id=1,
+        top_k=top_k, scores=["toy"], scores_weights=[1.0], get_reward=lambda ids, ref: (rs, None, None))
+    torch.manual_seed(seed + 2)                             # the sampling draws
+    ids = torch.zeros(B, T, dtype=torch.long)
+    loss, dr, drm, reward_sampling, _ = ns["forward_sampling"](standin, ids, None, enc, enc_mask, rg)
+    loss.backward()
+    # recover what the method computed internally: re-run generate with the same draws for the sequence and the processed scores
+    torch.manual_seed(seed + 2)
+    with torch.no_grad():
+        o = standin.decoder.generate(self=None, input_ids=torch.zeros(B, 1, dtype=torch.long), max_length=T, num_beams=1, num_return_sequences=1,
+                                     encoder_hidden_states=enc.detach(), encoder_attention_mask=enc_mask, bad_words_ids=[[1], [0]],
+                                     top_k=top_k, forced_eos_token_id=True, output_scores=True, do_sample=True, use_cache=True,
+                                     return_dict_in_generate=True)
+    logp = torch.log_softmax(torch.stack(o.scores, dim=1), -1).gather(2, o.sequences[:, 1:].unsqueeze(-1)).squeeze(-1)
+    print("sampled", o.sequences.tolist(), "loss", loss.item())
+    save("g19_scst_sampling", dict(cfg=cfg, seed=seed, B=B, S=S, T=T, top_k=top_k, recipe=recipe,
+                                   checksum=R.state_checksum(st), enc=enc.detach().clone(), enc_mask=enc_mask, rs=rs, rg=rg,
+                                   sequences=o.sequences.clone(), logp=logp.clone(), loss=loss.detach().clone(), delta_reward=dr.detach().clone(),
+                                   g_enc=enc.grad.clone()))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs", "vicreg", "bleu", "vit_multi", "schedulers", "model_compositions"]
+    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs", "vicreg", "bleu", "vit_multi", "schedulers", "model_compositions", "scst_sampling"]
     for w in which:
         globals()["gen_" + w]()
