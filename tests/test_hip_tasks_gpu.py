@@ -264,6 +264,35 @@ def test_trainor_keeps_the_reference_loop_semantics(tmp_path):
         Trainor(t, seed=0).start()                      # (c)
 
 
+def test_trainor_skips_a_nan_batch_on_the_device(tmp_path):
+    """the reference drops a batch whose loss is NaN / Inf (trainor.py:109-112).  Here the decision is taken inside the fused optimizer
+    kernel from a device scalar (no host read of the loss per iteration): the poisoned iteration must leave every parameter untouched,
+    must not count as an optimizer step for Adam's bias correction, and the epoch's mean loss must ignore it."""
+    from vilmedic_amd.arena import arena_of
+    from vilmedic_amd.config import executor_view
+    from vilmedic_amd.executors import Trainor
+    os.makedirs(tmp_path / "n")
+    cfg = _tiny_rrg_cfg(tmp_path / "n", ["trainor.epochs=0", "trainor.eval_start=99"])
+    tr = Trainor(executor_view(cfg, "trainor"), seed=0)
+    assert tr.device_gate
+    arena, seen = arena_of(tr.model), []
+    fwd = tr.model.forward
+
+    def poisoned(**batch):
+        out = fwd(**batch)
+        seen.append(arena.flat.clone())
+        if len(seen) == 2:                                   # second iteration: NaN loss (and NaN gradients)
+            out["loss"] = out["loss"] * float("nan")
+        return out
+    tr.model.forward = poisoned
+    tr.start()
+    assert len(seen) == 4
+    assert not torch.equal(seen[1], seen[0])                # iteration 1 updated the weights
+    assert torch.equal(seen[2], seen[1])                    # iteration 2 (NaN) did not
+    assert not torch.equal(seen[3], seen[2]) and torch.isfinite(arena.flat).all()
+    assert int(tr.optimizer.step_dev.item()) == 3           # three real steps out of four iterations
+
+
 def test_gloria_model_vs_oracle():
     """GLoRIA: CNN tower (MIOpen) + text tower, HIP embedders, on-device word-piece merge, GLoRIALoss --
     against the oracle composition on the CPU (same CNN module class in fp32)."""

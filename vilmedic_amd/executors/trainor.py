@@ -61,6 +61,9 @@ class Trainor(object):
         self.training_scheduler = create_training_scheduler(config, self.optimizer, self.logger, state_dict=self.state)
         self.saver = CheckpointSaver(self.ckpt_dir, self.logger, seed, ckpt=config.get("ckpt"))
         self.grad_accu = int(config.get("grad_accu") or 1)
+        # device-side NaN guard: fused optimizer and one micro-batch per step (with accumulation a bad micro-batch has to be dropped
+        # before it is summed into the others, which needs the host decision)
+        self.device_gate = hasattr(self.optimizer, "gate") and self.grad_accu == 1
         self.clip = config.get("clip_grad_norm")
         self.eval_start = int(config.get("eval_start") or 0)
         self.evaluator = Validator(config.validator_view, [self.model], self.dl, seed, True, self.logger, self.rank, self.world) \
@@ -71,6 +74,18 @@ class Trainor(object):
         if self.dist is not None:
             self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
         return bool(flag.item())
+
+    def _gate(self, loss):
+        """NaN / Inf guard WITHOUT a host read (the reference tests the loss on the host every iteration, trainor.py:109-112, which
+        here would make the host wait for the forward pass before it may enqueue the backward pass): the fused optimizer takes a device
+        scalar and skips its update while that scalar is not finite (FusedAdam.gate); under data parallelism the decision is taken
+        collectively with a device-side MIN all-reduce of the finiteness flag, so every rank skips the same step."""
+        gate = loss.detach().float().reshape(1)
+        if self.dist is not None:
+            flag = torch.isfinite(gate).float()
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+            gate = torch.where(flag > 0, gate, torch.full_like(gate, float("nan")))
+        self.optimizer.gate = gate
 
     def _zero_grad(self):
         """gradients of EVERY parameter stay inside the arena's flat buffer (that buffer is what ArenaDDP all-reduces): a
@@ -98,7 +113,9 @@ class Trainor(object):
                 if "loss" not in out:
                     continue
                 loss = out["loss"].mean()
-                if not self._all_finite(loss):            # trainor.py:109-112, decided collectively
+                if self.device_gate:                      # the skip happens inside the optimizer kernel; the gradients of a bad batch are
+                    self._gate(loss)                      # discarded by the zero_grad that follows every step
+                elif not self._all_finite(loss):          # trainor.py:109-112, decided collectively (host read: torch.optim / grad_accu > 1)
                     self.logger.warning("NaN/Inf loss: batch skipped on all ranks")
                     self._zero_grad()
                     pending = False
@@ -117,14 +134,22 @@ class Trainor(object):
                 losses.append(loss.detach())
                 if iteration % 50 == 0 and self.rank == 0:
                     self.logger.info("Epoch {}, iter {}, lr {:.2e}, loss {:.4f} {}".format(
-                        epoch + 1, iteration, self.optimizer.param_groups[0]["lr"], float(torch.stack(losses[-50:]).mean()),
+                        epoch + 1, iteration, self.optimizer.param_groups[0]["lr"], float(torch.nanmean(torch.stack(losses[-50:]).float())),
                         out.get("custom_print", "")))
             # last update of the epoch when len(dl) is not a multiple of grad_accu (trainor.py:139-150)
             if iteration % self.grad_accu != 0 and "loss" in out and pending:
                 if self.ddp is not None:
                     self.ddp.finish()
                 self._optimizer_step(epoch, iteration)
-            training_loss = float(torch.stack(losses).mean()) if losses else float("inf")
+            if losses:                                   # skipped (non-finite) batches do not enter the epoch's mean, as in the reference
+                t = torch.stack(losses).float()
+                ok = torch.isfinite(t)
+                n_bad = int((~ok).sum())
+                if n_bad:
+                    self.logger.warning("{} batch(es) with a NaN/Inf loss were skipped this epoch".format(n_bad))
+                training_loss = float(t[ok].mean()) if n_bad < t.numel() else float("inf")
+            else:
+                training_loss = float("inf")
             if self.dist is not None:       # the same number on every rank: it can drive early stopping / lr decay (a per-rank value
                 from ..parallel import mean_over_ranks      # would let ranks leave the loop at different epochs)
                 training_loss = mean_over_ranks(training_loss, self.dist, weight=max(1, len(losses)))

@@ -44,7 +44,10 @@ class FusedAdam(torch.optim.Optimizer):
         a = self.arena
         if float(g["lr"]) != self._lr_host:          # a scheduler moved the learning rate: refresh the device copy (outside any capture)
             self.sync_lr()
-        self.step_dev.add_(1)
+        if self.gate is not None:                    # a skipped (NaN / Inf) step does not count, as in the reference's loop (optimizer.step() not called)
+            self.step_dev.add_(torch.isfinite(self.gate).reshape(-1)[:1].to(torch.int64))
+        else:
+            self.step_dev.add_(1)
         check(lib().vm_adam_step_dev(ptr(a.flat), ptr(a.gflat), ptr(self.m), ptr(self.v), ptr(a.shadow_flat), a.numel,
                                      g["lr"], b1, b2, g["eps"], g["weight_decay"], int(g["decoupled_weight_decay"]),
                                      1 - b1 ** self.steps, 1 - b2 ** self.steps, self.grad_scale,
