@@ -13,7 +13,8 @@ HuggingFace ``transformers`` (the third-party dependency that holds the
 arithmetic; the reference pins ``transformers==4.55.3`` in ``setup.py:29``, the
 container carries 5.15.0 whose BERT/ViT block arithmetic is identical).
 Three later additions are COMPOSITIONS of pinned pieces rather than separately pinned:
-``rrg_hf_forward`` (pinned ViT + decoder wired as RRG_HF.py:107-176 does -- its 4-D path equals ``rrg_vit_forward``),
+``rrg_hf_forward`` (pinned ViT + decoder wired as RRG_HF.py:107-176 does; since round 2 pinned as a whole by fixture G20: the
+reference's own RRG_HF.forward body on a VisionEncoderDecoderModel, 4-D and 5-D images, enc_to_dec_proj),
 ``gloria_forward`` (pinned text tower, GLoRIA losses and the G11-pinned ``gloria_aggregate_tokens``; the CNN is run, not
 restated) and the ENSEMBLE branch of ``decoder_step_logits`` (summed logits, beam_search.py:243-262 -- the reference's
 own ensemble path cannot run at this snapshot, so this branch is parity-UNPINNED and the judge should read it so).

@@ -321,3 +321,26 @@ def test_g19_scst_forward_vs_the_reference_forward_sampling(golden):
     torch.testing.assert_close(logp[live], g["logp"][live], rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(loss.detach(), g["loss"], rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(enc.grad, g["g_enc"], rtol=1e-3, atol=1e-6)
+
+
+def test_g20_rrg_hf_forward_vs_the_reference_method(golden):
+    """G20: the reference's own ``RRG_HF.forward`` body on a VisionEncoderDecoderModel (ViT of width 64 -> enc_to_dec_proj -> decoder of
+    width 128): 5-D images with an images_mask (crops concatenated along the sequence, masked per crop in the cross-attention) and 4-D
+    images; oracle.rrg_hf_forward must reproduce loss and logits."""
+    g = golden("g20_rrg_hf")
+    vst = R.rand_state(R.vit_shapes(g["vit_cfg"]), g["seed"])
+    dst = R.rand_state(R.decoder_shapes(g["dec_cfg"]), g["seed"] + 1)
+    assert R.state_checksum(vst) == g["vit_checksum"] and R.state_checksum(dst) == g["dec_checksum"]
+    state = {"model.encoder." + k: v for k, v in vst.items()}
+    state.update({"model.decoder." + k: v for k, v in dst.items()})
+    state["model.enc_to_dec_proj.weight"], state["model.enc_to_dec_proj.bias"] = g["proj_w"], g["proj_b"]
+    B, N, size = g["B"], g["N"], g["vit_cfg"]["image_size"]
+    images = R.make_images(B * N, size, seed=g["seed"]).view(B, N, 3, size, size)
+    ids, am = R.make_reports(B, g["L"], g["dec_cfg"]["vocab_size"], seed=g["seed"])
+    with torch.no_grad():
+        loss5, logits5 = O.rrg_hf_forward(images, ids, am, state, g["vit_cfg"], g["dec_cfg"], images_mask=g["images_mask"])
+        loss4, logits4 = O.rrg_hf_forward(images[:, 0], ids, am, state, g["vit_cfg"], g["dec_cfg"])
+    torch.testing.assert_close(logits5, g["logits5"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(loss5, g["loss5"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(logits4, g["logits4"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(loss4, g["loss4"], rtol=1e-5, atol=1e-5)

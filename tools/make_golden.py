@@ -665,8 +665,47 @@ def gen_scst_sampling():
                                    g_enc=enc.grad.clone()))
 
 
+# ------------------------------------------------------------------ G20: RRG_HF.forward itself (multi-image + enc_to_dec_proj)
+def gen_rrg_hf():
+    """G20: ``RRG_HF.forward`` (models/rrg/RRG_HF.py:105-177), lifted out of its class and run on a ``VisionEncoderDecoderModel`` built
+    from a ViT whose width differs from the decoder's (so ``enc_to_dec_proj`` is in the path) -- 5-D images with an ``images_mask``
+    (crops encoded flat, concatenated along the sequence, masked per crop in the cross-attention) and 4-D images.  Pins
+    oracle.rrg_hf_forward."""
+    import ast
+    from transformers import ViTConfig, ViTModel, VisionEncoderDecoderModel
+    tree = ast.parse(open(REF + "models/rrg/RRG_HF.py").read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "RRG_HF"][0]
+    fn = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "forward"][0]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "RRG_HF.py", "exec"), ns)
+    vcfg = dict(R.VIT_TINY, hidden_size=64, intermediate_size=128)
+    dcfg, seed, B, N, L = R.DEC_TINY, 201, 3, 2, 14
+    vit = ViTModel(ViTConfig(**vcfg, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, attn_implementation="eager"), add_pooling_layer=False)
+    vst = R.rand_state(R.vit_shapes(vcfg), seed)
+    load_into(vit, vst, vit_to_hf5)
+    dec, dst = build_ref_decoder(dcfg, seed + 1)
+    model = VisionEncoderDecoderModel(encoder=vit, decoder=dec.decoder).eval()
+    g = torch.Generator().manual_seed(seed + 2)
+    pw = 0.1 * torch.randn(dcfg["hidden_size"], vcfg["hidden_size"], generator=g)
+    pb = 0.02 * torch.randn(dcfg["hidden_size"], generator=g)
+    model.enc_to_dec_proj.weight.data.copy_(pw), model.enc_to_dec_proj.bias.data.copy_(pb)
+    if not hasattr(model.decoder.config, "cross_attention_hidden_size"):
+        model.decoder.config.cross_attention_hidden_size = None      # PretrainedConfig default in the pinned 4.55.3; gone in 5.x
+    self_ = types.SimpleNamespace(model=model)
+    size = vcfg["image_size"]
+    images = R.make_images(B * N, size, seed=seed).view(B, N, 3, size, size)
+    images_mask = torch.tensor([[1, 1], [1, 0], [1, 1]], dtype=torch.bool)
+    ids, am = R.make_reports(B, L, dcfg["vocab_size"], seed=seed)
+    with torch.no_grad():
+        o5 = ns["forward"](self_, ids, am, images, images_mask=images_mask)
+        o4 = ns["forward"](self_, ids, am, images[:, 0])
+    save("g20_rrg_hf", dict(vit_cfg=vcfg, dec_cfg=dcfg, seed=seed, B=B, N=N, L=L, images_mask=images_mask, proj_w=pw, proj_b=pb,
+                            vit_checksum=R.state_checksum(vst), dec_checksum=R.state_checksum(dst),
+                            loss5=o5["loss"].clone(), logits5=o5["logits"].clone(), loss4=o4["loss"].clone(), logits4=o4["logits"].clone()))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs", "vicreg", "bleu", "vit_multi", "schedulers", "model_compositions", "scst_sampling"]
+    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs", "vicreg", "bleu", "vit_multi", "schedulers", "model_compositions", "scst_sampling", "rrg_hf"]
     for w in which:
         globals()["gen_" + w]()
