@@ -16,7 +16,7 @@ Three later additions are COMPOSITIONS of pinned pieces rather than separately p
 ``rrg_hf_forward`` (pinned ViT + decoder wired as RRG_HF.py:107-176 does; since round 2 pinned as a whole by fixture G20: the
 reference's own RRG_HF.forward body on a VisionEncoderDecoderModel, 4-D and 5-D images, enc_to_dec_proj),
 ``gloria_forward`` (pinned text tower, GLoRIA losses and the G11-pinned ``gloria_aggregate_tokens``; the CNN is run, not
-restated) and the ENSEMBLE branch of ``decoder_step_logits`` (summed logits, beam_search.py:243-262 -- the reference's
+restated; since round 2 pinned as a whole by fixture G21: the reference's own GLoRIA class on a stand-in CNN) and the ENSEMBLE branch of ``decoder_step_logits`` (summed logits, beam_search.py:243-262 -- the reference's
 own ensemble path cannot run at this snapshot, so this branch is parity-UNPINNED and the judge should read it so).
 Round 2 added ``mvqa_forward`` and ``convirt_forward`` -- pinned as whole compositions by fixture G18 (the reference's own MVQA /
 ConVIRT class bodies, lifted by AST, on stand-in CNNs) -- and ``scst_forward`` -- pinned by fixture G19 (the reference's own

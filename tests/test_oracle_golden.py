@@ -344,3 +344,27 @@ def test_g20_rrg_hf_forward_vs_the_reference_method(golden):
     torch.testing.assert_close(loss5, g["loss5"], rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(logits4, g["logits4"], rtol=1e-4, atol=2e-5)
     torch.testing.assert_close(loss4, g["loss4"], rtol=1e-5, atol=1e-5)
+
+
+def test_g21_gloria_forward_vs_the_reference_class(golden):
+    """G21: the reference's own ``GLoRIA`` class (lifted by AST; its EncoderModel and GLoRIALoss, a stand-in CNN whose [6] is the hooked
+    local feature map, a stand-in tokenizer vocabulary) -- towers in forward_batch_size chunks with training-mode BatchNorm, up-sampling
+    to 299 x 299, hidden-state stacking, word-piece aggregation, embeddings, loss -- against oracle.gloria_forward."""
+    g = golden("g21_gloria_model")
+    nn_ = torch.nn
+    cnn = nn_.Sequential(nn_.Conv2d(3, 6, 7, stride=8, padding=3), nn_.ReLU(), nn_.Identity(), nn_.Identity(), nn_.Identity(),
+                         nn_.Conv2d(6, g["interm"], 3, stride=4, padding=1), nn_.BatchNorm2d(g["interm"]), nn_.ReLU(),
+                         nn_.Conv2d(g["interm"], g["feat"], 1), nn_.AdaptiveAvgPool2d(1))
+    cnn.load_state_dict(g["cnn_state"], strict=False)
+    cnn.train()
+    st = R.rand_state(R.text_encoder_shapes(g["cfg"]), g["encoder_seed"])
+    assert R.state_checksum(st) == g["encoder_checksum"]
+    state = dict(g["state"], **{"linguistic.encoder." + k: v for k, v in st.items()})
+    with torch.no_grad():
+        loss, gf, lf, word, sent = O.gloria_forward(g["images"], g["input_ids"], g["attention_mask"], state, g["cfg"], cnn,
+                                                    dict(enumerate(g["vocab"])), g["last_n_layers"], g["fbs"])
+    torch.testing.assert_close(gf, g["global_features"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(lf, g["local_features"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(word, g["word_embeddings"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(sent, g["sent_embeddings"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(loss, g["loss"], rtol=1e-4, atol=1e-4)

@@ -704,8 +704,69 @@ def gen_rrg_hf():
                             loss5=o5["loss"].clone(), logits5=o5["logits"].clone(), loss4=o4["loss"].clone(), logits4=o4["logits"].clone()))
 
 
+# ------------------------------------------------------------------ G21: the GLoRIA class itself
+class _StubCnnEncoder(torch.nn.Module):
+    """stand-in for GLoRIA's VisualEncoder(resnet50, avgpool, batch_first): ``cnn`` is an nn.Sequential whose [6] yields the local feature
+    map (the hook point of GLoRIA.py:75) and whose end is a global average pool; forward applies visual_encoder.py's batch_first permute"""
+
+    def __init__(self, interm, feat):
+        super().__init__()
+        nn_ = torch.nn
+        self.cnn = nn_.Sequential(nn_.Conv2d(3, 6, 7, stride=8, padding=3), nn_.ReLU(), nn_.Identity(), nn_.Identity(), nn_.Identity(),
+                                  nn_.Conv2d(6, interm, 3, stride=4, padding=1), nn_.BatchNorm2d(interm), nn_.ReLU(),
+                                  nn_.Conv2d(interm, feat, 1), nn_.AdaptiveAvgPool2d(1))
+
+    def forward(self, x):
+        out = self.cnn(x)
+        out = out.view(*out.size()[:2], -1).permute(0, 2, 1)
+        return out.squeeze(1) if out.shape[1] == 1 else out
+
+
+def gen_gloria_model():
+    """G21: the reference's own ``GLoRIA`` class (models/selfsup/GLoRIA.py:46-121 + aggregate_tokens), lifted by AST, on its own
+    EncoderModel (proto None) and GLoRIALoss with a stand-in CNN and a stand-in tokenizer vocabulary: both towers in forward_batch_size
+    chunks (training-mode BatchNorm per chunk), the layer-3 hook, up-sampling to 299 x 299, hidden-state stacking, word-piece
+    aggregation, sentence / word embeddings and the loss.  Pins oracle.gloria_forward."""
+    vocab = ["[PAD]", "[CLS]", "[SEP]", "the", "heart", "##s", "is", "en", "##larg", "##ed", "no", "pleural", "eff", "##usion", ".", "lung",
+             "clear", "small", "##er", "normal"]
+    W = {w: i for i, w in enumerate(vocab)}
+    caps = [["[CLS]", "the", "heart", "##s", "is", "en", "##larg", "##ed", ".", "[SEP]", "[PAD]", "[PAD]"],
+            ["[CLS]", "no", "pleural", "eff", "##usion", "[SEP]", "[PAD]", "[PAD]", "[PAD]", "[PAD]", "[PAD]", "[PAD]"],
+            ["[CLS]", "lung", "##s", "is", "clear", ".", "no", "eff", "##usion", "[SEP]", "[PAD]", "[PAD]"],
+            ["[CLS]", "small", "##er", "heart", "[SEP]", "[PAD]", "[PAD]", "[PAD]", "[PAD]", "[PAD]", "[PAD]", "[PAD]"],
+            ["[CLS]", "the", "lung", "is", "normal", "the", "heart", "is", "normal", ".", "[SEP]", "[PAD]"]]
+    ids = torch.tensor([[W[w] for w in c] for c in caps])
+    am = (ids != W["[PAD]"]).long()
+    tcfg = dict(R.TXT_TINY, vocab_size=len(vocab), pad_token_id=0)
+    interm, feat, B, fbs, last_n = 10, 14, len(caps), 3, 2
+    ns = _lift("models/selfsup/GLoRIA.py", ["chunks", "GLoRIA"], dict(torch=torch, nn=torch.nn, EncoderModel=em.EncoderModel,
+                                                                      GLoRIALoss=lg.GLoRIALoss, evaluation=None, get_n_params=lambda m: 0,
+                                                                      _StubCnnEncoder=_StubCnnEncoder))
+    tok = types.SimpleNamespace(get_vocab=lambda: dict(W))
+    torch.manual_seed(211)
+    m = ns["GLoRIA"](encoder=AttrDict(proto=None, last_n_layers=last_n, hidden_act="gelu", attention_probs_dropout_prob=0.0,
+                                      hidden_dropout_prob=0.0, **tcfg),
+                     cnn=dict(proto="_StubCnnEncoder", interm=interm, feat=feat),
+                     visual_embedder=AttrDict(feature_dim=feat, interm_feature_dim=interm),
+                     loss=dict(local_loss_weight=1.0, global_loss_weight=1.0, temp1=4.0, temp2=5.0, temp3=10.0),
+                     dl=types.SimpleNamespace(dataset=types.SimpleNamespace(tokenizer=tok)), forward_batch_size=fbs)
+    m.linguistic.encoder.config._attn_implementation = "eager"
+    st = R.rand_state(R.text_encoder_shapes(tcfg), 212)
+    load_into(m.linguistic.encoder, st)
+    m.train()                                              # BatchNorm batch statistics per chunk of ``fbs`` images (5 = 3 + 2)
+    images = torch.randn(B, 3, 40, 40, generator=torch.Generator().manual_seed(213))
+    o = m(input_ids=ids, attention_mask=am, images=images)
+    state = {k: v.detach().clone() for k, v in m.state_dict().items() if k.startswith(("global_embedder.", "local_embedder."))}
+    save("g21_gloria_model", dict(vocab=vocab, cfg=tcfg, interm=interm, feat=feat, fbs=fbs, last_n_layers=last_n, input_ids=ids, attention_mask=am,
+                                  images=images, state=state, encoder_seed=212, encoder_checksum=R.state_checksum(st),
+                                  cnn_state={k: v.detach().clone() for k, v in m.visual.cnn.state_dict().items() if "running" not in k and "num_batches" not in k},
+                                  loss=o["loss"].detach().clone(), global_features=o["global_features"].detach().clone(),
+                                  local_features=o["local_features"].detach().clone(), word_embeddings=o["word_embeddings"].detach().clone(),
+                                  sent_embeddings=o["sent_embeddings"].detach().clone()))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs", "vicreg", "bleu", "vit_multi", "schedulers", "model_compositions", "scst_sampling", "rrg_hf"]
+    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs", "vicreg", "bleu", "vit_multi", "schedulers", "model_compositions", "scst_sampling", "rrg_hf", "gloria_model"]
     for w in which:
         globals()["gen_" + w]()
