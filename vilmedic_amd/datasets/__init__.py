@@ -4,6 +4,8 @@ dicts from synthetic or pre-tokenised tensors so that the executors and models r
 import torch
 from torch.utils.data import Dataset
 
+from .prefetch import PrefetchLoader, stack  # noqa: F401
+
 
 class _IdTokenizer:
     """stand-in tokenizer: decode = space-joined ids (enough for decode drivers / SCST rewards on synthetic data)"""
@@ -51,7 +53,7 @@ class SyntheticImSeq(Dataset):
 
     def get_collate_fn(self):
         def collate(items):
-            return {"images": torch.stack([x["images"] for x in items]), "images_mask": None,
+            return {"images": stack([x["images"] for x in items]), "images_mask": None,
                     "input_ids": torch.stack([x["input_ids"] for x in items]),
                     "attention_mask": torch.stack([x["attention_mask"] for x in items])}
         return collate
@@ -74,7 +76,7 @@ class SyntheticImLabel(Dataset):
 
     def get_collate_fn(self):
         def collate(items):
-            return {"images": torch.stack([x["images"] for x in items]), "labels": torch.stack([x["labels"] for x in items])}
+            return {"images": stack([x["images"] for x in items]), "labels": torch.stack([x["labels"] for x in items])}
         return collate
 
 

@@ -16,6 +16,7 @@ import torch
 from torch.utils.data import Dataset
 
 from .device_pipeline import DeviceImagePipeline
+from .prefetch import stack
 
 
 def r2gen_clean_report(report):
@@ -277,7 +278,7 @@ class ImageDataset(Dataset):
             n = self.multi_image if self.multi_image and self.multi_image > 1 else 1
             if self.tensor_images:                     # vilmedic_collate (ImageDataset.py:25-54): stack, pad with zero images
                 if n == 1:
-                    return {"images": torch.stack([s["image"][0] for s in batch]), "images_mask": None}
+                    return {"images": stack([s["image"][0] for s in batch]), "images_mask": None}
                 rows = []
                 for s in batch:
                     cur = list(s["image"][:n])

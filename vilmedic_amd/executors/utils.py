@@ -113,13 +113,27 @@ def create_data_loader(config, split, logger, called_by_validator=False, rank=0,
         for attr in ("tokenizer", "tokenizer_max_len", "seq", "src", "tgt", "tgt_tokenizer", "tgt_tokenizer_max_len", "labels_map"):
             if hasattr(dataset.dataset, attr):
                 setattr(dataset, attr, getattr(dataset.dataset, attr))
-    if split == "train" and not called_by_validator:
-        sampler = BatchSampler(RandomSampler(dataset), batch_size=config.batch_size, drop_last=True)
+    training = split == "train" and not called_by_validator
+    workers = int(config.get("num_workers") or 0)
+    # the training loader runs under a PrefetchLoader (datasets/prefetch.py): batches are collated into reusable pinned buffers
+    # and copied to the GPU by a background thread, ahead of the step.  ``prefetch: 0`` in the config turns it off.
+    prefetch = int(config.get("prefetch", 2) if config.get("prefetch", 2) is not None else 2) if training else 0
+    gen = None
+    if prefetch:
+        # the shuffling order comes from a generator of its own, seeded here from the global RNG: the sampler then runs on the
+        # prefetch thread without drawing from the global generator concurrently with the training step (reproducible runs)
+        gen = torch.Generator()
+        gen.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
+    if training:
+        sampler = BatchSampler(RandomSampler(dataset, generator=gen), batch_size=config.batch_size, drop_last=True)
     else:
         sampler = BatchSampler(SequentialSampler(dataset), batch_size=config.batch_size, drop_last=False)
     logger.settings("DataLoader {} ({}, {} samples) created".format(proto, split, len(dataset)))
-    loader = DataLoader(dataset, num_workers=int(config.get("num_workers") or 0), collate_fn=collate, batch_sampler=sampler,
-                        pin_memory=not hasattr(dataset, "device_transform"))
+    loader = DataLoader(dataset, num_workers=workers, collate_fn=collate, batch_sampler=sampler, generator=gen,
+                        pin_memory=not hasattr(dataset, "device_transform") and not prefetch)
+    if prefetch:
+        from ..datasets import PrefetchLoader
+        loader = PrefetchLoader(loader, depth=prefetch)
     base = dataset.dataset if isinstance(dataset, torch.utils.data.Subset) else dataset
     if hasattr(base, "device_transform"):          # decoded uint8 images -> the device-side Resize / crop / flip / normalise kernel
         from ..datasets import DeviceBatchLoader
