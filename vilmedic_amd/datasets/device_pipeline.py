@@ -23,6 +23,32 @@ def resized_hw(h, w, resize):
     return (resize, int(resize * w / h)) if h <= w else (int(resize * h / w), resize)
 
 
+def packed_layout(images):
+    """byte offset of each image in the packed batch buffer (16-byte aligned), their (H, W), and the buffer's length"""
+    sizes = [(int(im.shape[0]), int(im.shape[1])) for im in images]
+    offs = np.zeros(len(images), dtype=np.int64)
+    total = 0
+    for b, (h, w) in enumerate(sizes):
+        offs[b] = total
+        total += (h * w * 3 + 15) // 16 * 16
+    return offs, sizes, total
+
+
+def pack_host(images, buffer):
+    """the host half of ``DeviceImagePipeline.pack``: the images laid out in ONE byte buffer obtained from ``buffer(nbytes)`` (a
+    pinned staging buffer, datasets/prefetch.py), by plain memcpys -- the batch then crosses PCIe as one asynchronous copy
+    instead of one blocking pageable copy per image."""
+    offs, sizes, total = packed_layout(images)
+    buf = buffer(total)
+    dst = buf.numpy()
+    for b, im in enumerate(images):
+        a = im if isinstance(im, np.ndarray) else im.numpy()
+        if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+            raise ValueError("DeviceImagePipeline takes decoded uint8 [H,W,3] images")
+        np.copyto(dst[offs[b]:offs[b] + a.size].reshape(a.shape), a)
+    return buf[:total]
+
+
 class DeviceImagePipeline:
     def __init__(self, split, resize, crop, mean=MEAN, std=STD, flip_p=0.5, device="cuda", generator=None):
         self.train = split == "train"
@@ -53,13 +79,7 @@ class DeviceImagePipeline:
 
     def pack(self, images):
         """list of uint8 [H,W,3] images (numpy / torch, host or device) -> (device byte buffer, offsets, sizes)"""
-        B = len(images)
-        sizes = [(int(im.shape[0]), int(im.shape[1])) for im in images]
-        offs = np.zeros(B, dtype=np.int64)
-        total = 0
-        for b, (h, w) in enumerate(sizes):
-            offs[b] = total
-            total += (h * w * 3 + 15) // 16 * 16
+        offs, sizes, total = packed_layout(images)
         packed = torch.empty(total, dtype=torch.uint8, device=self.device)
         for b, im in enumerate(images):
             t = torch.as_tensor(np.ascontiguousarray(im) if isinstance(im, np.ndarray) else im.contiguous())

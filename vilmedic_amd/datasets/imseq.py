@@ -15,7 +15,7 @@ import numpy as np
 import torch
 from torch.utils.data import Dataset
 
-from .device_pipeline import DeviceImagePipeline
+from .device_pipeline import DeviceImagePipeline, pack_host, packed_layout
 from .prefetch import stack
 
 
@@ -352,6 +352,15 @@ class _DeviceImages:
     reference's ``images`` tensor on the device (one launch of the Resize / crop / flip / normalise kernel per batch)"""
     _pipeline = None
 
+    def stage_batch(self, batch, ring):
+        """(PrefetchLoader's thread) the decoded images of a collated batch packed into one pinned byte buffer"""
+        if "images_u8" not in batch:
+            return batch
+        real = [im for im in batch["images_u8"] if im is not None]
+        batch = dict(batch)
+        batch["images_packed"] = pack_host(real, lambda n: ring.flat("images_packed", n))
+        return batch
+
     def device_transform(self, batch):
         """decoded uint8 images of a collated batch -> the reference's ``images`` tensor, on the device"""
         if "images_u8" not in batch:
@@ -361,7 +370,12 @@ class _DeviceImages:
         batch = dict(batch)
         imgs, n = batch.pop("images_u8"), batch.pop("images_n")
         real = [im for im in imgs if im is not None]
-        out = self._pipeline(real)
+        packed = batch.pop("images_packed", None)
+        if packed is not None:                          # staged by the prefetch thread (stage_batch): already one buffer in HBM
+            offs, sizes, _ = packed_layout(real)
+            out = self._pipeline.run(packed, offs, sizes)
+        else:
+            out = self._pipeline(real)
         if n > 1:                                       # multi-image: zero images where the sample has fewer (ref vilmedic_collate)
             full = out.new_zeros(len(imgs), *out.shape[1:])
             idx = torch.tensor([i for i, im in enumerate(imgs) if im is not None], device=out.device)

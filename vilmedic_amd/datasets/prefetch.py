@@ -40,6 +40,15 @@ class StagingRing:
             d[k] = b
         return b
 
+    def flat(self, key, nbytes):
+        """a byte buffer of at least ``nbytes`` (grown by 25 % steps; for payloads whose size changes from batch to batch)"""
+        d = self.bufs[self.cur]
+        b = d.get(key)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(nbytes + nbytes // 4, dtype=torch.uint8, pin_memory=self.pin)
+            d[key] = b
+        return b
+
     def fence(self, event):
         self.events[self.cur] = event
         self.cur = (self.cur + 1) % self.slots
@@ -90,6 +99,8 @@ class PrefetchLoader:
         self.device = device
         self.ring = StagingRing(depth + 3, pin=device is not None)
         self.copy_stream = torch.cuda.Stream(device) if device is not None else None
+        base = getattr(self.dataset, "dataset", self.dataset)          # through a torch Subset (rank shards)
+        self.stage_hook = getattr(base, "stage_batch", None)            # dataset-specific host staging (imseq.py: image packing)
 
     def __len__(self):
         return len(self.loader)
@@ -123,6 +134,8 @@ class PrefetchLoader:
                 torch.cuda.set_device(self.device)
             for batch in self.loader:
                 ev = None
+                if self.stage_hook is not None:
+                    batch = self.stage_hook(batch, self.ring)
                 if self.device is not None:
                     with torch.cuda.stream(self.copy_stream):
                         batch = self._to_device(batch)
