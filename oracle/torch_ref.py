@@ -12,12 +12,14 @@ reference's own block files (``/root/reference/vilmedic/blocks/**``) on top of
 HuggingFace ``transformers`` (the third-party dependency that holds the
 arithmetic; the reference pins ``transformers==4.55.3`` in ``setup.py:29``, the
 container carries 5.15.0 whose BERT/ViT block arithmetic is identical).
-Three later additions are COMPOSITIONS of pinned pieces rather than separately pinned:
+Three later additions were COMPOSITIONS of pinned pieces in round 1; each is now pinned by a fixture of its own:
 ``rrg_hf_forward`` (pinned ViT + decoder wired as RRG_HF.py:107-176 does; since round 2 pinned as a whole by fixture G20: the
 reference's own RRG_HF.forward body on a VisionEncoderDecoderModel, 4-D and 5-D images, enc_to_dec_proj),
 ``gloria_forward`` (pinned text tower, GLoRIA losses and the G11-pinned ``gloria_aggregate_tokens``; the CNN is run, not
-restated; since round 2 pinned as a whole by fixture G21: the reference's own GLoRIA class on a stand-in CNN) and the ENSEMBLE branch of ``decoder_step_logits`` (summed logits, beam_search.py:243-262 -- the reference's
-own ensemble path cannot run at this snapshot, so this branch is parity-UNPINNED and the judge should read it so).
+restated; since round 2 pinned as a whole by fixture G21: the reference's own GLoRIA class on a stand-in CNN) and the ENSEMBLE branch of ``decoder_step_logits`` (summed logits, beam_search.py:243-262).  The reference's ensemble file
+imports HF modules that were removed long before its own pinned release, so it cannot be imported at this snapshot; since round 2
+the branch is pinned by fixture G22 instead: HF ``generate`` (greedy, beam-4 with two length penalties) over the summed logits of two
+of the reference's DecoderModels with different encoder lengths -- the one arithmetic change that file makes to HF's beam search.
 Round 2 added ``mvqa_forward`` and ``convirt_forward`` -- pinned as whole compositions by fixture G18 (the reference's own MVQA /
 ConVIRT class bodies, lifted by AST, on stand-in CNNs) -- and ``scst_forward`` -- pinned by fixture G19 (the reference's own
 ``SCST.forward_sampling`` body on its DecoderModel with HF ``generate``: sampled batch, gathered log-probabilities, loss, encoder gradient).

@@ -409,8 +409,8 @@ def test_rrg_hf_single_image_equals_rrg_and_multi_image_matches_oracle(golden):
 def test_ensemble_greedy_and_beam_decode_vs_oracle(golden):
     """n-best checkpoint ensembling: two decoders with their own encoder states and KV caches, logits
     summed before the log-softmax (ref: blocks/huggingface/decoder/beam_search.py:243-262) -- against the fp32 oracle's
-    ensemble decode with the same margin-aware criterion as the single-model test (the reference's own ensemble path is
-    dead at HEAD, so this piece is pinned by the oracle restatement only)."""
+    ensemble decode with the same margin-aware criterion as the single-model test (the reference's own ensemble file does not
+    import at HEAD; the oracle's ensemble branch is pinned by fixture G22, see the next test)."""
     from oracle import torch_ref as O
     g = golden("g7_decode")
     cfg, rc = g["cfg"], g["recipe"]
@@ -451,6 +451,33 @@ def test_ensemble_greedy_and_beam_decode_vs_oracle(golden):
             if idb[b, t] == 1:
                 break
             assert lp[b, t - 1].max() - lp[b, t - 1, idb[b, t]] <= 0.25, (b, t)
+
+
+def test_ensemble_decode_vs_hf_generate_fixture(golden):
+    """fixture G22: HF ``generate`` over the summed logits of two reference DecoderModels (different encoder lengths and masks) --
+    the HIP ensemble decode (fp32 decode step, per-model KV caches) gives the same greedy and beam-4 token ids, row for row"""
+    g = golden("g22_ensemble_decode")
+    cfg, rc = g["cfg"], g["recipe"]
+    decs, eo = [], []
+    for i, sd in enumerate(g["seeds"]):
+        d, _ = build_decoder(cfg, sd, **rc)
+        decs.append(d.eval())
+        gen = torch.Generator().manual_seed(sd + 1)
+        e = torch.randn(g["B"], g["S"] - i, cfg["hidden_size"], generator=gen)
+        e[~g["enc_masks"][i]] = 0.0
+        eo.append(dict(encoder_hidden_states=e.to(dev()), encoder_attention_mask=g["enc_masks"][i].to(dev())))
+    start = torch.zeros(g["B"], 1, dtype=torch.long, device=dev())
+    common = dict(bos_token_id=0, eos_token_id=2, pad_token_id=1, max_length=g["max_len"],
+                  hf_models=[d.decoder for d in decs], encoders_outputs=eo)
+    ids = decs[0].generate(input_ids=start, **common).cpu()
+    ref = g["beams1_lp1.0"]["sequences"]
+    assert ids.shape == ref.shape and torch.equal(ids, ref), (ids, ref)
+    for lp in (1.0, 2.0):
+        ref = g[f"beams4_lp{lp}"]
+        out = decs[0].generate(input_ids=start, num_beams=4, length_penalty=lp, return_dict_in_generate=True, **common)
+        seq = out.sequences.cpu()
+        assert seq.shape == ref["sequences"].shape and torch.equal(seq, ref["sequences"]), (lp, seq, ref["sequences"])
+        assert (out.sequences_scores.cpu() - ref["scores"]).abs().max().item() <= 1e-4
 
 
 def build_rrs(g, device=None):

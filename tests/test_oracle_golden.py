@@ -368,3 +368,32 @@ def test_g21_gloria_forward_vs_the_reference_class(golden):
     torch.testing.assert_close(word, g["word_embeddings"], rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(sent, g["sent_embeddings"], rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(loss, g["loss"], rtol=1e-4, atol=1e-4)
+
+
+def test_g22_ensemble_decode_summed_logits_bit_exact(golden):
+    """the ENSEMBLE branch of ``decoder_step_logits`` / ``greedy_decode`` / ``beam_decode`` against HF ``generate`` run over the
+    summed logits of two reference DecoderModels (tools/make_golden.py:gen_ensemble_decode; the change the reference's
+    beam_search.py:243-262 makes to HF's beam search)"""
+    g = golden("g22_ensemble_decode")
+    cfg, rc = g["cfg"], g["recipe"]
+    states, encs = [], []
+    for i, sd in enumerate(g["seeds"]):
+        st = R.rand_state(R.decoder_shapes(cfg), sd, std=rc["std"], emb_std=rc["emb_std"], qk_std=rc["qk_std"], pos_std=rc["pos_std"])
+        st["lm_head.bias"][cfg["eos_token_id"]] += rc["eos_bias"]
+        assert abs(R.state_checksum(st) - g["checksums"][i]) < 1e-6 * g["checksums"][i]
+        gen = torch.Generator().manual_seed(sd + 1)
+        e = torch.randn(g["B"], g["S"] - i, cfg["hidden_size"], generator=gen)
+        e[~g["enc_masks"][i]] = 0.0
+        states.append(st)
+        encs.append(e)
+    masks = list(g["enc_masks"])
+    ids = O.greedy_decode(encs, masks, states, cfg, 0, 2, 1, g["max_len"])
+    assert torch.equal(ids, g["beams1_lp1.0"]["sequences"])
+    for lp in (1.0, 2.0):
+        ref = g[f"beams4_lp{lp}"]
+        seqs, scores = O.beam_decode(encs, masks, states, cfg, 0, 2, 1, g["max_len"], 4, lp)
+        assert torch.equal(seqs, ref["sequences"]), (lp, seqs, ref["sequences"])
+        close(scores, ref["scores"], rtol=1e-4, atol=1e-4)
+    # and the sum matters: model 0 alone decodes something else
+    alone = O.greedy_decode(encs[0], masks[0], states[0], cfg, 0, 2, 1, g["max_len"])
+    assert torch.equal(alone, g["model0_alone_greedy"]) and not torch.equal(alone, ids)

@@ -765,8 +765,64 @@ def gen_gloria_model():
                                   sent_embeddings=o["sent_embeddings"].detach().clone()))
 
 
+# ------------------------------------------------------------------ G22: ensemble decode = HF generate over SUMMED logits
+def gen_ensemble_decode():
+    """The reference's ensemble path (blocks/huggingface/decoder/beam_search.py:165-400) is a copy of the beam_search of the HF release it
+    was written against with ONE arithmetic change, the marked lines 243-262: every model of the ensemble runs on the same
+    ``input_ids`` (each with its own encoder states) and the next-token logits are SUMMED before the log-softmax.  That file
+    imports ``transformers.generation_utils`` / ``generation_beam_search`` (removed long before the pinned 4.55.3), so it cannot be
+    imported at this snapshot.  The fixture therefore runs the SAME change through the installed HF beam search: the reference's
+    own DecoderModel twice (two seeds), the first one's ``forward`` wrapped to add the second one's logits, decoded by HF
+    ``generate`` exactly as evaluation.py:73-78 calls it (no KV cache: the cache is not part of the arithmetic)."""
+    from transformers import GenerationConfig
+    cfg, seeds, B, S, max_len = R.DEC_TINY, (41, 43), 5, 10, 24
+    recipe = dict(std=0.6, emb_std=0.2, eos_bias=3.0, qk_std=0.15, pos_std=0.6)      # the eos biases add up: 3 + 3 = G7's 6
+    decs = [build_ref_decoder(cfg, sd, **recipe) for sd in seeds]
+    hf1, hf2 = decs[0][0].decoder, decs[1][0].decoder
+    encs, masks = [], []
+    for i, sd in enumerate(seeds):
+        g = torch.Generator().manual_seed(sd + 1)
+        e = torch.randn(B, S - i, cfg["hidden_size"], generator=g)           # the models see different numbers of encoder positions
+        m = torch.ones(B, S - i, dtype=torch.bool)
+        m[2 + i, 6:] = False
+        e[~m] = 0.0
+        encs.append(e)
+        masks.append(m)
+    inner = hf1.forward
+
+    def summed(input_ids=None, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None, enc2=None, mask2=None, **kw):
+        o1 = inner(input_ids=input_ids, attention_mask=attention_mask, encoder_hidden_states=encoder_hidden_states,
+                   encoder_attention_mask=encoder_attention_mask, use_cache=False, return_dict=True)
+        o2 = hf2(input_ids=input_ids, attention_mask=attention_mask, encoder_hidden_states=enc2, encoder_attention_mask=mask2,
+                 use_cache=False, return_dict=True)
+        o1.logits = o1.logits + o2.logits                                       # beam_search.py:262
+        return o1
+
+    hf1.forward = summed
+    res = dict(cfg=cfg, seeds=seeds, B=B, S=S, max_len=max_len, recipe=recipe, enc_masks=masks,
+               checksums=[R.state_checksum(st) for _, st in decs])
+    for nb in (1, 4):
+        for lp in ((1.0,) if nb == 1 else (1.0, 2.0)):
+            args = dict(bos_token_id=0, eos_token_id=2, pad_token_id=1, num_return_sequences=1, max_length=max_len,
+                        use_cache=False, num_beams=nb, length_penalty=lp, return_dict_in_generate=True, output_scores=True)
+            with torch.no_grad():
+                o = hf1.generate(input_ids=torch.zeros((B, 1), dtype=torch.long), generation_config=GenerationConfig(**args),
+                                 encoder_hidden_states=encs[0], encoder_attention_mask=masks[0], enc2=encs[1], mask2=masks[1])
+            key = f"beams{nb}_lp{lp}"
+            res[key] = dict(sequences=o.sequences, scores=getattr(o, "sequences_scores", None))
+            print(key, o.sequences.tolist())
+    # the single models decode differently from the ensemble (otherwise the fixture would not see the sum)
+    hf1.forward = inner
+    with torch.no_grad():
+        alone = hf1.generate(input_ids=torch.zeros((B, 1), dtype=torch.long), encoder_hidden_states=encs[0], encoder_attention_mask=masks[0],
+                             generation_config=GenerationConfig(bos_token_id=0, eos_token_id=2, pad_token_id=1, max_length=max_len, use_cache=False, num_beams=1))
+    res["model0_alone_greedy"] = alone
+    print("model 0 alone", alone.tolist())
+    save("g22_ensemble_decode", res)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs", "vicreg", "bleu", "vit_multi", "schedulers", "model_compositions", "scst_sampling", "rrg_hf", "gloria_model"]
+    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs", "vicreg", "bleu", "vit_multi", "schedulers", "model_compositions", "scst_sampling", "rrg_hf", "gloria_model", "ensemble_decode"]
     for w in which:
         globals()["gen_" + w]()
