@@ -210,9 +210,12 @@ validator: {{batch_size: 4, beam_width: 2, splits: [validate]}}
 def _imseq(root, split="validate", n=6):
     from vilmedic_amd.datasets import ImSeq
     _make_corpus(root, n=n)
-    return ImSeq(seq=dict(root=root, file="report.tok", tokenizer=None, tokenizer_max_len=12, processing="r2gen_clean_report", source="tgt"),
-                 image=dict(root=root, file="image.tok", image_path=root, resize=40, crop=32, ext=".png"), split=split,
-                 ckpt_dir=os.path.join(root, "ckpt"))
+    ds = None
+    for sp in (["train"] if split == "train" else ["train", split]):          # the training split writes the vocabulary the others read
+        ds = ImSeq(seq=dict(root=root, file="report.tok", tokenizer=None, tokenizer_max_len=12, processing="r2gen_clean_report", source="tgt"),
+                   image=dict(root=root, file="image.tok", image_path=root, resize=40, crop=32, ext=".png"), split=sp,
+                   ckpt_dir=os.path.join(root, "ckpt"))
+    return ds
 
 
 def test_prefetch_thread_packs_decoded_images_into_one_staging_buffer(tmp_path):
@@ -238,9 +241,9 @@ def test_prefetch_thread_packs_decoded_images_into_one_staging_buffer(tmp_path):
 def test_device_transform_of_a_staged_batch_equals_the_unstaged_one(tmp_path):
     from torch.utils.data import DataLoader
     from vilmedic_amd.datasets import DeviceBatchLoader, PrefetchLoader
-    ds = _imseq(str(tmp_path), split="validate")           # evaluation transform: no random draws
-    plain = [b["images"].clone() for b in DeviceBatchLoader(DataLoader(ds, batch_size=4, collate_fn=ds.get_collate_fn()))]
-    staged = [b["images"].clone() for b in DeviceBatchLoader(PrefetchLoader(DataLoader(ds, batch_size=4, collate_fn=ds.get_collate_fn())))]
+    ds = _imseq(str(tmp_path), split="validate", n=16)     # evaluation transform: no random draws
+    plain = [b["images"].clone() for b in DeviceBatchLoader(DataLoader(ds, batch_size=3, collate_fn=ds.get_collate_fn()))]
+    staged = [b["images"].clone() for b in DeviceBatchLoader(PrefetchLoader(DataLoader(ds, batch_size=3, collate_fn=ds.get_collate_fn())))]
     assert len(plain) == len(staged) > 0
     for a, b in zip(plain, staged):
         assert a.is_cuda and torch.equal(a, b)
