@@ -337,7 +337,7 @@ class BertEmbeddings(nn.Module):
         return x
 
 
-class DropoutFn(torch.autograd.Function):
+class DropoutFn(ops.Fn):
     @staticmethod
     def forward(ctx, x, p):
         seed = ops.next_seed()

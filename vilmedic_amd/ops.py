@@ -222,7 +222,18 @@ def colsum(x, out, rows=None, cols=None, scale_dev=None):
 _bwd_mark = {"cb": None}
 
 
-class _BackwardMark(torch.autograd.Function):
+class Fn(torch.autograd.Function):
+    """``torch.autograd.Function`` whose ``apply`` goes straight to the C++ implementation.  The stock Python ``apply`` first
+    binds default arguments and unwraps functorch wrappers of every argument (``_functorch.utils.unwrap_dead_wrappers``): 7 % of
+    the host time of a training step here (199 applies of ~10 arguments each; ``tools/host_profile.py``), for transforms this
+    package never runs under."""
+
+    @classmethod
+    def apply(cls, *args):
+        return super(torch.autograd.Function, cls).apply(*args)
+
+
+class _BackwardMark(Fn):
     @staticmethod
     def forward(ctx, x, tag):
         ctx.tag = tag
@@ -380,7 +391,7 @@ def _2d(x):
 
 
 # ----------------------------------------------------------------------------- Linear (+bias, +dropout, +residual)
-class LinearFn(torch.autograd.Function):
+class LinearFn(Fn):
     """y = dropout(x W^T + b) + residual.   ``w_sh`` is the bf16 shadow [N,K] of the fp32 parameter(s);
     ``w_params`` / ``b_params`` are lists of the fp32 parameters whose contiguous arena grads receive dW / db
     (several when Q,K,V projections are fused into one GEMM)."""
@@ -438,7 +449,7 @@ def _masked_grad(dy2, dropout_p, seed):
 
 
 # ----------------------------------------------------------------------------- MLP: FC1 + erf-GELU + FC2 (+dropout) + residual
-class MlpFn(torch.autograd.Function):
+class MlpFn(Fn):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, residual, dropout_p, g_w1, g_b1, g_w2, g_b2, anchor, seed=0):
         x2 = _2d(x)
@@ -483,7 +494,7 @@ def mlp(x, w1, b1, w2, b2, *, residual=None, dropout_p=0.0, grads=(None, None, N
 
 
 # ----------------------------------------------------------------------------- LayerNorm
-class LayerNormFn(torch.autograd.Function):
+class LayerNormFn(Fn):
     """y = LN(x).  ``fork`` fuses the gradient sum of a residual fork into the backward kernel instead of leaving it to
     an autograd elementwise add:
       fork="in"  (pre-LN block):  returns (y, x_alias); the block feeds x_alias to its residual, so x has ONE consumer
@@ -557,7 +568,7 @@ def layer_norm(x, gamma, beta, eps, g_gamma=None, g_beta=None, fork=None):
 
 
 # ----------------------------------------------------------------------------- attention
-class AttentionFn(torch.autograd.Function):
+class AttentionFn(Fn):
     """q [B,Lq,*] k,v [B,Lk,*] are column slices (views) of projection outputs; heads are contiguous 64-wide blocks."""
 
     @staticmethod
@@ -596,7 +607,7 @@ class AttentionFn(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None
 
 
-class PackedSelfAttentionFn(torch.autograd.Function):
+class PackedSelfAttentionFn(Fn):
     """Self-attention on the fused QKV projection output [B,L,3*D]; the gradient comes back packed [B,L,3*D]
     so the QKV dgrad/wgrad run as single GEMMs."""
 
@@ -635,7 +646,7 @@ class PackedSelfAttentionFn(torch.autograd.Function):
         return dqkv, None, None, None, None
 
 
-class PackedCrossAttentionFn(torch.autograd.Function):
+class PackedCrossAttentionFn(Fn):
     """q [B,Lq,D] from the decoder, kv [B,Lk,2*D] = fused K|V projection of the encoder features (any row stride: the
     view of one layer inside the all-layer projection of CrossKVAllFn).  ``dkv_out``: optional pre-allocated gradient
     slot with kv's shape (written in place and returned as kv's gradient)."""
@@ -680,7 +691,7 @@ class PackedCrossAttentionFn(torch.autograd.Function):
         return dq, dkv, None, None, None, None
 
 
-class CrossKVAllFn(torch.autograd.Function):
+class CrossKVAllFn(Fn):
     """The K|V projections of ALL decoder layers' cross-attention in one GEMM: enc [B,S,De] x W_all^T [n*2D, De] -> one
     buffer [B*S, n*2D]; layer i reads the strided view [..., i*2D:(i+1)*2D].  Backward: every layer's attention kernel
     writes dK|dV straight into its slice of one gradient buffer, then ONE dgrad GEMM (contraction n*2D) yields d_enc --
@@ -746,7 +757,7 @@ def cross_attention(q, kv, key_mask, H, dropout_p=0.0, dkv_out=None):
 
 
 # ----------------------------------------------------------------------------- embeddings
-class EmbeddingFn(torch.autograd.Function):
+class EmbeddingFn(Fn):
     @staticmethod
     def forward(ctx, anchor, ids, word, pos, past_len, padding_idx, g_word, g_pos):
         B, L = ids.shape
@@ -778,7 +789,7 @@ def embedding(anchor, ids, word, pos, *, past_len=0, padding_idx=None, g_word=No
 
 
 # ----------------------------------------------------------------------------- ViT patch embedding (+cls +pos)
-class PatchEmbedFn(torch.autograd.Function):
+class PatchEmbedFn(Fn):
     @staticmethod
     def forward(ctx, anchor, images, w_sh, bias, cls, pos, patch, g_w, g_b, g_cls, g_pos):
         B, Cc, Hh, Ww = images.shape
@@ -811,7 +822,7 @@ def patch_embed(anchor, images, w_sh, bias, cls, pos, patch, grads=(None, None, 
 
 
 # ----------------------------------------------------------------------------- LM head + shifted CE (fused fwd/bwd)
-class LmHeadLossFn(torch.autograd.Function):
+class LmHeadLossFn(Fn):
     """logits = h E^T + b (bf16, padded leading dim); loss = sum_rows w_row CE(logits[b,t], ids[b,t+1]).
 
     Default (w = 1/(B(L-1))): mean CE of logits[:, :-1] vs ids[:, 1:] with pads INCLUDED (ref: decoder_model.py:46 passes
