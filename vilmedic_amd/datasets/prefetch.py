@@ -106,6 +106,8 @@ class PrefetchLoader:
         return len(self.loader)
 
     def __getattr__(self, name):          # batch_sampler, sampler, collate_fn, ... of the wrapped loader
+        if name in ("loader", "__setstate__", "__getstate__"):      # (copy / pickle probe these before __init__ has run)
+            raise AttributeError(name)
         return getattr(self.loader, name)
 
     # -- producer side --------------------------------------------------------------------------------------------------
