@@ -494,6 +494,17 @@ def mlp(x, w1, b1, w2, b2, *, residual=None, dropout_p=0.0, grads=(None, None, N
 
 
 # ----------------------------------------------------------------------------- LayerNorm
+_ln_ws = {}
+
+
+def _ln_ws_floats(rows, cols):
+    """workspace floats of the LayerNorm backward for this shape (a pure function of the shape: asked once, not per launch)"""
+    n = _ln_ws.get((rows, cols))
+    if n is None:
+        n = _ln_ws[(rows, cols)] = lib().vm_layernorm_bwd_ws(rows, cols) // 4
+    return n
+
+
 class LayerNormFn(Fn):
     """y = LN(x).  ``fork`` fuses the gradient sum of a residual fork into the backward kernel instead of leaving it to
     an autograd elementwise add:
@@ -535,7 +546,7 @@ class LayerNormFn(Fn):
             return dres, None, None, None, None, None, None, None
         dy2 = _2d(dy.contiguous())
         dx = torch.empty_like(x2)
-        ws = torch.empty(lib().vm_layernorm_bwd_ws(rows, cols) // 4, dtype=torch.float32, device=dy.device)
+        ws = torch.empty(_ln_ws_floats(rows, cols), dtype=torch.float32, device=dy.device)
         if g_gamma is None:   # frozen affine: still need dx; send the param grads to scratch
             g_gamma = torch.zeros(cols, dtype=torch.float32, device=dy.device)
             g_beta = torch.zeros(cols, dtype=torch.float32, device=dy.device)
