@@ -25,3 +25,16 @@ def test_launches_per_layer_and_fixed_part():
     assert per_layer_pair <= 46, (c2, c4)
     assert fixed <= 25, (c2, c4)
     assert fixed + 12 * per_layer_pair <= 577
+
+
+def test_call_trace_is_deterministic(tmp_path):
+    """the C-ABI call trace (entry point + scalar arguments) of a step is what host refactors are checked against: two runs must agree"""
+    outs = []
+    for k in range(2):
+        path = os.path.join(str(tmp_path), f"trace{k}.txt")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_profile.py"), "--steps", "1", "--top", "0", "--layers", "2", "--trace", path],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(open(path).read())
+    assert outs[0] == outs[1] and outs[0].count("vm_gemm_bf16") > 20
+    assert "vm_adam_step_dev" in outs[0] and "vm_ce_shift_fwd_bwd" in outs[0]
