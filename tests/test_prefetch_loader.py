@@ -66,3 +66,27 @@ def test_device_batches_match_host():
     torch.cuda.synchronize()
     for a, y in seen:
         assert torch.equal(a["images"] * 2.0, y.cpu())
+
+
+def test_create_data_loader_wraps_the_training_loader_reproducibly():
+    """executors/utils.create_data_loader: the training split runs under a PrefetchLoader whose shuffle order is a function of the
+    global seed alone (its own generator, so the producer thread never draws from the global RNG); ``prefetch: 0`` and the
+    evaluation splits keep the bare DataLoader"""
+    import logging
+
+    from vilmedic_amd.config import wrap
+    from vilmedic_amd.executors.utils import create_data_loader
+    log = logging.getLogger("t")
+    log.settings = log.info
+    cfg = wrap({"dataset": {"proto": "SyntheticImSeq", "num_samples": 40, "image_size": 8, "vocab_size": 30, "tokenizer_max_len": 8}, "batch_size": 4})
+    orders = []
+    for _ in range(2):
+        torch.manual_seed(123)
+        dl = create_data_loader(cfg, "train", log)
+        assert isinstance(dl, PrefetchLoader) and len(dl) == 10
+        orders.append(torch.cat([b["input_ids"] for b in dl]))
+    assert torch.equal(orders[0], orders[1])
+    ev = create_data_loader(cfg, "validate", log)
+    assert not isinstance(ev, PrefetchLoader)
+    off = wrap({"dataset": dict(cfg.dataset), "batch_size": 4, "prefetch": 0})
+    assert not isinstance(create_data_loader(off, "train", log), PrefetchLoader)
