@@ -11,7 +11,6 @@
 #include <algorithm>
 #include <vector>
 #include "../include/vmhip.h"
-#include "candidates/gemm_w128.hip"     // candidate kernels live in tools/ until they win here
 
 typedef short v4s __attribute__((ext_vector_type(4)));
 __global__ void tr_probe(short* out) {
@@ -220,152 +219,7 @@ static void bench_ab(int M, int N, int K, int la, int lb, int flags, int split) 
     hipFree(dbias); if (ws) hipFree(ws);
 }
 
-// candidate wave tiling (tools/candidates/gemm_w128.hip) against the production kernel: same operands, results compared element by element
-// (both accumulate the 32-wide k-chunks of a row in the same order, so bf16 outputs should be identical), then both timed on a warm L2
-static int cand_w128(int M, int N, int K) {
-    int64_t lda = K, ldb = K, ldc = (N + 7) / 8 * 8;
-    size_t na = (size_t)M * K, nb = (size_t)N * K, nc = (size_t)M * ldc;
-    std::vector<uint16_t> h(std::max(na, nb));
-    for (auto& x : h) x = f2bf(frand());
-    std::vector<float> hb(N);
-    for (auto& x : hb) x = frand();
-    void *dA, *dB, *dC, *dR, *dbias;
-    hipMalloc(&dA, na * 2); hipMalloc(&dB, nb * 2); hipMalloc(&dC, nc * 2); hipMalloc(&dR, nc * 2); hipMalloc(&dbias, N * 4);
-    hipMemcpy(dA, h.data(), na * 2, hipMemcpyHostToDevice);
-    std::reverse(h.begin(), h.end());
-    hipMemcpy(dB, h.data(), nb * 2, hipMemcpyHostToDevice);
-    hipMemcpy(dbias, hb.data(), N * 4, hipMemcpyHostToDevice);
-    vm_gemm_epilogue e = {}; e.alpha = 1.f; e.out_dtype = VM_BF16; e.split_k = 1; e.bias = (const float*)dbias;
-    hipMemset(dR, 0, nc * 2);
-    int rc = vm_gemm_bf16(dA, lda, 0, dB, ldb, 0, dR, ldc, M, N, K, &e, nullptr);
-    if (rc) { printf("production rc=%d %s\n", rc, vm_last_error()); return 1; }
-    hipDeviceSynchronize();
-    std::vector<uint16_t> ref(nc), got(nc);
-    hipMemcpy(ref.data(), dR, nc * 2, hipMemcpyDeviceToHost);
-    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    const int it = 20;
-    for (int i = -3; i < it; ++i) { if (i == 0) hipEventRecord(a, nullptr); vm_gemm_bf16(dA, lda, 0, dB, ldb, 0, dR, ldc, M, N, K, &e, nullptr); }
-    hipEventRecord(b, nullptr); hipEventSynchronize(b);
-    float ms; hipEventElapsedTime(&ms, a, b); ms /= it;
-    printf("w128 M=%d N=%d K=%d  production: %7.1f us %6.1f TFLOP/s\n", M, N, K, ms * 1e3, 2.0 * M * N * K / ms * 1e-9);
-    int fails = 0;
-    for (int v = 0; v < 6; ++v) {
-        hipMemset(dC, 0, nc * 2);
-        rc = w128::gemm(v, dA, lda, dB, ldb, (const float*)dbias, dC, ldc, M, N, K, nullptr);
-        hipError_t er = hipDeviceSynchronize();
-        if (rc || er != hipSuccess) { printf("  cand %d (%s): launch rc=%d sync=%d\n", v, w128::name(v), rc, (int)er); ++fails; continue; }
-        hipMemcpy(got.data(), dC, nc * 2, hipMemcpyDeviceToHost);
-        size_t bad = 0; double maxd = 0;
-        for (int m = 0; m < M; ++m) for (int n = 0; n < N; ++n) {
-            const size_t i = (size_t)m * ldc + n;
-            if (got[i] != ref[i]) { ++bad; maxd = std::max(maxd, (double)fabsf(bf2f(got[i]) - bf2f(ref[i]))); }
-        }
-        for (int i = -3; i < it; ++i) { if (i == 0) hipEventRecord(a, nullptr); w128::gemm(v, dA, lda, dB, ldb, (const float*)dbias, dC, ldc, M, N, K, nullptr); }
-        hipEventRecord(b, nullptr); hipEventSynchronize(b);
-        hipEventElapsedTime(&ms, a, b); ms /= it;
-        printf("  cand %d (%-20s): %7.1f us %6.1f TFLOP/s   differing outputs %zu of %zu (max |diff| %.3g)\n", v, w128::name(v), ms * 1e3,
-               2.0 * M * N * K / ms * 1e-9, bad, (size_t)M * N, maxd);
-        if (bad) ++fails;
-    }
-    hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dR); hipFree(dbias);
-    return fails;
-}
-
-// where a candidate's time goes: full kernel / no global stores / no epilogue at all / one K-tile only (prologue + epilogue)
-static void cand_w128_breakdown(int M, int N, int K) {
-    int64_t ldc = (N + 7) / 8 * 8;
-    size_t na = (size_t)M * K, nb = (size_t)N * K, nc = (size_t)M * ldc;
-    std::vector<uint16_t> h(std::max(na, nb));
-    for (auto& x : h) x = f2bf(frand());
-    void *dA, *dB, *dC, *dbias;
-    hipMalloc(&dA, na * 2); hipMalloc(&dB, nb * 2); hipMalloc(&dC, nc * 2); hipMalloc(&dbias, N * 4);
-    hipMemcpy(dA, h.data(), na * 2, hipMemcpyHostToDevice); hipMemcpy(dB, h.data(), nb * 2, hipMemcpyHostToDevice); hipMemset(dbias, 0, N * 4);
-    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    const int it = 20;
-    printf("w128 breakdown M=%d N=%d K=%d (us):", M, N, K);
-    {
-        vm_gemm_epilogue e = {}; e.alpha = 1.f; e.out_dtype = VM_BF16; e.split_k = 1; e.bias = (const float*)dbias;
-        for (int i = -3; i < it; ++i) { if (i == 0) hipEventRecord(a, nullptr); vm_gemm_bf16(dA, K, 0, dB, K, 0, dC, ldc, M, N, K, &e, nullptr); }
-        hipEventRecord(b, nullptr); hipEventSynchronize(b);
-        float ms; hipEventElapsedTime(&ms, a, b);
-        printf(" production %.1f", ms / it * 1e3);
-    }
-    for (int v : {0, 4, 5}) {
-        printf("   cand %d:", v);
-        for (int dbg : {0, 1, 4, 2, 6}) {
-            for (int i = -3; i < it; ++i) { if (i == 0) hipEventRecord(a, nullptr); w128::gemm(v, dA, K, dB, K, (const float*)dbias, dC, ldc, M, N, K, nullptr, dbg); }
-            hipEventRecord(b, nullptr); hipEventSynchronize(b);
-            float ms; hipEventElapsedTime(&ms, a, b);
-            printf(" %s %.1f", dbg == 0 ? "full" : dbg == 1 ? "nostore" : dbg == 4 ? "noepi" : dbg == 2 ? "k1" : "k1noepi", ms / it * 1e3);
-        }
-    }
-    printf("\n");
-    hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dbias);
-}
-
-// K-tile rotation per tile (the lockstep question of DESIGN section 8): rates of candidates 0 and 4 for several rotation strides, and the
-// largest deviation from the production result (a rotated order sums the same products in another order: not bit-identical any more)
-static void cand_w128_rot(int M, int N, int K) {
-    int64_t ldc = (N + 7) / 8 * 8;
-    size_t na = (size_t)M * K, nb = (size_t)N * K, nc = (size_t)M * ldc;
-    std::vector<uint16_t> h(std::max(na, nb));
-    for (auto& x : h) x = f2bf(frand());
-    void *dA, *dB, *dC, *dR, *dbias;
-    hipMalloc(&dA, na * 2); hipMalloc(&dB, nb * 2); hipMalloc(&dC, nc * 2); hipMalloc(&dR, nc * 2); hipMalloc(&dbias, N * 4);
-    hipMemcpy(dA, h.data(), na * 2, hipMemcpyHostToDevice);
-    std::reverse(h.begin(), h.end());
-    hipMemcpy(dB, h.data(), nb * 2, hipMemcpyHostToDevice); hipMemset(dbias, 0, N * 4);
-    vm_gemm_epilogue e = {}; e.alpha = 1.f; e.out_dtype = VM_BF16; e.split_k = 1; e.bias = (const float*)dbias;
-    vm_gemm_bf16(dA, K, 0, dB, K, 0, dR, ldc, M, N, K, &e, nullptr);
-    hipDeviceSynchronize();
-    std::vector<uint16_t> ref(nc), got(nc);
-    hipMemcpy(ref.data(), dR, nc * 2, hipMemcpyDeviceToHost);
-    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    const int it = 20;
-    printf("w128 rotation M=%d N=%d K=%d (us; max |diff| vs production):", M, N, K);
-    for (int v : {0, 4}) {
-        printf("   cand %d:", v);
-        for (int rot : {0, 1, 3, 5, 7}) {
-            hipMemset(dC, 0, nc * 2);
-            w128::gemm(v, dA, K, dB, K, (const float*)dbias, dC, ldc, M, N, K, nullptr, 0, rot);
-            hipDeviceSynchronize();
-            hipMemcpy(got.data(), dC, nc * 2, hipMemcpyDeviceToHost);
-            double maxd = 0;
-            for (int m = 0; m < M; m += 7) for (int n = 0; n < N; ++n) { const size_t i = (size_t)m * ldc + n; maxd = std::max(maxd, (double)fabsf(bf2f(got[i]) - bf2f(ref[i]))); }
-            for (int i = -3; i < it; ++i) { if (i == 0) hipEventRecord(a, nullptr); w128::gemm(v, dA, K, dB, K, (const float*)dbias, dC, ldc, M, N, K, nullptr, 0, rot); }
-            hipEventRecord(b, nullptr); hipEventSynchronize(b);
-            float ms; hipEventElapsedTime(&ms, a, b);
-            printf(" rot%d %.1f (%.2g)", rot, ms / it * 1e3, maxd);
-        }
-    }
-    printf("\n");
-    hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dR); hipFree(dbias);
-}
-
 int main(int argc, char** argv) {
-    if (argc >= 2 && !strcmp(argv[1], "w128rot")) {
-        const int shapes[][3] = {{4096, 4096, 768}, {12608, 2304, 768}, {12608, 768, 3072}, {8192, 3072, 768}};
-        for (auto& sh : shapes) cand_w128_rot(sh[0], sh[1], sh[2]);
-        return 0;
-    }
-    if (argc >= 2 && !strcmp(argv[1], "w128b")) {   // short combined run: correctness + rates on three shapes, then the time breakdown on two
-        int f = cand_w128(12608, 2304, 768) + cand_w128(4096, 4096, 768) + cand_w128(300, 200, 128);
-        cand_w128_breakdown(4096, 4096, 768);
-        cand_w128_breakdown(12608, 2304, 768);
-        return f != 0;
-    }
-    if (argc >= 2 && !strcmp(argv[1], "w128dbg")) {
-        const int shapes[][3] = {{12608, 2304, 768}, {12608, 768, 768}, {12608, 3072, 768}, {12608, 768, 3072}, {8192, 3072, 768}, {4096, 4096, 768}, {4096, 4096, 3072}, {2048, 2048, 768}};
-        for (auto& sh : shapes) cand_w128_breakdown(sh[0], sh[1], sh[2]);
-        return 0;
-    }
-    if (argc >= 2 && !strcmp(argv[1], "w128")) {    // gpu_probe.bin w128 [M N K]   (default: the forward shapes of the C2 step)
-        if (argc >= 5) return cand_w128(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]));
-        const int shapes[][3] = {{12608, 2304, 768}, {12608, 768, 768}, {12608, 3072, 768}, {12608, 768, 3072}, {8192, 2304, 768}, {8192, 3072, 768}, {300, 200, 128}};
-        int f = 0;
-        for (auto& sh : shapes) f += cand_w128(sh[0], sh[1], sh[2]);
-        return f != 0;
-    }
     if (argc >= 8 && !strcmp(argv[1], "one")) {     // gpu_probe.bin one M N K la lb split     (production kernel only: rocprofv3 --pmc workload)
         bench_gemm(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]));
         return 0;
