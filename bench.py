@@ -35,6 +35,7 @@ DEC_12L = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, in
                vocab_size=30522, max_position_embeddings=514, layer_norm_eps=1e-5, bos_token_id=0, pad_token_id=1,
                eos_token_id=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, initializer_range=0.02)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
+PMC_PROFILE = "profiles/r02_n_pmc_gemm.txt"      # separate rocprofv3 --pmc passes of the dominant shapes (traffic is not measurable in-process)
 
 
 def flops_per_pair_fwd(S=197, L=128, d=768, V=30522, layers=12):
@@ -60,21 +61,14 @@ def dominant_shape_roofline(dump_path):
         return None
     if n == 0:
         return None
-    traffic = None
-    try:
-        for line in open(os.path.join(ROOT, "profiles", "r02_n_pmc_gemm.txt")):
-            if "traffic per launch" in line:
-                traffic = float(line.split("traffic per launch =")[1].split("MB")[0]) * 1e6
-                break                       # the first entry of the file is this shape
-    except (OSError, ValueError, IndexError):
-        pass
+    traffic = None                  # HBM-side bytes need rocprofv3 --pmc passes (tools/pmc_kernels.sh); the latest are under profiles/
     dur = ms / n * 1e-3
     algo = 2.0 * (M * K + N * K + M * N)
     return {"kernel": "gemm_fast_kernel<0,0,...> C[12608,2304] = A[12608,768] . B[2304,768]^T + bias (ViT QKV projection)",
             "bound": "mfma", "achieved": round(2.0 * M * N * K / dur / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(2.0 * M * N * K / dur / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "avg_launch_ms": round(dur * 1e3, 4),
-            "launches": int(n), "algorithmic_bytes": algo, "traffic": traffic,
-            "hbm_frac_of_8TBps": round((traffic or algo) / dur / 8e12, 4)}
+            "launches": int(n), "algorithmic_bytes": algo, "traffic": traffic, "traffic_profile": PMC_PROFILE,
+            "hbm_frac_of_8TBps_algorithmic": round(algo / dur / 8e12, 4)}
 
 
 def build_model(device):
@@ -220,6 +214,142 @@ def cpu_baseline(timeout_s=240.0):
                 "sample": f"oracle (B=2 fwd+bwd+Adam) did not finish one step pair within {timeout_s:.0f} s on this host"}
 
 
+def spawn_ranks(n):
+    """``python bench.py --gpus N`` without a launcher: re-run this command line as N ranks (one per GPU, RCCL over xGMI) under
+    torch.distributed.run on 127.0.0.1 and return its exit code.  Rank 0's JSON line is the child's stdout."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} requested but this node exposes {have} GPU(s) "
+              f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES', '<unset>')}): RCCL needs one distinct device per rank, "
+              f"not starting {n} ranks", file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def allreduce_alone_ms(ddp, barrier, iters=5):
+    """the gradient exchange with nothing to hide behind: cast to the wire dtype, the RCCL all-reduces of the whole arena, cast back
+    (what ArenaDDP.finish() does), per step.  The timed steps overlap all but the front encoder bucket of this with the backward pass."""
+    ddp.finish()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        ddp.finish()
+    barrier()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def secondary_metrics(model, device):
+    """SURVEY §8(d)'s secondary figures and north_star's two named roofline targets, measured live on this GPU (rank 0, N = 1):
+    the decode step (greedy / beam-4, both step dtypes) against its HBM floor, the contrastive loss at the C3 size (global batch 2048,
+    768 features) and the decoder's cross-attention core (B = 64, 12 heads, 128 queries x 197 keys) against MFMA and HBM peaks."""
+    import ctypes as C
+    from vilmedic_amd import ops
+    from vilmedic_amd._lib import lib
+    from vilmedic_amd.blocks.losses.selfsup import _SimilarityLossFn
+    out = {}
+    L_ = lib()
+
+    def kernel_ms(fn, iters):
+        """vmhip kernel time per call (HIP events on the launch stream, every kernel alone) and launches per call"""
+        L_.vm_prof_reset(); L_.vm_prof_enable(1)
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        L_.vm_prof_enable(0)
+        tot, n_tot = 0.0, 0
+        ms, work, n = C.c_double(), C.c_double(), C.c_int64()
+        for f in range(8):
+            if L_.vm_prof_read(f, C.byref(ms), C.byref(work), C.byref(n)) == 0:
+                tot += ms.value; n_tot += n.value
+        L_.vm_prof_reset()
+        return tot / iters, n_tot // iters
+
+    # ---- decode step: weights are read once per step (bf16: the decoder's shadows + tied LM head; fp32: the master copies)
+    dec = model.dec.decoder
+    was_training = model.training
+    model.eval()
+    B, S, T = 64, 197, 65
+    n_dec = sum(p.numel() for p in dec.parameters())
+    g = torch.Generator(device=device).manual_seed(3)
+    enc = torch.randn(B, S, 768, device=device, generator=g).bfloat16()
+    mask = torch.ones(B, S, dtype=torch.bool, device=device)
+    start = torch.zeros(B, 1, dtype=torch.long, device=device)
+    out["decode"] = {"batch": B, "new_tokens": T - 1, "weight_bytes_bf16": 2 * n_dec,
+                     "floor_note": "HBM floor per step = decoder weights read once (2 B/param bf16, 4 B/param fp32) at 8 TB/s"}
+    for beams, dtype in ((1, "bf16"), (1, "fp32"), (4, "bf16"), (4, "fp32")):
+        kw = dict(bos_token_id=0, eos_token_id=2, pad_token_id=1, max_length=T, decode_dtype=dtype)
+        if beams > 1:
+            kw["num_beams"] = beams
+        with torch.no_grad():
+            dec.generate(input_ids=start, encoder_hidden_states=enc, encoder_attention_mask=mask, **kw)      # builds the graphs
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ids = dec.generate(input_ids=start, encoder_hidden_states=enc, encoder_attention_mask=mask, **kw)
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        steps = max(1, ids.shape[1] - 1)
+        ms_step = dt / steps * 1e3
+        floor_ms = n_dec * (2 if dtype == "bf16" else 4) / 8e12 * 1e3
+        out["decode"][f"beams{beams}_{dtype}"] = {"tokens_per_s": round(B * steps / dt, 1), "ms_per_step": round(ms_step, 3),
+                                                   "hbm_frac": round(floor_ms / ms_step, 4)}
+    model.train(was_training)
+
+    # ---- contrastive similarity loss, C3 size (forward + backward)
+    Bc, Dc = 2048, 768
+    a = torch.randn(Bc, Dc, device=device, generator=g).requires_grad_(True)
+    b = torch.randn(Bc, Dc, device=device, generator=g).requires_grad_(True)
+
+    def contrastive_step():
+        a.grad = b.grad = None
+        r, c = _SimilarityLossFn.apply(a, b, True, 10.0, 1e-8)
+        (r.mean() + c.mean()).backward()
+    for _ in range(3):
+        contrastive_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        contrastive_step()
+    torch.cuda.synchronize()
+    wall_us = (time.perf_counter() - t0) / 20 * 1e6
+    k_ms, k_n = kernel_ms(contrastive_step, 5)
+    flop = 6.0 * Bc * Bc * Dc
+    out["contrastive_B2048_D768"] = {"kernel_us_fwd_bwd": round(k_ms * 1e3, 1), "vmhip_launches": k_n, "wall_us_fwd_bwd": round(wall_us, 1),
+                                      "gflop": round(flop * 1e-9, 1), "mfma_frac": round(flop / (k_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
+
+    # ---- attention cores at the step's shapes (forward; dropout 0.1 as in the step)
+    H, dh = 12, 64
+    shapes = {"cross_attention_fwd": (128, 197, False, "cross"), "vit_self_attention_fwd": (197, 197, False, "self"),
+              "causal_self_attention_fwd": (128, 128, True, "self")}
+    for name, (Lq, Lk, causal, kind) in shapes.items():
+        km = torch.ones(B, Lk, dtype=torch.uint8, device=device) if name != "vit_self_attention_fwd" else None
+        if kind == "cross":
+            q = (torch.randn(B, Lq, H * dh, device=device, generator=g) * 0.5).bfloat16()
+            kv = (torch.randn(B, Lk, 2 * H * dh, device=device, generator=g) * 0.5).bfloat16()
+            f = lambda: ops.cross_attention(q, kv, km, H, 0.1)
+        else:
+            qkv = (torch.randn(B, Lq, 3 * H * dh, device=device, generator=g) * 0.5).bfloat16()
+            f = lambda: ops.self_attention(qkv, km, H, causal, 0.1)
+        with torch.no_grad():
+            for _ in range(3):
+                f()
+            k_ms, _ = kernel_ms(f, 20)
+        us = k_ms * 1e3
+        flop = 4.0 * B * H * Lq * Lk * dh * (0.5 if causal else 1.0)
+        byt = 2.0 * (2 * B * Lq * H * dh + 2 * B * Lk * H * dh)
+        out[name] = {"us": round(us, 2), "mfma_frac": round(flop / (us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "hbm_frac": round(byt / (us * 1e-6) / 8e12, 4), "algorithmic_mb": round(byt / 1e6, 1)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -230,6 +360,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the decode / contrastive / attention-core figures (rank 0, N = 1)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("VM_TRAIN_GRAPH", "0")),
                     help="1: replay the whole step from one captured HIP graph (vilmedic_amd.graph); 0: eager launches")
     args = ap.parse_args()
@@ -237,12 +368,17 @@ def main():
         cpu_baseline_child()
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))        # `python bench.py --gpus N` alone: start the N ranks ourselves
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus})")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but this node exposes {torch.cuda.device_count()} device(s); "
+                         "RCCL needs one distinct GPU per rank")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from vilmedic_amd import ops
@@ -348,6 +484,24 @@ def main():
             L_.vm_prof_reset()
         barrier()
 
+    rccl = None
+    if ddp is not None:
+        ar_ms = allreduce_alone_ms(ddp, barrier)
+        names = [None] * world
+        dist.all_gather_object(names, f"rank {rank}: cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}")
+        rccl = {"rccl_ranks": world, "devices": names, "backend": dist.get_backend(), "all_reduce_ms_per_step": round(ar_ms, 3),
+                "all_reduce_note": "whole-arena gradient exchange ALONE (casts + 4 pipelined all-reduces + casts back); inside the timed steps "
+                                   "all but the front encoder bucket overlaps the backward pass",
+                "wire_dtype": "bf16" if ddp.bf16_wire else "fp32", "wire_bytes_per_step": int(opt.arena.numel * (2 if ddp.bf16_wire else 4)),
+                "encoder_buckets_started_from_backward_marks": ddp.mark_starts}
+
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        try:
+            secondary = secondary_metrics(model, device)
+        except Exception as e:      # the headline line must survive a failing side measurement; the failure is reported, not hidden
+            secondary = {"error": f"{type(e).__name__}: {e}"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -366,8 +520,10 @@ def main():
             "model_tflops_per_s": round(step_flops * args.steps / elapsed / 1e12 * world, 1),
             "launch_mode": "hip-graph replay" if (args.graph and ddp is None) else "eager",
             "final_loss": round(final_loss, 4),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,
         }
+        if rccl is not None:
+            line.update(rccl)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

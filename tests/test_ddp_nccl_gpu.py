@@ -94,3 +94,132 @@ def test_bf16_wire_error_on_the_c2_model(nccl):
     err, worst = _rel(got, ref), ((got - ref).abs().max() / ref.abs().max()).item()
     print(f"[parity] bf16 gradient wire on the C2 model ({got.numel() / 1e6:.1f} M parameters): rel L2 {err:.3e}, max abs / max |g| {worst:.3e}", flush=True)
     assert err <= 4e-3 and worst <= 4e-3           # one round-to-nearest bf16: 2^-9 = 1.95e-3 relative per element
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# VM_FORCE_DDP=1 makes a ONE-rank group take every collective path (vilmedic_amd/parallel.py: active / force_collectives), so the RCCL
+# calls of the training loop, of the contrastive-negatives all-gather and of the GLoRIA gather execute on the GPU box's communicator.
+# With one rank every collective is the identity, so the results must equal the run without a process group.
+def _tiny_trainor(tmp_path, tag, extra=()):
+    from vilmedic_amd.config import executor_view, get_config
+    from vilmedic_amd.executors import Trainor
+    os.makedirs(tmp_path / tag, exist_ok=True)
+    cfg = get_config(os.path.join(os.path.dirname(__file__), "..", "config", "RRG", "rrg-vit-synthetic.yml"),
+                     ["dataset.num_samples=16", "dataset.image_size=32", "dataset.vocab_size=97", "dataset.tokenizer_max_len=16",
+                      "model.decoder.hidden_size=128", "model.decoder.num_attention_heads=2", "model.decoder.intermediate_size=256",
+                      "model.decoder.num_hidden_layers=2", "model.decoder.max_position_embeddings=64",
+                      "model.cnn.image_size=32", "model.cnn.patch_size=8", "model.cnn.hidden_size=128", "model.cnn.num_attention_heads=2",
+                      "model.cnn.intermediate_size=256", "model.cnn.num_hidden_layers=2",
+                      "trainor.batch_size=4", "trainor.epochs=1", "trainor.eval_start=0", "validator.batch_size=4", "validator.beam_width=2",
+                      f"ckpt_dir={tmp_path / tag}", "trainor.optim_params.lr=0.003"] + list(extra))
+    t = executor_view(cfg, "trainor")
+    t["validator_view"] = executor_view(cfg, "validator")
+    tr = Trainor(t, seed=0)
+    losses, fwd = [], tr.model.forward
+
+    def recording(**batch):
+        out = fwd(**batch)
+        if "loss" in out and tr.model.training:
+            losses.append(out["loss"].detach().float().reshape(()).clone())
+        return out
+    tr.model.forward = recording
+    tr.start()
+    torch.cuda.synchronize()
+    from vilmedic_amd.arena import arena_of
+    return tr, torch.stack(losses).cpu(), arena_of(tr.model).flat.clone(), tr.evaluator.scores
+
+
+@pytest.mark.parametrize("wire", ["fp32", "bf16"])
+def test_trainor_start_on_rccl_equals_single_process(nccl, tmp_path, monkeypatch, wire):
+    """ref: trainor_accelerate.py:91-93,111-156.  Trainor.start() (two epochs of 4 iterations, validation with beam search, checkpoint)
+    once without a process group and once with VM_FORCE_DDP on the 1-rank RCCL group: ArenaDDP's two-phase backward, the collective
+    NaN flag (MIN all-reduce), mean_over_ranks and gather_interleaved of the validator all run on the communicator.  fp32 wire: the
+    loss trajectory and the final parameters agree to 1e-5; bf16 wire: one rounding of each gradient per step."""
+    monkeypatch.delenv("VM_FORCE_DDP", raising=False)
+    tr0, l0, p0, s0 = _tiny_trainor(tmp_path, "plain")
+    assert tr0.ddp is None
+    monkeypatch.setenv("VM_FORCE_DDP", "1")
+    tr1, l1, p1, s1 = _tiny_trainor(tmp_path, "ddp_" + wire, [f"trainor.ddp_wire={wire}"])
+    assert tr1.ddp is not None and tr1.dist is nccl and tr1.ddp.bf16_wire == (wire == "bf16")
+    assert tr1.ddp.split_at is not None and tr1.ddp.mark_starts >= 1
+    assert l0.numel() == l1.numel() == 8
+    err_l, err_p = (l1 - l0).abs().max().item(), _rel(p1, p0)
+    print(f"[parity] Trainor.start() on 1-rank RCCL, wire={wire}: max |loss_t - loss_t(single)| {err_l:.3e}, rel L2 of the final parameters {err_p:.3e}; "
+          f"validation {s1[0]} vs {s0[0]}", flush=True)
+    if wire == "fp32":          # (not bit-for-bit: the loss is a float atomicAdd over rows, and the two-phase backward regroups the flushes)
+        assert err_l <= 1e-5 and err_p <= 1e-5
+        assert abs(s1[0]["validation_loss"] - s0[0]["validation_loss"]) <= 1e-4 and s1[0]["n_hyps"] == s0[0]["n_hyps"]
+    else:
+        assert err_l <= 5e-2 and err_p <= 2e-2
+    assert len([f for f in os.listdir(tmp_path / ("ddp_" + wire)) if f.endswith(".pth")]) == 1
+
+
+def test_convirt_forward_all_gathers_negatives_on_rccl(nccl, monkeypatch):
+    """ConVIRT.forward in training mode with the contrastive-negatives exchange (parallel.all_gather_with_grad: all_gather forward,
+    all-reduce + own slice backward; ref: SURVEY §8e row 2) on the 1-rank RCCL group == the same forward without a group."""
+    from vilmedic_amd.models import ConVIRT
+    from vilmedic_amd import parallel
+    TXT = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=211, max_position_embeddings=40,
+               layer_norm_eps=1e-5, bos_token_id=0, pad_token_id=1, eos_token_id=2)
+    RESNET = dict(num_channels=3, embedding_size=16, hidden_sizes=[16, 32], depths=[1, 1], layer_type="basic", hidden_act="relu")
+    torch.manual_seed(7)
+    model = ConVIRT(encoder=dict(proto=None, add_pooling_layer=True, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **TXT),
+                    cnn=dict(proto="VisualEncoder", backbone="hfresnet", permute="batch_first", dropout_out=0.0, **RESNET),
+                    projection=dict(visual_embedding_dim=32, textual_embedding_dim=128, projection_dim=64),
+                    loss=dict(proto="ConVIRTLoss", tau=0.1, lambda_=0.75), forward_batch_size=8).to(dev())
+    images = R.make_images(8, 8, seed=3).to(dev())
+    ids, am = R.make_reports(8, 16, TXT["vocab_size"], seed=3)
+    ids, am = ids.to(dev()), am.to(dev())
+    model.train()
+    calls = {"n": 0}
+    real = parallel._AllGather.forward
+
+    def counting(ctx, x, dist):
+        calls["n"] += 1
+        return real(ctx, x, dist)
+    monkeypatch.setattr(parallel._AllGather, "forward", staticmethod(counting))
+    res = []
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("VM_FORCE_DDP", "1")
+        else:
+            monkeypatch.delenv("VM_FORCE_DDP", raising=False)
+        for p in model.parameters():
+            p.grad = None
+        from vilmedic_amd.arena import arena_of
+        arena_of(model).zero_grad()
+        out = model(input_ids=ids, attention_mask=am, images=images)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        res.append((out["loss"].item(), out["loss_l"].float().clone(), arena_of(model).gflat.clone()))
+    assert calls["n"] == 2, calls                      # linguistic + visual embeddings went through the RCCL all-gather exactly once
+    (la, ra, ga), (lb, rb, gb) = res
+    print(f"[parity] ConVIRT all-gather on 1-rank RCCL: loss {lb:.6f} vs {la:.6f}, gradient rel L2 {_rel(gb, ga):.3e}", flush=True)
+    assert abs(la - lb) <= 1e-6 and (ra - rb).abs().max().item() <= 1e-6 and _rel(gb, ga) <= 1e-5
+
+
+def test_gloria_loss_gathers_local_features_on_rccl(nccl, monkeypatch):
+    """GLoRIALoss under (forced) data parallelism: global embeddings, the [b, D, h, w] region features, the word embeddings and the word
+    lists are gathered -- and with gather_local=False only the two global embeddings.  One rank: all three equal."""
+    from vilmedic_amd.blocks.losses import GLoRIALoss
+    B, D, T, hw = 6, 32, 9, 5
+    gen = torch.Generator().manual_seed(5)
+    base = [torch.randn(B, D, generator=gen), torch.randn(B, D, hw, hw, generator=gen), torch.randn(B, D, T, generator=gen),
+            torch.randn(B, D, generator=gen)]
+    lens = [3, 8, 5, 2, 7, 4]
+    sents = [["[CLS]"] + ["w"] * (n - 1) + ["[SEP]"] + ["[PAD]"] * (T - n - 1) for n in lens]
+    res = []
+    for force, gather_local in ((False, True), (True, True), (True, False)):
+        if force:
+            monkeypatch.setenv("VM_FORCE_DDP", "1")
+        else:
+            monkeypatch.delenv("VM_FORCE_DDP", raising=False)
+        xs = [t.clone().to(dev()).requires_grad_(True) for t in base]
+        loss, attn = GLoRIALoss(1.0, 1.0, 4.0, 5.0, 10.0, gather_local=gather_local)(xs[0], xs[1], xs[2], xs[3], sents)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((loss.item(), [x.grad.clone() for x in xs], attn[0].clone()))
+    for k in (1, 2):
+        assert abs(res[k][0] - res[0][0]) <= 1e-6, (res[k][0], res[0][0])
+        assert all(_rel(a, b) <= 1e-5 for a, b in zip(res[k][1], res[0][1])) and _rel(res[k][2], res[0][2]) <= 1e-6
+    print(f"[parity] GLoRIALoss gathers on 1-rank RCCL: loss {res[1][0]:.6f} == {res[0][0]:.6f} (local features gathered / global only)", flush=True)

@@ -92,9 +92,9 @@ def _maybe_gather(*xs):
     """global negatives under data parallelism -- in TRAINING only: validation shards may differ by one batch between ranks, and a
     collective inside the loss would then wait forever; under no_grad the loss contrasts within the local shard (what the reference
     does under DDP)"""
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and torch.is_grad_enabled():
-        from ...parallel import all_gather_with_grad
+    from ...parallel import active, all_gather_with_grad
+    dist = active()
+    if dist is not None and torch.is_grad_enabled():
         n = xs[0].shape[0]
         r = dist.get_rank()
         return [all_gather_with_grad(x.contiguous(), dist) for x in xs], slice(r * n, (r + 1) * n), dist.get_world_size()
@@ -348,22 +348,44 @@ class _GloriaLocalFn(torch.autograd.Function):
 
 
 class GLoRIALoss(nn.Module):
-    def __init__(self, local_loss_weight=1.0, global_loss_weight=1.0, temp1=4.0, temp2=5.0, temp3=10.0):
+    # fp32 working set of the local loss is ~6 matrices of [B*Tp, B*Pp]: beyond this budget the local part falls back to the rank's shard
+    LOCAL_GATHER_BYTES = 48 << 30
+
+    def __init__(self, local_loss_weight=1.0, global_loss_weight=1.0, temp1=4.0, temp2=5.0, temp3=10.0, gather_local=True):
+        """``gather_local`` (data parallel training only): True = every caption is contrasted with the region features of the GLOBAL
+        batch while that fits ``LOCAL_GATHER_BYTES``; False = the local loss contrasts within the rank's shard --
+        what the reference computes under DDP (ref:vilmedic/blocks/losses/selfsup/GLoRIALoss.py:78-129 sees the local batch only) --
+        and only the two global embeddings are gathered."""
         super().__init__()
         self.local_loss_weight, self.global_loss_weight = local_loss_weight, global_loss_weight
         self.temp1, self.temp2, self.temp3 = temp1, temp2, temp3
+        self.gather_local = gather_local
+
+    def _gather_local_fits(self, local_features, word_embeddings):
+        from ...parallel import active
+        dist = active()
+        if dist is None or not torch.is_grad_enabled():
+            return True
+        Bg = local_features.shape[0] * dist.get_world_size()
+        Pp = _pad8(local_features.shape[2] * local_features.shape[3])
+        Tp = _pad8(word_embeddings.shape[2])
+        return 6 * 4 * (Bg * Tp) * (Bg * Pp) <= self.LOCAL_GATHER_BYTES
 
     def forward(self, global_features, local_features, word_embeddings, sent_embeddings, sents):
         # data parallel training: every caption is contrasted with the images of the GLOBAL batch (and vice versa), so the local
         # feature maps [b, D, 19, 19], the word embeddings [b, D, T] and both global embeddings are all-gathered (RCCL; backward =
         # sum over ranks + own slice) together with the word lists -- SURVEY §8e "GLoRIA local loss"
-        (global_features, local_features, word_embeddings, sent_embeddings), _, world = _maybe_gather(
-            global_features, local_features, word_embeddings, sent_embeddings)
-        if world > 1:
-            import torch.distributed as dist
-            parts = [None] * world
-            dist.all_gather_object(parts, list(sents))
-            sents = [s_ for p_ in parts for s_ in p_]
+        if self.gather_local and self._gather_local_fits(local_features, word_embeddings):
+            (global_features, local_features, word_embeddings, sent_embeddings), _, world = _maybe_gather(
+                global_features, local_features, word_embeddings, sent_embeddings)
+            from ...parallel import active
+            if active() is not None and torch.is_grad_enabled():
+                import torch.distributed as dist
+                parts = [None] * world
+                dist.all_gather_object(parts, list(sents))
+                sents = [s_ for p_ in parts for s_ in p_]
+        else:                    # local loss on the rank's shard (the reference's DDP behaviour); global loss over the gathered embeddings
+            (global_features, sent_embeddings), _, world = _maybe_gather(global_features, sent_embeddings)
         cap_lens = [len([w for w in sent if not w.startswith("[")]) + 1 for sent in sents]
         l0, l1, attn_maps = self._local(local_features.float(), word_embeddings.float(), cap_lens)
         # global: cosine-sim [B,B] * temp3 -> CE both ways == the HIP similarity loss with inv_tau = temp3 (mean over rows)

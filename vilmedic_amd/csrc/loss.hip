@@ -82,9 +82,11 @@ struct CeRow {
 };
 
 template <bool RESIDENT>
-__global__ __launch_bounds__(256) void ce_shift_kernel(const bf16_t* __restrict__ logits, int64_t ldl, const int64_t* __restrict__ ids,
+// logits and dlogits may be the SAME buffer (the training path lets the gradient overwrite the logits), so neither is __restrict__ and
+// every value the row statistics need -- including the label's logit -- is read before the first barrier, i.e. before any wave can store.
+__global__ __launch_bounds__(256) void ce_shift_kernel(const bf16_t* logits, int64_t ldl, const int64_t* __restrict__ ids,
                                                        int L, int V, float* __restrict__ loss_sum, float* __restrict__ row_logp,
-                                                       bf16_t* __restrict__ dlogits, float grad_scale,
+                                                       bf16_t* dlogits, float grad_scale,
                                                        const float* __restrict__ row_weight, CeBanned ban,
                                                        const float* __restrict__ row_min_logit) {
     __shared__ float sh[4];
@@ -102,6 +104,11 @@ __global__ __launch_bounds__(256) void ce_shift_kernel(const bf16_t* __restrict_
     CeRow R;
     R.V = V; R.ban = ban; R.thr = row_min_logit ? row_min_logit[row] : -INFINITY;
     R.plain_row = ban.n == 0 && !row_min_logit;
+    // the label's logit, read by every thread from the row BEFORE the block reductions: their barriers order this load ahead of every
+    // gradient store of the (possibly aliased) row.  A banned or thresholded-out label contributes lab = 0 like the per-element form did
+    // (reference: its log-probability is -inf there and SCST never scores such a token)
+    const float labv = bf16_to_f32(lrow[label]);
+    const float lab = R.live(label, labv) ? labv : 0.f;
     uint4 raw[RESIDENT ? CE_NCH : 1];
     float mx = -INFINITY;
     if (RESIDENT) {
@@ -132,11 +139,6 @@ __global__ __launch_bounds__(256) void ce_shift_kernel(const bf16_t* __restrict_
         for (int ch = threadIdx.x; ch < nch; ch += 256) se = R.chunk_sumexp(*reinterpret_cast<const uint4*>(lrow + ch * 8), ch, nm, se);
     }
     se = block_reduce_sum(se, sh);
-    // the label's logit, read by every thread from the row (one 2-byte load that hits the cache the row just came through); a banned or
-    // thresholded-out label contributes lab = 0 like the per-element form did (reference: its log-probability is -inf there and SCST
-    // never scores such a token)
-    const float labv = bf16_to_f32(lrow[label]);
-    const float lab = R.live(label, labv) ? labv : 0.f;
     const float lse = mx + __logf(se);
     if (threadIdx.x == 0) {
         atomicAdd(loss_sum, w * (lse - lab));
@@ -187,7 +189,7 @@ __device__ __forceinline__ uint32_t bf16_order_key(bf16_t h) { return (h & 0x800
 __global__ __launch_bounds__(256) void topk_threshold_kernel(const bf16_t* __restrict__ logits, int64_t ldl, int V, int k, CeBanned ban,
                                                              float* __restrict__ thr) {
     __shared__ uint32_t hist[256];
-    __shared__ int sel[2];       // selected bin, remaining rank inside it
+    __shared__ int sel[3];       // selected bin, remaining rank inside it, 1 = the row has fewer than k live columns
     const int row = blockIdx.x;
     const bf16_t* lrow = logits + (int64_t)row * ldl;
     auto live = [&](int c) { return c < V && !(ban.n > 0 && (c == ban.col[0] || (ban.n > 1 && c == ban.col[1]) || (ban.n > 2 && c == ban.col[2]) || (ban.n > 3 && c == ban.col[3]))); };
@@ -213,14 +215,15 @@ __global__ __launch_bounds__(256) void topk_threshold_kernel(const bf16_t* __res
         if (threadIdx.x == 0) {
             int acc = 0, b = 255;
             for (; b > 0; --b) { if (acc + (int)hist[b] >= want) break; acc += (int)hist[b]; }
-            sel[0] = b; sel[1] = want - acc;       // (fewer than k live columns: b = 0, the smallest key -> everything is kept)
+            sel[0] = b; sel[1] = want - acc;
+            if (pass == 0) sel[2] = (acc + (int)hist[0] < want) ? 1 : 0;     // fewer than k live columns: keep everything (HF clamps top_k to the row)
         }
         __syncthreads();
         if (pass == 0) want = sel[1];
         else if (threadIdx.x == 0) {
             const uint32_t key = (hi_sel << 8) | (uint32_t)sel[0];
             const bf16_t h = (key & 0x8000u) ? (bf16_t)(key & 0x7fffu) : (bf16_t)(~key & 0xffffu);
-            thr[row] = bf16_to_f32(h);
+            thr[row] = sel[2] ? -INFINITY : bf16_to_f32(h);
         }
         __syncthreads();
     }

@@ -49,15 +49,19 @@ class Trainor(object):
         # The RCCL communicator is created AFTER the model, its arena and the optimizer state exist: device memory allocated
         # after init_process_group was measurably slower on this stack (measured in round 1: +5.6 ms per RRG step).
         self.ddp = None
-        if self.world > 1:
+        from ..parallel import force_collectives
+        if self.world > 1 or force_collectives():       # (VM_FORCE_DDP: the RCCL path with a 1-rank group, tests/test_ddp_nccl_gpu.py)
             import torch.distributed as dist
             from ..arena import arena_of
             from ..parallel import ArenaDDP
             wire = torch.empty(arena_of(self.model).numel, dtype=torch.bfloat16, device=torch.device("cuda", self.local_rank))
             if not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29534")
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local_rank))
             self.dist = dist
-            self.ddp = ArenaDDP(self.model, self.dist, wire=wire)
+            # trainor.ddp_wire: "bf16" (default: half the bytes over xGMI, one rounding per gradient) or "fp32" (exact mean)
+            self.ddp = ArenaDDP(self.model, self.dist, wire=wire, bf16_wire=str(config.get("ddp_wire") or "bf16") != "fp32")
         self.training_scheduler = create_training_scheduler(config, self.optimizer, self.logger, state_dict=self.state)
         self.saver = CheckpointSaver(self.ckpt_dir, self.logger, seed, ckpt=config.get("ckpt"))
         self.grad_accu = int(config.get("grad_accu") or 1)
@@ -98,7 +102,7 @@ class Trainor(object):
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
         self.optimizer.step()
         self._zero_grad()
-        self.training_scheduler.iteration_step()
+        self.training_scheduler.iteration_step(epoch + float(iteration) / max(len(self.dl), 1))      # frac_epoch, trainor.py:125-126,152-153
 
     def start(self):
         cfg = self.config

@@ -193,13 +193,18 @@ class TrainingScheduler(object):
             self.lr_decay_params = {}
             self.scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lambda _: 1.0)
 
-    def iteration_step(self):
+    def iteration_step(self, epoch_value=None):
+        """``epoch_value`` = epoch + iteration / len(dl): iteration-stepped schedulers are stepped with the fractional epoch, so e.g.
+        CosineAnnealingWarmRestarts counts T_0 in epochs (ref:vilmedic/executors/utils.py:404-424, trainor.py:125-126)"""
         self.iteration_count += 1
         if self.warmup_steps and self.iteration_count <= self.warmup_steps:
             for g in self.optimizer.param_groups:
                 g["lr"] = self.base_lr * self.iteration_count / float(self.warmup_steps)
         elif self.scheduler_name in self.ITER_STEP:
-            self.scheduler.step()
+            if epoch_value is not None and self.scheduler_name == "CosineAnnealingWarmRestarts":
+                self.scheduler.step(epoch_value)          # (CyclicLR / OneCycleLR count calls; their step() ignores-or-rejects an epoch)
+            else:
+                self.scheduler.step()
 
     def epoch_step(self):
         self.epoch += 1

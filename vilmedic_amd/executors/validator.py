@@ -16,8 +16,8 @@ class Validator(object):
         self.world, self.rank = world, rank
 
     def _dist(self):
-        import torch.distributed as dist
-        return dist if (self.world > 1 and dist.is_available() and dist.is_initialized()) else None
+        from ..parallel import active
+        return active()
 
     def start(self):
         models = [m.eval() for m in self.models]

@@ -858,7 +858,7 @@ class LmHeadLossFn(Fn):
         ban = (C.c_int32 * 4)(*(list(banned) + [0] * (4 - len(banned)))) if banned else None
         if top_k:                     # per-row k-th largest live logit: exact radix select on the bf16 logits (no fp32 copy, no sort)
             thr = torch.empty(B * L, dtype=torch.float32, device=h.device)
-            check(lib().vm_topk_threshold_bf16(ptr(logits), Vp, B * L, V, min(int(top_k), V), ban, len(banned) if banned else 0, ptr(thr),
+            check(lib().vm_topk_threshold_bf16(ptr(logits), Vp, B * L, V, max(1, min(int(top_k), V - (len(banned) if banned else 0))), ban, len(banned) if banned else 0, ptr(thr),
                                                stream()), "vm_topk_threshold_bf16")
         check(lib().vm_ce_shift_fwd_bwd(ptr(logits), Vp, ptr(ids), B, L, V, ptr(loss_sum), ptr(row_logp),
                                         ptr(dlogits) if dlogits is not None else None, inv,

@@ -61,6 +61,9 @@ class FusedAdam(torch.optim.Optimizer):
 
     def state_dict(self):
         groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
+        # the step count that the bias corrections use is the DEVICE counter: gated (NaN / Inf) steps and skipped graph replays do not
+        # advance it, while the host-side ``steps`` counts calls.  One host read at checkpoint time.
+        self.steps = int(self.step_dev.item())
         return {"m": self.m, "v": self.v, "steps": self.steps, "param_groups": groups}      # (step_dev / lr_dev are rebuilt from these)
 
     def load_state_dict(self, sd):

@@ -9,7 +9,24 @@ Because all gradients live in one flat fp32 buffer, the exchange is a handful of
 per-link bound: fewer, bigger messages) instead of DDP's 25 MB buckets; optionally compressed to bf16 on the wire
 (446 MB instead of 892 MB at the RRG ViT-B + 12-layer-decoder size).
 """
+import os
+
 import torch
+
+
+def force_collectives():
+    """VM_FORCE_DDP=1: take every collective path even with a ONE-rank group, so that a single-GPU box executes the RCCL calls
+    (tests/test_ddp_nccl_gpu.py, bench.py).  Production runs never set it: a 1-rank group then skips the communication."""
+    return bool(os.environ.get("VM_FORCE_DDP"))
+
+
+def active(dist=None):
+    """the process group to communicate over, or None: initialised AND (more than one rank, or collectives forced)"""
+    if dist is None:
+        import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    return dist if (dist.get_world_size() > 1 or force_collectives()) else None
 
 
 def _avg_allreduce(t, dist, world, async_op=False):
@@ -37,7 +54,7 @@ def allreduce_mean_(flat, dist, chunks=4, wire_dtype=None, to_wire=None, from_wi
     """In-place mean over ranks of a flat tensor, as ``chunks`` pipelined collectives.
     wire_dtype: None (same dtype) or torch.bfloat16 (compress on the wire; to_wire/from_wire do the casts)."""
     world = dist.get_world_size()
-    if world == 1:
+    if world == 1 and not force_collectives():
         return flat
     ranges = chunk_ranges(flat.numel(), chunks)
     if wire_dtype is None:
@@ -57,7 +74,7 @@ def allreduce_mean_(flat, dist, chunks=4, wire_dtype=None, to_wire=None, from_wi
 
 
 def broadcast_(flat, dist, src=0):
-    if dist.get_world_size() > 1:
+    if dist.get_world_size() > 1 or force_collectives():
         dist.broadcast(flat, src=src)
     return flat
 
@@ -246,7 +263,7 @@ def gather_interleaved(items, dist):
     """per-rank lists of a round-robin sharded dataset (rank r holds samples r, r + world, ...) -> the full list in dataset
     order, on every rank"""
     world = dist.get_world_size()
-    if world == 1:
+    if world == 1 and not force_collectives():
         return list(items)
     parts = [None] * world
     dist.all_gather_object(parts, list(items))
@@ -260,7 +277,7 @@ def gather_interleaved(items, dist):
 
 def mean_over_ranks(value, dist, weight=1.0, device=None):
     """weighted mean of a python scalar over ranks (weight = the number of samples it averages), identical on every rank"""
-    if dist.get_world_size() == 1:
+    if dist.get_world_size() == 1 and not force_collectives():
         return float(value)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
