@@ -283,8 +283,11 @@ def secondary_metrics(model, device):
     enc = torch.randn(B, S, 768, device=device, generator=g).bfloat16()
     mask = torch.ones(B, S, dtype=torch.bool, device=device)
     start = torch.zeros(B, 1, dtype=torch.long, device=device)
-    out["decode"] = {"batch": B, "new_tokens": T - 1, "weight_bytes_bf16": 2 * n_dec,
-                     "floor_note": "HBM floor per step = decoder weights read once (2 B/param bf16, 4 B/param fp32) at 8 TB/s"}
+    n_layers, D = len(dec.bert.encoder.layer), 768
+    kv_elems = n_layers * (B * S * 2 * D)            # cross K|V of every layer, read once per step (shared by the beams of a sample)
+    out["decode"] = {"batch": B, "new_tokens": T - 1, "weight_bytes_bf16": 2 * n_dec, "cross_kv_bytes_bf16": 2 * kv_elems,
+                     "floor_note": "HBM floor per step (SURVEY 8d) = decoder weights + tied LM head read once + the cross K|V of all layers + the "
+                                   "self K|V cache at half its final length, 2 B/element bf16 and 4 B/element fp32, at 8 TB/s"}
     for beams, dtype in ((1, "bf16"), (1, "fp32"), (4, "bf16"), (4, "fp32")):
         kw = dict(bos_token_id=0, eos_token_id=2, pad_token_id=1, max_length=T, decode_dtype=dtype)
         if beams > 1:
@@ -298,9 +301,10 @@ def secondary_metrics(model, device):
         dt = time.perf_counter() - t0
         steps = max(1, ids.shape[1] - 1)
         ms_step = dt / steps * 1e3
-        floor_ms = n_dec * (2 if dtype == "bf16" else 4) / 8e12 * 1e3
+        self_elems = n_layers * (B * beams * (T // 2) * 2 * D)
+        floor_ms = (n_dec + kv_elems + self_elems) * (2 if dtype == "bf16" else 4) / 8e12 * 1e3
         out["decode"][f"beams{beams}_{dtype}"] = {"tokens_per_s": round(B * steps / dt, 1), "ms_per_step": round(ms_step, 3),
-                                                   "hbm_frac": round(floor_ms / ms_step, 4)}
+                                                   "floor_ms": round(floor_ms, 4), "hbm_frac": round(floor_ms / ms_step, 4)}
     model.train(was_training)
 
     # ---- contrastive similarity loss, C3 size (forward + backward)

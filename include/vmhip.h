@@ -199,23 +199,31 @@ int vm_topk_threshold_bf16(const void* logits, int64_t ldl, int rows, int V, int
 int vm_ce_smooth_fwd_bwd(const float* logits, const int64_t* target, int R, int C, float smoothing,
                          float* loss_sum, float* dlogits, float grad_scale, void* stream);
 
-/* Image-text contrastive similarity (ref:vilmedic/blocks/losses/selfsup/ConVIRTLoss.py:12-31, InfoNCELoss.py:11-19,
- * GLoRIALoss.py:54-75).  S[R,C] = a_hat b_hat^T / tau is one vm_gemm_bf16 call (fp32 out, alpha = 1/tau); these are
- * the pieces around it.  Row i pairs with column i + diag_offset (local rows of a rank vs all gathered columns). */
+/* Image-text contrastive similarity losses (ref:vilmedic/blocks/losses/selfsup/ConVIRTLoss.py:12-31, InfoNCELoss.py:11-19,
+ * GLoRIALoss.py:54-75): with S[R,C] = n(a) n(b)^T * inv_tau (n = x / max(|x|, eps) when ``normalize``, identity otherwise) and row i
+ * paired with column i + diag_offset (the local rows of a rank against all gathered columns):
+ *     loss_rows[i] = log sum_j exp(S_ij) - S_{i,i+off}      loss_cols[j] = log sum_i exp(S_ij) - S_{j-off,j}
+ * (the paired term is dropped for a row / column without a partner).  S never reaches HBM.
+ * vm_contrastive_loss_fwd: TWO launches -- normalise + cast both matrices (a_hat [R,D], b_hat [C,D] bf16, the norms), then one workgroup
+ *   per 128 x 128 tile of S on the MFMA; the workgroup that arrives last merges the per-tile (max, sum exp) partials into lse_rows /
+ *   lse_cols and writes the losses.
+ * vm_contrastive_loss_bwd: ONE persistent launch pulling from a device work queue -- G tiles
+ *   G_ij = g_rows[i] softmax_row(S)_ij + g_cols[j] softmax_col(S)_ij - [j == i+off](g_rows[i] + g_cols[j])  (bf16, in ``ws``), then
+ *   64 x 96 tiles of da = d/da (sum_i g_rows[i] loss_rows[i] + sum_j g_cols[j] loss_cols[j]) and db likewise (fp32 [R,D] / [C,D]), the
+ *   L2-normalisation backward applied in the GEMM epilogue.  ``ws``: vm_contrastive_ws(R, C) bytes, 256-B aligned, the SAME buffer in both
+ *   calls is not required (the backward recomputes S); word 2 of ``ws`` is non-zero after a backward whose bounded waits expired.
+ * vm_rownorm_cast: the normalise + cast of one matrix on its own (GLoRIA's global embeddings share it). */
 int vm_rownorm_cast(const float* x /* [rows,D] */, void* out_bf16, float* norms /* [rows] or NULL */, int rows, int D,
                     int normalize /* 1: x/max(|x|,eps) (ConVIRT cosine)  0: plain cast (InfoNCE) */, float eps, void* stream);
-/* The similarity matrix never reaches HBM: a_hat [R,D], b_hat [C,D] bf16 = the outputs of vm_rownorm_cast.
- * vm_contrastive_fwd: lse_rows[i] = log sum_j exp(S_ij), lse_cols[j] = log sum_i exp(S_ij), diag[i] = S_{i, i+diag_offset} with
- *   S = a_hat b_hat^T * inv_tau computed tile by tile on the MFMA and reduced in LDS (ws: vm_contrastive_ws(R, C) bytes of partials).
- * vm_contrastive_bwd: G[i,j] = g_rows[i] softmax_row(S)[i,j] + g_cols[j] softmax_col(S)[i,j] - [j == i+diag_offset] (g_rows[i] + g_cols[j])
- *   (bf16 [R, ldg]) from recomputed tiles.  dA_hat = G b_hat * inv_tau and
- *   dB_hat = G^T a_hat * inv_tau are two vm_gemm_bf16 calls on G. */
 size_t vm_contrastive_ws(int R, int C);
-int vm_contrastive_fwd(const void* a_hat, const void* b_hat, int R, int C, int D, float inv_tau, int diag_offset,
-                       float* lse_rows, float* lse_cols, float* diag /* [R] or NULL */, void* ws, size_t ws_bytes, void* stream);
-int vm_contrastive_bwd(const void* a_hat, const void* b_hat, int R, int C, int D, float inv_tau, int diag_offset,
-                       const float* lse_rows, const float* lse_cols, const float* g_rows, const float* g_cols,
-                       void* G_bf16, int64_t ldg, void* stream);
+int vm_contrastive_loss_fwd(const float* a /* [R,D] */, const float* b /* [C,D] */, int R, int C, int D, int normalize, float eps,
+                            float inv_tau, int diag_offset, void* a_hat_bf16, void* b_hat_bf16, float* norm_a, float* norm_b,
+                            float* lse_rows, float* lse_cols, float* loss_rows /* [R] */, float* loss_cols /* [C] */,
+                            void* ws, size_t ws_bytes, void* stream);
+int vm_contrastive_loss_bwd(const float* a, const float* b, const void* a_hat_bf16, const void* b_hat_bf16, const float* norm_a,
+                            const float* norm_b, int R, int C, int D, int normalize, float eps, float inv_tau, int diag_offset,
+                            const float* lse_rows, const float* lse_cols, const float* g_rows /* [R] */, const float* g_cols /* [C] */,
+                            float* da /* [R,D] */, float* db /* [C,D] */, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ GLoRIA local (word x image-region) loss
  * ref:vilmedic/blocks/losses/selfsup/GLoRIALoss.py:14-51 (gloria_attention_fn), :78-129 (local_loss): every (caption i, image j) pair of

@@ -353,3 +353,53 @@ def test_contrastive_losses_global_batch_2048(kind):
     assert r["loss_err"] <= 2e-3 * max(1.0, abs(r["loss"]))
     assert r["rows_err"] <= 5e-2
     assert r["grad_cos"] >= 0.999 and r["grad_rel"] <= 3e-2
+
+
+def _sim_ref(a, b, normalize, inv_tau, off):
+    """fp32 reference of _SimilarityLossFn: row / column losses of the pairs (i, i + off) that exist"""
+    ah = a / a.norm(dim=1, keepdim=True).clamp_min(1e-8) if normalize else a
+    bh = b / b.norm(dim=1, keepdim=True).clamp_min(1e-8) if normalize else b
+    S = ah @ bh.t() * inv_tau
+    lo, hi = max(0, -off), min(a.shape[0], b.shape[0] - off)
+    idx = torch.arange(lo, hi)
+    d = S[idx, idx + off]
+    return torch.logsumexp(S, 1)[lo:hi] - d, torch.logsumexp(S, 0)[lo + off:hi + off] - d
+
+
+@pytest.mark.parametrize("R,C,D,off,normalize", [(2048, 2048, 768, 0, True), (256, 2048, 768, 512, True), (300, 1000, 96, 37, True),
+                                                  (77, 50, 40, -5, False), (1000, 300, 264, 0, True)])
+def test_similarity_loss_kernels_rectangular_ragged_offset(R, C, D, off, normalize):
+    """csrc/contrastive.hip through _SimilarityLossFn: square (BASELINE configs[2]), a rank's row block of the global similarity
+    (256 local rows against 2048 gathered columns, paired column = row + 512), ragged tile edges in every dimension, a negative offset,
+    no normalisation; both outputs weighted by random upstream gradients.  Also: the backward's bounded waits never expired."""
+    from vilmedic_amd.blocks.losses.selfsup import _SimilarityLossFn
+    g = torch.Generator().manual_seed(R + C + D)
+    sc = 1.0 if normalize else 0.15
+    a, b = torch.randn(R, D, generator=g) * sc, torch.randn(C, D, generator=g) * sc
+    lo, hi = max(0, -off), min(R, C - off)
+    b[lo + off:hi + off] += 0.7 * a[lo:hi]                       # the pairs are positively correlated
+    wr, wc = torch.rand(hi - lo, generator=g), torch.rand(hi - lo, generator=g)
+    inv_tau = 10.0 if normalize else 1.0
+    ad, bd = a.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+    lr, lc = _SimilarityLossFn.apply(ad, bd, normalize, inv_tau, 1e-8, off)
+    ((lr * wr.to(dev())).sum() + (lc * wc.to(dev())).sum()).backward()
+    torch.cuda.synchronize()
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rr, rc = _sim_ref(ar, br, normalize, inv_tau, off)
+    ((rr * wr).sum() + (rc * wc).sum()).backward()
+    res = dict(rows_err=max((lr.cpu() - rr.detach()).abs().max().item(), (lc.cpu() - rc.detach()).abs().max().item()), loss_absmax=rr.abs().max().item(),
+               grad_cos=min(cosine(ad.grad.cpu(), ar.grad), cosine(bd.grad.cpu(), br.grad)),
+               grad_rel=max(rel_l2(ad.grad.cpu(), ar.grad), rel_l2(bd.grad.cpu(), br.grad)))
+    report(f"similarity loss R={R} C={C} D={D} off={off} normalize={normalize}", **res)
+    assert lr.shape == rr.shape and lc.shape == rc.shape
+    assert res["rows_err"] <= 5e-2 and res["grad_cos"] >= 0.999 and res["grad_rel"] <= 3e-2
+    # determinism + the backward of a second forward reuses nothing stale: run again, must reproduce bit for bit
+    ad2, bd2 = a.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+    lr2, lc2 = _SimilarityLossFn.apply(ad2, bd2, normalize, inv_tau, 1e-8, off)
+    ws = lr2.grad_fn.saved_tensors[-1]               # the workspace (held here: autograd frees its own reference after backward)
+    ((lr2 * wr.to(dev())).sum() + (lc2 * wc.to(dev())).sum()).backward()
+    torch.cuda.synchronize()
+    assert int(ws[8:12].view(torch.int32).item()) == 0, "a bounded wait of the persistent backward expired"
+    assert torch.equal(lr2, lr) and torch.equal(lc2, lc)
+    gerr = max(rel_l2(ad2.grad, ad.grad), rel_l2(bd2.grad, bd.grad))
+    assert gerr == 0.0, gerr                         # no atomics, no order-dependent reduction anywhere in the three launches

@@ -84,8 +84,8 @@ SIGNATURES = {
     "vm_ce_smooth_fwd_bwd": (_I, [_P, _P, _I, _I, _F, _P, _P, _F, _P]),
     "vm_rownorm_cast": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
     "vm_contrastive_ws": (_SZ, [_I, _I]),
-    "vm_contrastive_fwd": (_I, [_P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P, _SZ, _P]),
-    "vm_contrastive_bwd": (_I, [_P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _L, _P]),
+    "vm_contrastive_loss_fwd": (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "vm_contrastive_loss_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "vm_cast_f32_to_bf16": (_I, [_P, _P, _L, _P]),
     "vm_cast_bf16_to_f32": (_I, [_P, _P, _L, _P]),
     "vm_cast_pad_f32_to_bf16": (_I, [_P, _P, _I, _I, _L, _P]),

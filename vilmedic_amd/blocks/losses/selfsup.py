@@ -4,7 +4,7 @@ ref: vilmedic/blocks/losses/selfsup/ConVIRTLoss.py:5-38, InfoNCELoss.py:5-24, GL
 
 The [B,B] similarity S = n(a) n(b)^T / tau is computed tile by tile on the MFMA and never reaches HBM: row / column
 log-sum-exp and the diagonal in the forward pass, the gradient matrix G from recomputed tiles in the backward pass
-(csrc/contrastive.hip); dA = G B / tau and dB = G^T A / tau are two GEMMs.  When torch.distributed is initialised with world_size > 1 the text / image embeddings are
+(csrc/contrastive.hip); dA = G B / tau and dB = G^T A / tau are tiles of the same persistent backward launch.  When torch.distributed is initialised with world_size > 1 the text / image embeddings are
 all-gathered first (RCCL), so every rank sees the GLOBAL batch of negatives (SURVEY §8e -- a capability the reference
 lacks: under DDP it contrasts within the local shard only, conVIRT.py:97-100).
 """
@@ -22,70 +22,52 @@ def _pad8(n):
 
 
 class _SimilarityLossFn(torch.autograd.Function):
-    """(a [R,D], b [C,D]) -> per-row losses  row_i = lse_j S_ij - S_ii,  col_i = lse_j S_ji - S_ii  with
-    S = n(a) n(b)^T * inv_tau  (n = L2 normalisation when ``normalize``)."""
+    """(a [R,D], b [C,D]) -> per-row losses  row_i = lse_j S_ij - S_{i,i+off},  col_i = lse_j S_{j,i+off} - S_{i,i+off}  with
+    S = n(a) n(b)^T * inv_tau  (n = L2 normalisation when ``normalize``); ``diag_offset`` = off pairs row i with column i + off
+    (a rank's local rows against the gathered columns).  Three kernel launches forward + backward (csrc/contrastive.hip): the
+    [R, C] matrix never reaches HBM and the normalisation backward is the epilogue of the gradient GEMMs."""
 
     @staticmethod
-    def forward(ctx, a, b, normalize, inv_tau, eps):
+    def forward(ctx, a, b, normalize, inv_tau, eps, diag_offset=0):
         R, D = a.shape
         Cn = b.shape[0]
         if D % 8:
             raise ValueError("embedding dim must be a multiple of 8")
         dev = a.device
         a32, b32 = a.detach().float().contiguous(), b.detach().float().contiguous()
-        ah = torch.zeros(_pad8(R), D, dtype=BF16, device=dev)
-        bh = torch.zeros(_pad8(Cn), D, dtype=BF16, device=dev)
-        na = torch.empty(R, dtype=torch.float32, device=dev)
-        nb = torch.empty(Cn, dtype=torch.float32, device=dev)
         L = lib()
-        check(L.vm_rownorm_cast(ptr(a32), ptr(ah), ptr(na), R, D, int(normalize), eps, stream()), "vm_rownorm_cast")
-        check(L.vm_rownorm_cast(ptr(b32), ptr(bh), ptr(nb), Cn, D, int(normalize), eps, stream()), "vm_rownorm_cast")
-        lse_r = torch.empty(R, dtype=torch.float32, device=dev)
-        lse_c = torch.empty(Cn, dtype=torch.float32, device=dev)
-        diag = torch.empty(R, dtype=torch.float32, device=dev)
-        n = min(R, Cn)
-        # S tile by tile on the MFMA, reduced in LDS: the [R, C] matrix never reaches HBM
+        f32 = dict(dtype=torch.float32, device=dev)
+        ah = torch.empty(R, D, dtype=BF16, device=dev)
+        bh = torch.empty(Cn, D, dtype=BF16, device=dev)
+        stats = torch.empty(3 * (R + Cn), **f32)         # norms | log-sum-exps | losses, rows then columns in each third
+        na, nb, lse_r, lse_c, loss_r, loss_c = stats.split([R, Cn, R, Cn, R, Cn])
         ws = torch.empty(L.vm_contrastive_ws(R, Cn), dtype=torch.uint8, device=dev)
-        if n < R:
-            diag.zero_()
-        check(L.vm_contrastive_fwd(ptr(ah), ptr(bh), R, Cn, D, inv_tau, 0, ptr(lse_r), ptr(lse_c), ptr(diag), ptr(ws), ws.numel(), stream()),
-              "vm_contrastive_fwd")
-        ctx.save_for_backward(a32, b32, ah, bh, na, nb, lse_r, lse_c)
-        ctx.meta = (normalize, inv_tau, eps, R, Cn, D)
-        return lse_r[:n] - diag[:n], lse_c[:n] - diag[:n]
+        check(L.vm_contrastive_loss_fwd(ptr(a32), ptr(b32), R, Cn, D, int(normalize), eps, inv_tau, int(diag_offset), ptr(ah), ptr(bh), ptr(na), ptr(nb),
+                                        ptr(lse_r), ptr(lse_c), ptr(loss_r), ptr(loss_c), ptr(ws), ws.numel(), stream()), "vm_contrastive_loss_fwd")
+        ctx.save_for_backward(a32, b32, ah, bh, stats, ws)
+        ctx.meta = (normalize, inv_tau, eps, R, Cn, D, int(diag_offset))
+        # the pairs (i, i + off) that exist: rows lo..hi-1 and the columns they are paired with
+        lo, hi = max(0, -diag_offset), min(R, Cn - diag_offset)
+        ctx.span = (lo, hi)
+        return loss_r[lo:hi], loss_c[lo + diag_offset:hi + diag_offset]
 
     @staticmethod
     def backward(ctx, g_row, g_col):
-        a32, b32, ah, bh, na, nb, lse_r, lse_c = ctx.saved_tensors
-        normalize, inv_tau, eps, R, Cn, D = ctx.meta
+        a32, b32, ah, bh, stats, ws = ctx.saved_tensors
+        normalize, inv_tau, eps, R, Cn, D, off = ctx.meta
+        lo, hi = ctx.span
+        na, nb, lse_r, lse_c, _, _ = stats.split([R, Cn, R, Cn, R, Cn])
         dev = ah.device
-        gr = torch.zeros(R, dtype=torch.float32, device=dev)
-        gc = torch.zeros(Cn, dtype=torch.float32, device=dev)
-        n = min(R, Cn)
-        gr[:n] = g_row.float()
-        gc[:n] = g_col.float()
-        ldg = _pad8(Cn)
-        G = torch.zeros(_pad8(R), ldg, dtype=BF16, device=dev)
-        check(lib().vm_contrastive_bwd(ptr(ah), ptr(bh), R, Cn, D, inv_tau, 0, ptr(lse_r), ptr(lse_c), ptr(gr), ptr(gc), ptr(G), ldg,
-                                       stream()), "vm_contrastive_bwd")          # G from recomputed tiles
-        dah = torch.empty(R, D, dtype=torch.float32, device=dev)
-        dbh = torch.empty(Cn, D, dtype=torch.float32, device=dev)
-        ops.gemm(G, 0, bh, 1, dah, R, D, ldg, alpha=inv_tau)            # dA^ = G B^ / tau      (contraction over columns)
-        ops.gemm(G, 1, ah, 1, dbh, Cn, D, _pad8(R), alpha=inv_tau)      # dB^ = G^T A^ / tau    (contraction over rows)
-        if normalize:
-            da = _normalize_bwd(a32, na, dah, eps)
-            db = _normalize_bwd(b32, nb, dbh, eps)
-        else:
-            da, db = dah, dbh
-        return da, db, None, None, None
-
-
-def _normalize_bwd(x, norms, dxh, eps):
-    """x^ = x / max(|x|, eps):  dx = (dx^ - x^ (x^ . dx^)) / |x|   for |x| > eps, dx^ / eps otherwise."""
-    d = norms.clamp(min=eps)[:, None]
-    xh = x / d
-    proj = (xh * dxh).sum(1, keepdim=True)
-    return torch.where(norms[:, None] > eps, (dxh - xh * proj) / d, dxh / d)
+        g = torch.zeros(R + Cn, dtype=torch.float32, device=dev)
+        if g_row is not None:
+            g[lo:hi] = g_row.float()
+        if g_col is not None:
+            g[R + lo + off:R + hi + off] = g_col.float()
+        d = torch.empty(R + Cn, D, dtype=torch.float32, device=dev)
+        check(lib().vm_contrastive_loss_bwd(ptr(a32), ptr(b32), ptr(ah), ptr(bh), ptr(na), ptr(nb), R, Cn, D, int(normalize), eps, inv_tau, off,
+                                            ptr(lse_r), ptr(lse_c), ptr(g[:R]), ptr(g[R:]), ptr(d[:R]), ptr(d[R:]), ptr(ws), ws.numel(), stream()),
+              "vm_contrastive_loss_bwd")
+        return d[:R], d[R:], None, None, None, None
 
 
 def _maybe_gather(*xs):
@@ -101,6 +83,23 @@ def _maybe_gather(*xs):
     return list(xs), slice(None), 1
 
 
+def _paired_losses(first, second, normalize, inv_tau, eps=1e-8):
+    """per-sample contrastive losses of the LOCAL pairs: (first -> second, second -> first).  Single process / evaluation: one problem on the
+    [B, B] similarity.  Data parallel training: both embedding matrices are all-gathered (RCCL; backward = sum over ranks +
+    own slice) and every rank evaluates only ITS rows of the global similarity -- two [b, B_global] problems whose paired column is
+    rank * b + i -- instead of recomputing the whole [B_global, B_global] matrix on every rank (2 / world of the work).  The mean over the
+    local rows, averaged over ranks by the gradient all-reduce, is the global-batch loss and its exact gradient."""
+    from ...parallel import active, all_gather_with_grad
+    dist = active()
+    if dist is None or not torch.is_grad_enabled():
+        return _SimilarityLossFn.apply(first, second, normalize, inv_tau, eps)
+    off = dist.get_rank() * first.shape[0]
+    fg, sg = all_gather_with_grad(first.contiguous(), dist), all_gather_with_grad(second.contiguous(), dist)
+    lf, _ = _SimilarityLossFn.apply(first, sg, normalize, inv_tau, eps, off)       # rows of S:   first_i  against every second_j
+    ls, _ = _SimilarityLossFn.apply(second, fg, normalize, inv_tau, eps, off)      # rows of S^T: second_i against every first_j
+    return lf, ls
+
+
 class ConVIRTLoss(nn.Module):
     def __init__(self, tau, lambda_, **kwargs):
         super().__init__()
@@ -108,10 +107,9 @@ class ConVIRTLoss(nn.Module):
         self.lambda_ = lambda_
 
     def forward(self, linguistic, visual):
-        (lg, vg), local, world = _maybe_gather(linguistic, visual)
-        loss_l, loss_v = _SimilarityLossFn.apply(lg, vg, True, 1.0 / self.tau, 1e-8)
+        loss_l, loss_v = _paired_losses(linguistic, visual, True, 1.0 / self.tau)
         loss = torch.mean(self.lambda_ * loss_v + (1 - self.lambda_) * loss_l)
-        return loss, loss_l[local], loss_v[local]
+        return loss, loss_l, loss_v
 
     def __repr__(self):
         return "ConVIRTLoss(\n\t(cos_loss): CosineSimilarity()\n\t(tau): {}\n\t(lambda_): {}\n)".format(self.tau, self.lambda_)
@@ -125,10 +123,9 @@ class InfoNCELoss(nn.Module):
         self.tau = tau
 
     def forward(self, linguistic, visual):
-        (lg, vg), local, world = _maybe_gather(linguistic, visual)
-        loss_t, loss_i = _SimilarityLossFn.apply(lg, vg, False, 1.0, 1e-8)
+        loss_t, loss_i = _paired_losses(linguistic, visual, False, 1.0)
         loss = ((loss_i + loss_t) / 2).mean()
-        return loss, loss_t[local], loss_i[local]
+        return loss, loss_t, loss_i
 
     def __repr__(self):
         return "InfoNCELoss(\n\t(tau): {}\n)".format(self.tau)

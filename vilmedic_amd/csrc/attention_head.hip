@@ -2,8 +2,8 @@
 // (every ViT-B/16, BERT-base self- and cross-attention of the RRG hot path).
 //
 // One workgroup = one (batch, head) pair (x a chunk of 256 owner rows).  The "other" sequence of the pair (K,V for
-// forward / dQ; Q,dO for dK,dV) is loaded from HBM exactly ONCE per head -- all loads issued before the first LDS
-// store, one barrier per kernel -- into un-padded 128-B LDS rows, and the 4 waves then loop over 16-row owner groups
+// forward / dQ; Q,dO for dK,dV) is loaded from HBM exactly ONCE per head -- by LDS-DMA, consumed tile by tile as it lands (see the
+// staging helpers below) -- into un-padded 128-B LDS rows, and the 4 waves then loop over 16-row owner groups
 // (13 groups for L = 197: waves get 4/3/3/3).  The math of a group is the transposed flash scheme of attention.hip
 // (S^T = K Q^T, P^T feeds the next MFMA as the B operand, transposed A operands via ds_read_b64_tr_b16).
 //
@@ -13,7 +13,7 @@
 //   * ds_read_b64_tr_b16 fragments: one cycle serves 8 consecutive rows x 32 B (a chunk pair each) -> 16 distinct slots.
 // Per-lane fragment offsets are kernel constants (the swizzle of row 16 F + c does not depend on F), control flow is
 // wave-uniform (fragment counts live in SGPRs), and fragments that need no key mask / causal / ragged-tail handling
-// take a one-multiply-per-score path.  Rows are zero-filled past L.  With L = 197 a workgroup needs ~52 KiB, so THREE
+// take a one-multiply-per-score path.  Rows past L repeat the last valid row.  With L = 197 a workgroup needs ~52 KiB, so THREE
 // workgroups (12 waves) share a CU and the 768 (b,h) pairs of a B=64 x 12-head layer are all resident at once.
 #include "attention_common.h"
 
@@ -21,29 +21,58 @@
 #define HCHUNK 256                                 // owner rows per workgroup
 __device__ __forceinline__ int hswz(int row) { return ((row >> 1) & 3) << 1; }
 
-// rows [0, nalloc) of two [*, ld] matrices (64 columns at the pointer) -> swizzled LDS; rows >= nvalid are zero.
-__device__ __forceinline__ void head_stage2(const bf16_t* a, int64_t lda, const bf16_t* b, int64_t ldb, int nvalid, int nalloc,
-                                            char* sa, char* sb, int tid) {
-    uint4 ra[8], rb[8];
-    const int r0 = tid >> 3, ch = tid & 7;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = r0 + 32 * i;
-        if (32 * i < nalloc) {
-            ra[i] = ld16_or_zero(a + (int64_t)row * lda + ch * 8, a, row < nvalid);
-            rb[i] = ld16_or_zero(b + (int64_t)row * ldb + ch * 8, b, row < nvalid);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = r0 + 32 * i;
-        if (32 * i < nalloc && row < nalloc) {
-            const int off = row * HB + ((ch ^ hswz(row)) << 4);
-            *reinterpret_cast<uint4*>(sa + off) = ra[i];
-            *reinterpret_cast<uint4*>(sb + off) = rb[i];
-        }
+// ---- staging by LDS-DMA, consumed progressively (round 3)
+// Round 2 staged the resident sequence through registers (16 uint4 per thread) and started the math behind ONE barrier: with 768 (b, h)
+// pairs = exactly one round of three workgroups per CU, every workgroup of the chip sat in that load phase at the same time and nothing
+// covered it (25-35 % of a forward launch).  Now each wave requests its share of the rows with global_load_lds_dwordx4 (1 KiB = 8 rows
+// per wave-instruction, no VGPR round trip), TILE-MAJOR -- the K and V (resp. Q and dO) rows of 64-row tile 0 first, then tile 1, ... --
+// and the first owner group of every wave starts on tile 0 as soon as ITS requests have landed (s_waitcnt vmcnt(4 x later full tiles) +
+// s_barrier) while tiles 1.. are still in flight: the load phase overlaps the first group's math instead of preceding it.
+// The swizzle is applied to the DMA SOURCE: lane l writes LDS bytes [16 l, 16 l + 16) of the block, i.e. row l >> 3, slot l & 7, which
+// must hold chunk slot ^ hswz(row).  DMA cannot zero-fill: rows past the valid length re-read the last valid row (finite values that
+// only ever meet P = dS = 0: keys >= Lk score -inf, queries >= Lq carry nm = -inf).
+// The DMA is issued by inline asm (invisible to hipcc's waitcnt pass, see gemm_fast.hip glds16_asm), so every compiler-visible global
+// load that precedes the first MFMA is pinned into registers BEFORE the burst (head_pin) -- otherwise the compiler's own
+// "s_waitcnt vmcnt(0)" in front of their first use would wait for the whole burst.
+__device__ __forceinline__ void hdma16(const bf16_t* src, char* lds_dst) {
+    const uint32_t l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_dst;      // wave-uniform
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(l) : "memory", "m0");
+}
+// 8-row block jb of both matrices is requested by wave jb & 3: per wave and per full 64-row tile exactly 4 requests (a, b, a, b), in tile order
+__device__ __forceinline__ void head_dma2(const bf16_t* a, int64_t lda, const bf16_t* b, int64_t ldb, int nvalid, int nalloc,
+                                          char* sa, char* sb, int wave, int lane) {
+    const int rl = lane >> 3, ch = (lane & 7) ^ hswz(rl);          // hswz(8 jb + rl) = hswz(rl)
+    for (int jb = wave; jb * 8 < nalloc; jb += 4) {
+        const int row = min(jb * 8 + rl, nvalid - 1);
+        hdma16(a + (int64_t)row * lda + ch * 8, sa + jb * 1024);
+        hdma16(b + (int64_t)row * ldb + ch * 8, sb + jb * 1024);
     }
 }
+// the wave's requests for tile kt have landed (and, behind the barrier, every wave's).  ``precise``: nothing but the DMA burst has been
+// issued to vector memory since the pin, so "all but the 4 x (later full tiles) youngest" is exact; afterwards (stores and prefetches may
+// be in flight, and stores are not ordered with loads in the counter) the wait is for everything.
+__device__ __forceinline__ void head_wait_tile(int nfull, int kt, bool precise) {
+    const int later = (precise && kt < nfull) ? nfull - 1 - kt : 0;
+    if (later >= 3) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    else if (later == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// every wave arrives at exactly ``ntiles`` barriers per kernel, wherever it first touches a tile
+struct HeadStage {
+    int nfull, ntiles, waited; bool precise;
+    __device__ __forceinline__ void need(int kt) { while (waited <= kt) { head_wait_tile(nfull, waited, precise); ++waited; } }
+    __device__ __forceinline__ void finish() { need(ntiles - 1); }
+};
+__device__ __forceinline__ void head_pin(bf16x8_t& v) {
+    uint4_t u = __builtin_bit_cast(uint4_t, v);
+    asm volatile("" : "+v"(u));
+    v = __builtin_bit_cast(bf16x8_t, u);
+}
+__device__ __forceinline__ void head_pin(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void head_pin(int& v) { asm volatile("" : "+v"(v)); }
 // Per-lane LDS byte offsets, constant for the whole kernel (row r = 16 F + (lane&15): (r>>1)&3 does not depend on F):
 //   row[kk]  ds_read_b128 A fragment of 16-row fragment F at k-step kk:     tile + F*2048 + row[kk]
 //   tr[df]   ds_read_b64_tr_b16 of rows 16 F + 4g + e, columns 16 df + ..:   tile + F*2048 + tr[df]  (second half: F+1)
@@ -121,8 +150,6 @@ __global__ __launch_bounds__(256, 3) void attn_head_fwd_kernel(const AttnArgs p)
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z, h = blockIdx.y, qc0 = blockIdx.x * HCHUNK;
-    head_stage2(p.k + (int64_t)b * p.Lk * p.ldk + h * 64, p.ldk, p.v + (int64_t)b * p.Lk * p.ldv + h * 64, p.ldv, p.Lk, nalloc, sk, sv, tid);
-    smask[tid] = (p.key_mask && tid < p.Lk) ? p.key_mask[(int64_t)b * p.Lk + tid] : (uint8_t)1;
     const int ngroups = (min(HCHUNK, p.Lq - qc0) + 15) / 16;
     const int kfr_all = (p.Lk + 15) / 16;
     const bool has_mask = p.key_mask != nullptr;
@@ -137,10 +164,17 @@ __global__ __launch_bounds__(256, 3) void attn_head_fwd_kernel(const AttnArgs p)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) qf[kk] = ld_frag_global(qp + kk * 32 + g * 8, p.q, qrow < p.Lq && grp < ngroups);
     };
+    // (1) what this wave reads from global memory before its first MFMA -- the first group's queries, the key mask -- pinned in registers
     bf16x8_t qn[NG][2];
 #pragma unroll
     for (int i = 0; i < NG; ++i) load_q(wave + 4 * i, qn[i]);
-    __syncthreads();
+    smask[tid] = (p.key_mask && tid < p.Lk) ? p.key_mask[(int64_t)b * p.Lk + tid] : (uint8_t)1;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) { head_pin(qn[i][0]); head_pin(qn[i][1]); }
+    // (2) K / V -> LDS by DMA, tile-major; (3) tile 0 (and with the barrier the mask bytes of every thread)
+    head_dma2(p.k + (int64_t)b * p.Lk * p.ldk + h * 64, p.ldk, p.v + (int64_t)b * p.Lk * p.ldv + h * 64, p.ldv, p.Lk, nalloc, sk, sv, wave, lane);
+    HeadStage stage = {nalloc >> 6, (nalloc + 63) >> 6, 0, true};
+    stage.need(0);
     // bit F of unmasked = every key of 16-key fragment F is attendable (key mask byte != 0; bytes past Lk are 1): decided at
     // run time, so a mask that is all ones (real images, unpadded reports) costs nothing
     uint32_t unmasked = 0xffffu;
@@ -164,7 +198,7 @@ __global__ __launch_bounds__(256, 3) void attn_head_fwd_kernel(const AttnArgs p)
             const int q0 = qc0 + (grp0 + 4 * i) * 16;
             qrow[i] = q0 + c;
             qf[i][0] = qn[i][0]; qf[i][1] = qn[i][1];
-            load_q(grp0 + 4 * NG + 4 * i, qn[i]);      // prefetch the next iteration's queries behind this iteration's math
+            if (!stage.precise) load_q(grp0 + 4 * NG + 4 * i, qn[i]);      // prefetch the next iteration's queries behind this iteration's math
 #pragma unroll
             for (int f = 0; f < 4; ++f) o[i][f] = (float4_t){0.f, 0.f, 0.f, 0.f};
             m[i] = -INFINITY; l[i] = 0.f;
@@ -176,6 +210,7 @@ __global__ __launch_bounds__(256, 3) void attn_head_fwd_kernel(const AttnArgs p)
 #pragma unroll
         for (int i = 1; i < NG; ++i) nfr_max = max(nfr_max, nfr[i]);
         for (int kt = 0; kt * 4 < nfr_max; ++kt) {
+            stage.need(kt);
             const char* skt = sk + kt * 8192;
             const char* svt = sv + kt * 8192;
             // "clean" tile (the common case): 4 full fragments, no key mask, not touching a causal diagonal or the ragged tail -- for
@@ -300,6 +335,11 @@ __global__ __launch_bounds__(256, 3) void attn_head_fwd_kernel(const AttnArgs p)
                 }
             }
         }
+        if (stage.precise) {             // the first group ran beside the DMA burst: its prefetch comes now, waits are "everything" from here on
+            stage.precise = false;
+#pragma unroll
+            for (int i = 0; i < NG; ++i) load_q(grp0 + 4 * NG + 4 * i, qn[i]);
+        }
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             if (grp0 + 4 * i < ngroups && qrow[i] < p.Lq) {
@@ -311,6 +351,8 @@ __global__ __launch_bounds__(256, 3) void attn_head_fwd_kernel(const AttnArgs p)
             }
         }
     }
+    stage.precise = false;
+    stage.finish();
 }
 
 // =============================================================================== dQ  (owner: 16 queries per group)
@@ -323,8 +365,6 @@ __global__ __launch_bounds__(256, 3) void attn_head_dq_kernel(const AttnArgs p) 
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z, h = blockIdx.y, qc0 = blockIdx.x * HCHUNK;
-    head_stage2(p.k + (int64_t)b * p.Lk * p.ldk + h * 64, p.ldk, p.v + (int64_t)b * p.Lk * p.ldv + h * 64, p.ldv, p.Lk, nalloc, sk, sv, tid);
-    smask[tid] = (p.key_mask && tid < p.Lk) ? p.key_mask[(int64_t)b * p.Lk + tid] : (uint8_t)1;
     const int ngroups = (min(HCHUNK, p.Lq - qc0) + 15) / 16;
     const int kfr_all = (p.Lk + 15) / 16;
     const bool has_mask = p.key_mask != nullptr;
@@ -352,7 +392,13 @@ __global__ __launch_bounds__(256, 3) void attn_head_dq_kernel(const AttnArgs p) 
     };
     Own nx;
     load_own(wave, nx);
-    __syncthreads();
+    smask[tid] = (p.key_mask && tid < p.Lk) ? p.key_mask[(int64_t)b * p.Lk + tid] : (uint8_t)1;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) { head_pin(nx.qf[kk]); head_pin(nx.dof[kk]); head_pin(nx.of[kk]); }
+    head_pin(nx.m); head_pin(nx.inv_l);
+    head_dma2(p.k + (int64_t)b * p.Lk * p.ldk + h * 64, p.ldk, p.v + (int64_t)b * p.Lk * p.ldv + h * 64, p.ldv, p.Lk, nalloc, sk, sv, wave, lane);
+    HeadStage stage = {nalloc >> 6, (nalloc + 63) >> 6, 0, true};
+    stage.need(0);
     uint32_t unmasked = 0xffffu;              // see attn_head_fwd_kernel
     if (has_mask) {
         unmasked = 0;
@@ -367,7 +413,7 @@ __global__ __launch_bounds__(256, 3) void attn_head_dq_kernel(const AttnArgs p) 
         const int q0 = qc0 + grp * 16, qrow = q0 + c;
         const bool qok = qrow < p.Lq;
         const Own w = nx;
-        load_own(grp + 4, nx);
+        if (!stage.precise) load_own(grp + 4, nx);
         const float nm = fmaf(-w.m, LOG2E_F, __builtin_amdgcn_logf(w.inv_l));   // log2 of exp(-m)/l; -inf for dead queries
         // delta = rowsum(dO * O) of the lane's query: 16 of the 64 columns per lane, summed over the 4 lane groups; saved for dK/dV
         float delta = 0.f;
@@ -379,8 +425,7 @@ __global__ __launch_bounds__(256, 3) void attn_head_dq_kernel(const AttnArgs p) 
 #pragma unroll
             for (int e = 0; e < 8; ++e) delta = fmaf(a8[e], b8[e], delta);
         }
-        delta = col_sum(delta);
-        if (qok && g == 0) p.delta[(int64_t)(b * p.H + h) * p.Lq + qrow] = delta;
+        delta = col_sum(delta);          // (stored after the key loop: no vector-memory traffic besides the DMA burst while the waits are precise)
         float4_t dq[4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) dq[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
@@ -388,6 +433,7 @@ __global__ __launch_bounds__(256, 3) void attn_head_dq_kernel(const AttnArgs p) 
         const int nfr = p.causal ? min(kfr_all, diag + 1) : kfr_all;
         const uint32_t dbase = (uint32_t)(((uint64_t)(b * p.H + h) * p.Lq + qrow) * lk_even >> 1);
         for (int kt = 0; kt * 4 < nfr; ++kt) {
+            stage.need(kt);
             const int nf = min(4, nfr - 4 * kt);
             const char* skt = sk + kt * 8192;
             const char* svt = sv + kt * 8192;
@@ -466,13 +512,17 @@ __global__ __launch_bounds__(256, 3) void attn_head_dq_kernel(const AttnArgs p) 
                 }
             }
         }
+        if (stage.precise) { stage.precise = false; load_own(grp + 4, nx); }      // the first group ran beside the DMA burst
+        if (qok && g == 0) p.delta[(int64_t)(b * p.H + h) * p.Lq + qrow] = delta;
         if (qok) hstore_t_acc(p.dq + (int64_t)(b * p.Lq + qrow) * p.lddq + h * 64, dq, p.scale, lane);
     }
+    stage.precise = false;
+    stage.finish();
 }
 
 // =============================================================================== dK, dV  (owner: 16 keys per group)
-// Q/dO rows are allocated up to Lq rounded to 4 only (with the 3 stats per query this is what still lets three
-// workgroups share a CU at Lq = 197): the last, partial 16-row fragment uses clamped per-lane addresses, and the
+// Q/dO rows are allocated up to Lq rounded to 8 only (whole DMA blocks; with the 3 stats per query this is what still lets three
+// workgroups share a CU at Lq = 197: 3 x 53.6 KB): the last, partial 16-row fragment uses clamped per-lane addresses, and the
 // transposed reads of its missing rows are zeroed in registers (they meet P = dS = 0, and 0 x garbage must stay 0).
 __global__ __launch_bounds__(256, 3) void attn_head_dkv_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -485,7 +535,6 @@ __global__ __launch_bounds__(256, 3) void attn_head_dkv_kernel(const AttnArgs p)
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z, h = blockIdx.y, kc0 = blockIdx.x * HCHUNK;
-    head_stage2(p.q + (int64_t)b * p.Lq * p.ldq + h * 64, p.ldq, p.d_o + (int64_t)b * p.Lq * p.lddo + h * 64, p.lddo, p.Lq, nalloc, sq, sdo, tid);
     if (tid < nalloc) {
         float mm = 0.f, nm = -INFINITY, dl = 0.f;
         if (tid < p.Lq) {
@@ -534,12 +583,26 @@ __global__ __launch_bounds__(256, 3) void attn_head_dkv_kernel(const AttnArgs p)
         }
         return lds_tr(tile + F * 2048 + L.tr[df]);
     };
-    __syncthreads();
+    // the first group's keys / values and the per-query statistics come from global memory before the DMA burst (pinned), then Q / dO
+    // tile-major by DMA; the barrier of tile 0 also publishes the statistics
+    Own w0;
+    load_own(wave, w0);
+    {
+        int kp = w0.keep ? 1 : 0;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) { head_pin(w0.kf[kk]); head_pin(w0.vf[kk]); }
+        head_pin(kp);
+        w0.keep = kp != 0;
+    }
+    head_dma2(p.q + (int64_t)b * p.Lq * p.ldq + h * 64, p.ldq, p.d_o + (int64_t)b * p.Lq * p.lddo + h * 64, p.lddo, p.Lq, nalloc, sq, sdo, wave, lane);
+    HeadStage stage = {nalloc >> 6, (nalloc + 63) >> 6, 0, true};
+    stage.need(0);
     for (int grp = wave; grp < ngroups; grp += 4) {
         const int k0 = kc0 + grp * 16, key = k0 + c;
         const bool kok = key < p.Lk;
         Own w;                      // (no next-group prefetch here: the kernel is at its VGPR budget for 3 waves/SIMD)
-        load_own(grp, w);
+        if (stage.precise) w = w0;
+        else load_own(grp, w);
         float4_t dk[4], dv[4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) { dk[f] = (float4_t){0.f, 0.f, 0.f, 0.f}; dv[f] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
@@ -547,6 +610,7 @@ __global__ __launch_bounds__(256, 3) void attn_head_dkv_kernel(const AttnArgs p)
         const bool group_full = k0 + 16 <= p.Lk;
         const bool group_unmasked = !has_mask || __all(w.keep);         // run-time: an all-ones mask costs nothing
         for (int qt = fr_begin >> 2; qt * 4 < qfr_all; ++qt) {
+            stage.need(qt);
             const int f_lo = max(0, fr_begin - 4 * qt), nf = min(4, qfr_all - 4 * qt);
             if (f_lo == 0 && nf == 4 && group_full && group_unmasked && !(F_part >= 0 && 4 * qt + 3 >= F_part) && !(p.causal && fr_begin >= 4 * qt)) {
                 // clean tile: 4 full query fragments, every key of the group live, no mask / diagonal / partial rows
@@ -650,11 +714,14 @@ __global__ __launch_bounds__(256, 3) void attn_head_dkv_kernel(const AttnArgs p)
                 }
             }
         }
+        stage.precise = false;
         if (kok) {
             hstore_t_acc(p.dk + (int64_t)(b * p.Lk + key) * p.lddk + h * 64, dk, p.scale, lane);
             hstore_t_acc(p.dv + (int64_t)(b * p.Lk + key) * p.lddv + h * 64, dv, 1.0f, lane);
         }
     }
+    stage.precise = false;
+    stage.finish();
 }
 
 // =============================================================================== host
@@ -681,7 +748,7 @@ int vm_attn_head_fwd(const AttnArgs& a0, hipStream_t s) {
 int vm_attn_head_bwd(const AttnArgs& a0, hipStream_t s) {
     AttnArgs a = a0;
     a.ralloc_k = (a.Lk + 15) / 16 * 16;
-    a.ralloc_q = (a.Lq + 3) / 4 * 4;
+    a.ralloc_q = (a.Lq + 7) / 8 * 8;          // whole 8-row DMA blocks
     launch_head(attn_head_dq_kernel, dim3((a.Lq + HCHUNK - 1) / HCHUNK, a.H, a.B), (size_t)2 * a.ralloc_k * HB + 256, s, a);
     launch_head(attn_head_dkv_kernel, dim3((a.Lk + HCHUNK - 1) / HCHUNK, a.H, a.B), (size_t)2 * a.ralloc_q * HB + 12 * a.ralloc_q, s, a);
     return vm_check_launch("vm_attention_bwd(head)");

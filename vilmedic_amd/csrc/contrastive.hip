@@ -31,33 +31,93 @@ extern "C" int vm_rownorm_cast(const float* x, void* out_bf16, float* norms, int
 
 
 
-// ------------------------------------------------------------------ fused similarity tiles: S is never written to HBM
-// One workgroup owns a 128 x 128 tile of S = A_hat B_hat^T * inv_tau (bf16 MFMA, fp32 accumulate; operands are the normalised
-// embeddings, 2 x R x D bf16 = 6 MB at R = 2048, D = 768: L2 / MALL resident, so they go global -> registers -> LDS with a
-// one-tile software pipeline), keeps the tile in LDS as fp32 and turns it into
-//   MODE 0 (forward):  per-row and per-column (max, sum exp) PARTIALS over the tile + the paired-diagonal entries; a second tiny
-//                      kernel merges the partials of a row / column across tiles into the log-sum-exps (online-softmax merge);
-//   MODE 1 (backward): G = g_row_i softmax_row(S)_ij + g_col_j softmax_col(S)_ij - [j == i + off] (g_row_i + g_col_j) as bf16,
-//                      from a RECOMPUTED tile (one more pass of the 2 R C D product instead of a 4 R C byte read of a stored S).
-// Versus the unfused path (S fp32 written once and read by three scalar kernels): at R = C = 2048 the 16.8 MB matrix and its
-// three re-reads disappear; HBM traffic of the loss is the 6 MB of embeddings plus G (8 MB, bf16) for the two gradient GEMMs.
+// ------------------------------------------------------------------ the similarity loss in three launches: S never reaches HBM
+//   contr_prep_kernel   both embedding matrices in ONE launch: x/max(|x|,eps) -> bf16 (or a plain cast), the norms; zeroes the
+//                       arrival counters and the paired-diagonal buffer of the launch that follows
+//   contr_fwd_kernel    one workgroup per 128 x 128 tile of S = A^ B^^T * inv_tau (bf16 MFMA, fp32 accumulate, the tile staged in LDS
+//                       as fp32): per-row / per-column (max, sum exp) partials + the paired-diagonal entries; the workgroup that
+//                       ARRIVES LAST (agent-scope release -> ticket -> acquire, no spinning, no residency assumption) merges the
+//                       partials of every row and column into the log-sum-exps and writes the per-row losses
+//   contr_bwd_kernel    a persistent grid pulling work items from ONE device queue:
+//                         items [0, TA)   a recomputed S tile -> G = g_r softmax_row + g_c softmax_col - [paired](g_r + g_c) as bf16
+//                                         (8 MB at B = 2048: L2 / MALL resident), the partial sums p_i = sum_j G_ij S_ij and
+//                                         q_j = sum_i G_ij S_ij (the a^.da^ / b^.db^ projections of the normalisation backward),
+//                                         then an arrival on the tile's row-block and column-block counters;
+//                         items [TA, ..)  64 x BN output tiles of dA = G B^ / tau (waits for its row block of G) and dB = G^T A^ / tau
+//                                         (waits for its column block), the L2-normalisation backward applied in the epilogue:
+//                                         dx = (dx^ - x^ (x^ . dx^)) / |x| -- no cross-tile reduction is left because x^ . dx^ = p.
+//                       A phase-B item only ever waits for phase-A tiles, and every phase-A tile was dequeued -- by a workgroup that is
+//                       running -- before the first phase-B item was handed out, so the queue cannot deadlock whatever the dispatch
+//                       order or residency is (cdna_hip_programming.md Guideline 16; every spin is bounded and reports through ws).
+// Round 2 ran this as six library launches + a dozen torch glue kernels (0.147 ms of kernel time, 0.34 ms wall at B = 2048); the two
+// gradient GEMMs alone took 61 us because 2048 x 768 outputs are 96 tiles of 128 x 128 on 256 CUs.  Here they are 512 items of 64 x 96.
 typedef __bf16 c_bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short c_v4s __attribute__((ext_vector_type(4)));
 #define CT 128
 #define CT_KS 72          // LDS row stride in elements for a [128][64] operand slab (144 B: conflict-spreading pad)
 #define CT_CS 132         // fp32 row stride of the staged S tile
 #define CT_LDS (2 * 2 * CT * CT_KS * 2)      // two stages x two operands = 73728 B >= 128 * 132 * 4 = 67584 B
+#define CT_RED_OFF (CT * CT_CS * 4)          // 2 KB of cross-wave column partials behind the staged tile
+#define CT_ITEM_OFF CT_LDS                   // 16 B: the dequeued item / "I am last" broadcast
+#define CT_LDS_ALL (CT_LDS + 16)
+#define CB_M 64           // phase-B output tile: 64 rows x BN columns (BN = 96 when D % 96 == 0, else 128), K chunks of 64
+#define CB_PS 72          // LDS row stride (elements) of the G chunk  [64][64]
+#define CB_QS 136         // LDS row stride (elements) of the operand chunk [64][<=128]
+#define CB_STAGE (CB_M * CB_PS * 2 + 64 * CB_QS * 2)      // 9216 + 17408 B per stage
+#define CONTR_SPIN_LIMIT (1u << 21)
+
 struct ContrArgs {
     const bf16_t* A; const bf16_t* B; int R, C, D, diag_offset, tiles_m, tiles_n; float inv_tau;
-    float* row_part; float* col_part; float* diag;                                   // MODE 0 outputs
-    const float* lse_r; const float* lse_c; const float* g_r; const float* g_c; bf16_t* G; int64_t ldg;   // MODE 1
+    // forward
+    float* row_part; float* col_part; float* diag; float* lse_r_out; float* lse_c_out; float* loss_r; float* loss_c;
+    unsigned* ctr;                                   // [0] forward arrivals, [1] backward queue head, [2] error word, [4..] row-block / column-block arrivals
+    // backward
+    const float* lse_r; const float* lse_c; const float* g_r; const float* g_c; bf16_t* G; int64_t ldg;
+    float* p_part; float* q_part;                    // [tiles_n][R], [tiles_m][C]
+    const float* a32; const float* b32; const float* na; const float* nb; float* da; float* db;
+    int normalize, bn, items_a, items_da, items_db; float eps;
 };
 
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void contrastive_tile_kernel(const ContrArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__global__ __launch_bounds__(256) void contr_prep_kernel(const float* __restrict__ a, const float* __restrict__ b, bf16_t* __restrict__ ah,
+                                                         bf16_t* __restrict__ bh, float* __restrict__ na, float* __restrict__ nb, int R, int C, int D,
+                                                         int normalize, float eps, unsigned* __restrict__ ctr, int nctr, float* __restrict__ diag) {
+    const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < nctr; i += 256) ctr[i] = 0u;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < R; i += gridDim.x * 256) diag[i] = 0.f;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < R + C; row += gridDim.x * 4) {
+        const bool first = row < R;
+        const int r = first ? row : row - R;
+        const float* xr = (first ? a : b) + (int64_t)r * D;
+        bf16_t* o = (first ? ah : bh) + (int64_t)r * D;
+        float ss = 0.f;
+        for (int c = lane * 4; c < D; c += 256) { const float4 v = *reinterpret_cast<const float4*>(xr + c); ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+        const float nrm = sqrtf(wave_sum(ss));
+        const float inv = normalize ? 1.0f / fmaxf(nrm, eps) : 1.0f;
+        for (int c = lane * 4; c < D; c += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + c);
+            uint2 u; u.x = pack_bf16x2(v.x * inv, v.y * inv); u.y = pack_bf16x2(v.z * inv, v.w * inv);
+            *reinterpret_cast<uint2*>(o + c) = u;
+        }
+        if (lane == 0) (first ? na : nb)[r] = nrm;
+    }
+}
+
+// publish this workgroup's global stores and draw a ticket (thread 0 returns it): plain stores -> every wave drains -> barrier ->
+// one agent-scope release -> the asm wait the compiler may not drop -> relaxed agent-scope fetch_add (Guideline 16, counter form)
+__device__ __forceinline__ void contr_publish() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+__device__ __forceinline__ unsigned contr_ticket(unsigned* c) { return __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// acc = A^[m0.., :] B^[n0.., :]^T for one 128 x 128 tile (operands global -> registers -> LDS with a one-chunk software pipeline), then the
+// scaled tile staged in LDS as fp32 [128][CT_CS].  Ends with a barrier: every thread may read the whole tile.
+__device__ __forceinline__ void contr_s_tile(const ContrArgs& p, char* smem, int m0, int n0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x - tm * p.tiles_n;
-    const int m0 = tm * CT, n0 = tn * CT;
     float4_t acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -116,75 +176,295 @@ __global__ __launch_bounds__(256, 2) void contrastive_tile_kernel(const ContrArg
             for (int r = 0; r < 4; ++r) cs[(row + r) * CT_CS + col] = acc[i][j][r] * p.inv_tau;
         }
     __syncthreads();
+}
+
+__global__ __launch_bounds__(256, 2) void contr_fwd_kernel(const ContrArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x - tm * p.tiles_n;
+    const int m0 = tm * CT, n0 = tn * CT;
+    contr_s_tile(p, smem, m0, n0);
+    const float* cs = reinterpret_cast<const float*>(smem);
     const int rows = min(CT, p.R - m0), cols = min(CT, p.C - n0);
-    if (MODE == 0) {
-        if (tid < CT) {                        // threads 0..127: one row each
-            const int r = tid;
-            if (r < rows) {
-                float mx = -INFINITY;
-                for (int j = 0; j < cols; ++j) mx = fmaxf(mx, cs[r * CT_CS + j]);
-                float se = 0.f;
-                for (int j = 0; j < cols; ++j) se += expf(cs[r * CT_CS + j] - mx);
-                float* o = p.row_part + ((int64_t)tn * p.R + m0 + r) * 2;
-                o[0] = mx; o[1] = se;
-                const int dj = m0 + r + p.diag_offset - n0;             // column of the paired entry inside this tile
-                if (p.diag && dj >= 0 && dj < cols) p.diag[m0 + r] = cs[r * CT_CS + dj];
-            }
-        } else {                               // threads 128..255: one column each
-            const int c = tid - CT;
-            if (c < cols) {
-                float mx = -INFINITY;
-                for (int i = 0; i < rows; ++i) mx = fmaxf(mx, cs[i * CT_CS + c]);
-                float se = 0.f;
-                for (int i = 0; i < rows; ++i) se += expf(cs[i * CT_CS + c] - mx);
-                float* o = p.col_part + ((int64_t)tm * p.C + n0 + c) * 2;
-                o[0] = mx; o[1] = se;
-            }
+    if (tid < CT) {                        // threads 0..127: one row each
+        const int r = tid;
+        if (r < rows) {
+            float mx = -INFINITY;
+            for (int j = 0; j < cols; ++j) mx = fmaxf(mx, cs[r * CT_CS + j]);
+            float se = 0.f;
+            for (int j = 0; j < cols; ++j) se += __expf(cs[r * CT_CS + j] - mx);
+            float* o = p.row_part + ((int64_t)tn * p.R + m0 + r) * 2;
+            o[0] = mx; o[1] = se;
+            const int dj = m0 + r + p.diag_offset - n0;             // column of the paired entry inside this tile
+            if (dj >= 0 && dj < cols) p.diag[m0 + r] = cs[r * CT_CS + dj];
         }
-    } else {
-        for (int it = 0; it < 8; ++it) {       // 8 consecutive columns of a row per thread: 16-B bf16 stores, whole 256-B rows per 16 lanes
-            const int id = tid + 256 * it, r = id >> 4, c0 = (id & 15) * 8;
-            if (r >= rows || c0 >= cols) continue;
-            const int gr = m0 + r;
-            const float gri = p.g_r[gr], lri = p.lse_r[gr];
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int gc = n0 + c0 + j;
-                float g = 0.f;
-                if (c0 + j < cols) {
-                    const float sv = cs[r * CT_CS + c0 + j];
-                    const float gcj = p.g_c[gc];
-                    g = gri * expf(sv - lri) + gcj * expf(sv - p.lse_c[gc]);
-                    if (gc == gr + p.diag_offset) g -= gri + gcj;
-                }
-                v[j] = g;
-            }
-            bf16_t* o = p.G + (int64_t)gr * p.ldg + n0 + c0;
-            if (c0 + 8 <= cols) *reinterpret_cast<uint4*>(o) = pack8(v);
-            else for (int j = 0; j < cols - c0; ++j) o[j] = f32_to_bf16(v[j]);
+    } else {                               // threads 128..255: one column each
+        const int c = tid - CT;
+        if (c < cols) {
+            float mx = -INFINITY;
+            for (int i = 0; i < rows; ++i) mx = fmaxf(mx, cs[i * CT_CS + c]);
+            float se = 0.f;
+            for (int i = 0; i < rows; ++i) se += __expf(cs[i * CT_CS + c] - mx);
+            float* o = p.col_part + ((int64_t)tm * p.C + n0 + c) * 2;
+            o[0] = mx; o[1] = se;
+        }
+    }
+    // ---- arrival; the last workgroup merges every row and column:  lse = M + log(sum_t s_t exp(m_t - M))
+    unsigned* flag = reinterpret_cast<unsigned*>(smem + CT_ITEM_OFF);
+    contr_publish();
+    if (tid == 0) {
+        const unsigned t = contr_ticket(p.ctr);
+        const bool last = t == (unsigned)(p.tiles_m * p.tiles_n - 1);
+        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *flag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*flag == 0u) return;
+    for (int i = tid; i < p.R + p.C; i += 256) {
+        const bool isrow = i < p.R;
+        const int x = isrow ? i : i - p.R, n = isrow ? p.R : p.C, nt = isrow ? p.tiles_n : p.tiles_m;
+        const float* part = isrow ? p.row_part : p.col_part;
+        float M = -INFINITY;
+        for (int t = 0; t < nt; ++t) M = fmaxf(M, part[((int64_t)t * n + x) * 2]);
+        float L = 0.f;
+        for (int t = 0; t < nt; ++t) L += part[((int64_t)t * n + x) * 2 + 1] * __expf(part[((int64_t)t * n + x) * 2] - M);
+        const float lse = M + __logf(L);
+        if (isrow) {
+            p.lse_r_out[x] = lse;
+            p.loss_r[x] = lse - p.diag[x];                        // (diag is 0 for a row without a paired column)
+        } else {
+            p.lse_c_out[x] = lse;
+            const int pr = x - p.diag_offset;                     // the row this column is paired with
+            p.loss_c[x] = lse - ((pr >= 0 && pr < p.R) ? p.diag[pr] : 0.f);
         }
     }
 }
 
-// merge the per-tile (max, sum exp) partials of every row and every column: lse = M + log(sum_t s_t exp(m_t - M))
-__global__ __launch_bounds__(256) void contrastive_merge_kernel(const float* __restrict__ row_part, const float* __restrict__ col_part,
-                                                                float* __restrict__ lse_r, float* __restrict__ lse_c, int R, int C,
-                                                                int tiles_m, int tiles_n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < R) {
-        float M = -INFINITY;
-        for (int t = 0; t < tiles_n; ++t) M = fmaxf(M, row_part[((int64_t)t * R + i) * 2]);
-        float L = 0.f;
-        for (int t = 0; t < tiles_n; ++t) L += row_part[((int64_t)t * R + i) * 2 + 1] * expf(row_part[((int64_t)t * R + i) * 2] - M);
-        lse_r[i] = M + logf(L);
-    } else if (i - R < C) {
-        const int j = i - R;
-        float M = -INFINITY;
-        for (int t = 0; t < tiles_m; ++t) M = fmaxf(M, col_part[((int64_t)t * C + j) * 2]);
-        float L = 0.f;
-        for (int t = 0; t < tiles_m; ++t) L += col_part[((int64_t)t * C + j) * 2 + 1] * expf(col_part[((int64_t)t * C + j) * 2] - M);
-        lse_c[j] = M + logf(L);
+// ---------------------------------------------------------------------------------------------------------------- backward
+__device__ __forceinline__ c_v4s contr_lds_tr(const char* q) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) c_v4s*)(const __attribute__((address_space(3))) c_v4s*)q);
+}
+// MFMA operand (16 rows or columns x 32 k) from a chunk stored [k][x] row-major (stride bytes): lane (c = lane & 15, g = lane >> 4) gets
+// x = x0 + c, k = k0 + 8 g .. + 7: two transposing reads, each over the 4 x 16 block  rows k0 + 8 g (+ 4) .. + 3,  columns x0 .. x0 + 15
+__device__ __forceinline__ c_bf16x8_t contr_frag_t(const char* chunk, int stride, int k0, int x0, int lane) {
+    const int g = lane >> 4, c = lane & 15;
+    const char* q = chunk + (k0 + 8 * g + (c >> 2)) * stride + (x0 + 4 * (c & 3)) * 2;
+    const c_v4s lo = contr_lds_tr(q), hi = contr_lds_tr(q + 4 * stride);
+    short8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(c_bf16x8_t, v);
+}
+// sum over the 16 lanes of a DPP row (every lane of the row ends with the total)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f32<0xB1>(v); v += dpp_f32<0x4E>(v); v += dpp_f32<0x141>(v); v += dpp_f32<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ float quarters_sum(float v) {      // over lanes l, l^16, l^32, l^48
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// phase A: one tile of G (+ the projection partials), then the arrivals on its row block and its column block
+__device__ __noinline__ void contr_g_tile(const ContrArgs& p, char* smem, int tm, int tn) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = tm * CT, n0 = tn * CT;
+    contr_s_tile(p, smem, m0, n0);
+    const float* cs = reinterpret_cast<const float*>(smem);
+    float* red = reinterpret_cast<float*>(smem + CT_RED_OFF);
+    const int rows = min(CT, p.R - m0), cols = min(CT, p.C - n0);
+    const int c0 = (tid & 15) * 8;
+    float colacc[8];
+    float gcj[8], lcj[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int gc = n0 + c0 + j;
+        colacc[j] = 0.f;
+        gcj[j] = (c0 + j < cols) ? p.g_c[gc] : 0.f;
+        lcj[j] = (c0 + j < cols) ? p.lse_c[gc] : 0.f;
+    }
+    for (int it = 0; it < 8; ++it) {       // 8 consecutive columns of a row per thread: 16-B bf16 stores, whole 256-B rows per 16 lanes
+        const int r = (tid >> 4) + 16 * it;
+        const int gr = m0 + r;
+        const bool rok = r < rows;
+        const float gri = rok ? p.g_r[gr] : 0.f, lri = rok ? p.lse_r[gr] : 0.f;
+        float v[8], rs = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float g = 0.f;
+            if (rok && c0 + j < cols) {
+                const float sv = cs[r * CT_CS + c0 + j];
+                g = gri * __expf(sv - lri) + gcj[j] * __expf(sv - lcj[j]);
+                if (n0 + c0 + j == gr + p.diag_offset) g -= gri + gcj[j];
+                rs += g * sv;
+                colacc[j] += g * sv;
+            }
+            v[j] = g;
+        }
+        rs = row16_sum(rs);
+        if (rok) {
+            if ((tid & 15) == 0) p.p_part[(int64_t)tn * p.R + gr] = rs;
+            if (c0 < cols) {
+                bf16_t* o = p.G + (int64_t)gr * p.ldg + n0 + c0;
+                if (c0 + 8 <= cols) *reinterpret_cast<uint4*>(o) = pack8(v);
+                else for (int j = 0; j < cols - c0; ++j) o[j] = f32_to_bf16(v[j]);
+            }
+        }
+    }
+    // column partials: the 4 row groups of a wave (lanes l, l^16, l^32, l^48), then the 4 waves through LDS
+#pragma unroll
+    for (int j = 0; j < 8; ++j) colacc[j] = quarters_sum(colacc[j]);
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[wave * CT + lane * 8 + j] = colacc[j];
+    }
+    __syncthreads();
+    if (tid < cols) p.q_part[(int64_t)tm * p.C + n0 + tid] = red[tid] + red[CT + tid] + red[2 * CT + tid] + red[3 * CT + tid];
+    contr_publish();
+    if (tid == 0) { contr_ticket(p.ctr + 4 + tm); contr_ticket(p.ctr + 4 + p.tiles_m + tn); }
+}
+
+// phase B: out[m0.., n0..] (64 x BN, fp32) = sum_k P[m][k] X^[k][n] / tau, normalisation backward in the epilogue.
+//   PT = false (dA): P[m][k] = G[m0 + m][k],  X^ = B^,  K = C;    PT = true (dB): P[m][k] = G[k][m0 + m],  X^ = A^,  K = R
+// The product is formed transposed (A operand = X^ chunk read through ds_read_b64_tr_b16, rows = n; B operand = the G chunk, columns = m)
+// so that a lane ends with 4 consecutive n of one output row: 16-B stores.
+template <int NB, bool PT>
+__device__ __noinline__ void contr_grad_tile(const ContrArgs& p, char* smem, int m0, int n0) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave >> 1, wm = wave & 1;
+    constexpr int BN = NB * 32;                       // NB 16-column blocks per wave x 2 waves
+    const int M = PT ? p.C : p.R, K = PT ? p.R : p.C;
+    const bf16_t* X = PT ? p.A : p.B;
+    float4_t acc[NB][2];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) { acc[i][0] = (float4_t){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
+    uint4 rp[2], rq[NB];
+    // G chunk: 64 x 64 elements = 512 16-B pieces (2 per thread); operand chunk: 64 x BN = 8 NB x 64 pieces (NB per thread)
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+            const int gr = (PT ? k0 : m0) + row, gc = (PT ? m0 : k0) + ch * 8;     // G[gr][gc .. gc + 7]
+            rp[i] = (gr < p.R && gc < p.C) ? *reinterpret_cast<const uint4*>(p.G + (int64_t)gr * p.ldg + gc) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int id = tid + 256 * i, row = id / (BN / 8), ch = id - row * (BN / 8);
+            const int gk = k0 + row, gn = n0 + ch * 8;
+            rq[i] = (gk < K && gn < p.D) ? *reinterpret_cast<const uint4*>(X + (int64_t)gk * p.D + gn) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store = [&](char* st) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+            *reinterpret_cast<uint4*>(st + row * (CB_PS * 2) + ch * 16) = rp[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int id = tid + 256 * i, row = id / (BN / 8), ch = id - row * (BN / 8);
+            *reinterpret_cast<uint4*>(st + CB_M * CB_PS * 2 + row * (CB_QS * 2) + ch * 16) = rq[i];
+        }
+    };
+    // (the tail of G past the row's C columns is never read as data: pieces are guarded by gc < C, and ldg >= C rounded to 8 with the
+    //  phase-A tile writing only columns < C -- the last piece of a row may hold up to 7 stale bf16 values when C % 8 != 0, so zero them)
+    const int ktiles = (K + 63) / 64;
+    load(0);
+    store(smem);
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const char* sp = smem + (kt & 1) * CB_STAGE;
+        const char* sq = sp + CB_M * CB_PS * 2;
+        if (kt + 1 < ktiles) load((kt + 1) * 64);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            c_bf16x8_t fq[NB], fp[2];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) fq[i] = contr_frag_t(sq, CB_QS * 2, kk * 32, wn * (BN / 2) + i * 16, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (PT) fp[j] = contr_frag_t(sp, CB_PS * 2, kk * 32, wm * 32 + j * 16, lane);
+                else fp[j] = *reinterpret_cast<const c_bf16x8_t*>(sp + (wm * 32 + j * 16 + (lane & 15)) * (CB_PS * 2) + (kk * 32 + (lane >> 4) * 8) * 2);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[i], fp[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < ktiles) store(smem + ((kt + 1) & 1) * CB_STAGE);
+        __syncthreads();
+    }
+    // epilogue: lane holds out[m][n .. n + 3], m = m0 + wm 32 + j 16 + (lane & 15), n = n0 + wn BN/2 + i 16 + (lane >> 4) 4
+    const float* x32 = PT ? p.b32 : p.a32;
+    const float* nrm = PT ? p.nb : p.na;
+    const float* part = PT ? p.q_part : p.p_part;
+    const int nparts = PT ? p.tiles_m : p.tiles_n;
+    float* out = PT ? p.db : p.da;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + wm * 32 + j * 16 + (lane & 15);
+        if (m >= M) continue;
+        float proj = 0.f, d = 1.f;
+        bool unit = false;
+        if (p.normalize) {
+            for (int t = 0; t < nparts; ++t) proj += part[(int64_t)t * M + m];
+            const float nm = nrm[m];
+            d = fmaxf(nm, p.eps);
+            unit = nm > p.eps;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int n = n0 + wn * (BN / 2) + i * 16 + (lane >> 4) * 4;
+            if (n >= p.D) continue;
+            float4 o;
+            float* ov = reinterpret_cast<float*>(&o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = acc[i][j][r] * p.inv_tau;
+            if (p.normalize) {
+                const float4 xv = *reinterpret_cast<const float4*>(x32 + (int64_t)m * p.D + n);
+                const float* xs = reinterpret_cast<const float*>(&xv);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = (ov[r] - (unit ? xs[r] / d * proj : 0.f)) / d;
+            }
+            *reinterpret_cast<float4*>(out + (int64_t)m * p.D + n) = o;
+        }
+    }
+    __syncthreads();                 // the LDS stages are reused by the next item
+}
+
+__global__ __launch_bounds__(256, 2) void contr_bwd_kernel(const ContrArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* item_s = reinterpret_cast<int*>(smem + CT_ITEM_OFF);
+    const int tid = threadIdx.x;
+    const int total = p.items_a + p.items_da + p.items_db;
+    const int nbt = (p.D + p.bn - 1) / p.bn;                 // output column blocks
+    for (;;) {
+        if (tid == 0) *item_s = (int)contr_ticket(p.ctr + 1);
+        __syncthreads();
+        const int item = *item_s;
+        __syncthreads();
+        if (item >= total) return;
+        if (item < p.items_a) {
+            contr_g_tile(p, smem, item / p.tiles_n, item % p.tiles_n);
+            continue;
+        }
+        const bool isb = item >= p.items_a + p.items_da;
+        const int it = item - p.items_a - (isb ? p.items_da : 0);
+        const int rb = it / nbt, cb = it - rb * nbt;
+        const int m0 = rb * CB_M, n0 = cb * p.bn;
+        // wait for the G tiles this item contracts over: ONE lane polls ONE word (relaxed, agent scope), then ONE acquire
+        if (tid == 0) {
+            unsigned* flag = p.ctr + 4 + (isb ? p.tiles_m : 0) + m0 / CT;
+            const unsigned need = (unsigned)(isb ? p.tiles_m : p.tiles_n);
+            unsigned spins = 0;
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > CONTR_SPIN_LIMIT) { __hip_atomic_store(p.ctr + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        if (p.bn == 96) { if (isb) contr_grad_tile<3, true>(p, smem, m0, n0); else contr_grad_tile<3, false>(p, smem, m0, n0); }
+        else            { if (isb) contr_grad_tile<4, true>(p, smem, m0, n0); else contr_grad_tile<4, false>(p, smem, m0, n0); }
     }
 }
 
@@ -196,47 +476,104 @@ static int contr_common(const char* fn, const void* a, const void* b, int R, int
 static void contr_attr() {
     static bool set = false;
     if (set) return;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&contrastive_tile_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, CT_LDS);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&contrastive_tile_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, CT_LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&contr_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CT_LDS_ALL);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&contr_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CT_LDS_ALL);
     set = true;
 }
-
-extern "C" size_t vm_contrastive_ws(int R, int C) {
+static int contr_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+// workspace layout (bytes, every block 256-B aligned): counters | diag [R] | row_part [tn][R][2] | col_part [tm][C][2] | p_part [tn][R] |
+// q_part [tm][C] | G bf16 [R][ldg]
+struct ContrWs { size_t ctr, nctr, diag, row_part, col_part, p_part, q_part, G, total; int64_t ldg; };
+static ContrWs contr_ws_layout(int R, int C) {
     const size_t tm = (R + CT - 1) / CT, tn = (C + CT - 1) / CT;
-    return (tn * (size_t)R + tm * (size_t)C) * 2 * sizeof(float);
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    ContrWs w;
+    w.ldg = (C + 7) / 8 * 8;
+    w.nctr = 4 + tm + tn;
+    w.ctr = 0;
+    w.diag = up(w.nctr * 4);
+    w.row_part = w.diag + up((size_t)R * 4);
+    w.col_part = w.row_part + up(tn * (size_t)R * 8);
+    w.p_part = w.col_part + up(tm * (size_t)C * 8);
+    w.q_part = w.p_part + up(tn * (size_t)R * 4);
+    w.G = w.q_part + up(tm * (size_t)C * 4);
+    w.total = w.G + up((size_t)R * w.ldg * 2);
+    return w;
+}
+extern "C" size_t vm_contrastive_ws(int R, int C) { return (R > 0 && C > 0) ? contr_ws_layout(R, C).total : 0; }
+
+static void contr_fill(ContrArgs& p, const void* ah, const void* bh, int R, int C, int D, float inv_tau, int diag_offset, char* ws, const ContrWs& w) {
+    p.A = (const bf16_t*)ah; p.B = (const bf16_t*)bh; p.R = R; p.C = C; p.D = D; p.diag_offset = diag_offset; p.inv_tau = inv_tau;
+    p.tiles_m = (R + CT - 1) / CT; p.tiles_n = (C + CT - 1) / CT;
+    p.ctr = (unsigned*)(ws + w.ctr); p.diag = (float*)(ws + w.diag);
+    p.row_part = (float*)(ws + w.row_part); p.col_part = (float*)(ws + w.col_part);
+    p.p_part = (float*)(ws + w.p_part); p.q_part = (float*)(ws + w.q_part);
+    p.G = (bf16_t*)(ws + w.G); p.ldg = w.ldg;
 }
 
-extern "C" int vm_contrastive_fwd(const void* a_hat, const void* b_hat, int R, int C, int D, float inv_tau, int diag_offset,
-                                  float* lse_rows, float* lse_cols, float* diag, void* ws, size_t ws_bytes, void* stream) {
-    int rc = contr_common("vm_contrastive_fwd", a_hat, b_hat, R, C, D);
+extern "C" int vm_contrastive_loss_fwd(const float* a, const float* b, int R, int C, int D, int normalize, float eps, float inv_tau, int diag_offset,
+                                       void* a_hat, void* b_hat, float* norm_a, float* norm_b, float* lse_rows, float* lse_cols,
+                                       float* loss_rows, float* loss_cols, void* ws, size_t ws_bytes, void* stream) {
+    int rc = contr_common("vm_contrastive_loss_fwd", a, b, R, C, D);
     if (rc) return rc;
-    VM_REQUIRE(lse_rows && lse_cols && ws && ws_bytes >= vm_contrastive_ws(R, C), "vm_contrastive_fwd: outputs / workspace (%zu bytes needed)", vm_contrastive_ws(R, C));
-    ContrArgs p = {};
-    p.A = (const bf16_t*)a_hat; p.B = (const bf16_t*)b_hat; p.R = R; p.C = C; p.D = D; p.diag_offset = diag_offset; p.inv_tau = inv_tau;
-    p.tiles_m = (R + CT - 1) / CT; p.tiles_n = (C + CT - 1) / CT;
-    p.row_part = (float*)ws; p.col_part = p.row_part + (size_t)p.tiles_n * R * 2; p.diag = diag;
+    const ContrWs w = contr_ws_layout(R, C);
+    VM_REQUIRE(a_hat && b_hat && norm_a && norm_b && lse_rows && lse_cols && loss_rows && loss_cols && ws && ws_bytes >= w.total &&
+               ((uintptr_t)ws % 256) == 0 && ((uintptr_t)a_hat % 16) == 0 && ((uintptr_t)b_hat % 16) == 0,
+               "vm_contrastive_loss_fwd: outputs / workspace (%zu bytes, 256-B aligned)", w.total);
     hipStream_t s = (hipStream_t)stream;
-    VmProfScope prof(VM_FAM_LOSS, 2.0 * R * (double)C * D, s, "contrastive_fwd_R%d_C%d_D%d", R, C, D);
+    ContrArgs p = {};
+    contr_fill(p, a_hat, b_hat, R, C, D, inv_tau, diag_offset, (char*)ws, w);
+    p.lse_r_out = lse_rows; p.lse_c_out = lse_cols; p.loss_r = loss_rows; p.loss_c = loss_cols;
     contr_attr();
-    hipLaunchKernelGGL(contrastive_tile_kernel<0>, dim3(p.tiles_m * p.tiles_n), dim3(256), CT_LDS, s, p);
-    hipLaunchKernelGGL(contrastive_merge_kernel, dim3((R + C + 255) / 256), dim3(256), 0, s, p.row_part, p.col_part, lse_rows, lse_cols, R, C,
-                       p.tiles_m, p.tiles_n);
-    return vm_check_launch("vm_contrastive_fwd");
+    {
+        VmProfScope prof(VM_FAM_LOSS, 12.0 * (R + C) * (double)D, s, "contrastive_prep_R%d_C%d_D%d", R, C, D);
+        int blocks = (R + C + 3) / 4; if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(contr_prep_kernel, dim3(blocks), dim3(256), 0, s, a, b, (bf16_t*)a_hat, (bf16_t*)b_hat, norm_a, norm_b, R, C, D, normalize, eps,
+                           p.ctr, (int)w.nctr, p.diag);
+    }
+    {
+        VmProfScope prof(VM_FAM_LOSS, 2.0 * R * (double)C * D, s, "contrastive_fwd_R%d_C%d_D%d", R, C, D);
+        hipLaunchKernelGGL(contr_fwd_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), CT_LDS_ALL, s, p);
+    }
+    return vm_check_launch("vm_contrastive_loss_fwd");
 }
 
-extern "C" int vm_contrastive_bwd(const void* a_hat, const void* b_hat, int R, int C, int D, float inv_tau, int diag_offset,
-                                  const float* lse_rows, const float* lse_cols, const float* g_rows, const float* g_cols,
-                                  void* G_bf16, int64_t ldg, void* stream) {
-    int rc = contr_common("vm_contrastive_bwd", a_hat, b_hat, R, C, D);
+extern "C" int vm_contrastive_loss_bwd(const float* a, const float* b, const void* a_hat, const void* b_hat, const float* norm_a, const float* norm_b,
+                                       int R, int C, int D, int normalize, float eps, float inv_tau, int diag_offset,
+                                       const float* lse_rows, const float* lse_cols, const float* g_rows, const float* g_cols,
+                                       float* da, float* db, void* ws, size_t ws_bytes, void* stream) {
+    int rc = contr_common("vm_contrastive_loss_bwd", a_hat, b_hat, R, C, D);
     if (rc) return rc;
-    VM_REQUIRE(lse_rows && lse_cols && g_rows && g_cols && G_bf16 && ldg >= C && (ldg % 8) == 0, "vm_contrastive_bwd: bad arguments");
-    ContrArgs p = {};
-    p.A = (const bf16_t*)a_hat; p.B = (const bf16_t*)b_hat; p.R = R; p.C = C; p.D = D; p.diag_offset = diag_offset; p.inv_tau = inv_tau;
-    p.tiles_m = (R + CT - 1) / CT; p.tiles_n = (C + CT - 1) / CT;
-    p.lse_r = lse_rows; p.lse_c = lse_cols; p.g_r = g_rows; p.g_c = g_cols; p.G = (bf16_t*)G_bf16; p.ldg = ldg;
+    const ContrWs w = contr_ws_layout(R, C);
+    VM_REQUIRE(a && b && norm_a && norm_b && lse_rows && lse_cols && g_rows && g_cols && da && db && ws && ws_bytes >= w.total &&
+               ((uintptr_t)ws % 256) == 0 && ((uintptr_t)da % 16) == 0 && ((uintptr_t)db % 16) == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0,
+               "vm_contrastive_loss_bwd: bad arguments (workspace %zu bytes, 256-B aligned)", w.total);
     hipStream_t s = (hipStream_t)stream;
-    VmProfScope prof(VM_FAM_LOSS, 2.0 * R * (double)C * D, s, "contrastive_bwd_R%d_C%d_D%d", R, C, D);
+    ContrArgs p = {};
+    contr_fill(p, a_hat, b_hat, R, C, D, inv_tau, diag_offset, (char*)ws, w);
+    p.lse_r = lse_rows; p.lse_c = lse_cols; p.g_r = g_rows; p.g_c = g_cols;
+    p.a32 = a; p.b32 = b; p.na = norm_a; p.nb = norm_b; p.da = da; p.db = db; p.normalize = normalize; p.eps = eps;
+    p.bn = (D % 96 == 0) ? 96 : 128;
+    const int nbt = (D + p.bn - 1) / p.bn;
+    p.items_a = p.tiles_m * p.tiles_n;
+    p.items_da = ((R + CB_M - 1) / CB_M) * nbt;
+    p.items_db = ((C + CB_M - 1) / CB_M) * nbt;
     contr_attr();
-    hipLaunchKernelGGL(contrastive_tile_kernel<1>, dim3(p.tiles_m * p.tiles_n), dim3(256), CT_LDS, s, p);
-    return vm_check_launch("vm_contrastive_bwd");
+    hipMemsetAsync(p.ctr, 0, w.nctr * 4, s);           // queue head, error word, row-block / column-block arrivals (a memset node under capture)
+    if (w.ldg != C) hipMemsetAsync(p.G, 0, (size_t)R * w.ldg * 2, s);      // ragged C: the pad columns of G are read as zeros
+    int grid = 2 * contr_num_cus();
+    const int total = p.items_a + p.items_da + p.items_db;
+    if (grid > total) grid = total;
+    VmProfScope prof(VM_FAM_LOSS, 6.0 * R * (double)C * D, s, "contrastive_bwd_R%d_C%d_D%d", R, C, D);
+    hipLaunchKernelGGL(contr_bwd_kernel, dim3(grid), dim3(256), CT_LDS_ALL, s, p);
+    return vm_check_launch("vm_contrastive_loss_bwd");
 }

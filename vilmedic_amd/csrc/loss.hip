@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void topk_threshold_kernel(const bf16_t* __res
             int acc = 0, b = 255;
             for (; b > 0; --b) { if (acc + (int)hist[b] >= want) break; acc += (int)hist[b]; }
             sel[0] = b; sel[1] = want - acc;
-            if (pass == 0) sel[2] = (acc + (int)hist[0] < want) ? 1 : 0;     // fewer than k live columns: keep everything (HF clamps top_k to the row)
+            if (pass == 0) sel[2] = (b == 0 && acc + (int)hist[0] < want) ? 1 : 0;     // fewer than k live columns: keep everything (HF clamps top_k to the row)
         }
         __syncthreads();
         if (pass == 0) want = sel[1];
