@@ -102,6 +102,30 @@ typedef struct {
 int vm_gemm_grouped(const vm_gemm_problem* problems, int n, int a_layout, int b_layout, int out_dtype /* VM_BF16 / VM_F32 */, int accumulate,
                     void* stream);
 
+/* ------------------------------------------------------------------ decode-step projections (M = batch x beams <= 256 rows)
+ * One launch per projection of a decoder layer with its neighbours folded in (csrc/decode_gemm.hip):
+ *   C[M,N] = act(LN(A)[M,K] . W[N,K]^T + bias) + residual
+ * LN (when ln_gamma is given): LayerNorm over K of A's rows, computed by every workgroup for its own row block while it loads the
+ * operand; the normalised rows are also written to ln_out (the residual input of the following sub-layer).  c2: output columns
+ * >= split_n go to c2[m, n - split_n] (ldc2) -- the fused Q|K|V projection writes K|V of the new token straight into its cache row.
+ * dtype VM_BF16: A, W, C, c2, residual, ln_out bf16 (fp32 accumulation, v_mfma_f32_16x16x32_bf16); VM_F32: everything fp32 on the
+ * exact f32-input MFMA.  bias, ln_gamma, ln_beta fp32.  Replaces per decode step hf:models/bert_generation/modeling_bert_generation.py:
+ * 60-106 (self/cross attention projections), :181-231 (output dense + LayerNorm), :264-358 (intermediate / output). */
+typedef struct {
+    int dtype;
+    const void* A; int64_t lda;
+    const void* W; int64_t ldw;
+    void* C; int64_t ldc;
+    void* c2; int64_t ldc2; int split_n;      /* second destination, or NULL */
+    int M, N, K;
+    const float* bias;                        /* [N] or NULL */
+    int act;                                  /* 0 none, 1 erf-GELU */
+    const void* residual; int64_t ldr;        /* [M,N] or NULL */
+    const float* ln_gamma; const float* ln_beta; float ln_eps;      /* NULL: A is used as it is */
+    void* ln_out; int64_t ln_out_ld;          /* [M,K] or NULL */
+} vm_decode_gemm_args;
+int vm_decode_gemm(const vm_decode_gemm_args* args, void* stream);
+
 /* ------------------------------------------------------------------ LayerNorm
  * hf:...bert_generation.py:49,55 (post-LN, eps from YAML), hf:models/vit/modeling_vit.py:261-262,348 (pre-LN).
  * y = (x-mean)*rstd*gamma+beta over the last dim; x,y bf16 [rows,cols]; mean/rstd fp32 [rows]. */

@@ -157,6 +157,59 @@ def test_decode_gemms_at_256_rows(N, K):
     assert e16 <= 8e-3 and e32 <= 2e-4
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+@pytest.mark.parametrize("M,N,K,mode", [(64, 2304, 768, "qkv"), (256, 2304, 768, "qkv"), (64, 768, 768, "ln"), (256, 3072, 768, "ln_gelu"),
+                                        (64, 768, 3072, "res"), (256, 768, 768, "res"), (5, 200, 128, "qkv"), (37, 136, 1024, "ln_gelu")])
+def test_decode_gemm_fused_features_vs_torch(dtype, M, N, K, mode):
+    """vm_decode_gemm (csrc/decode_gemm.hip): LayerNorm on load with the normalised rows written out, two destinations (Q | cache row with
+    its own leading dimension), erf-GELU, residual -- against fp32 torch on the same operands, in both step dtypes"""
+    import ctypes as C
+    from vilmedic_amd._lib import VM_BF16, VM_F32, DecodeGemmArgs, check, lib, stream
+    f32 = dtype == "fp32"
+    td = torch.float32 if f32 else BF
+    g = torch.Generator(device=dev()).manual_seed(M * 131 + N + K)
+    A = (torch.randn(M, K, generator=g, device=dev()) * 1.5 + 0.3).to(td)
+    W = (torch.randn(N, K, generator=g, device=dev()) * 0.05).to(td)
+    bias = torch.randn(N, generator=g, device=dev())
+    gam, bet = torch.randn(K, generator=g, device=dev()) * 0.2 + 1.0, torch.randn(K, generator=g, device=dev()) * 0.1
+    res = torch.randn(M, N, generator=g, device=dev()).to(td)
+    a = DecodeGemmArgs()
+    a.dtype = VM_F32 if f32 else VM_BF16
+    a.A, a.lda, a.W, a.ldw, a.M, a.N, a.K, a.bias = A.data_ptr(), K, W.data_ptr(), K, M, N, K, bias.data_ptr()
+    x_ref = A.float()
+    use_ln = mode in ("qkv", "ln", "ln_gelu")
+    ln_out = torch.zeros(M, K, dtype=td, device=dev())
+    if use_ln:
+        x_ref = torch.nn.functional.layer_norm(A.float(), (K,), gam, bet, 1e-5)
+        a.ln_gamma, a.ln_beta, a.ln_eps, a.ln_out, a.ln_out_ld = gam.data_ptr(), bet.data_ptr(), 1e-5, ln_out.data_ptr(), K
+        if not f32:
+            x_ref = x_ref.to(BF).float()                 # the bf16 step rounds the normalised rows (as its LayerNorm kernel's output did)
+    ref = x_ref @ W.float().t() + bias
+    split = (N // 3) // 4 * 4 if mode == "qkv" else 0
+    T_ld = 5 * (N - split) if split else 0               # the cache row's leading dimension: T x 2D
+    Cq = torch.full((M, N if not split else split), 7.0, dtype=td, device=dev())
+    Ckv = torch.full((M, max(T_ld, 1)), 7.0, dtype=td, device=dev())
+    a.C, a.ldc = Cq.data_ptr(), Cq.stride(0)
+    if split:
+        a.c2, a.ldc2, a.split_n = Ckv.data_ptr(), T_ld, split
+    if mode == "ln_gelu":
+        a.act = 1
+        ref = torch.nn.functional.gelu(ref)
+    if mode == "res":
+        a.residual, a.ldr = res.data_ptr(), N
+        ref = ref + res.float()
+    check(lib().vm_decode_gemm(C.byref(a), stream()), "vm_decode_gemm")
+    torch.cuda.synchronize()
+    got = torch.cat([Cq.float(), Ckv[:, :N - split].float()], 1) if split else Cq.float()
+    tol = 2e-4 if f32 else 2e-2
+    err = ((got - ref).abs() / (ref.abs() + 1.0)).max().item()
+    lerr = ((ln_out.float() - x_ref).abs().max().item() if use_ln else 0.0)
+    report(f"vm_decode_gemm {dtype} {M}x{N}x{K} {mode}", rel_err=err, ln_out_err=lerr)
+    assert err <= tol and lerr <= (1e-5 if f32 else 2e-2)
+    if split:
+        assert bool((Ckv[:, N - split:] == 7.0).all())    # nothing written past the K|V columns of the cache row
+
+
 # ------------------------------------------------------------------------------------------------------------ the benched model, end to end
 def test_bench_model_end_to_end_vs_oracle():
     """bench.build_model (ViT-B/16 encoder, 12-layer decoder, V = 30522; dropout switched off) at B = 2, L = 128: loss, logits and the

@@ -48,6 +48,13 @@ def main():
         if L.vm_prof_read(f, ctypes.byref(t), ctypes.byref(w), ctypes.byref(n)) == 0 and n.value:
             fam[name] = (round(t.value / 5, 4), n.value // 5)
             tot += t.value / 5
+    import tempfile
+    dump = os.path.join(tempfile.gettempdir(), "contr_prof.txt")
+    L.vm_prof_dump(dump.encode())
+    for line in open(dump):
+        f = line.split()
+        if len(f) >= 4 and f[1].startswith("contrastive"):
+            print(f"    {f[1]:40s} {float(f[3]) / float(f[2]) * 1e3:8.1f} us per launch ({int(float(f[2]))} launches)")
     flop = 6.0 * B * B * D
     print(f"contrastive B={B} D={D}: wall {wall:.3f} ms fwd+bwd (host-bound launches included); vmhip kernels {tot:.3f} ms {fam}; "
           f"algorithmic {flop * 1e-9:.1f} GFLOP -> {flop / tot * 1e-9:.1f} TFLOP/s = {flop / tot * 1e-9 / 2500:.3f} of the bf16 MFMA peak")

@@ -33,6 +33,13 @@ class GemmProblem(C.Structure):
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int)]
 
 
+class DecodeGemmArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("A", C.c_void_p), ("lda", C.c_int64), ("W", C.c_void_p), ("ldw", C.c_int64), ("C", C.c_void_p), ("ldc", C.c_int64),
+                ("c2", C.c_void_p), ("ldc2", C.c_int64), ("split_n", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("bias", C.c_void_p),
+                ("act", C.c_int), ("residual", C.c_void_p), ("ldr", C.c_int64), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
+                ("ln_out", C.c_void_p), ("ln_out_ld", C.c_int64)]
+
+
 class LnReduceProblem(C.Structure):
     _fields_ = [("ws", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int)]
 
@@ -97,6 +104,7 @@ SIGNATURES = {
     "vm_adam_step_dev": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _F, _F, _P, _P, _P, _P]),
     "vm_logsoftmax_f32": (_I, [_P, _L, _P, _I, _I, _P]),
     "vm_argmax_f32": (_I, [_P, _L, _P, _P, _I, _I, _P]),
+    "vm_decode_gemm": (_I, [C.POINTER(DecodeGemmArgs), _P]),
     "vm_gemm_f32": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _I, _P, _L, _P]),
     "vm_layernorm_f32": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "vm_embedding_fwd_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),

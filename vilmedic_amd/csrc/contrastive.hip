@@ -36,8 +36,8 @@ extern "C" int vm_rownorm_cast(const float* x, void* out_bf16, float* norms, int
 //                       arrival counters and the paired-diagonal buffer of the launch that follows
 //   contr_fwd_kernel    one workgroup per 128 x 128 tile of S = A^ B^^T * inv_tau (bf16 MFMA, fp32 accumulate, the tile staged in LDS
 //                       as fp32): per-row / per-column (max, sum exp) partials + the paired-diagonal entries; the workgroup that
-//                       ARRIVES LAST (agent-scope release -> ticket -> acquire, no spinning, no residency assumption) merges the
-//                       partials of every row and column into the log-sum-exps and writes the per-row losses
+//                       ARRIVES LAST on a row block / column block (agent-scope release -> ticket -> acquire, no spinning, no residency
+//                       assumption) merges the partials of those 128 rows / columns into the log-sum-exps and writes their losses
 //   contr_bwd_kernel    a persistent grid pulling work items from ONE device queue:
 //                         items [0, TA)   a recomputed S tile -> G = g_r softmax_row + g_c softmax_col - [paired](g_r + g_c) as bf16
 //                                         (8 MB at B = 2048: L2 / MALL resident), the partial sums p_i = sum_j G_ij S_ij and
@@ -74,6 +74,7 @@ struct ContrArgs {
     // backward
     const float* lse_r; const float* lse_c; const float* g_r; const float* g_c; bf16_t* G; int64_t ldg;
     float* p_part; float* q_part;                    // [tiles_n][R], [tiles_m][C]
+    float* p_sum; float* q_sum;                      // [R], [C]: the summed partials (written by the last arriver of a block)
     const float* a32; const float* b32; const float* na; const float* nb; float* da; float* db;
     int normalize, bn, items_a, items_da, items_db; float eps;
 };
@@ -116,7 +117,31 @@ __device__ __forceinline__ unsigned contr_ticket(unsigned* c) { return __hip_ato
 
 // acc = A^[m0.., :] B^[n0.., :]^T for one 128 x 128 tile (operands global -> registers -> LDS with a one-chunk software pipeline), then the
 // scaled tile staged in LDS as fp32 [128][CT_CS].  Ends with a barrier: every thread may read the whole tile.
-__device__ __forceinline__ void contr_s_tile(const ContrArgs& p, char* smem, int m0, int n0) {
+// 16-B load through an explicitly GLOBAL pointer: the pinned SGPR copies below lose their address space, and a flat load also counts in
+// lgkmcnt -- the waits in front of the MFMAs' LDS reads would then wait for the next chunk's operand prefetch as well
+__device__ __forceinline__ uint4 contr_ldg16(const void* q) {
+    typedef __attribute__((address_space(1))) const uint4_t gu4;
+    const uint4_t v = *(gu4*)(uint64_t)q;      // integer -> global pointer: no generic pointer in between
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+struct ContrOperands { const bf16_t* A; const bf16_t* B; int R, C, D; float inv_tau; };
+// wave-uniform values that arrive through a by-reference argument block (the noinline phase functions of the backward kernel): pulled
+// into SGPRs ONCE -- left in memory, hipcc re-loaded each field in front of every use (flat_load + s_waitcnt vmcnt(0) ahead of each operand
+// load of the K loop: four dependent round trips per K chunk, the 0.2 ms backward of the first version)
+// (the empty asm makes the SGPR copy an opaque definition: without it the compiler re-materialises the value from memory inside the loops)
+__device__ __forceinline__ int contr_uni(int v) { int u = __builtin_amdgcn_readfirstlane(v); asm volatile("" : "+s"(u)); return u; }
+__device__ __forceinline__ float contr_uni(float v) { return __uint_as_float((uint32_t)contr_uni((int)__float_as_uint(v))); }
+template <typename P> __device__ __forceinline__ P* contr_uni(P* q) {
+    const uint64_t v = (uint64_t)q;
+    const uint32_t lo = (uint32_t)contr_uni((int)(uint32_t)v), hi = (uint32_t)contr_uni((int)(uint32_t)(v >> 32));
+    return (P*)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ ContrOperands contr_operands(const ContrArgs& a) {
+    ContrOperands o;
+    o.A = contr_uni(a.A); o.B = contr_uni(a.B); o.R = contr_uni(a.R); o.C = contr_uni(a.C); o.D = contr_uni(a.D); o.inv_tau = contr_uni(a.inv_tau);
+    return o;
+}
+__device__ __forceinline__ void contr_s_tile(const ContrOperands p, char* smem, int m0, int n0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     float4_t acc[4][4];
 #pragma unroll
@@ -129,8 +154,8 @@ __device__ __forceinline__ void contr_s_tile(const ContrArgs& p, char* smem, int
         for (int i = 0; i < 4; ++i) {
             const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
             const int ga = m0 + row, gb = n0 + row, gk = k0 + ch * 8;
-            ra[i] = (ga < p.R && gk < p.D) ? *reinterpret_cast<const uint4*>(p.A + (int64_t)ga * p.D + gk) : make_uint4(0, 0, 0, 0);
-            rb[i] = (gb < p.C && gk < p.D) ? *reinterpret_cast<const uint4*>(p.B + (int64_t)gb * p.D + gk) : make_uint4(0, 0, 0, 0);
+            ra[i] = (ga < p.R && gk < p.D) ? contr_ldg16(p.A + (int64_t)ga * p.D + gk) : make_uint4(0, 0, 0, 0);
+            rb[i] = (gb < p.C && gk < p.D) ? contr_ldg16(p.B + (int64_t)gb * p.D + gk) : make_uint4(0, 0, 0, 0);
         }
     };
     auto store = [&](char* st) {
@@ -178,12 +203,43 @@ __device__ __forceinline__ void contr_s_tile(const ContrArgs& p, char* smem, int
     __syncthreads();
 }
 
+// log-sum-exp over the nt per-tile (max, sum exp) partials of row / column x: lse = M + log(sum_t s_t exp(m_t - M)).  Eight independent
+// 8-B loads in flight per step: the partials were written by other CUs (L2 misses), a dependent chain of nt loads cost ~0.7 us each.
+__device__ __forceinline__ float contr_merge_lse(const float* part, int64_t n, int x, int nt) {
+    float M = -INFINITY, L = 0.f;
+    for (int t0 = 0; t0 < nt; t0 += 8) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            v[u] = (t0 + u < nt) ? *reinterpret_cast<const float2*>(part + ((int64_t)(t0 + u) * n + x) * 2) : make_float2(-INFINITY, 0.f);
+        float m2 = M;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m2 = fmaxf(m2, v[u].x);
+        L *= __expf(M - m2);                      // (0 on the first step: M = -inf, m2 finite)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) L += v[u].y * __expf(v[u].x - m2);
+        M = m2;
+    }
+    return M + __logf(L);
+}
+__device__ __forceinline__ float contr_sum_parts(const float* part, int64_t n, int x, int nt) {
+    float s = 0.f;
+    for (int t0 = 0; t0 < nt; t0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (t0 + u < nt) ? part[(int64_t)(t0 + u) * n + x] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    return s;
+}
+
 __global__ __launch_bounds__(256, 2) void contr_fwd_kernel(const ContrArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x - tm * p.tiles_n;
     const int m0 = tm * CT, n0 = tn * CT;
-    contr_s_tile(p, smem, m0, n0);
+    contr_s_tile(contr_operands(p), smem, m0, n0);
     const float* cs = reinterpret_cast<const float*>(smem);
     const int rows = min(CT, p.R - m0), cols = min(CT, p.C - n0);
     if (tid < CT) {                        // threads 0..127: one row each
@@ -209,32 +265,30 @@ __global__ __launch_bounds__(256, 2) void contr_fwd_kernel(const ContrArgs p) {
             o[0] = mx; o[1] = se;
         }
     }
-    // ---- arrival; the last workgroup merges every row and column:  lse = M + log(sum_t s_t exp(m_t - M))
+    // ---- arrivals on the tile's row block and column block; the workgroup that completes a block merges ITS 128 rows (columns):
+    // 16 + 16 small merges spread over the chip instead of one workgroup walking all R + C partial lists
     unsigned* flag = reinterpret_cast<unsigned*>(smem + CT_ITEM_OFF);
     contr_publish();
     if (tid == 0) {
-        const unsigned t = contr_ticket(p.ctr);
-        const bool last = t == (unsigned)(p.tiles_m * p.tiles_n - 1);
-        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        *flag = last ? 1u : 0u;
+        const bool lastrow = contr_ticket(p.ctr + 4 + tm) == (unsigned)(p.tiles_n - 1);
+        const bool lastcol = contr_ticket(p.ctr + 4 + p.tiles_m + tn) == (unsigned)(p.tiles_m - 1);
+        if (lastrow || lastcol) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        flag[0] = lastrow ? 1u : 0u; flag[1] = lastcol ? 1u : 0u;
     }
     __syncthreads();
-    if (*flag == 0u) return;
-    for (int i = tid; i < p.R + p.C; i += 256) {
-        const bool isrow = i < p.R;
-        const int x = isrow ? i : i - p.R, n = isrow ? p.R : p.C, nt = isrow ? p.tiles_n : p.tiles_m;
-        const float* part = isrow ? p.row_part : p.col_part;
-        float M = -INFINITY;
-        for (int t = 0; t < nt; ++t) M = fmaxf(M, part[((int64_t)t * n + x) * 2]);
-        float L = 0.f;
-        for (int t = 0; t < nt; ++t) L += part[((int64_t)t * n + x) * 2 + 1] * __expf(part[((int64_t)t * n + x) * 2] - M);
-        const float lse = M + __logf(L);
-        if (isrow) {
+    if (tid < CT) {
+        const int x = m0 + tid;
+        if (flag[0] && x < p.R) {
+            const float lse = contr_merge_lse(p.row_part, p.R, x, p.tiles_n);
             p.lse_r_out[x] = lse;
             p.loss_r[x] = lse - p.diag[x];                        // (diag is 0 for a row without a paired column)
-        } else {
+        }
+    } else {
+        const int x = n0 + tid - CT;
+        if (flag[1] && x < p.C) {
+            const float lse = contr_merge_lse(p.col_part, p.C, x, p.tiles_m);
             p.lse_c_out[x] = lse;
-            const int pr = x - p.diag_offset;                     // the row this column is paired with
+            const int pr = x - p.diag_offset;                     // the row this column is paired with: its tile lies in this column block
             p.loss_c[x] = lse - ((pr >= 0 && pr < p.R) ? p.diag[pr] : 0.f);
         }
     }
@@ -266,10 +320,20 @@ __device__ __forceinline__ float quarters_sum(float v) {      // over lanes l, l
 }
 
 // phase A: one tile of G (+ the projection partials), then the arrivals on its row block and its column block
-__device__ __noinline__ void contr_g_tile(const ContrArgs& p, char* smem, int tm, int tn) {
+struct ContrGTile {         // the fields phase A uses, in SGPRs
+    int R, C, diag_offset, tiles_m, tiles_n; int64_t ldg;
+    const float* lse_r; const float* lse_c; const float* g_r; const float* g_c; bf16_t* G; float* p_part; float* q_part; float* p_sum; float* q_sum; unsigned* ctr;
+};
+__device__ __noinline__ void contr_g_tile(const ContrArgs& pa, char* smem, int tm, int tn) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = tm * CT, n0 = tn * CT;
-    contr_s_tile(p, smem, m0, n0);
+    const ContrOperands ops = contr_operands(pa);
+    ContrGTile p;
+    p.R = ops.R; p.C = ops.C; p.diag_offset = contr_uni(pa.diag_offset); p.tiles_m = contr_uni(pa.tiles_m); p.tiles_n = contr_uni(pa.tiles_n);
+    p.ldg = (int64_t)contr_uni((int)pa.ldg);
+    p.lse_r = contr_uni(pa.lse_r); p.lse_c = contr_uni(pa.lse_c); p.g_r = contr_uni(pa.g_r); p.g_c = contr_uni(pa.g_c); p.G = contr_uni(pa.G);
+    p.p_part = contr_uni(pa.p_part); p.q_part = contr_uni(pa.q_part); p.p_sum = contr_uni(pa.p_sum); p.q_sum = contr_uni(pa.q_sum); p.ctr = contr_uni(pa.ctr);
+    contr_s_tile(ops, smem, m0, n0);
     const float* cs = reinterpret_cast<const float*>(smem);
     float* red = reinterpret_cast<float*>(smem + CT_RED_OFF);
     const int rows = min(CT, p.R - m0), cols = min(CT, p.C - n0);
@@ -320,8 +384,26 @@ __device__ __noinline__ void contr_g_tile(const ContrArgs& p, char* smem, int tm
     }
     __syncthreads();
     if (tid < cols) p.q_part[(int64_t)tm * p.C + n0 + tid] = red[tid] + red[CT + tid] + red[2 * CT + tid] + red[3 * CT + tid];
+    // arrivals; the workgroup that completes a row block (column block) sums the block's projection partials in a fixed order and
+    // arrives once more: consumers wait for tiles + 1
+    unsigned* flag = reinterpret_cast<unsigned*>(smem + CT_ITEM_OFF) + 2;
     contr_publish();
-    if (tid == 0) { contr_ticket(p.ctr + 4 + tm); contr_ticket(p.ctr + 4 + p.tiles_m + tn); }
+    if (tid == 0) {
+        const bool lastrow = contr_ticket(p.ctr + 4 + tm) == (unsigned)(p.tiles_n - 1);
+        const bool lastcol = contr_ticket(p.ctr + 4 + p.tiles_m + tn) == (unsigned)(p.tiles_m - 1);
+        if (lastrow || lastcol) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        flag[0] = lastrow ? 1u : 0u; flag[1] = lastcol ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool lastrow = flag[0] != 0u, lastcol = flag[1] != 0u;
+    if (!lastrow && !lastcol) return;
+    if (tid < CT) { if (lastrow && m0 + tid < p.R) p.p_sum[m0 + tid] = contr_sum_parts(p.p_part, p.R, m0 + tid, p.tiles_n); }
+    else if (lastcol && n0 + tid - CT < p.C) p.q_sum[n0 + tid - CT] = contr_sum_parts(p.q_part, p.C, n0 + tid - CT, p.tiles_m);
+    contr_publish();
+    if (tid == 0) {
+        if (lastrow) contr_ticket(p.ctr + 4 + tm);
+        if (lastcol) contr_ticket(p.ctr + 4 + p.tiles_m + tn);
+    }
 }
 
 // phase B: out[m0.., n0..] (64 x BN, fp32) = sum_k P[m][k] X^[k][n] / tau, normalisation backward in the epilogue.
@@ -329,11 +411,14 @@ __device__ __noinline__ void contr_g_tile(const ContrArgs& p, char* smem, int tm
 // The product is formed transposed (A operand = X^ chunk read through ds_read_b64_tr_b16, rows = n; B operand = the G chunk, columns = m)
 // so that a lane ends with 4 consecutive n of one output row: 16-B stores.
 template <int NB, bool PT>
-__device__ __noinline__ void contr_grad_tile(const ContrArgs& p, char* smem, int m0, int n0) {
+__device__ __noinline__ void contr_grad_tile(const ContrArgs& pa, char* smem, int m0, int n0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave >> 1, wm = wave & 1;
     constexpr int BN = NB * 32;                       // NB 16-column blocks per wave x 2 waves
+    struct { int R, C, D, normalize; int64_t ldg; float inv_tau, eps; const bf16_t* G; } p;      // in SGPRs (see contr_uni)
+    p.R = contr_uni(pa.R); p.C = contr_uni(pa.C); p.D = contr_uni(pa.D); p.normalize = contr_uni(pa.normalize); p.ldg = (int64_t)contr_uni((int)pa.ldg);
+    p.inv_tau = contr_uni(pa.inv_tau); p.eps = contr_uni(pa.eps); p.G = contr_uni((const bf16_t*)pa.G);
     const int M = PT ? p.C : p.R, K = PT ? p.R : p.C;
-    const bf16_t* X = PT ? p.A : p.B;
+    const bf16_t* X = contr_uni(PT ? pa.A : pa.B);
     float4_t acc[NB][2];
 #pragma unroll
     for (int i = 0; i < NB; ++i) { acc[i][0] = (float4_t){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
@@ -344,13 +429,13 @@ __device__ __noinline__ void contr_grad_tile(const ContrArgs& p, char* smem, int
         for (int i = 0; i < 2; ++i) {
             const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
             const int gr = (PT ? k0 : m0) + row, gc = (PT ? m0 : k0) + ch * 8;     // G[gr][gc .. gc + 7]
-            rp[i] = (gr < p.R && gc < p.C) ? *reinterpret_cast<const uint4*>(p.G + (int64_t)gr * p.ldg + gc) : make_uint4(0, 0, 0, 0);
+            rp[i] = (gr < p.R && gc < p.C) ? contr_ldg16(p.G + (int64_t)gr * p.ldg + gc) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int id = tid + 256 * i, row = id / (BN / 8), ch = id - row * (BN / 8);
             const int gk = k0 + row, gn = n0 + ch * 8;
-            rq[i] = (gk < K && gn < p.D) ? *reinterpret_cast<const uint4*>(X + (int64_t)gk * p.D + gn) : make_uint4(0, 0, 0, 0);
+            rq[i] = (gk < K && gn < p.D) ? contr_ldg16(X + (int64_t)gk * p.D + gn) : make_uint4(0, 0, 0, 0);
         }
     };
     auto store = [&](char* st) {
@@ -394,11 +479,10 @@ __device__ __noinline__ void contr_grad_tile(const ContrArgs& p, char* smem, int
         __syncthreads();
     }
     // epilogue: lane holds out[m][n .. n + 3], m = m0 + wm 32 + j 16 + (lane & 15), n = n0 + wn BN/2 + i 16 + (lane >> 4) 4
-    const float* x32 = PT ? p.b32 : p.a32;
-    const float* nrm = PT ? p.nb : p.na;
-    const float* part = PT ? p.q_part : p.p_part;
-    const int nparts = PT ? p.tiles_m : p.tiles_n;
-    float* out = PT ? p.db : p.da;
+    const float* x32 = contr_uni(PT ? pa.b32 : pa.a32);
+    const float* nrm = contr_uni(PT ? pa.nb : pa.na);
+    const float* psum = contr_uni(PT ? pa.q_sum : pa.p_sum);
+    float* out = contr_uni(PT ? pa.db : pa.da);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int m = m0 + wm * 32 + j * 16 + (lane & 15);
@@ -406,7 +490,7 @@ __device__ __noinline__ void contr_grad_tile(const ContrArgs& p, char* smem, int
         float proj = 0.f, d = 1.f;
         bool unit = false;
         if (p.normalize) {
-            for (int t = 0; t < nparts; ++t) proj += part[(int64_t)t * M + m];
+            proj = psum[m];
             const float nm = nrm[m];
             d = fmaxf(nm, p.eps);
             unit = nm > p.eps;
@@ -454,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void contr_bwd_kernel(const ContrArgs p) {
         // wait for the G tiles this item contracts over: ONE lane polls ONE word (relaxed, agent scope), then ONE acquire
         if (tid == 0) {
             unsigned* flag = p.ctr + 4 + (isb ? p.tiles_m : 0) + m0 / CT;
-            const unsigned need = (unsigned)(isb ? p.tiles_m : p.tiles_n);
+            const unsigned need = (unsigned)(isb ? p.tiles_m : p.tiles_n) + 1u;       // every tile of the block + the projection sums
             unsigned spins = 0;
             while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
                 __builtin_amdgcn_s_sleep(8);
@@ -491,8 +575,8 @@ static int contr_num_cus() {
     return n;
 }
 // workspace layout (bytes, every block 256-B aligned): counters | diag [R] | row_part [tn][R][2] | col_part [tm][C][2] | p_part [tn][R] |
-// q_part [tm][C] | G bf16 [R][ldg]
-struct ContrWs { size_t ctr, nctr, diag, row_part, col_part, p_part, q_part, G, total; int64_t ldg; };
+// q_part [tm][C] | p_sum [R] | q_sum [C] | G bf16 [R][ldg]
+struct ContrWs { size_t ctr, nctr, diag, row_part, col_part, p_part, q_part, p_sum, q_sum, G, total; int64_t ldg; };
 static ContrWs contr_ws_layout(int R, int C) {
     const size_t tm = (R + CT - 1) / CT, tn = (C + CT - 1) / CT;
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
@@ -505,7 +589,9 @@ static ContrWs contr_ws_layout(int R, int C) {
     w.col_part = w.row_part + up(tn * (size_t)R * 8);
     w.p_part = w.col_part + up(tm * (size_t)C * 8);
     w.q_part = w.p_part + up(tn * (size_t)R * 4);
-    w.G = w.q_part + up(tm * (size_t)C * 4);
+    w.p_sum = w.q_part + up(tm * (size_t)C * 4);
+    w.q_sum = w.p_sum + up((size_t)R * 4);
+    w.G = w.q_sum + up((size_t)C * 4);
     w.total = w.G + up((size_t)R * w.ldg * 2);
     return w;
 }
@@ -517,6 +603,7 @@ static void contr_fill(ContrArgs& p, const void* ah, const void* bh, int R, int 
     p.ctr = (unsigned*)(ws + w.ctr); p.diag = (float*)(ws + w.diag);
     p.row_part = (float*)(ws + w.row_part); p.col_part = (float*)(ws + w.col_part);
     p.p_part = (float*)(ws + w.p_part); p.q_part = (float*)(ws + w.q_part);
+    p.p_sum = (float*)(ws + w.p_sum); p.q_sum = (float*)(ws + w.q_sum);
     p.G = (bf16_t*)(ws + w.G); p.ldg = w.ldg;
 }
 

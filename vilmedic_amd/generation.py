@@ -13,18 +13,21 @@ MI355X-first differences (same results, different data flow):
   * a beam reorder never copies the self-attention KV cache (HF: hf:generation/utils.py:3478-3485): the attention
     kernel gathers keys through a small int32 row-index table, and reordering gathers that table;
   * K|V of the new token are written straight into the cache by the projection GEMM (strided output);
-  * the ~170 kernel launches of one decode step are captured into a HIP graph per position (the step is launch-bound:
-    M = batch x beams rows), and the decode state -- caches, cross K|V buffers, graphs -- is kept on the decoder and
-    reused by later generate() calls of the same shape (VM_DECODE_GRAPH=0 turns both off).
+  * a decoder layer is 8 launches per step -- fused Q|K|V projection (LayerNorm of the previous sub-layer on load, Q to its buffer,
+    K|V into the cache row), attention, output projection + residual, cross-Q (LayerNorm on load), cross-attention, output
+    projection + residual, MLP up (LayerNorm on load, GELU), MLP down + residual (csrc/decode_gemm.hip; round 2: 12) -- and the
+    ~100 launches of a step are captured into a HIP graph per position (the step is launch-bound: M = batch x beams rows); the decode
+    state -- caches, cross K|V buffers, graphs -- is kept on the decoder and reused by later generate() calls of the same shape
+    (VM_DECODE_GRAPH=0 turns both off).
 """
-import ctypes as C
+import ctypes as C_
 import os
 import weakref
 
 import torch
 
 from . import ops
-from ._lib import check, lib, ptr, stream
+from ._lib import VM_BF16, VM_F32, DecodeGemmArgs, check, lib, ptr, stream
 from .arena import arena_of
 from .nn import to_key_mask
 
@@ -110,6 +113,11 @@ class DecodeState:
         self.tok = torch.zeros(self.M, dtype=torch.long, device=dev)
         self.V = cfg.vocab_size
         self.emb_sh = self.arena.shadow_rows(decoder.bert.embeddings.word_embeddings.weight, decoder.padded_vocab)
+        # the step's activations (static: their addresses are baked into the captured graphs): pre-LN running sum, its LayerNorm (the
+        # residual), the attention queries, the MLP hidden
+        ff = max(l.intermediate.dense.weight.shape[0] for l in self.layers)
+        self.buf_s, self.buf_x, self.buf_q = (torch.empty(self.M, self.D, dtype=self.act, device=dev) for _ in range(3))
+        self.buf_h = torch.empty(self.M, ff, dtype=self.act, device=dev)
         self.graphs = {}
         self.load_encoder(enc, enc_mask)
 
@@ -159,81 +167,77 @@ class DecodeState:
         entry[0].replay()
         return entry[1]
 
-    def _step_f32(self, tokens, t):
-        """the step below with every tensor and every product in fp32 (csrc/decode_f32.hip); same data flow: K|V of the new token
-        written straight into the cache by the projection, keys gathered through the row-index table, cross K|V shared by beams"""
-        a, cfg, D, H, M, T = self.arena, self.cfg, self.D, self.H, self.M, self.T
-        emb = self.dec.bert.embeddings
-        dev = tokens.device
-        x = torch.empty(M, D, dtype=F32, device=dev)
-        check(lib().vm_embedding_fwd_f32(ptr(tokens.contiguous()), ptr(emb.word_embeddings.weight), ptr(emb.position_embeddings.weight),
-                                         ptr(x), M, 1, D, t, stream()), "vm_embedding_fwd_f32")
-        x = _ln32(x, emb.LayerNorm, cfg.layer_norm_eps)
-        q = torch.empty(M, D, dtype=F32, device=dev)
-        s = torch.empty(M, D, dtype=F32, device=dev)
-        for li, layer in enumerate(self.layers):
-            sa = layer.attention.self
-            _gemm32(x, sa.query.weight, sa.query.bias, q, M, D, D)
-            cache = self.self_kv[li]
-            _gemm32(x, a.f32_group([sa.key.weight, sa.value.weight]), a.f32_group([sa.key.bias, sa.value.bias]), cache[t:], M, 2 * D, D,
-                    ldc=T * 2 * D)
-            ctx = _attn32(q, cache, 2 * D, cache[:, D:], 2 * D, M, H, t + 1, D // H, 1, kv_index=self.index, kv_index_ld=T)
-            blk = layer.attention.output
-            _gemm32(ctx, blk.dense.weight, blk.dense.bias, s, M, D, D, residual=x)
-            x = _ln32(s, blk.LayerNorm, cfg.layer_norm_eps)
-            ca = layer.crossattention.self
-            _gemm32(x, ca.query.weight, ca.query.bias, q, M, D, D)
-            kv = self.cross_kv[li]
-            ctx = _attn32(q, kv, 2 * D, kv[:, D:], 2 * D, M, H, self.S, D // H, self.nb, key_mask=self.enc_mask)
-            blk = layer.crossattention.output
-            _gemm32(ctx, blk.dense.weight, blk.dense.bias, s, M, D, D, residual=x)
-            x = _ln32(s, blk.LayerNorm, cfg.layer_norm_eps)
-            i, o = layer.intermediate.dense, layer.output.dense
-            F = i.weight.shape[0]
-            h = torch.empty(M, F, dtype=F32, device=dev)
-            _gemm32(x, i.weight, i.bias, h, M, F, D, act=1)
-            _gemm32(h, o.weight, o.bias, s, M, D, F, residual=x)
-            x = _ln32(s, layer.output.LayerNorm, cfg.layer_norm_eps)
-        V = self.V
-        logits = torch.empty(M, (V + 3) // 4 * 4, dtype=F32, device=dev)
-        _gemm32(x, emb.word_embeddings.weight, self.dec.lm_head.bias, logits, M, V, D)
-        return logits[:, :V]
+    # ---- one decode step = embedding + 8 launches per layer + final LayerNorm + LM head (csrc/decode_gemm.hip: every LayerNorm but the
+    # last is computed by the projection that consumes it, Q|K|V is one projection with two destinations)
+    def _w(self, params):
+        """the [N, K] operand of one weight or of an arena-adjacent group, in the step's dtype (fp32 masters / bf16 shadows)"""
+        a = self.arena
+        if len(params) == 1:
+            return params[0] if self.f32 else a.shadow(params[0])
+        return a.f32_group(params) if self.f32 else a.shadow_group(params)
+
+    def _dg(self, A, W, C, M, N, K, *, bias=None, act=0, residual=None, ln=None, ln_out=None, c2=None, ldc2=0, split_n=0):
+        g = DecodeGemmArgs()
+        g.dtype = VM_F32 if self.f32 else VM_BF16
+        g.A, g.lda, g.W, g.ldw, g.C, g.ldc = A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0), C.data_ptr(), C.stride(0)
+        g.M, g.N, g.K, g.act = M, N, K, act
+        g.bias = bias.data_ptr() if bias is not None else None
+        if residual is not None:
+            g.residual, g.ldr = residual.data_ptr(), residual.stride(0)
+        if c2 is not None:
+            g.c2, g.ldc2, g.split_n = c2.data_ptr(), ldc2, split_n
+        if ln is not None:
+            g.ln_gamma, g.ln_beta, g.ln_eps = ln.weight.data_ptr(), ln.bias.data_ptr(), self.cfg.layer_norm_eps
+            if ln_out is not None:
+                g.ln_out, g.ln_out_ld = ln_out.data_ptr(), ln_out.stride(0)
+        check(lib().vm_decode_gemm(C_.byref(g), stream()), "vm_decode_gemm")
 
     def _step(self, tokens, t):
-        if self.f32:
-            return self._step_f32(tokens, t)
         a, cfg, D, H, M, T = self.arena, self.cfg, self.D, self.H, self.M, self.T
         emb = self.dec.bert.embeddings
-        x = torch.empty(M, D, dtype=BF16, device=tokens.device)
-        check(lib().vm_embedding_fwd(ptr(tokens.contiguous()), ptr(emb.word_embeddings.weight), ptr(emb.position_embeddings.weight),
-                                     ptr(x), M, 1, D, t, stream()), "vm_embedding_fwd")
-        x = _ln(x, emb.LayerNorm, cfg.layer_norm_eps)
+        s, x, q = self.buf_s, self.buf_x, self.buf_q
+        fn = lib().vm_embedding_fwd_f32 if self.f32 else lib().vm_embedding_fwd
+        check(fn(ptr(tokens.contiguous()), ptr(emb.word_embeddings.weight), ptr(emb.position_embeddings.weight), ptr(s), M, 1, D, t, stream()),
+              "vm_embedding_fwd")
+        ln = emb.LayerNorm                       # the LayerNorm that turns the running pre-LN sum ``s`` into the next sub-layer's input
         for li, layer in enumerate(self.layers):
             sa = layer.attention.self
-            q = torch.empty(M, D, dtype=BF16, device=x.device)
-            ops.gemm(x, 0, a.shadow(sa.query.weight), 0, q, M, D, D, bias=sa.query.bias)
             cache = self.self_kv[li]
-            ops.gemm(x, 0, a.shadow_group([sa.key.weight, sa.value.weight]), 0, cache[t:], M, 2 * D, D, ldc=T * 2 * D,
-                     bias=a.f32_group([sa.key.bias, sa.value.bias]))
-            ctx = _attn(q, D, cache, 2 * D, cache[:, D:], 2 * D, M, H, 1, t + 1, D // H, kv_index=self.index, kv_index_ld=T)
+            if getattr(sa, "fuse_q", False):     # Q|K|V in one launch: Q -> q, K|V of the new token -> cache row t
+                self._dg(s, self._w([sa.query.weight, sa.key.weight, sa.value.weight]), q, M, 3 * D, D,
+                         bias=a.f32_group([sa.query.bias, sa.key.bias, sa.value.bias]), ln=ln, ln_out=x, c2=cache[t:], ldc2=T * 2 * D, split_n=D)
+            else:
+                self._dg(s, self._w([sa.query.weight]), q, M, D, D, bias=sa.query.bias, ln=ln, ln_out=x)
+                self._dg(x, self._w([sa.key.weight, sa.value.weight]), cache[t:].as_strided((M, 2 * D), (T * 2 * D, 1)), M, 2 * D, D,
+                         bias=a.f32_group([sa.key.bias, sa.value.bias]))
+            if self.f32:
+                ctx = _attn32(q, cache, 2 * D, cache[:, D:], 2 * D, M, H, t + 1, D // H, 1, kv_index=self.index, kv_index_ld=T)
+            else:
+                ctx = _attn(q, D, cache, 2 * D, cache[:, D:], 2 * D, M, H, 1, t + 1, D // H, kv_index=self.index, kv_index_ld=T)
             blk = layer.attention.output
-            s = torch.empty(M, D, dtype=BF16, device=x.device)
-            ops.gemm(ctx, 0, a.shadow(blk.dense.weight), 0, s, M, D, D, bias=blk.dense.bias, residual=x)
-            x = _ln(s, blk.LayerNorm, cfg.layer_norm_eps)
+            self._dg(ctx, self._w([blk.dense.weight]), s, M, D, D, bias=blk.dense.bias, residual=x)
             ca = layer.crossattention.self
-            ops.gemm(x, 0, a.shadow(ca.query.weight), 0, q, M, D, D, bias=ca.query.bias)
+            self._dg(s, self._w([ca.query.weight]), q, M, D, D, bias=ca.query.bias, ln=blk.LayerNorm, ln_out=x)
             kv = self.cross_kv[li]
-            ctx = _attn(q, D, kv, 2 * D, kv[:, D:], 2 * D, self.B, H, self.nb, self.S, D // H, key_mask=self.enc_mask)
+            if self.f32:
+                ctx = _attn32(q, kv, 2 * D, kv[:, D:], 2 * D, M, H, self.S, D // H, self.nb, key_mask=self.enc_mask)
+            else:
+                ctx = _attn(q, D, kv, 2 * D, kv[:, D:], 2 * D, self.B, H, self.nb, self.S, D // H, key_mask=self.enc_mask)
             blk = layer.crossattention.output
-            ops.gemm(ctx, 0, a.shadow(blk.dense.weight), 0, s, M, D, D, bias=blk.dense.bias, residual=x)
-            x = _ln(s, blk.LayerNorm, cfg.layer_norm_eps)
+            self._dg(ctx, self._w([blk.dense.weight]), s, M, D, D, bias=blk.dense.bias, residual=x)
             i, o = layer.intermediate.dense, layer.output.dense
             F = i.weight.shape[0]
-            h = torch.empty(M, F, dtype=BF16, device=x.device)
-            ops.gemm(x, 0, a.shadow(i.weight), 0, h, M, F, D, bias=i.bias, act=1)
-            ops.gemm(h, 0, a.shadow(o.weight), 0, s, M, D, F, bias=o.bias, residual=x)
-            x = _ln(s, layer.output.LayerNorm, cfg.layer_norm_eps)
-        return ops.lm_logits_f32(x, self.emb_sh, self.dec.lm_head.bias, self.V)
+            h = self.buf_h
+            self._dg(s, self._w([i.weight]), h, M, F, D, bias=i.bias, act=1, ln=blk.LayerNorm, ln_out=x)
+            self._dg(h, self._w([o.weight]), s, M, D, F, bias=o.bias, residual=x)
+            ln = layer.output.LayerNorm
+        if self.f32:
+            xl = _ln32(s, ln, cfg.layer_norm_eps)
+            V = self.V
+            logits = torch.empty(M, (V + 3) // 4 * 4, dtype=F32, device=s.device)
+            _gemm32(xl, emb.word_embeddings.weight, self.dec.lm_head.bias, logits, M, V, D)
+            return logits[:, :V]
+        return ops.lm_logits_f32(_ln(s, ln, cfg.layer_norm_eps), self.emb_sh, self.dec.lm_head.bias, self.V)
 
 
 class EnsembleState:
