@@ -126,6 +126,17 @@ typedef struct {
 } vm_decode_gemm_args;
 int vm_decode_gemm(const vm_decode_gemm_args* args, void* stream);
 
+/* Token selection of one decode step in one launch (csrc/decode_select.hip; hf:generation/utils.py _sample :2783-2975 with
+ * NoBadWordsLogitsProcessor + TopKLogitsWarper, as driven by ref:vilmedic/blocks/rl/SCST.py:112-174 and
+ * ref:vilmedic/blocks/huggingface/decoder/evaluation.py:73-78).  logits fp32 [rows, ldl].  Rows < greedy_rows: arg-max of the raw logits
+ * (lowest index among ties).  Other rows: banned columns (<= 4, a HOST array) removed, logits below the top_k-th largest live one removed
+ * (0 = no filter, ties kept, top_k <= 256), one draw from the softmax of what is left by Gumbel-max with a counter-based hash of
+ * (seed, cur, row, column).  unfinished (uint8 [rows], may be NULL): finished rows emit ``pad``; a row that emits ``eos`` becomes finished.
+ * next_tokens int64 [rows]; seq (may be NULL): seq[row, cur] = the token. */
+int vm_select_tokens(const float* logits, int64_t ldl, int rows, int V, int greedy_rows, const int32_t* banned, int n_banned, int top_k,
+                     uint64_t seed, int64_t* next_tokens, int64_t* seq, int64_t ld_seq, int cur, uint8_t* unfinished, int eos, int pad,
+                     void* stream);
+
 /* ------------------------------------------------------------------ LayerNorm
  * hf:...bert_generation.py:49,55 (post-LN, eps from YAML), hf:models/vit/modeling_vit.py:261-262,348 (pre-LN).
  * y = (x-mean)*rstd*gamma+beta over the last dim; x,y bf16 [rows,cols]; mean/rstd fp32 [rows]. */

@@ -210,6 +210,60 @@ def test_decode_gemm_fused_features_vs_torch(dtype, M, N, K, mode):
         assert bool((Ckv[:, N - split:] == 7.0).all())    # nothing written past the K|V columns of the cache row
 
 
+@pytest.mark.parametrize("V,top_k,ties", [(1000, 20, False), (30522, 20, False), (30522, 0, False), (500, 7, True), (97, 50, False)])
+def test_select_tokens_greedy_rows_and_sampling_distribution(V, top_k, ties):
+    """vm_select_tokens (csrc/decode_select.hip): greedy rows = torch.argmax of the raw logits; sampled rows never leave the bad-word +
+    top-k filtered set (HF: NoBadWordsLogitsProcessor, TopKLogitsWarper keeps ties at the k-th value) and their frequencies follow the
+    softmax of the filtered logits (Gumbel-max is an exact sampler: 4 sigma of the binomial over 16384 draws); finished rows emit pad,
+    rows that draw eos become finished, the tokens land in seq[:, cur]."""
+    import ctypes as C
+    from vilmedic_amd._lib import check, lib, ptr, stream
+    g = torch.Generator().manual_seed(V + top_k)
+    N, G = 16384, 8
+    base = torch.randn(V, generator=g) * 2.0
+    if ties:
+        base = torch.randint(0, 6, (V,), generator=g).float()          # ~V/6 copies of each value: the k-th value is heavily tied
+    logits = base[None, :].repeat(N + G, 1).contiguous()
+    logits[:G] = torch.randn(G, V, generator=g)                         # the greedy rows get their own logits
+    logits[1, 17] = logits[1, 3] = logits[1].max() + 1.0                # a tie for the arg-max: lowest index wins
+    ld = logits.to(dev())
+    banned = [1, 0]
+    ban = (C.c_int32 * 4)(*(banned + [0, 0]))
+    nxt = torch.empty(N + G, dtype=torch.long, device=dev())
+    seq = torch.full((N + G, 6), -1, dtype=torch.long, device=dev())
+    unf = torch.ones(N + G, dtype=torch.uint8, device=dev())
+    unf[G + 5] = 0
+    eos, pad = 2, 1
+    check(lib().vm_select_tokens(ptr(ld), V, N + G, V, G, ban, 2, top_k, 12345, ptr(nxt), ptr(seq), 6, 3, ptr(unf), eos, pad, stream()), "vm_select_tokens")
+    torch.cuda.synchronize()
+    nx, un = nxt.cpu(), unf.cpu()
+    assert torch.equal(seq[:, 3].cpu(), nx) and bool((seq[:, [0, 1, 2, 4, 5]] == -1).all())
+    assert torch.equal(nx[:G], logits[:G].argmax(-1)) and nx[1].item() == 3
+    assert nx[G + 5].item() == pad and un[G + 5].item() == 0
+    live = torch.ones(N + G, dtype=torch.bool); live[G + 5] = False
+    assert torch.equal(un.bool(), live & (nx != eos))
+    filt = base.clone()
+    filt[banned] = -float("inf")
+    if top_k and top_k < V - 2:
+        kth = filt.topk(top_k)[0][-1]
+        filt[filt < kth] = -float("inf")
+    probs = torch.softmax(filt, -1)
+    draws = torch.cat([nx[G:G + 5], nx[G + 6:]])
+    assert bool((probs[draws] > 0).all()), "a sampled token lies outside the filtered set"
+    freq = torch.bincount(draws, minlength=V).float() / draws.numel()
+    sigma = (probs * (1 - probs) / draws.numel()).sqrt()
+    z = ((freq - probs).abs() / sigma.clamp_min(1e-9))[probs > 0]
+    report(f"vm_select_tokens V={V} top_k={top_k} ties={ties}", kept=int((probs > 0).sum()), max_z=z.max().item(), max_abs=(freq - probs).abs().max().item())
+    assert z.max().item() <= 4.5
+    # a different seed / step draws differently, the same one reproduces
+    nxt2 = torch.empty_like(nxt)
+    check(lib().vm_select_tokens(ptr(ld), V, N + G, V, G, ban, 2, top_k, 12345, ptr(nxt2), None, 0, 3, None, eos, pad, stream()), "vm_select_tokens")
+    nxt3 = torch.empty_like(nxt)
+    check(lib().vm_select_tokens(ptr(ld), V, N + G, V, G, ban, 2, top_k, 12345, ptr(nxt3), None, 0, 4, None, eos, pad, stream()), "vm_select_tokens")
+    torch.cuda.synchronize()
+    assert torch.equal(nxt2.cpu()[G:G + 5], nx[G:G + 5]) and not torch.equal(nxt3.cpu()[G:], nxt2.cpu()[G:])
+
+
 # ------------------------------------------------------------------------------------------------------------ the benched model, end to end
 def test_bench_model_end_to_end_vs_oracle():
     """bench.build_model (ViT-B/16 encoder, 12-layer decoder, V = 30522; dropout switched off) at B = 2, L = 128: loss, logits and the

@@ -148,32 +148,29 @@ __device__ __forceinline__ void contr_s_tile(const ContrOperands p, char* smem, 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-    uint4 ra[4], rb[4];
-    auto load = [&](int k0) {
+    // Operand chunks travel global -> registers -> LDS (two LDS stages).  TWO chunks are in flight in registers (sets 0 / 1): chunk
+    // kt + 2 is requested at the top of iteration kt and stored to LDS at the end of iteration kt + 1 -- the kernel is bound by the
+    // latency of these requests (a 64-deep chunk of MFMAs is 0.2 us, an L2 / MALL round trip 1 us), one chunk in flight cost 1 us per chunk
+    uint4 ra[2][4], rb[2][4];
+    auto load = [&](int set, int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
             const int ga = m0 + row, gb = n0 + row, gk = k0 + ch * 8;
-            ra[i] = (ga < p.R && gk < p.D) ? contr_ldg16(p.A + (int64_t)ga * p.D + gk) : make_uint4(0, 0, 0, 0);
-            rb[i] = (gb < p.C && gk < p.D) ? contr_ldg16(p.B + (int64_t)gb * p.D + gk) : make_uint4(0, 0, 0, 0);
+            ra[set][i] = (ga < p.R && gk < p.D) ? contr_ldg16(p.A + (int64_t)ga * p.D + gk) : make_uint4(0, 0, 0, 0);
+            rb[set][i] = (gb < p.C && gk < p.D) ? contr_ldg16(p.B + (int64_t)gb * p.D + gk) : make_uint4(0, 0, 0, 0);
         }
     };
-    auto store = [&](char* st) {
+    auto store = [&](int set, char* st) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
-            *reinterpret_cast<uint4*>(st + row * (CT_KS * 2) + ch * 16) = ra[i];
-            *reinterpret_cast<uint4*>(st + CT * CT_KS * 2 + row * (CT_KS * 2) + ch * 16) = rb[i];
+            *reinterpret_cast<uint4*>(st + row * (CT_KS * 2) + ch * 16) = ra[set][i];
+            *reinterpret_cast<uint4*>(st + CT * CT_KS * 2 + row * (CT_KS * 2) + ch * 16) = rb[set][i];
         }
     };
-    const int ktiles = (p.D + 63) / 64;
-    load(0);
-    store(smem);
-    __syncthreads();
-    for (int kt = 0; kt < ktiles; ++kt) {
-        const char* sa = smem + (kt & 1) * (2 * CT * CT_KS * 2);
+    auto mma_chunk = [&](const char* sa) {
         const char* sb = sa + CT * CT_KS * 2;
-        if (kt + 1 < ktiles) load((kt + 1) * 64);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             c_bf16x8_t fa[4], fb[4];
@@ -187,7 +184,24 @@ __device__ __forceinline__ void contr_s_tile(const ContrOperands p, char* smem, 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < ktiles) store(smem + ((kt + 1) & 1) * (2 * CT * CT_KS * 2));
+    };
+    const int ktiles = (p.D + 63) / 64;
+    constexpr int STG = 2 * CT * CT_KS * 2;
+    load(0, 0);
+    if (ktiles > 1) load(1, 64);
+    store(0, smem);
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; kt += 2) {
+        // even chunk kt (LDS stage 0): set 0 is free (stored), set 1 holds chunk kt + 1
+        if (kt + 2 < ktiles) load(0, (kt + 2) * 64);
+        mma_chunk(smem);
+        if (kt + 1 < ktiles) store(1, smem + STG);
+        __syncthreads();
+        if (kt + 1 >= ktiles) break;
+        // odd chunk kt + 1 (LDS stage 1): set 1 is free, set 0 holds chunk kt + 2
+        if (kt + 3 < ktiles) load(1, (kt + 3) * 64);
+        mma_chunk(smem + STG);
+        if (kt + 2 < ktiles) store(0, smem);
         __syncthreads();
     }
     // stage S tile (fp32, scaled): C/D layout col = lane & 15, row = (lane >> 4) * 4 + reg

@@ -183,32 +183,75 @@ struct AttnF32Args {
     int rows, H, Lk, dh, q_per_kv; float scale;
 };
 
+// Round 3: K and V reach the wave through LDS in 64-key tiles -- every lane requests dh / 4 consecutive 16-B pieces of the tile
+// (coalesced: dh / 4 lanes per key row, all requests of a tile in flight together, the next tile requested before the current one is
+// used) -- instead of one lane walking a whole key row (QK^T: 16 dependent-stride loads per key per lane) and 8 keys per memory round
+// trip in P.V (25 round trips for the 197 image keys): 27 us -> the traffic's own time per launch.  The arithmetic and its ORDER are
+// unchanged (a lane accumulates one key's dot product over d = 0 .. dh - 1, one output column over the keys in order), so the
+// results are bit-identical to the round-2 kernel.
+#define AF_TS 64                      // keys per tile
+template <int N4>                     // N4 = dh / 4 pieces per key row
+__device__ __forceinline__ void af32_request(const float* base, int64_t ld, const int* ro, int j0, int Lk, int lane, float4 (&r)[N4]) {
+#pragma unroll
+    for (int u = 0; u < N4; ++u) {
+        const int f = lane + 64 * u, kk = f / N4, c4 = f - kk * N4;
+        const int j = j0 + kk;
+        r[u] = j < Lk ? *reinterpret_cast<const float4*>(base + (int64_t)ro[j] * ld + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <int N4>
+__device__ __forceinline__ void af32_stage(float* tile, int lane, const float4 (&r)[N4]) {
+    constexpr int TS = 4 * N4 + 4;    // padded row: lane l reads row l at 16-B steps -> 4 l (mod 64) words apart: conflict-free
+#pragma unroll
+    for (int u = 0; u < N4; ++u) {
+        const int f = lane + 64 * u, kk = f / N4, c4 = f - kk * N4;
+        *reinterpret_cast<float4*>(tile + kk * TS + 4 * c4) = r[u];
+    }
+}
+
+template <int N4>
 __global__ __launch_bounds__(64) void attn_decode_f32_kernel(const AttnF32Args p) {
-    extern __shared__ float sc[];                 // [Lk8] scores, then probabilities (zero past Lk); [Lk8] key-row numbers; [dh] query
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [64][dh + 4] tile | [Lk8] scores -> probabilities | [Lk8] key rows | [dh] query
+    constexpr int DH = 4 * N4, TS = DH + 4;
     const int lane = threadIdx.x;
     const int r = blockIdx.x / p.H, h = blockIdx.x - r * p.H;
     const int kvb = r / p.q_per_kv;
     const int Lk8 = (p.Lk + 7) & ~7;
+    float* tile = sm;
+    float* sc = sm + AF_TS * TS;
     int* ro = reinterpret_cast<int*>(sc + Lk8);
     float* qs = sc + 2 * Lk8;
-    const float* qr = p.q + (int64_t)r * p.ldq + h * p.dh;
-    for (int d = lane; d < p.dh; d += 64) qs[d] = qr[d];
+    const float* qr = p.q + (int64_t)r * p.ldq + h * DH;
+    for (int d = lane; d < DH; d += 64) qs[d] = qr[d];
+    for (int j = lane; j < Lk8; j += 64) ro[j] = j >= p.Lk ? 0 : (p.kv_index ? p.kv_index[(int64_t)r * p.kv_index_ld + j] : kvb * p.Lk + j);
     __syncthreads();
+    const int ntiles = (p.Lk + AF_TS - 1) / AF_TS;
+    float4 cur[N4], nxt[N4];
+    // ---- scores
+    const float* kb = p.k + h * DH;
+    af32_request<N4>(kb, p.ldk, ro, 0, p.Lk, lane, cur);
     float mx = -INFINITY;
-    for (int j = lane; j < Lk8; j += 64) {
-        if (j >= p.Lk) { sc[j] = -INFINITY; ro[j] = 0; continue; }
-        const int row = p.kv_index ? p.kv_index[(int64_t)r * p.kv_index_ld + j] : kvb * p.Lk + j;
-        ro[j] = row;                                                       // the P.V pass reads it from LDS: no dependent index load there
-        const float* kr = p.k + (int64_t)row * p.ldk + h * p.dh;
-        float s = 0.f;
-        for (int d = 0; d < p.dh; d += 4) {
-            const float4 kk = *reinterpret_cast<const float4*>(kr + d);
-            s = fmaf(qs[d], kk.x, s); s = fmaf(qs[d + 1], kk.y, s); s = fmaf(qs[d + 2], kk.z, s); s = fmaf(qs[d + 3], kk.w, s);
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) af32_request<N4>(kb, p.ldk, ro, (t + 1) * AF_TS, p.Lk, lane, nxt);
+        af32_stage<N4>(tile, lane, cur);
+        __syncthreads();
+        const int j = t * AF_TS + lane;
+        if (j < Lk8) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < DH; d += 4) {
+                const float4 kk = *reinterpret_cast<const float4*>(tile + lane * TS + d);
+                s = fmaf(qs[d], kk.x, s); s = fmaf(qs[d + 1], kk.y, s); s = fmaf(qs[d + 2], kk.z, s); s = fmaf(qs[d + 3], kk.w, s);
+            }
+            s *= p.scale;
+            if (j >= p.Lk) s = -INFINITY;
+            else if (p.key_mask && !p.key_mask[(int64_t)kvb * p.Lk + j]) s += -3.4028234663852886e38f;
+            sc[j] = s;
+            mx = fmaxf(mx, s);
         }
-        s *= p.scale;
-        if (p.key_mask && !p.key_mask[(int64_t)kvb * p.Lk + j]) s += -3.4028234663852886e38f;
-        sc[j] = s;
-        mx = fmaxf(mx, s);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < N4; ++u) cur[u] = nxt[u];
     }
     mx = wave_max(mx);
     float se = 0.f;
@@ -216,20 +259,46 @@ __global__ __launch_bounds__(64) void attn_decode_f32_kernel(const AttnF32Args p
     se = wave_sum(se);
     __syncthreads();
     const float inv = 1.0f / se;
-    // P.V with the lanes over the head dimension: 8 keys' V values requested before the 8 multiply-adds (the serial form paid one
-    // L2 round trip per key: 197 in a row for cross-attention); the accumulation order over the keys is unchanged
-    for (int d = lane; d < p.dh; d += 64) {
-        const float* vb = p.v + h * p.dh + d;
-        float acc = 0.f;
-        for (int j0 = 0; j0 < Lk8; j0 += 8) {
-            float v[8];
+    // ---- P.V: lane d (and d + 64 for wider heads) accumulates its output column over the keys in order
+    const float* vb = p.v + h * DH;
+    constexpr int ND = (DH + 63) / 64;
+    float acc[ND];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = vb[(int64_t)ro[j0 + u] * p.ldv];
+    for (int i = 0; i < ND; ++i) acc[i] = 0.f;
+    af32_request<N4>(vb, p.ldv, ro, 0, p.Lk, lane, cur);
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) af32_request<N4>(vb, p.ldv, ro, (t + 1) * AF_TS, p.Lk, lane, nxt);
+        af32_stage<N4>(tile, lane, cur);
+        __syncthreads();
+        const int nk = min(AF_TS, Lk8 - t * AF_TS);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = fmaf(sc[j0 + u], v[u], acc);
+        for (int i = 0; i < ND; ++i) {
+            const int d = lane + 64 * i;
+            if (d < DH) {
+                float a = acc[i];
+                for (int kk = 0; kk < nk; ++kk) a = fmaf(sc[t * AF_TS + kk], tile[kk * TS + d], a);
+                acc[i] = a;
+            }
         }
-        p.o[(int64_t)r * p.ldo + h * p.dh + d] = acc * inv;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < N4; ++u) cur[u] = nxt[u];
     }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int d = lane + 64 * i;
+        if (d < DH) p.o[(int64_t)r * p.ldo + h * DH + d] = acc[i] * inv;
+    }
+}
+template <int N4>
+static void af32_launch(const AttnF32Args& a, hipStream_t s) {
+    const size_t lds = (size_t)(AF_TS * (4 * N4 + 4) + 2 * ((a.Lk + 7) & ~7) + 4 * N4) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && lds > 65536) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_decode_f32_kernel<N4>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_decode_f32_kernel<N4>, dim3((unsigned)(a.rows * a.H)), dim3(64), lds, s, a);
 }
 extern "C" int vm_attention_decode_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                                        float* o, int64_t ldo, const uint8_t* key_mask, const int32_t* kv_row_index, int64_t kv_index_ld,
@@ -240,6 +309,12 @@ extern "C" int vm_attention_decode_f32(const float* q, int64_t ldq, const float*
     AttnF32Args a = {q, k, v, o, key_mask, kv_row_index, ldq, ldk, ldv, ldo, kv_index_ld, rows, H, Lk, dh, q_per_kv, scale};
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_DECODE, 4.0 * rows * H * (double)Lk * dh, s, "attn_f32_r%d_H%d_Lk%d", rows, H, Lk);
-    hipLaunchKernelGGL(attn_decode_f32_kernel, dim3((unsigned)(rows * H)), dim3(64), (size_t)(2 * ((Lk + 7) & ~7) + dh) * sizeof(float), s, a);
+    switch (dh) {
+        case 32: af32_launch<8>(a, s); break;
+        case 64: af32_launch<16>(a, s); break;
+        case 96: af32_launch<24>(a, s); break;
+        case 128: af32_launch<32>(a, s); break;
+        default: vm_set_error("vm_attention_decode_f32: head dim %d (32, 64, 96 or 128)", dh); return VM_EUNSUPPORTED;
+    }
     return vm_check_launch("vm_attention_decode_f32");
 }

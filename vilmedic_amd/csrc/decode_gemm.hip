@@ -104,6 +104,20 @@ __global__ __launch_bounds__(DG_NW * 64) void decode_gemm_kernel(const DgArgs p)
                 for (int i = 0; i < MF; ++i) af[d][i] = lda(i, ks0 + d);
             }
         }
+        // gamma / beta of the wave's K slice, requested together with the operands (one memory round trip for everything the kernel reads)
+        float gam[S][T::PER_LANE], bet[S][T::PER_LANE];
+#pragma unroll
+        for (int d = 0; d < S; ++d) {
+            if (ks0 + d < ks1) {
+                const int k = (ks0 + d) * T::STEP + g * T::PER_LANE;
+#pragma unroll
+                for (int e = 0; e < T::PER_LANE; e += 4) {
+                    const float4 gv = *reinterpret_cast<const float4*>(p.ln_gamma + k + e), bv = *reinterpret_cast<const float4*>(p.ln_beta + k + e);
+                    gam[d][e] = gv.x; gam[d][e + 1] = gv.y; gam[d][e + 2] = gv.z; gam[d][e + 3] = gv.w;
+                    bet[d][e] = bv.x; bet[d][e + 1] = bv.y; bet[d][e + 2] = bv.z; bet[d][e + 3] = bv.w;
+                }
+            }
+        }
         // ---- LayerNorm statistics of the block's rows: pass 1 mean, pass 2 centred variance (both over all 8 waves through LDS)
         float mean[MF], rstd[MF];
 #pragma unroll
@@ -142,15 +156,12 @@ __global__ __launch_bounds__(DG_NW * 64) void decode_gemm_kernel(const DgArgs p)
         for (int d = 0; d < S; ++d) {
             if (ks0 + d < ks1) {
                 const int k = (ks0 + d) * T::STEP + g * T::PER_LANE;
-                float gam[T::PER_LANE], bet[T::PER_LANE];
-#pragma unroll
-                for (int e = 0; e < T::PER_LANE; ++e) { gam[e] = p.ln_gamma[k + e]; bet[e] = p.ln_beta[k + e]; }
 #pragma unroll
                 for (int i = 0; i < MF; ++i) {
                     float v[T::PER_LANE];
                     T::unpack(af[d][i], v);
 #pragma unroll
-                    for (int e = 0; e < T::PER_LANE; ++e) v[e] = (v[e] - mean[i]) * rstd[i] * gam[e] + bet[e];
+                    for (int e = 0; e < T::PER_LANE; ++e) v[e] = (v[e] - mean[i]) * rstd[i] * gam[d][e] + bet[d][e];
                     af[d][i] = T::pack(v);
                     const int gm = m0 + 16 * i + c;
                     if (p.ln_out && blockIdx.x == 0 && gm < p.M)
@@ -244,9 +255,11 @@ static int dg_dispatch(const DgArgs& a, int mf, hipStream_t s) {
     switch (mf) {
         case 1: return dg_launch<F32, 1, LN>(a, s);
         case 2: return dg_launch<F32, 2, LN>(a, s);
-        case 4: return dg_launch<F32, 4, LN>(a, s);
+        case 4:
+            if constexpr (LN) return dg_launch<F32, 2, LN>(a, s);
+            else return dg_launch<F32, 4, LN>(a, s);
         default:
-            if constexpr (LN && F32) return dg_launch<F32, 4, LN>(a, s);       // (fp32 + LN keeps 8 k-steps of every fragment resident: <= 64 rows)
+            if constexpr (LN) return dg_launch<F32, 2, LN>(a, s);       // (LN keeps the whole K slice of every fragment + gamma / beta resident)
             else return dg_launch<F32, 8, LN>(a, s);
     }
 }
@@ -263,13 +276,13 @@ extern "C" int vm_decode_gemm(const vm_decode_gemm_args* x, void* stream) {
     VM_REQUIRE(x->act == 0 || x->act == 1, "vm_decode_gemm: act must be 0 or 1 (erf-GELU)");
     VM_REQUIRE(!x->c2 || (x->split_n > 0 && x->split_n < x->N && (x->split_n % 4) == 0 && ((uintptr_t)x->c2 % 8) == 0), "vm_decode_gemm: bad second destination");
     const bool ln = x->ln_gamma != nullptr;
-    VM_REQUIRE(!ln || (x->ln_beta && x->K <= 1024 && (!x->ln_out || ((x->ln_out_ld % al) == 0 && ((uintptr_t)x->ln_out % 16) == 0))),
+    VM_REQUIRE(!ln || (x->ln_beta && x->K <= 1024 && ((uintptr_t)x->ln_gamma % 16) == 0 && ((uintptr_t)x->ln_beta % 16) == 0 && (!x->ln_out || ((x->ln_out_ld % al) == 0 && ((uintptr_t)x->ln_out % 16) == 0))),
                "vm_decode_gemm: LayerNorm-on-load needs beta, K <= 1024 and an aligned ln_out");
     DgArgs a = {x->A, x->W, x->C, x->c2, x->bias, x->residual, x->ln_gamma, x->ln_beta, x->ln_out,
                 x->lda, x->ldw, x->ldc, x->ldc2, x->ldr, x->ln_out_ld, x->M, x->N, x->K, x->act, x->split_n, x->ln_eps};
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_DECODE, 2.0 * x->M * (double)x->N * x->K, s, "dg_%s_M%d_N%d_K%d_ln%d", f32 ? "f32" : "bf16", x->M, x->N, x->K, (int)ln);
-    const int mf = vm_skinny_rows_per_wg(x->M, x->N, (ln && f32) ? 4 : 8);       // rows per workgroup: at least one workgroup per CU (gemm_skinny.hip)
+    const int mf = vm_skinny_rows_per_wg(x->M, x->N, ln ? 2 : 8);       // rows per workgroup: at least one workgroup per CU (gemm_skinny.hip)
     if (f32) return ln ? dg_dispatch<true, true>(a, mf, s) : dg_dispatch<true, false>(a, mf, s);
     return ln ? dg_dispatch<false, true>(a, mf, s) : dg_dispatch<false, false>(a, mf, s);
 }

@@ -319,6 +319,9 @@ def _process(logits, bad_ids, top_k):
     return logits
 
 
+_select_calls = [0]
+
+
 @torch.no_grad()
 def trim_to_last_eos(seq, eos_token_id):
     """HF's stopping point for a finished batch: generation ends right after the step at which its last row emitted eos"""
@@ -339,11 +342,32 @@ def sample(decoder, input_ids, enc, enc_mask, *, max_length, eos_token_id, pad_t
     dev = enc0.device
     seq = torch.full((B, max_length), pad_token_id, dtype=torch.long, device=dev)
     seq[:, 0] = input_ids[:, 0]
-    unfinished = torch.ones(B, dtype=torch.bool, device=dev)
     bad = [w[0] for w in (bad_words_ids or [])]
     scores = []
     cur = 1
-    while cur < max_length:
+    fused = not output_scores and len(bad) <= 4 and (do_sample or not bad) and not (top_k and top_k > 256)
+    if fused:
+        # one selection launch per step (csrc/decode_select.hip): arg-max / filtered draw, finished-row padding, the write into ``seq``
+        V = decoder.config.vocab_size
+        g_rows = (int(greedy_rows) if greedy_rows else 0) if do_sample else B
+        unf = torch.ones(B, dtype=torch.uint8, device=dev)
+        nxt = torch.empty(B, dtype=torch.long, device=dev)
+        ban = (C_.c_int32 * 4)(*(bad + [0] * (4 - len(bad)))) if bad else None
+        # the draws follow torch's seeding (torch.manual_seed / an explicit CPU generator) through ONE host-side draw per call
+        gen = generator if (generator is not None and generator.device.type == "cpu") else None
+        seed = int(torch.randint(0, 2 ** 62, (1,), generator=gen).item()) if do_sample else 0
+        if generator is not None and generator.device.type != "cpu":
+            seed = (int(generator.initial_seed()) * 0x9E3779B1 + _select_calls[0]) & (2 ** 63 - 1)
+            _select_calls[0] += 1
+        while cur < max_length:
+            logits = st.step(seq[:, cur - 1], cur - 1)
+            check(lib().vm_select_tokens(ptr(logits), logits.stride(0), B, V, g_rows, ban, len(bad), int(top_k or 0) if do_sample else 0, seed, ptr(nxt),
+                                         ptr(seq), seq.stride(0), cur, ptr(unf), eos_token_id, pad_token_id, stream()), "vm_select_tokens")
+            cur += 1
+            if cur % 8 == 0 and not bool(unf.any()):           # host sync only every 8 steps; trimmed exactly below
+                break
+    unfinished = torch.ones(B, dtype=torch.bool, device=dev)
+    while not fused and cur < max_length:
         logits = st.step(seq[:, cur - 1], cur - 1)
         if do_sample and greedy_rows:
             g = int(greedy_rows)
@@ -431,7 +455,11 @@ def beam_search(decoder, input_ids, enc, enc_mask, *, max_length, eos_token_id, 
         best_possible = running_scores[:, :1] / ((cur - prompt) ** length_penalty)
         worst_fin = torch.where(finished, beam_scores.min(1, keepdim=True)[0], torch.full_like(beam_scores, -1e9))
         unsat = unsat & (best_possible > worst_fin).any(-1, keepdim=True)
-        if not (bool(unsat.any()) and not bool(hits.all())):
+        # HF stops as soon as no row can improve.  A step taken after that point changes nothing that is returned (a finished candidate is
+        # only accepted while its row is unsatisfied: fin_lp gets -1e9 otherwise, and seqs[:, 0] / seq_len[:, 0] keep the best finished
+        # hypothesis), so the host reads the flag every 4th step only -- a read per step left the ~40 selection launches of the next step
+        # un-enqueued until the GPU had drained.  The last position always ends the loop.
+        if cur + 1 > max_length or ((cur - prompt) % 4 == 0 and not bool(unsat.any())):
             break
     out_len = prompt + int(seq_len[:, 0].max())
     return GenerateOutput(seqs[:, 0, :out_len], beam_scores[:, 0])
