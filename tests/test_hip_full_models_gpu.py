@@ -252,9 +252,9 @@ def test_select_tokens_greedy_rows_and_sampling_distribution(V, top_k, ties):
     assert bool((probs[draws] > 0).all()), "a sampled token lies outside the filtered set"
     freq = torch.bincount(draws, minlength=V).float() / draws.numel()
     sigma = (probs * (1 - probs) / draws.numel()).sqrt()
-    z = ((freq - probs).abs() / sigma.clamp_min(1e-9))[probs > 0]
+    z = ((freq - probs).abs() / sigma.clamp_min(1e-9))[probs * draws.numel() >= 10]      # (a normal test needs an expected count; rare tokens: max_abs)
     report(f"vm_select_tokens V={V} top_k={top_k} ties={ties}", kept=int((probs > 0).sum()), max_z=z.max().item(), max_abs=(freq - probs).abs().max().item())
-    assert z.max().item() <= 4.5
+    assert z.max().item() <= 4.5 and (freq - probs).abs().max().item() <= 2e-2
     # a different seed / step draws differently, the same one reproduces
     nxt2 = torch.empty_like(nxt)
     check(lib().vm_select_tokens(ptr(ld), V, N + G, V, G, ban, 2, top_k, 12345, ptr(nxt2), None, 0, 3, None, eos, pad, stream()), "vm_select_tokens")

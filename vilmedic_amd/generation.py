@@ -118,6 +118,7 @@ class DecodeState:
         ff = max(l.intermediate.dense.weight.shape[0] for l in self.layers)
         self.buf_s, self.buf_x, self.buf_q = (torch.empty(self.M, self.D, dtype=self.act, device=dev) for _ in range(3))
         self.buf_h = torch.empty(self.M, ff, dtype=self.act, device=dev)
+        self.buf_stat = torch.empty(2 * self.M, dtype=torch.float32, device=dev)
         self.graphs = {}
         self.load_encoder(enc, enc_mask)
 
@@ -192,6 +193,20 @@ class DecodeState:
                 g.ln_out, g.ln_out_ld = ln_out.data_ptr(), ln_out.stride(0)
         check(lib().vm_decode_gemm(C_.byref(g), stream()), "vm_decode_gemm")
 
+    def _dgl(self, s, ln, x, W, C, M, N, K, **kw):
+        """projection of LN(s), with x = LN(s) kept for the residual.  Up to 64 rows the LayerNorm rides on the projection's operand load
+        (one launch); beyond (beams x batch = 256) a workgroup would have to keep 8+ row fragments x the whole K slice resident, the fused
+        kernel falls back to 32-row blocks that re-stream the weights 8 times, and the separate LayerNorm launch is cheaper (measured:
+        beam-4 step 3.8 ms fused vs 2.1 ms)."""
+        if M <= 64:
+            return self._dg(s, W, C, M, N, K, ln=ln, ln_out=x, **kw)
+        if self.f32:
+            check(lib().vm_layernorm_f32(ptr(s), ptr(ln.weight), ptr(ln.bias), ptr(x), M, K, self.cfg.layer_norm_eps, stream()), "vm_layernorm_f32")
+        else:
+            check(lib().vm_layernorm_fwd(ptr(s), ptr(ln.weight), ptr(ln.bias), ptr(x), ptr(self.buf_stat), ptr(self.buf_stat[M:]), M, K,
+                                         self.cfg.layer_norm_eps, stream()), "vm_layernorm_fwd")
+        return self._dg(x, W, C, M, N, K, **kw)
+
     def _step(self, tokens, t):
         a, cfg, D, H, M, T = self.arena, self.cfg, self.D, self.H, self.M, self.T
         emb = self.dec.bert.embeddings
@@ -204,10 +219,10 @@ class DecodeState:
             sa = layer.attention.self
             cache = self.self_kv[li]
             if getattr(sa, "fuse_q", False):     # Q|K|V in one launch: Q -> q, K|V of the new token -> cache row t
-                self._dg(s, self._w([sa.query.weight, sa.key.weight, sa.value.weight]), q, M, 3 * D, D,
-                         bias=a.f32_group([sa.query.bias, sa.key.bias, sa.value.bias]), ln=ln, ln_out=x, c2=cache[t:], ldc2=T * 2 * D, split_n=D)
+                self._dgl(s, ln, x, self._w([sa.query.weight, sa.key.weight, sa.value.weight]), q, M, 3 * D, D,
+                          bias=a.f32_group([sa.query.bias, sa.key.bias, sa.value.bias]), c2=cache[t:], ldc2=T * 2 * D, split_n=D)
             else:
-                self._dg(s, self._w([sa.query.weight]), q, M, D, D, bias=sa.query.bias, ln=ln, ln_out=x)
+                self._dgl(s, ln, x, self._w([sa.query.weight]), q, M, D, D, bias=sa.query.bias)
                 self._dg(x, self._w([sa.key.weight, sa.value.weight]), cache[t:].as_strided((M, 2 * D), (T * 2 * D, 1)), M, 2 * D, D,
                          bias=a.f32_group([sa.key.bias, sa.value.bias]))
             if self.f32:
@@ -217,7 +232,7 @@ class DecodeState:
             blk = layer.attention.output
             self._dg(ctx, self._w([blk.dense.weight]), s, M, D, D, bias=blk.dense.bias, residual=x)
             ca = layer.crossattention.self
-            self._dg(s, self._w([ca.query.weight]), q, M, D, D, bias=ca.query.bias, ln=blk.LayerNorm, ln_out=x)
+            self._dgl(s, blk.LayerNorm, x, self._w([ca.query.weight]), q, M, D, D, bias=ca.query.bias)
             kv = self.cross_kv[li]
             if self.f32:
                 ctx = _attn32(q, kv, 2 * D, kv[:, D:], 2 * D, M, H, self.S, D // H, self.nb, key_mask=self.enc_mask)
@@ -228,7 +243,7 @@ class DecodeState:
             i, o = layer.intermediate.dense, layer.output.dense
             F = i.weight.shape[0]
             h = self.buf_h
-            self._dg(s, self._w([i.weight]), h, M, F, D, bias=i.bias, act=1, ln=blk.LayerNorm, ln_out=x)
+            self._dgl(s, blk.LayerNorm, x, self._w([i.weight]), h, M, F, D, bias=i.bias, act=1)
             self._dg(h, self._w([o.weight]), s, M, D, F, bias=o.bias, residual=x)
             ln = layer.output.LayerNorm
         if self.f32:
