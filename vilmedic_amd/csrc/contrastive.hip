@@ -124,12 +124,6 @@ __device__ __forceinline__ uint4 contr_ldg16(const void* q) {
     const uint4_t v = *(gu4*)(uint64_t)q;      // integer -> global pointer: no generic pointer in between
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
-// predicated form: out-of-range lanes re-read a valid address and zero the result -- a plain load, no branch around it
-__device__ __forceinline__ uint4 contr_ldg16z(const void* q, const void* safe, bool ok) {
-    uint4 v = contr_ldg16(ok ? q : safe);
-    if (!ok) v = make_uint4(0, 0, 0, 0);
-    return v;
-}
 struct ContrOperands { const bf16_t* A; const bf16_t* B; int R, C, D; float inv_tau; };
 // wave-uniform values that arrive through a by-reference argument block (the noinline phase functions of the backward kernel): pulled
 // into SGPRs ONCE -- left in memory, hipcc re-loaded each field in front of every use (flat_load + s_waitcnt vmcnt(0) ahead of each operand
@@ -154,29 +148,32 @@ __device__ __forceinline__ void contr_s_tile(const ContrOperands p, char* smem, 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-    // Operand chunks travel global -> registers -> LDS (two LDS stages).  TWO chunks are in flight in registers (sets 0 / 1): chunk
-    // kt + 2 is requested at the top of iteration kt and stored to LDS at the end of iteration kt + 1 -- the kernel is bound by the
-    // latency of these requests (a 64-deep chunk of MFMAs is 0.2 us, an L2 / MALL round trip 1 us), one chunk in flight cost 1 us per chunk
-    uint4 ra[2][4], rb[2][4];
-    auto load = [&](int set, int k0) {
+    uint4 ra[4], rb[4];
+    auto load = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
             const int ga = m0 + row, gb = n0 + row, gk = k0 + ch * 8;
-            ra[set][i] = contr_ldg16z(p.A + (int64_t)ga * p.D + gk, p.A, ga < p.R && gk < p.D);
-            rb[set][i] = contr_ldg16z(p.B + (int64_t)gb * p.D + gk, p.B, gb < p.C && gk < p.D);
+            ra[i] = (ga < p.R && gk < p.D) ? contr_ldg16(p.A + (int64_t)ga * p.D + gk) : make_uint4(0, 0, 0, 0);
+            rb[i] = (gb < p.C && gk < p.D) ? contr_ldg16(p.B + (int64_t)gb * p.D + gk) : make_uint4(0, 0, 0, 0);
         }
     };
-    auto store = [&](int set, char* st) {
+    auto store = [&](char* st) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
-            *reinterpret_cast<uint4*>(st + row * (CT_KS * 2) + ch * 16) = ra[set][i];
-            *reinterpret_cast<uint4*>(st + CT * CT_KS * 2 + row * (CT_KS * 2) + ch * 16) = rb[set][i];
+            *reinterpret_cast<uint4*>(st + row * (CT_KS * 2) + ch * 16) = ra[i];
+            *reinterpret_cast<uint4*>(st + CT * CT_KS * 2 + row * (CT_KS * 2) + ch * 16) = rb[i];
         }
     };
-    auto mma_chunk = [&](const char* sa) {
+    const int ktiles = (p.D + 63) / 64;
+    load(0);
+    store(smem);
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const char* sa = smem + (kt & 1) * (2 * CT * CT_KS * 2);
         const char* sb = sa + CT * CT_KS * 2;
+        if (kt + 1 < ktiles) load((kt + 1) * 64);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             c_bf16x8_t fa[4], fb[4];
@@ -190,24 +187,7 @@ __device__ __forceinline__ void contr_s_tile(const ContrOperands p, char* smem, 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-    };
-    const int ktiles = (p.D + 63) / 64;
-    constexpr int STG = 2 * CT * CT_KS * 2;
-    load(0, 0);
-    if (ktiles > 1) load(1, 64);
-    store(0, smem);
-    __syncthreads();
-    for (int kt = 0; kt < ktiles; kt += 2) {
-        // even chunk kt (LDS stage 0): set 0 is free (stored), set 1 holds chunk kt + 1
-        if (kt + 2 < ktiles) load(0, (kt + 2) * 64);
-        mma_chunk(smem);
-        if (kt + 1 < ktiles) store(1, smem + STG);
-        __syncthreads();
-        if (kt + 1 >= ktiles) break;
-        // odd chunk kt + 1 (LDS stage 1): set 1 is free, set 0 holds chunk kt + 2
-        if (kt + 3 < ktiles) load(1, (kt + 3) * 64);
-        mma_chunk(smem + STG);
-        if (kt + 2 < ktiles) store(0, smem);
+        if (kt + 1 < ktiles) store(smem + ((kt + 1) & 1) * (2 * CT * CT_KS * 2));
         __syncthreads();
     }
     // stage S tile (fp32, scaled): C/D layout col = lane & 15, row = (lane >> 4) * 4 + reg
@@ -442,36 +422,44 @@ __device__ __noinline__ void contr_grad_tile(const ContrArgs& pa, char* smem, in
     float4_t acc[NB][2];
 #pragma unroll
     for (int i = 0; i < NB; ++i) { acc[i][0] = (float4_t){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
-    uint4 rp[2][2], rq[2][NB];            // two chunks in flight in registers (see contr_s_tile)
+    uint4 rp[2], rq[NB];
     // G chunk: 64 x 64 elements = 512 16-B pieces (2 per thread); operand chunk: 64 x BN = 8 NB x 64 pieces (NB per thread)
-    auto load = [&](int set, int k0) {
+    auto load = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
             const int gr = (PT ? k0 : m0) + row, gc = (PT ? m0 : k0) + ch * 8;     // G[gr][gc .. gc + 7]
-            rp[set][i] = contr_ldg16z(p.G + (int64_t)gr * p.ldg + gc, p.G, gr < p.R && gc < p.C);
+            rp[i] = (gr < p.R && gc < p.C) ? contr_ldg16(p.G + (int64_t)gr * p.ldg + gc) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int id = tid + 256 * i, row = id / (BN / 8), ch = id - row * (BN / 8);
             const int gk = k0 + row, gn = n0 + ch * 8;
-            rq[set][i] = contr_ldg16z(X + (int64_t)gk * p.D + gn, X, gk < K && gn < p.D);
+            rq[i] = (gk < K && gn < p.D) ? contr_ldg16(X + (int64_t)gk * p.D + gn) : make_uint4(0, 0, 0, 0);
         }
     };
-    auto store = [&](int set, char* st) {
+    auto store = [&](char* st) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
-            *reinterpret_cast<uint4*>(st + row * (CB_PS * 2) + ch * 16) = rp[set][i];
+            *reinterpret_cast<uint4*>(st + row * (CB_PS * 2) + ch * 16) = rp[i];
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int id = tid + 256 * i, row = id / (BN / 8), ch = id - row * (BN / 8);
-            *reinterpret_cast<uint4*>(st + CB_M * CB_PS * 2 + row * (CB_QS * 2) + ch * 16) = rq[set][i];
+            *reinterpret_cast<uint4*>(st + CB_M * CB_PS * 2 + row * (CB_QS * 2) + ch * 16) = rq[i];
         }
     };
-    auto mma_chunk = [&](const char* sp) {
+    // (the tail of G past the row's C columns is never read as data: pieces are guarded by gc < C, and ldg >= C rounded to 8 with the
+    //  phase-A tile writing only columns < C -- the last piece of a row may hold up to 7 stale bf16 values when C % 8 != 0, so zero them)
+    const int ktiles = (K + 63) / 64;
+    load(0);
+    store(smem);
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const char* sp = smem + (kt & 1) * CB_STAGE;
         const char* sq = sp + CB_M * CB_PS * 2;
+        if (kt + 1 < ktiles) load((kt + 1) * 64);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             c_bf16x8_t fq[NB], fp[2];
@@ -487,22 +475,7 @@ __device__ __noinline__ void contr_grad_tile(const ContrArgs& pa, char* smem, in
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[i], fp[j], acc[i][j], 0, 0, 0);
         }
-    };
-    // (the pad columns of G past C are zero: phase A writes only columns < C and the launch function zero-fills G when C % 8 != 0)
-    const int ktiles = (K + 63) / 64;
-    load(0, 0);
-    if (ktiles > 1) load(1, 64);
-    store(0, smem);
-    __syncthreads();
-    for (int kt = 0; kt < ktiles; kt += 2) {
-        if (kt + 2 < ktiles) load(0, (kt + 2) * 64);
-        mma_chunk(smem);
-        if (kt + 1 < ktiles) store(1, smem + CB_STAGE);
-        __syncthreads();
-        if (kt + 1 >= ktiles) break;
-        if (kt + 3 < ktiles) load(1, (kt + 3) * 64);
-        mma_chunk(smem + CB_STAGE);
-        if (kt + 2 < ktiles) store(0, smem);
+        if (kt + 1 < ktiles) store(smem + ((kt + 1) & 1) * CB_STAGE);
         __syncthreads();
     }
     // epilogue: lane holds out[m][n .. n + 3], m = m0 + wm 32 + j 16 + (lane & 15), n = n0 + wn BN/2 + i 16 + (lane >> 4) 4
