@@ -264,6 +264,31 @@ def test_select_tokens_greedy_rows_and_sampling_distribution(V, top_k, ties):
     assert torch.equal(nxt2.cpu()[G:G + 5], nx[G:G + 5]) and not torch.equal(nxt3.cpu()[G:], nxt2.cpu()[G:])
 
 
+@pytest.mark.parametrize("B,nb,V", [(64, 4, 30522), (5, 4, 97), (3, 8, 1000), (7, 1, 513)])
+def test_beam_topk_equals_logsoftmax_plus_torch_topk(B, nb, V):
+    """vm_beam_topk against the path it replaces -- vm_logsoftmax_f32, + running scores, torch.topk(2 * num_beams) over (beam, token):
+    the same values bit for bit (the kernel restates the log-softmax kernel's arithmetic) and the same flat indices, in the same order"""
+    from vilmedic_amd._lib import check, lib, ptr, stream
+    from vilmedic_amd.generation import log_softmax_f32
+    g = torch.Generator(device=dev()).manual_seed(B * 7 + nb)
+    ldl = (V + 3) // 4 * 4
+    logits = torch.randn(B * nb, ldl, generator=g, device=dev()) * 3.0
+    scores = torch.randn(B, nb, generator=g, device=dev()) * 2.0
+    scores[:, 1:] -= 1.0
+    if nb > 1:
+        scores[0, 1:] = -1e9                                   # the first step of a beam search
+    keep = 2 * nb
+    val = torch.empty(B, keep, dtype=torch.float32, device=dev())
+    idx = torch.empty(B, keep, dtype=torch.long, device=dev())
+    check(lib().vm_beam_topk(ptr(logits), ldl, B, nb, V, ptr(scores), keep, ptr(val), ptr(idx), stream()), "vm_beam_topk")
+    ref = (log_softmax_f32(logits[:, :V].contiguous()).view(B, nb, V) + scores[:, :, None]).view(B, nb * V)
+    rv, ri = torch.topk(ref, keep)
+    torch.cuda.synchronize()
+    assert torch.equal(val, rv), (val - rv).abs().max()
+    assert torch.equal(idx, ri)
+    report(f"vm_beam_topk B={B} beams={nb} V={V}", keep=keep)
+
+
 # ------------------------------------------------------------------------------------------------------------ the benched model, end to end
 def test_bench_model_end_to_end_vs_oracle():
     """bench.build_model (ViT-B/16 encoder, 12-layer decoder, V = 30522; dropout switched off) at B = 2, L = 128: loss, logits and the

@@ -442,12 +442,18 @@ def beam_search(decoder, input_ids, enc, enc_mask, *, max_length, eos_token_id, 
     unsat = torch.ones(B, 1, dtype=torch.bool, device=dev)
     top_mask = torch.cat([torch.ones(nb, dtype=torch.bool), torch.zeros(keep - nb, dtype=torch.bool)]).to(dev)
     row_base = (torch.arange(B, device=dev) * nb)[:, None]
+    topk_lp = torch.empty(B, keep, dtype=torch.float32, device=dev)
+    topk_idx = torch.empty(B, keep, dtype=torch.long, device=dev)
     cur = prompt
     while True:
         logits = st.step(running[:, :, cur - 1].reshape(-1), cur - 1)
-        logp = log_softmax_f32(logits.contiguous()).view(B, nb, V)
-        logp = (logp + running_scores[:, :, None]).view(B, nb * V)
-        topk_lp, topk_idx = torch.topk(logp, keep)
+        if nb <= 8:           # log-softmax + running scores + top-2nb in one launch (csrc/loss.hip beam_topk_kernel)
+            check(lib().vm_beam_topk(ptr(logits), logits.stride(0), B, nb, V, ptr(running_scores), keep, ptr(topk_lp), ptr(topk_idx), stream()),
+                  "vm_beam_topk")
+        else:
+            logp = log_softmax_f32(logits.contiguous()).view(B, nb, V)
+            logp = (logp + running_scores[:, :, None]).view(B, nb * V)
+            topk_lp, topk_idx = torch.topk(logp, keep)
         src_beam = topk_idx // V
         tok = topk_idx % V
         cand = _gather(running, src_beam).clone()
