@@ -265,3 +265,70 @@ def test_topk_threshold_kernel_is_exact():
             ref[:, banned] = -float("inf")
         want = ref.topk(k, dim=-1)[0][:, -1]
         assert torch.equal(thr.cpu(), want), (k, banned, (thr.cpu() - want).abs().max())
+
+
+def test_rrg_scst_graphed_step_equals_the_eager_step():
+    """BASELINE configs[4] "HIP-graph-captured step" (ref: vilmedic/models/rrg/RRG_SCST.py:59-85): RRG_SCST.graphed_step -- rollouts, then the
+    train-mode encoder pass + teacher-forced decoder pass + policy-gradient loss + backward + fused Adam replayed from ONE captured graph
+    on the rollout padded to max_length -- against forward() + backward() + optimizer.step() on the same fixed rollouts: the loss of every
+    step (warm-up, capture, replays) and the parameters after 5 steps."""
+    import zlib
+    from vilmedic_amd.arena import arena_of
+    from vilmedic_amd.datasets import SyntheticImSeq
+    from vilmedic_amd.models import RRG_SCST
+    from vilmedic_amd.optim import FusedAdam
+    ds = SyntheticImSeq(num_samples=4, image_size=32, vocab_size=97, tokenizer_max_len=12)
+    dl = torch.utils.data.DataLoader(ds, batch_size=4, collate_fn=ds.get_collate_fn())
+    dcfg = dict(R.DEC_TINY, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+
+    def toy_reward(refs, hyps):
+        vals = [(zlib.crc32((r + "|" + h).encode()) % 1000) / 1000.0 for r, h in zip(refs, hyps)]
+        return sum(vals) / len(vals), vals
+    batch = next(iter(dl))
+    B = batch["input_ids"].shape[0]
+    g = torch.Generator().manual_seed(3)
+    rollouts = []
+    for _ in range(5):                                   # a different fixed (greedy, sampled) pair per step, different lengths
+        T = int(torch.randint(5, 11, (1,), generator=g))
+        sq = torch.randint(3, 97, (2 * B, T), generator=g)
+        sq[:, 0] = 0
+        sq[1, 3] = 2; sq[1, 4:] = 1
+        sq[B + 2, T - 2] = 2; sq[B + 2, T - 1:] = 1
+        rollouts.append(sq)
+
+    class _Gen:
+        def __init__(self, sequences):
+            self.sequences = sequences
+
+    def build():
+        torch.manual_seed(5)
+        m = RRG_SCST(decoder=dict(proto=None, **dcfg), cnn=dict(proto="VisualEncoder", backbone="vit", permute="no_permute", **R.VIT_TINY),
+                     dl=dl, scores=[toy_reward], top_k=None).to(dev())
+        calls = {"n": 0}
+
+        def fake_generate(**kw):
+            sq = rollouts[calls["n"]]
+            calls["n"] += 1
+            return _Gen(sq.to(dev()))
+        m.model.dec.decoder.generate = fake_generate
+        return m, FusedAdam(m, lr=2e-3)
+    m1, o1 = build()
+    m2, o2 = build()
+    m2.load_state_dict(m1.state_dict())
+    l1, l2, modes = [], [], []
+    for _ in range(5):
+        out = m1(**batch)
+        o1.zero_grad()
+        out["loss"].backward()
+        o1.step()
+        l1.append(out["loss"].detach().float().item())
+        out2 = m2.graphed_step(o2, **batch)
+        l2.append(float(out2["loss"]))
+        modes.append(out2["launch_mode"])
+    torch.cuda.synchronize()
+    err = max(abs(a - b) for a, b in zip(l1, l2))
+    perr = _rel(arena_of(m2).flat, arena_of(m1).flat)
+    print(f"[parity] RRG_SCST.graphed_step vs eager: losses {l2} vs {l1}; max |diff| {err:.3e}; parameters rel L2 {perr:.3e}; modes {modes}", flush=True)
+    assert modes[:2] == ["eager (graph warm-up)"] * 2 and modes[2:] == ["hip-graph replay"] * 3
+    assert all(abs(x) > 1e-4 for x in l1), "fixture: the reward difference must not vanish"
+    assert err <= 2e-3 and perr <= 2e-3

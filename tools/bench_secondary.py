@@ -75,17 +75,22 @@ def run_task(task, args):
         return
     model.train()
 
+    mode = {"launch_mode": "eager"}
+
     def train_step():
+        if task == "scst" and args.scst_graph:       # rollouts + the update replayed from one captured HIP graph (RRG_SCST.graphed_step)
+            mode["launch_mode"] = model.graphed_step(opt, **batch).get("launch_mode", "eager")
+            return
         out = model(**batch, epoch=1, iteration=1)
         out["loss"].mean().backward()
         opt.step()
         opt.zero_grad()
 
     steps = max(2, args.steps // 4) if task == "scst" else args.steps            # an SCST step is ~2 x 128 decode steps long
-    dt = timed(train_step, steps, min(args.warmup, steps))
+    dt = timed(train_step, steps, max(3, min(args.warmup, steps)) if task == "scst" else min(args.warmup, steps))      # (scst: 2 eager warm-ups + the capture)
     unit = "images/s" if task == "mvqa" else "pairs/s"
     print(json.dumps({"task": task, "metric": f"{task} training step", "value": round(B / dt, 1), "unit": unit, "ms_per_step": round(dt * 1e3, 2),
-                      "batch": B, "params": n_params, "steps": steps}), flush=True)
+                      "batch": B, "params": n_params, "steps": steps, **(mode if task == "scst" else {})}), flush=True)
     if task == "mvqa":
         model.eval()
 
@@ -130,6 +135,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--only", default="convirt,gloria,mvqa,rrs,scst,decode")
     ap.add_argument("--dry", action="store_true")
+    ap.add_argument("--scst-graph", type=int, default=1, help="scst: 1 = the update replayed from one captured HIP graph, 0 = eager")
     args = ap.parse_args()
     for task in args.only.split(","):
         if task == "decode":

@@ -93,13 +93,13 @@ class SCST(nn.Module):
                                         encoder_attention_mask=encoder_attention_mask.detach())
         return self._policy_gradient(out.sequences, input_ids, attention_mask, encoder_hidden_states, encoder_attention_mask, reward_greedy)
 
-    def forward_rollouts(self, input_ids, attention_mask, greedy_encoder, sampling_encoder):
+    def forward_rollouts(self, input_ids, attention_mask, greedy_encoder, sampling_encoder, rollouts_only=False):
         """Both rollouts of a step in ONE decode loop (a decode step is launch-latency-bound: 2B rows cost about what B rows cost, so
         the greedy baseline rides along with the sampled rollout): rows [0, B) decode greedily on ``greedy_encoder`` = (features,
         mask) of the eval-mode encoder pass, rows [B, 2B) sample on ``sampling_encoder`` = those of the train-mode pass -- exactly the
         inputs forward_greedy / forward_sampling get (ref:vilmedic/models/rrg/RRG_SCST.py:53-75) -- then the rewards and the
         policy-gradient loss.  -> (forward_sampling's return tuple, reward_greedy)"""
-        assert torch.is_grad_enabled()
+        assert torch.is_grad_enabled() or rollouts_only
         from ...generation import trim_to_last_eos
         (enc_g, mask_g), (enc_s, mask_s) = greedy_encoder, sampling_encoder
         dev, B = enc_s.device, input_ids.shape[0]
@@ -112,8 +112,40 @@ class SCST(nn.Module):
                                         encoder_attention_mask=torch.cat([mask_g.detach(), mask_s.detach()]))
         greedy = trim_to_last_eos(out.sequences[:B], self.eos_token_id)
         sampled = trim_to_last_eos(out.sequences[B:], self.eos_token_id)
+        if rollouts_only:
+            return greedy, sampled
         reward_greedy, _, _ = self.get_reward(greedy.detach(), input_ids)
         return self._policy_gradient(sampled, input_ids, attention_mask, enc_s, mask_s, reward_greedy), reward_greedy
+
+    def pg_weights(self, seq, input_ids, reward_greedy, pad_to=None):
+        """rewards of the sampled rollout (host: tokenizer + scorers) -> (seq [B, T], row weights [B, T], bookkeeping).  Row (b, t) predicts
+        seq[b, t + 1] with weight mask * (r_sample - r_greedy) / sum(mask) (ref:...SCST.py:14-45).  ``pad_to``: T is padded to this length
+        with pad tokens of weight 0 -- the static shape of the graph-captured step; the loss does not change (weight-0 rows contribute 0,
+        the causal mask keeps the pad positions out of every weighted row)."""
+        dev = seq.device
+        sampled_ids = seq[:, 1:].contiguous()
+        reward_sampling, hyp_list, _ = self.get_reward(sampled_ids, input_ids)
+        weights = self.scores_weights[-len(self.scorers):]
+        delta = [torch.tensor(rs, device=dev, dtype=torch.float32) - torch.tensor(rg, device=dev, dtype=torch.float32)
+                 for rs, rg in zip(reward_sampling, reward_greedy)]
+        coef = sum(w * d for w, d in zip(weights, delta))                                   # [B]
+        mask = (sampled_ids > self.pad_token_id).float()                                    # [B, T-1]
+        T = seq.shape[1] if pad_to is None else max(int(pad_to), seq.shape[1])
+        row_w = torch.zeros(seq.shape[0], T, dtype=torch.float32, device=dev)
+        row_w[:, :seq.shape[1] - 1] = mask * coef[:, None] / mask.sum()
+        if T > seq.shape[1]:
+            seq = torch.cat([seq, torch.full((seq.shape[0], T - seq.shape[1]), self.pad_token_id, dtype=seq.dtype, device=dev)], 1)
+        delta_reward = torch.mean(torch.stack(delta))
+        delta_reward_per_metric = torch.mean(torch.stack(delta), dim=-1)
+        return seq.contiguous(), row_w.contiguous(), (delta_reward, delta_reward_per_metric, reward_sampling, hyp_list)
+
+    def pg_loss(self, seq, row_w, encoder_hidden_states, encoder_attention_mask):
+        """the teacher-forced pass over the sampled rollout: sum of row_w * (-log p(seq[b, t + 1])) under the bad-word + top-k filtered
+        distribution the tokens were drawn from (ref:...SCST.py:159-185)"""
+        banned = [self.pad_token_id, self.bos_token_id]
+        return self.decoder(input_ids=seq, attention_mask=None, encoder_hidden_states=encoder_hidden_states,
+                            encoder_attention_mask=encoder_attention_mask, labels=seq, return_logits=False,
+                            row_weight=row_w, banned=banned, top_k=self.top_k)["loss"]
 
     def _policy_gradient(self, seq, input_ids, attention_mask, encoder_hidden_states, encoder_attention_mask, reward_greedy):
         """seq [B, T] with bos at 0 = the sampled rollout -> SCST loss through one teacher-forced pass (ref:...SCST.py:14-45,159-185)"""
@@ -123,24 +155,10 @@ class SCST(nn.Module):
             nll_loss = self.decoder(input_ids=input_ids.to(dev), attention_mask=attention_mask.to(dev),
                                     encoder_hidden_states=encoder_hidden_states, encoder_attention_mask=encoder_attention_mask,
                                     labels=input_ids.to(dev), return_logits=False)["loss"]
-        banned = [self.pad_token_id, self.bos_token_id]
-        sampled_ids = seq[:, 1:].contiguous()
-        reward_sampling, hyp_list, _ = self.get_reward(sampled_ids, input_ids)
-        weights = self.scores_weights[-len(self.scorers):]
-        delta = [torch.tensor(rs, device=dev, dtype=torch.float32) - torch.tensor(rg, device=dev, dtype=torch.float32)
-                 for rs, rg in zip(reward_sampling, reward_greedy)]
-        coef = sum(w * d for w, d in zip(weights, delta))                                   # [B]
-        mask = (sampled_ids > self.pad_token_id).float()                                    # [B, T-1]
-        row_w = torch.zeros(seq.shape, dtype=torch.float32, device=dev)
-        row_w[:, :-1] = mask * coef[:, None] / mask.sum()                                   # row (b,t) predicts seq[b,t+1]
-        o = self.decoder(input_ids=seq, attention_mask=None, encoder_hidden_states=encoder_hidden_states,
-                         encoder_attention_mask=encoder_attention_mask, labels=seq, return_logits=False,
-                         row_weight=row_w.contiguous(), banned=banned, top_k=self.top_k)
-        loss = o["loss"]
+        seq, row_w, (delta_reward, delta_reward_per_metric, reward_sampling, hyp_list) = self.pg_weights(seq, input_ids, reward_greedy)
+        loss = self.pg_loss(seq, row_w, encoder_hidden_states, encoder_attention_mask)
         if self.use_nll:
             loss = loss + self.scores_weights[0] * nll_loss
-        delta_reward = torch.mean(torch.stack(delta))
-        delta_reward_per_metric = torch.mean(torch.stack(delta), dim=-1)
         return loss, delta_reward, delta_reward_per_metric, reward_sampling, hyp_list
 
     def get_reward(self, rollout_input_ids, input_ids):

@@ -69,6 +69,10 @@ class Trainor(object):
         # before it is summed into the others, which needs the host decision)
         self.device_gate = hasattr(self.optimizer, "gate") and self.grad_accu == 1
         self.clip = config.get("clip_grad_norm")
+        # trainor.graph_step: true -- models that can replay their whole update (rollouts aside) from one captured graph do so
+        # (BASELINE configs[4]: RRG + SCST with a HIP-graph-captured step); single process, one micro-batch per step, no clipping
+        self.graph_step = bool(config.get("graph_step")) and hasattr(self.model, "graphed_step") and self.ddp is None and \
+            self.grad_accu == 1 and self.clip is None and hasattr(self.optimizer, "gate")
         self.eval_start = int(config.get("eval_start") or 0)
         self.evaluator = Validator(config.validator_view, [self.model], self.dl, seed, True, self.logger, self.rank, self.world) \
             if config.get("validator_view") is not None else None
@@ -113,6 +117,11 @@ class Trainor(object):
             losses = []
             iteration, pending, out = 0, False, {}
             for iteration, batch in enumerate(self.dl, start=1):
+                if self.graph_step:                      # the model replays its own update from a captured HIP graph (RRG_SCST.graphed_step)
+                    out = self.model.graphed_step(self.optimizer, **batch, epoch=epoch, iteration=iteration)
+                    self.training_scheduler.iteration_step(epoch + float(iteration) / max(len(self.dl), 1))
+                    losses.append(out["loss"].detach().clone())
+                    continue
                 out = self.model(**batch, epoch=epoch, iteration=iteration)
                 if "loss" not in out:
                     continue

@@ -52,5 +52,47 @@ class RRG_SCST(nn.Module):
                 "custom_print": "reward_sampling {}, delta_reward: {}".format(torch.mean(torch.tensor(reward_sampling)),
                                                                               float(delta_reward))}
 
+    # ---- BASELINE configs[4] "HIP-graph-captured step": the differentiated half of the SCST step -- train-mode encoder pass,
+    # teacher-forced decoder pass over the sampled rollout, policy-gradient loss, backward, fused Adam -- replayed from ONE captured graph
+    # (vilmedic_amd.graph.GraphedTrainStep); the rollouts (data-dependent length, host-side rewards) run in front of it on the fused decode
+    # step.  Static shapes: the sampled rollout is padded to max_length with weight-0 rows (SCST.pg_weights).  ref: RRG_SCST.py:59-85.
+    def graphed_step(self, optimizer, input_ids, attention_mask, images, images_mask=None, **kwargs):
+        """one whole training step (rollouts + captured update); returns what forward() returns, ``loss`` being a static device scalar.
+        Falls back to forward() + backward() + optimizer.step() when the step cannot be replayed (use_nll, a different batch shape,
+        an encoder whose train-mode features are random)."""
+        images = images.cuda()
+        key = (tuple(images.shape), tuple(input_ids.shape))
+        g = getattr(self, "_graphed", None)
+        if self.scst.use_nll or images_mask is not None or float(getattr(getattr(self.model.enc, "dropout_out", None), "p", 0.0) or 0.0) > 0 or (g is not None and g[0] != key):
+            out = self(input_ids=input_ids, attention_mask=attention_mask, images=images, images_mask=images_mask, **kwargs)
+            optimizer.zero_grad()
+            out["loss"].backward()
+            optimizer.step()
+            return out
+        with torch.no_grad():
+            self.model.eval()
+            enc_g = self.model.encode(images, None)
+            self.model.train()
+            enc_s = self.model.encode(images, None)              # (= the features the captured pass recomputes: no dropout in this encoder)
+            greedy, sampled = self.scst.forward_rollouts(input_ids=input_ids, attention_mask=attention_mask, greedy_encoder=enc_g,
+                                                         sampling_encoder=enc_s, rollouts_only=True)
+        reward_greedy, _, _ = self.scst.get_reward(greedy.detach(), input_ids)
+        seq, row_w, (delta_reward, _, reward_sampling, _) = self.scst.pg_weights(sampled, input_ids, reward_greedy, pad_to=self.scst.max_length)
+        if g is None:
+            from ...graph import GraphedTrainStep
+
+            def pg_step(images, seq, row_w):
+                enc, enc_mask = self.model.encode(images, None)
+                loss = self.scst.pg_loss(seq, row_w, enc, enc_mask)
+                optimizer.zero_grad()
+                optimizer.gate = loss.detach()
+                loss.backward()
+                optimizer.step()
+                return loss
+            g = self._graphed = (key, GraphedTrainStep(pg_step, dict(images=images, seq=seq, row_w=row_w), optimizer=optimizer, warmup=2))
+        loss = g[1](images=images, seq=seq, row_w=row_w)
+        return {"loss": loss, "launch_mode": "hip-graph replay" if g[1].graph is not None else "eager (graph warm-up)",
+                "custom_print": "reward_sampling {}, delta_reward: {}".format(torch.mean(torch.tensor(reward_sampling)), float(delta_reward))}
+
     def __repr__(self):
         return "RRG_SCST\n" + str(self.scst) + "\n{}\n".format(get_n_params(self))
