@@ -310,3 +310,48 @@ def test_gloria_local_loss_contrasts_the_global_batch():
         assert r[rank][0] == pytest.approx(r[rank][1], rel=1e-6)
         torch.testing.assert_close(r[rank][2], r[rank][3], rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(r[rank][4], r[rank][5], rtol=1e-5, atol=1e-6)
+
+
+def _torch_similarity(a, b, normalize, inv_tau, eps, off=0):
+    """CPU stand-in for the HIP _SimilarityLossFn (same signature, plain autograd): row / column losses of the pairs (i, i + off)"""
+    ah = a / a.norm(dim=1, keepdim=True).clamp_min(eps) if normalize else a
+    bh = b / b.norm(dim=1, keepdim=True).clamp_min(eps) if normalize else b
+    S = ah @ bh.t() * inv_tau
+    lo, hi = max(0, -off), min(a.shape[0], b.shape[0] - off)
+    idx = torch.arange(lo, hi)
+    d = S[idx, idx + off]
+    return torch.logsumexp(S, 1)[lo:hi] - d, torch.logsumexp(S, 0)[lo + off:hi + off] - d
+
+
+def _row_sharded_contrastive(rank, world):
+    """ConVIRTLoss under data parallelism: each rank evaluates only ITS rows of the global similarity (two [b, B] problems with the paired
+    column at rank * b + i, blocks/losses/selfsup._paired_losses) -- the per-sample losses must be the rank's slice of the single-process
+    losses on the concatenated batch and the gradients its slice x world (ArenaDDP then averages over ranks)."""
+    from oracle import torch_ref as O
+    from vilmedic_amd.blocks.losses import selfsup
+
+    class _Fn:
+        apply = staticmethod(_torch_similarity)
+    selfsup._SimilarityLossFn = _Fn                    # the HIP kernels need a GPU; the host logic under test is everything around them
+    g = torch.Generator().manual_seed(13)
+    T, V = torch.randn(8, 32, generator=g), torch.randn(8, 32, generator=g)
+    t = T[rank * 4:(rank + 1) * 4].clone().requires_grad_(True)
+    v = V[rank * 4:(rank + 1) * 4].clone().requires_grad_(True)
+    loss, loss_l, loss_v = selfsup.ConVIRTLoss(tau=0.1, lambda_=0.75)(t, v)
+    loss.backward()
+    Tr, Vr = T.clone().requires_grad_(True), V.clone().requires_grad_(True)
+    lref, ref_l, ref_v = O.convirt_loss(Tr, Vr, 0.1, 0.75)
+    lref.backward()
+    sl = slice(rank * 4, (rank + 1) * 4)
+    return dict(ll=loss_l.detach(), rl=ref_l.detach()[sl], lv=loss_v.detach(), rv=ref_v.detach()[sl], gt=t.grad, rt=world * Tr.grad[sl], gv=v.grad, rvg=world * Vr.grad[sl],
+                loss=loss.detach(), local_mean=(0.75 * ref_v.detach()[sl] + 0.25 * ref_l.detach()[sl]).mean())
+
+
+def test_row_sharded_contrastive_losses_equal_the_global_batch():
+    r = _run(_row_sharded_contrastive)
+    for rank in (0, 1):
+        torch.testing.assert_close(r[rank]["ll"], r[rank]["rl"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(r[rank]["lv"], r[rank]["rv"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(r[rank]["loss"], r[rank]["local_mean"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(r[rank]["gt"], r[rank]["rt"], rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(r[rank]["gv"], r[rank]["rvg"], rtol=1e-4, atol=1e-6)

@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--only", default="convirt,gloria,mvqa,rrs,scst,decode")
     ap.add_argument("--dry", action="store_true")
-    ap.add_argument("--scst-graph", type=int, default=1, help="scst: 1 = the update replayed from one captured HIP graph, 0 = eager")
+    ap.add_argument("--scst-graph", type=int, default=0, help="scst: 1 = the update replayed from one captured HIP graph (RRG_SCST.graphed_step; measured 231 vs 200 ms: an extra encoder pass and the rollout padded to max_length), 0 = eager")
     args = ap.parse_args()
     for task in args.only.split(","):
         if task == "decode":
