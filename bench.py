@@ -478,8 +478,9 @@ def main():
             roof = {"bound": "mfma", "kernel": "gemm_fast_kernel<LA,LB,...> + gemm_grouped_kernel (every forward / dgrad launch of vm_gemm_bf16 and the "
                                              "grouped weight + bias gradient launches of vm_wgrad_grouped)", "achieved": round(ach, 1),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                    "traffic_note": "family of ~30 shapes; PMC passes for the dominant shapes (12608x2304x768 forward: 144.6 MB per launch at the fabric "
-                                    "vs 81.0 MB algorithmic; its dgrad: 118.1 MB) in profiles/r02_n_pmc_gemm.txt",
+                    "traffic_note": "family of ~30 shapes, not measurable in-process; separate rocprofv3 --pmc passes of the dominant shapes (unchanged GEMM "
+                                    "kernels since round 2: 12608x2304x768 forward 144.6 MB per launch at the fabric vs 81.0 MB algorithmic; its dgrad "
+                                    "118.1 MB) in " + PMC_PROFILE,
                     "launches_per_step": gn // 2, "avg_launch_ms": round(gms / max(gn, 1), 4),
                     "family_ms_per_step": {k: round(v[0] / 2, 3) for k, v in fam.items()}}
             dump = os.environ.get("VM_PROF_DUMP") or os.path.join(tempfile.gettempdir(), f"vm_prof_{os.getpid()}.txt")
