@@ -245,14 +245,16 @@ int vm_ce_smooth_fwd_bwd(const float* logits, const int64_t* target, int R, int 
  * paired with column i + diag_offset (the local rows of a rank against all gathered columns):
  *     loss_rows[i] = log sum_j exp(S_ij) - S_{i,i+off}      loss_cols[j] = log sum_i exp(S_ij) - S_{j-off,j}
  * (the paired term is dropped for a row / column without a partner).  S never reaches HBM.
- * vm_contrastive_loss_fwd: TWO launches -- normalise + cast both matrices (a_hat [R,D], b_hat [C,D] bf16, the norms), then one workgroup
- *   per 128 x 128 tile of S on the MFMA; the workgroup that arrives last merges the per-tile (max, sum exp) partials into lse_rows /
- *   lse_cols and writes the losses.
- * vm_contrastive_loss_bwd: ONE persistent launch pulling from a device work queue -- G tiles
- *   G_ij = g_rows[i] softmax_row(S)_ij + g_cols[j] softmax_col(S)_ij - [j == i+off](g_rows[i] + g_cols[j])  (bf16, in ``ws``), then
- *   64 x 96 tiles of da = d/da (sum_i g_rows[i] loss_rows[i] + sum_j g_cols[j] loss_cols[j]) and db likewise (fp32 [R,D] / [C,D]), the
- *   L2-normalisation backward applied in the GEMM epilogue.  ``ws``: vm_contrastive_ws(R, C) bytes, 256-B aligned, the SAME buffer in both
- *   calls is not required (the backward recomputes S); word 2 of ``ws`` is non-zero after a backward whose bounded waits expired.
+ * vm_contrastive_loss_fwd: three short dependent launches -- normalise + cast both matrices (a_hat [R,D], b_hat [C,D] bf16, the norms),
+ *   one workgroup per 128 x 128 tile of S on the MFMA writing per-tile (max, sum exp) partials, one thread per row / column merging them
+ *   into lse_rows / lse_cols and the losses.
+ * vm_contrastive_loss_bwd: two launches -- G tiles
+ *   G_ij = g_rows[i] softmax_row(S)_ij + g_cols[j] softmax_col(S)_ij - [j == i+off](g_rows[i] + g_cols[j])  (bf16, in ``ws``, with the
+ *   partial sums of G.S that the normalisation backward needs), then 64 x 96 tiles of
+ *   da = d/da (sum_i g_rows[i] loss_rows[i] + sum_j g_cols[j] loss_cols[j]) and db likewise (fp32 [R,D] / [C,D]), the L2-normalisation
+ *   backward applied in the GEMM epilogue.  ``ws``: vm_contrastive_ws(R, C) bytes, 256-B aligned; the backward recomputes S, so it does
+ *   not need the forward's buffer.  (A single persistent backward launch with in-kernel hand-offs was built first and measured slower:
+ *   every release / acquire hand-off costs more than a kernel boundary on this chip -- csrc/contrastive.hip.)
  * vm_rownorm_cast: the normalise + cast of one matrix on its own (GLoRIA's global embeddings share it). */
 int vm_rownorm_cast(const float* x /* [rows,D] */, void* out_bf16, float* norms /* [rows] or NULL */, int rows, int D,
                     int normalize /* 1: x/max(|x|,eps) (ConVIRT cosine)  0: plain cast (InfoNCE) */, float eps, void* stream);

@@ -31,26 +31,26 @@ extern "C" int vm_rownorm_cast(const float* x, void* out_bf16, float* norms, int
 
 
 
-// ------------------------------------------------------------------ the similarity loss in three launches: S never reaches HBM
-//   contr_prep_kernel   both embedding matrices in ONE launch: x/max(|x|,eps) -> bf16 (or a plain cast), the norms; zeroes the
-//                       arrival counters and the paired-diagonal buffer of the launch that follows
-//   contr_fwd_kernel    one workgroup per 128 x 128 tile of S = A^ B^^T * inv_tau (bf16 MFMA, fp32 accumulate, the tile staged in LDS
-//                       as fp32): per-row / per-column (max, sum exp) partials + the paired-diagonal entries; the workgroup that
-//                       ARRIVES LAST on a row block / column block (agent-scope release -> ticket -> acquire, no spinning, no residency
-//                       assumption) merges the partials of those 128 rows / columns into the log-sum-exps and writes their losses
-//   contr_bwd_kernel    a persistent grid pulling work items from ONE device queue:
-//                         items [0, TA)   a recomputed S tile -> G = g_r softmax_row + g_c softmax_col - [paired](g_r + g_c) as bf16
-//                                         (8 MB at B = 2048: L2 / MALL resident), the partial sums p_i = sum_j G_ij S_ij and
-//                                         q_j = sum_i G_ij S_ij (the a^.da^ / b^.db^ projections of the normalisation backward),
-//                                         then an arrival on the tile's row-block and column-block counters;
-//                         items [TA, ..)  64 x BN output tiles of dA = G B^ / tau (waits for its row block of G) and dB = G^T A^ / tau
-//                                         (waits for its column block), the L2-normalisation backward applied in the epilogue:
-//                                         dx = (dx^ - x^ (x^ . dx^)) / |x| -- no cross-tile reduction is left because x^ . dx^ = p.
-//                       A phase-B item only ever waits for phase-A tiles, and every phase-A tile was dequeued -- by a workgroup that is
-//                       running -- before the first phase-B item was handed out, so the queue cannot deadlock whatever the dispatch
-//                       order or residency is (cdna_hip_programming.md Guideline 16; every spin is bounded and reports through ws).
-// Round 2 ran this as six library launches + a dozen torch glue kernels (0.147 ms of kernel time, 0.34 ms wall at B = 2048); the two
-// gradient GEMMs alone took 61 us because 2048 x 768 outputs are 96 tiles of 128 x 128 on 256 CUs.  Here they are 512 items of 64 x 96.
+// ------------------------------------------------------------------ the similarity loss in five short launches: S never reaches HBM
+//   forward   contr_prep_kernel    both embedding matrices in ONE launch: x/max(|x|,eps) -> bf16 (or a plain cast), the norms; zeroes the
+//                                  paired-diagonal buffer
+//             contr_fwd_kernel     one workgroup per 128 x 128 tile of S = A^ B^^T * inv_tau (bf16 MFMA, fp32 accumulate, the tile staged in
+//                                  LDS as fp32): per-row / per-column (max, sum exp) partials + the paired-diagonal entries
+//             contr_merge_kernel   one thread per row / column: log-sum-exp over the per-tile partials, the per-row losses
+//   backward  contr_g_kernel       a recomputed S tile -> G = g_r softmax_row + g_c softmax_col - [paired](g_r + g_c) as bf16 (8 MB at
+//                                  B = 2048: L2 / MALL resident) and the partial sums p_i = sum_j G_ij S_ij, q_j = sum_i G_ij S_ij
+//                                  (the a^.da^ / b^.db^ projections of the normalisation backward)
+//             contr_grad_kernel    64 x BN output tiles of dA = G B^ / tau and dB = G^T A^ / tau, the L2-normalisation backward applied in
+//                                  the epilogue: dx = (dx^ - x^ (x^ . dx^)) / |x| -- no cross-tile reduction is left because x^ . dx^ = p.
+// History (profiles/r03_*): round 2 ran this as six library launches + a dozen torch glue kernels (147 us + ~50 us of kernels, 0.34 ms wall at
+// B = 2048; the two gradient GEMMs alone took 61 us because 2048 x 768 outputs are 96 tiles of 128 x 128 on 256 CUs).  Round 3 first built it
+// as ONE persistent backward launch pulling tiles from a device queue with agent-scope release / acquire hand-offs between the phases, and a
+// forward whose last-arriving workgroups merged the partials: correct, deterministic -- and 161 us, because every hand-off (release fence,
+// returned ticket atomics, flag poll, acquire fence) costs microseconds on this chip (MI355X_MICROARCH.md price list: 1.7 us per fence,
+// ~1 us per returned atomic) where a dependent kernel boundary costs 1.5 us.  Timing the forward tile kernel with its tail removed:
+// 7.7 us for launch + one K chunk, 16.1 us for the twelve chunks, 34.5 us with partial passes + arrival + merge -- 18 us of tail for 8 us of
+// math.  The phases are therefore plain dependent launches again; what is kept from the persistent version is the arithmetic (G with the
+// projections, the normalisation backward in the GEMM epilogue, 64 x 96 gradient tiles that fill the chip).
 typedef __bf16 c_bf16x8_t __attribute__((ext_vector_type(8)));
 typedef short c_v4s __attribute__((ext_vector_type(4)));
 #define CT 128
@@ -58,32 +58,27 @@ typedef short c_v4s __attribute__((ext_vector_type(4)));
 #define CT_CS 132         // fp32 row stride of the staged S tile
 #define CT_LDS (2 * 2 * CT * CT_KS * 2)      // two stages x two operands = 73728 B >= 128 * 132 * 4 = 67584 B
 #define CT_RED_OFF (CT * CT_CS * 4)          // 2 KB of cross-wave column partials behind the staged tile
-#define CT_ITEM_OFF CT_LDS                   // 16 B: the dequeued item / "I am last" broadcast
-#define CT_LDS_ALL (CT_LDS + 16)
+#define CT_LDS_ALL CT_LDS
 #define CB_M 64           // phase-B output tile: 64 rows x BN columns (BN = 96 when D % 96 == 0, else 128), K chunks of 64
 #define CB_PS 72          // LDS row stride (elements) of the G chunk  [64][64]
 #define CB_QS 136         // LDS row stride (elements) of the operand chunk [64][<=128]
 #define CB_STAGE (CB_M * CB_PS * 2 + 64 * CB_QS * 2)      // 9216 + 17408 B per stage
-#define CONTR_SPIN_LIMIT (1u << 21)
 
 struct ContrArgs {
     const bf16_t* A; const bf16_t* B; int R, C, D, diag_offset, tiles_m, tiles_n; float inv_tau;
     // forward
     float* row_part; float* col_part; float* diag; float* lse_r_out; float* lse_c_out; float* loss_r; float* loss_c;
-    unsigned* ctr;                                   // [0] forward arrivals, [1] backward queue head, [2] error word, [4..] row-block / column-block arrivals
     // backward
     const float* lse_r; const float* lse_c; const float* g_r; const float* g_c; bf16_t* G; int64_t ldg;
     float* p_part; float* q_part;                    // [tiles_n][R], [tiles_m][C]
-    float* p_sum; float* q_sum;                      // [R], [C]: the summed partials (written by the last arriver of a block)
     const float* a32; const float* b32; const float* na; const float* nb; float* da; float* db;
     int normalize, bn, items_a, items_da, items_db; float eps;
 };
 
 __global__ __launch_bounds__(256) void contr_prep_kernel(const float* __restrict__ a, const float* __restrict__ b, bf16_t* __restrict__ ah,
                                                          bf16_t* __restrict__ bh, float* __restrict__ na, float* __restrict__ nb, int R, int C, int D,
-                                                         int normalize, float eps, unsigned* __restrict__ ctr, int nctr, float* __restrict__ diag) {
+                                                         int normalize, float eps, float* __restrict__ diag) {
     const int lane = threadIdx.x & 63;
-    if (blockIdx.x == 0) for (int i = threadIdx.x; i < nctr; i += 256) ctr[i] = 0u;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < R; i += gridDim.x * 256) diag[i] = 0.f;
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < R + C; row += gridDim.x * 4) {
         const bool first = row < R;
@@ -102,18 +97,6 @@ __global__ __launch_bounds__(256) void contr_prep_kernel(const float* __restrict
         if (lane == 0) (first ? na : nb)[r] = nrm;
     }
 }
-
-// publish this workgroup's global stores and draw a ticket (thread 0 returns it): plain stores -> every wave drains -> barrier ->
-// one agent-scope release -> the asm wait the compiler may not drop -> relaxed agent-scope fetch_add (Guideline 16, counter form)
-__device__ __forceinline__ void contr_publish() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-}
-__device__ __forceinline__ unsigned contr_ticket(unsigned* c) { return __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // acc = A^[m0.., :] B^[n0.., :]^T for one 128 x 128 tile (operands global -> registers -> LDS with a one-chunk software pipeline), then the
 // scaled tile staged in LDS as fp32 [128][CT_CS].  Ends with a barrier: every thread may read the whole tile.
@@ -265,32 +248,21 @@ __global__ __launch_bounds__(256, 2) void contr_fwd_kernel(const ContrArgs p) {
             o[0] = mx; o[1] = se;
         }
     }
-    // ---- arrivals on the tile's row block and column block; the workgroup that completes a block merges ITS 128 rows (columns):
-    // 16 + 16 small merges spread over the chip instead of one workgroup walking all R + C partial lists
-    unsigned* flag = reinterpret_cast<unsigned*>(smem + CT_ITEM_OFF);
-    contr_publish();
-    if (tid == 0) {
-        const bool lastrow = contr_ticket(p.ctr + 4 + tm) == (unsigned)(p.tiles_n - 1);
-        const bool lastcol = contr_ticket(p.ctr + 4 + p.tiles_m + tn) == (unsigned)(p.tiles_m - 1);
-        if (lastrow || lastcol) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        flag[0] = lastrow ? 1u : 0u; flag[1] = lastcol ? 1u : 0u;
-    }
-    __syncthreads();
-    if (tid < CT) {
-        const int x = m0 + tid;
-        if (flag[0] && x < p.R) {
-            const float lse = contr_merge_lse(p.row_part, p.R, x, p.tiles_n);
-            p.lse_r_out[x] = lse;
-            p.loss_r[x] = lse - p.diag[x];                        // (diag is 0 for a row without a paired column)
-        }
-    } else {
-        const int x = n0 + tid - CT;
-        if (flag[1] && x < p.C) {
-            const float lse = contr_merge_lse(p.col_part, p.C, x, p.tiles_m);
-            p.lse_c_out[x] = lse;
-            const int pr = x - p.diag_offset;                     // the row this column is paired with: its tile lies in this column block
-            p.loss_c[x] = lse - ((pr >= 0 && pr < p.R) ? p.diag[pr] : 0.f);
-        }
+}
+
+// one thread per row / column of S: lse over the per-tile partials, the losses of the pairs (dependent launch behind contr_fwd_kernel)
+__global__ __launch_bounds__(256) void contr_merge_kernel(const ContrArgs p) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < p.R) {
+        const float lse = contr_merge_lse(p.row_part, p.R, i, p.tiles_n);
+        p.lse_r_out[i] = lse;
+        p.loss_r[i] = lse - p.diag[i];                            // (diag is 0 for a row without a paired column)
+    } else if (i - p.R < p.C) {
+        const int x = i - p.R;
+        const float lse = contr_merge_lse(p.col_part, p.C, x, p.tiles_m);
+        p.lse_c_out[x] = lse;
+        const int pr = x - p.diag_offset;                         // the row this column is paired with
+        p.loss_c[x] = lse - ((pr >= 0 && pr < p.R) ? p.diag[pr] : 0.f);
     }
 }
 
@@ -319,10 +291,10 @@ __device__ __forceinline__ float quarters_sum(float v) {      // over lanes l, l
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-// phase A: one tile of G (+ the projection partials), then the arrivals on its row block and its column block
+// one tile of G (+ the projection partials)
 struct ContrGTile {         // the fields phase A uses, in SGPRs
     int R, C, diag_offset, tiles_m, tiles_n; int64_t ldg;
-    const float* lse_r; const float* lse_c; const float* g_r; const float* g_c; bf16_t* G; float* p_part; float* q_part; float* p_sum; float* q_sum; unsigned* ctr;
+    const float* lse_r; const float* lse_c; const float* g_r; const float* g_c; bf16_t* G; float* p_part; float* q_part;
 };
 __device__ __noinline__ void contr_g_tile(const ContrArgs& pa, char* smem, int tm, int tn) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -332,7 +304,7 @@ __device__ __noinline__ void contr_g_tile(const ContrArgs& pa, char* smem, int t
     p.R = ops.R; p.C = ops.C; p.diag_offset = contr_uni(pa.diag_offset); p.tiles_m = contr_uni(pa.tiles_m); p.tiles_n = contr_uni(pa.tiles_n);
     p.ldg = (int64_t)contr_uni((int)pa.ldg);
     p.lse_r = contr_uni(pa.lse_r); p.lse_c = contr_uni(pa.lse_c); p.g_r = contr_uni(pa.g_r); p.g_c = contr_uni(pa.g_c); p.G = contr_uni(pa.G);
-    p.p_part = contr_uni(pa.p_part); p.q_part = contr_uni(pa.q_part); p.p_sum = contr_uni(pa.p_sum); p.q_sum = contr_uni(pa.q_sum); p.ctr = contr_uni(pa.ctr);
+    p.p_part = contr_uni(pa.p_part); p.q_part = contr_uni(pa.q_part);
     contr_s_tile(ops, smem, m0, n0);
     const float* cs = reinterpret_cast<const float*>(smem);
     float* red = reinterpret_cast<float*>(smem + CT_RED_OFF);
@@ -347,11 +319,19 @@ __device__ __noinline__ void contr_g_tile(const ContrArgs& pa, char* smem, int t
         gcj[j] = (c0 + j < cols) ? p.g_c[gc] : 0.f;
         lcj[j] = (c0 + j < cols) ? p.lse_c[gc] : 0.f;
     }
+    float gr8[8], lr8[8];                  // the 8 rows' upstream gradient and log-sum-exp, requested together (not one round trip per row)
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int r = (tid >> 4) + 16 * it;
+        gr8[it] = r < rows ? p.g_r[m0 + r] : 0.f;
+        lr8[it] = r < rows ? p.lse_r[m0 + r] : 0.f;
+    }
+#pragma unroll
     for (int it = 0; it < 8; ++it) {       // 8 consecutive columns of a row per thread: 16-B bf16 stores, whole 256-B rows per 16 lanes
         const int r = (tid >> 4) + 16 * it;
         const int gr = m0 + r;
         const bool rok = r < rows;
-        const float gri = rok ? p.g_r[gr] : 0.f, lri = rok ? p.lse_r[gr] : 0.f;
+        const float gri = gr8[it], lri = lr8[it];
         float v[8], rs = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -384,29 +364,9 @@ __device__ __noinline__ void contr_g_tile(const ContrArgs& pa, char* smem, int t
     }
     __syncthreads();
     if (tid < cols) p.q_part[(int64_t)tm * p.C + n0 + tid] = red[tid] + red[CT + tid] + red[2 * CT + tid] + red[3 * CT + tid];
-    // arrivals; the workgroup that completes a row block (column block) sums the block's projection partials in a fixed order and
-    // arrives once more: consumers wait for tiles + 1
-    unsigned* flag = reinterpret_cast<unsigned*>(smem + CT_ITEM_OFF) + 2;
-    contr_publish();
-    if (tid == 0) {
-        const bool lastrow = contr_ticket(p.ctr + 4 + tm) == (unsigned)(p.tiles_n - 1);
-        const bool lastcol = contr_ticket(p.ctr + 4 + p.tiles_m + tn) == (unsigned)(p.tiles_m - 1);
-        if (lastrow || lastcol) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        flag[0] = lastrow ? 1u : 0u; flag[1] = lastcol ? 1u : 0u;
-    }
-    __syncthreads();
-    const bool lastrow = flag[0] != 0u, lastcol = flag[1] != 0u;
-    if (!lastrow && !lastcol) return;
-    if (tid < CT) { if (lastrow && m0 + tid < p.R) p.p_sum[m0 + tid] = contr_sum_parts(p.p_part, p.R, m0 + tid, p.tiles_n); }
-    else if (lastcol && n0 + tid - CT < p.C) p.q_sum[n0 + tid - CT] = contr_sum_parts(p.q_part, p.C, n0 + tid - CT, p.tiles_m);
-    contr_publish();
-    if (tid == 0) {
-        if (lastrow) contr_ticket(p.ctr + 4 + tm);
-        if (lastcol) contr_ticket(p.ctr + 4 + p.tiles_m + tn);
-    }
 }
 
-// phase B: out[m0.., n0..] (64 x BN, fp32) = sum_k P[m][k] X^[k][n] / tau, normalisation backward in the epilogue.
+// gradient tiles: out[m0.., n0..] (64 x BN, fp32) = sum_k P[m][k] X^[k][n] / tau, normalisation backward in the epilogue.
 //   PT = false (dA): P[m][k] = G[m0 + m][k],  X^ = B^,  K = C;    PT = true (dB): P[m][k] = G[k][m0 + m],  X^ = A^,  K = R
 // The product is formed transposed (A operand = X^ chunk read through ds_read_b64_tr_b16, rows = n; B operand = the G chunk, columns = m)
 // so that a lane ends with 4 consecutive n of one output row: 16-B stores.
@@ -419,6 +379,15 @@ __device__ __noinline__ void contr_grad_tile(const ContrArgs& pa, char* smem, in
     p.inv_tau = contr_uni(pa.inv_tau); p.eps = contr_uni(pa.eps); p.G = contr_uni((const bf16_t*)pa.G);
     const int M = PT ? p.C : p.R, K = PT ? p.R : p.C;
     const bf16_t* X = contr_uni(PT ? pa.A : pa.B);
+    // the projections x^ . dx^ = sum over the G tiles' partial sums for this lane's two output rows: requested NOW (independent loads, two
+    // memory round trips) so that they have landed long before the epilogue needs them
+    const float* part = contr_uni(PT ? pa.q_part : pa.p_part);
+    const int nparts = contr_uni(PT ? pa.tiles_m : pa.tiles_n);
+    float proj_j[2] = {0.f, 0.f};
+    if (p.normalize) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) proj_j[j] = contr_sum_parts(part, M, min(m0 + wm * 32 + j * 16 + (lane & 15), M - 1), nparts);
+    }
     float4_t acc[NB][2];
 #pragma unroll
     for (int i = 0; i < NB; ++i) { acc[i][0] = (float4_t){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
@@ -481,7 +450,6 @@ __device__ __noinline__ void contr_grad_tile(const ContrArgs& pa, char* smem, in
     // epilogue: lane holds out[m][n .. n + 3], m = m0 + wm 32 + j 16 + (lane & 15), n = n0 + wn BN/2 + i 16 + (lane >> 4) 4
     const float* x32 = contr_uni(PT ? pa.b32 : pa.a32);
     const float* nrm = contr_uni(PT ? pa.nb : pa.na);
-    const float* psum = contr_uni(PT ? pa.q_sum : pa.p_sum);
     float* out = contr_uni(PT ? pa.db : pa.da);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -490,7 +458,7 @@ __device__ __noinline__ void contr_grad_tile(const ContrArgs& pa, char* smem, in
         float proj = 0.f, d = 1.f;
         bool unit = false;
         if (p.normalize) {
-            proj = psum[m];
+            proj = proj_j[j];
             const float nm = nrm[m];
             d = fmaxf(nm, p.eps);
             unit = nm > p.eps;
@@ -515,41 +483,20 @@ __device__ __noinline__ void contr_grad_tile(const ContrArgs& pa, char* smem, in
     __syncthreads();                 // the LDS stages are reused by the next item
 }
 
-__global__ __launch_bounds__(256, 2) void contr_bwd_kernel(const ContrArgs p) {
+__global__ __launch_bounds__(256, 2) void contr_g_kernel(const ContrArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* item_s = reinterpret_cast<int*>(smem + CT_ITEM_OFF);
-    const int tid = threadIdx.x;
-    const int total = p.items_a + p.items_da + p.items_db;
+    contr_g_tile(p, smem, blockIdx.x / p.tiles_n, blockIdx.x % p.tiles_n);
+}
+// items [0, items_da): tiles of dA; [items_da, items_da + items_db): tiles of dB (dependent launch behind contr_g_kernel)
+__global__ __launch_bounds__(256, 2) void contr_grad_kernel(const ContrArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nbt = (p.D + p.bn - 1) / p.bn;                 // output column blocks
-    for (;;) {
-        if (tid == 0) *item_s = (int)contr_ticket(p.ctr + 1);
-        __syncthreads();
-        const int item = *item_s;
-        __syncthreads();
-        if (item >= total) return;
-        if (item < p.items_a) {
-            contr_g_tile(p, smem, item / p.tiles_n, item % p.tiles_n);
-            continue;
-        }
-        const bool isb = item >= p.items_a + p.items_da;
-        const int it = item - p.items_a - (isb ? p.items_da : 0);
-        const int rb = it / nbt, cb = it - rb * nbt;
-        const int m0 = rb * CB_M, n0 = cb * p.bn;
-        // wait for the G tiles this item contracts over: ONE lane polls ONE word (relaxed, agent scope), then ONE acquire
-        if (tid == 0) {
-            unsigned* flag = p.ctr + 4 + (isb ? p.tiles_m : 0) + m0 / CT;
-            const unsigned need = (unsigned)(isb ? p.tiles_m : p.tiles_n) + 1u;       // every tile of the block + the projection sums
-            unsigned spins = 0;
-            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > CONTR_SPIN_LIMIT) { __hip_atomic_store(p.ctr + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-        if (p.bn == 96) { if (isb) contr_grad_tile<3, true>(p, smem, m0, n0); else contr_grad_tile<3, false>(p, smem, m0, n0); }
-        else            { if (isb) contr_grad_tile<4, true>(p, smem, m0, n0); else contr_grad_tile<4, false>(p, smem, m0, n0); }
-    }
+    const bool isb = (int)blockIdx.x >= p.items_da;
+    const int it = (int)blockIdx.x - (isb ? p.items_da : 0);
+    const int rb = it / nbt, cb = it - rb * nbt;
+    const int m0 = rb * CB_M, n0 = cb * p.bn;
+    if (p.bn == 96) { if (isb) contr_grad_tile<3, true>(p, smem, m0, n0); else contr_grad_tile<3, false>(p, smem, m0, n0); }
+    else            { if (isb) contr_grad_tile<4, true>(p, smem, m0, n0); else contr_grad_tile<4, false>(p, smem, m0, n0); }
 }
 
 static int contr_common(const char* fn, const void* a, const void* b, int R, int C, int D) {
@@ -561,37 +508,24 @@ static void contr_attr() {
     static bool set = false;
     if (set) return;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&contr_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CT_LDS_ALL);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&contr_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CT_LDS_ALL);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&contr_g_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CT_LDS_ALL);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&contr_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CT_LDS_ALL);
     set = true;
 }
-static int contr_num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipGetDevice(&dev);
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
-// workspace layout (bytes, every block 256-B aligned): counters | diag [R] | row_part [tn][R][2] | col_part [tm][C][2] | p_part [tn][R] |
-// q_part [tm][C] | p_sum [R] | q_sum [C] | G bf16 [R][ldg]
-struct ContrWs { size_t ctr, nctr, diag, row_part, col_part, p_part, q_part, p_sum, q_sum, G, total; int64_t ldg; };
+// workspace layout (bytes, every block 256-B aligned): diag [R] | row_part [tn][R][2] | col_part [tm][C][2] | p_part [tn][R] | q_part [tm][C] |
+// G bf16 [R][ldg]
+struct ContrWs { size_t diag, row_part, col_part, p_part, q_part, G, total; int64_t ldg; };
 static ContrWs contr_ws_layout(int R, int C) {
     const size_t tm = (R + CT - 1) / CT, tn = (C + CT - 1) / CT;
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     ContrWs w;
     w.ldg = (C + 7) / 8 * 8;
-    w.nctr = 4 + tm + tn;
-    w.ctr = 0;
-    w.diag = up(w.nctr * 4);
+    w.diag = 0;
     w.row_part = w.diag + up((size_t)R * 4);
     w.col_part = w.row_part + up(tn * (size_t)R * 8);
     w.p_part = w.col_part + up(tm * (size_t)C * 8);
     w.q_part = w.p_part + up(tn * (size_t)R * 4);
-    w.p_sum = w.q_part + up(tm * (size_t)C * 4);
-    w.q_sum = w.p_sum + up((size_t)R * 4);
-    w.G = w.q_sum + up((size_t)C * 4);
+    w.G = w.q_part + up(tm * (size_t)C * 4);
     w.total = w.G + up((size_t)R * w.ldg * 2);
     return w;
 }
@@ -600,10 +534,9 @@ extern "C" size_t vm_contrastive_ws(int R, int C) { return (R > 0 && C > 0) ? co
 static void contr_fill(ContrArgs& p, const void* ah, const void* bh, int R, int C, int D, float inv_tau, int diag_offset, char* ws, const ContrWs& w) {
     p.A = (const bf16_t*)ah; p.B = (const bf16_t*)bh; p.R = R; p.C = C; p.D = D; p.diag_offset = diag_offset; p.inv_tau = inv_tau;
     p.tiles_m = (R + CT - 1) / CT; p.tiles_n = (C + CT - 1) / CT;
-    p.ctr = (unsigned*)(ws + w.ctr); p.diag = (float*)(ws + w.diag);
+    p.diag = (float*)(ws + w.diag);
     p.row_part = (float*)(ws + w.row_part); p.col_part = (float*)(ws + w.col_part);
     p.p_part = (float*)(ws + w.p_part); p.q_part = (float*)(ws + w.q_part);
-    p.p_sum = (float*)(ws + w.p_sum); p.q_sum = (float*)(ws + w.q_sum);
     p.G = (bf16_t*)(ws + w.G); p.ldg = w.ldg;
 }
 
@@ -625,11 +558,15 @@ extern "C" int vm_contrastive_loss_fwd(const float* a, const float* b, int R, in
         VmProfScope prof(VM_FAM_LOSS, 12.0 * (R + C) * (double)D, s, "contrastive_prep_R%d_C%d_D%d", R, C, D);
         int blocks = (R + C + 3) / 4; if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(contr_prep_kernel, dim3(blocks), dim3(256), 0, s, a, b, (bf16_t*)a_hat, (bf16_t*)b_hat, norm_a, norm_b, R, C, D, normalize, eps,
-                           p.ctr, (int)w.nctr, p.diag);
+                           p.diag);
     }
     {
         VmProfScope prof(VM_FAM_LOSS, 2.0 * R * (double)C * D, s, "contrastive_fwd_R%d_C%d_D%d", R, C, D);
         hipLaunchKernelGGL(contr_fwd_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), CT_LDS_ALL, s, p);
+    }
+    {
+        VmProfScope prof(VM_FAM_LOSS, 16.0 * ((double)p.tiles_n * R + (double)p.tiles_m * C), s, "contrastive_merge_R%d_C%d", R, C);
+        hipLaunchKernelGGL(contr_merge_kernel, dim3((R + C + 255) / 256), dim3(256), 0, s, p);
     }
     return vm_check_launch("vm_contrastive_loss_fwd");
 }
@@ -655,12 +592,14 @@ extern "C" int vm_contrastive_loss_bwd(const float* a, const float* b, const voi
     p.items_da = ((R + CB_M - 1) / CB_M) * nbt;
     p.items_db = ((C + CB_M - 1) / CB_M) * nbt;
     contr_attr();
-    hipMemsetAsync(p.ctr, 0, w.nctr * 4, s);           // queue head, error word, row-block / column-block arrivals (a memset node under capture)
     if (w.ldg != C) hipMemsetAsync(p.G, 0, (size_t)R * w.ldg * 2, s);      // ragged C: the pad columns of G are read as zeros
-    int grid = 2 * contr_num_cus();
-    const int total = p.items_a + p.items_da + p.items_db;
-    if (grid > total) grid = total;
-    VmProfScope prof(VM_FAM_LOSS, 6.0 * R * (double)C * D, s, "contrastive_bwd_R%d_C%d_D%d", R, C, D);
-    hipLaunchKernelGGL(contr_bwd_kernel, dim3(grid), dim3(256), CT_LDS_ALL, s, p);
+    {
+        VmProfScope prof(VM_FAM_LOSS, 2.0 * R * (double)C * D, s, "contrastive_g_R%d_C%d_D%d", R, C, D);
+        hipLaunchKernelGGL(contr_g_kernel, dim3(p.items_a), dim3(256), CT_LDS_ALL, s, p);
+    }
+    {
+        VmProfScope prof(VM_FAM_LOSS, 4.0 * R * (double)C * D, s, "contrastive_grad_R%d_C%d_D%d", R, C, D);
+        hipLaunchKernelGGL(contr_grad_kernel, dim3(p.items_da + p.items_db), dim3(256), CT_LDS_ALL, s, p);
+    }
     return vm_check_launch("vm_contrastive_loss_bwd");
 }
