@@ -282,7 +282,11 @@ extern "C" int vm_decode_gemm(const vm_decode_gemm_args* x, void* stream) {
                 x->lda, x->ldw, x->ldc, x->ldc2, x->ldr, x->ln_out_ld, x->M, x->N, x->K, x->act, x->split_n, x->ln_eps};
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_DECODE, 2.0 * x->M * (double)x->N * x->K, s, "dg_%s_M%d_N%d_K%d_ln%d", f32 ? "f32" : "bf16", x->M, x->N, x->K, (int)ln);
-    const int mf = vm_skinny_rows_per_wg(x->M, x->N, ln ? 2 : 8);       // rows per workgroup: at least one workgroup per CU (gemm_skinny.hip)
+    // rows per workgroup: at least one workgroup per CU (gemm_skinny.hip), at most 64 rows -- measured at 256 rows (beam 4) on the step's
+    // shapes: 64-row blocks 14.9 / 15.3 / 17.8 us (N = 2304 / 3072 / 768 x K = 3072) against 18.4 / 18.8 / 28.3 us for 128-row blocks and
+    // 15.0 / 17.5 / 20.3 us for 32-row blocks; fp32 likewise (26.0 / 26.8 / 32.6 vs 33.3 / 33.9 / 56.6 us)
+    int mf = vm_skinny_rows_per_wg(x->M, x->N, ln ? 2 : 4);
+    if (!ln && mf == 2 && x->M > 128 && ((x->N + 15) / 16) * ((x->M + 63) / 64) >= 192) mf = 4;
     if (f32) return ln ? dg_dispatch<true, true>(a, mf, s) : dg_dispatch<true, false>(a, mf, s);
     return ln ? dg_dispatch<false, true>(a, mf, s) : dg_dispatch<false, false>(a, mf, s);
 }

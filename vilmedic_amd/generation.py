@@ -250,7 +250,8 @@ class DecodeState:
             xl = _ln32(s, ln, cfg.layer_norm_eps)
             V = self.V
             logits = torch.empty(M, (V + 3) // 4 * 4, dtype=F32, device=s.device)
-            _gemm32(xl, emb.word_embeddings.weight, self.dec.lm_head.bias, logits, M, V, D)
+            # (the decode GEMM's 64-row blocks: 128- / 256-row blocks measured 285 us for this product at 256 rows)
+            self._dg(xl, emb.word_embeddings.weight, logits, M, V, D, bias=self.dec.lm_head.bias)
             return logits[:, :V]
         return ops.lm_logits_f32(_ln(s, ln, cfg.layer_norm_eps), self.emb_sh, self.dec.lm_head.bias, self.V)
 
