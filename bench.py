@@ -405,6 +405,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     ddp = ArenaDDP(model, dist, wire=wire) if dist is not None else None
+    if ddp is not None:
+        ddp.attach_optimizer(opt)            # Adam reads the averaged bf16 wire buffer (vm_adam_step_wire): no cast pass back to fp32
     B, L, V = args.batch, args.seq, DEC_12L["vocab_size"]
     images, ids, am = synthetic_batch(B, L, V, device, seed=rank)
 

@@ -325,6 +325,13 @@ int vm_adam_step_dev(float* p, const float* g, float* m, float* v, void* shadow_
                      float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled_wd,
                      float bias_corr1, float bias_corr2, float grad_scale,
                      const float* lr_dev, const int64_t* step_dev, const float* gate_dev, void* stream);
+/* vm_adam_step_dev with the gradient read as bf16 [n]: the averaged wire buffer of the data-parallel gradient all-reduce
+ * (ref:vilmedic/executors/trainor_accelerate.py:111-156 -- accelerate's DDP averages .grad before optimizer.step()) consumed directly,
+ * without a cast pass back into the fp32 gradient arena; bf16 -> fp32 is exact, so the update equals vm_adam_step_dev on the cast values. */
+int vm_adam_step_wire(float* p, const void* g_bf16, float* m, float* v, void* shadow_bf16, int64_t n,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled_wd,
+                      float bias_corr1, float bias_corr2, float grad_scale,
+                      const float* lr_dev, const int64_t* step_dev, const float* gate_dev, void* stream);
 
 /* ------------------------------------------------------------------ decode step helpers
  * hf:generation/utils.py:3384-3389 (fp32 log_softmax), :3113-3119 (top-k over beams*V), :2925 (argmax). */

@@ -71,6 +71,42 @@ def test_arena_ddp_step_equals_single_process_step(nccl, bf16_wire):
     assert _rel(arena_of(m2).gflat, arena_of(m1).gflat) <= (4e-3 if bf16_wire else 1e-5)
 
 
+def test_optimizer_reads_the_wire_buffer_and_takes_the_same_step(nccl):
+    """ArenaDDP.attach_optimizer: FusedAdam consumes the averaged bf16 wire buffer (vm_adam_step_wire) instead of gradients cast back to
+    fp32 first.  bf16 -> fp32 is exact, so parameters, moments and bf16 shadows after two steps are BIT-identical to the unattached
+    path; the fp32 gradient arena keeps the local gradients (documented side effect)."""
+    from vilmedic_amd.arena import arena_of
+    from vilmedic_amd.optim import FusedAdam
+    from vilmedic_amd.parallel import ArenaDDP
+    m1, m2 = _rrg(R.VIT_TINY, R.DEC_TINY), _rrg(R.VIT_TINY, R.DEC_TINY)
+    m2.load_state_dict(m1.state_dict())
+    images = R.make_images(8, R.VIT_TINY["image_size"], seed=5).to(dev())
+    ids, am = R.make_reports(8, 64, R.DEC_TINY["vocab_size"], seed=5)
+    ids, am = ids.to(dev()), am.to(dev())
+    m1.train(), m2.train()
+    o1, o2 = FusedAdam(m1, lr=1e-3), FusedAdam(m2, lr=1e-3)
+    d1, d2 = ArenaDDP(m1, nccl, bf16_wire=True), ArenaDDP(m2, nccl, bf16_wire=True)
+    d2.attach_optimizer(o2)
+    for step in range(2):
+        for m, o, d in ((m1, o1, d1), (m2, o2, d2)):
+            out = m(input_ids=ids, attention_mask=am, images=images)
+            o.zero_grad()
+            d.backward(out["loss"])
+            if d is d2:
+                assert o.grad_wire is d._wire
+            o.step()
+            assert o.grad_wire is None
+    torch.cuda.synchronize()
+    a1, a2 = arena_of(m1), arena_of(m2)
+    assert torch.equal(a1.flat, a2.flat) and torch.equal(o1.m, o2.m) and torch.equal(o1.v, o2.v) and torch.equal(a1.shadow_flat, a2.shadow_flat)
+    print("[parity] FusedAdam on the bf16 wire buffer == FusedAdam on the cast-back gradients after 2 steps: bit-identical", flush=True)
+    # an fp32 wire, or an optimizer of another arena, is left alone
+    d3 = ArenaDDP(m1, nccl, bf16_wire=False)
+    d3.attach_optimizer(o1)
+    d1.attach_optimizer(o2)
+    assert d3._opt is None and d1._opt is None
+
+
 def test_bf16_wire_error_on_the_c2_model(nccl):
     """the default wire format rounds every gradient to bf16 once before the all-reduce (446 MB instead of 892 MB per step at the
     BASELINE configs[1] size): its error against the fp32 gradients of the same backward pass, on the full ViT-B/16 + 12-layer model"""

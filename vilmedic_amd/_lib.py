@@ -102,6 +102,7 @@ SIGNATURES = {
     "vm_feature_mask": (_I, [_P, _P, _I, _I, _P]),
     "vm_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _F, _F, _P]),
     "vm_adam_step_dev": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _F, _F, _P, _P, _P, _P]),
+    "vm_adam_step_wire": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _F, _F, _P, _P, _P, _P]),
     "vm_logsoftmax_f32": (_I, [_P, _L, _P, _I, _I, _P]),
     "vm_argmax_f32": (_I, [_P, _L, _P, _P, _I, _I, _P]),
     "vm_decode_gemm": (_I, [C.POINTER(DecodeGemmArgs), _P]),

@@ -69,6 +69,8 @@ class Trainor(object):
         # before it is summed into the others, which needs the host decision)
         self.device_gate = hasattr(self.optimizer, "gate") and self.grad_accu == 1
         self.clip = config.get("clip_grad_norm")
+        if self.ddp is not None and self.clip is None:
+            self.ddp.attach_optimizer(self.optimizer)      # the optimizer reads the averaged bf16 wire buffer itself (no cast pass back)
         # trainor.graph_step: true -- models that can replay their whole update (rollouts aside) from one captured graph do so
         # (BASELINE configs[4]: RRG + SCST with a HIP-graph-captured step); single process, one micro-batch per step, no clipping
         self.graph_step = bool(config.get("graph_step")) and hasattr(self.model, "graphed_step") and self.ddp is None and \

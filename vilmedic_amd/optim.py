@@ -26,6 +26,9 @@ class FusedAdam(torch.optim.Optimizer):
         self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=a.flat.device)
         self._lr_host = float(lr)
         self.gate = None
+        # set by ArenaDDP (attach_optimizer) after a reducing backward: the averaged bf16 wire buffer the next step() reads INSTEAD of the
+        # fp32 gradient arena (consumed once)
+        self.grad_wire = None
         # frozen parameters: their gradient slices stay zero and m=v=0 -> update is exactly 0 (no weight decay applied
         # would still move them, so decay is rejected when something is frozen)
         if weight_decay and any(not p.requires_grad for p in params):
@@ -48,11 +51,13 @@ class FusedAdam(torch.optim.Optimizer):
             self.step_dev.add_(torch.isfinite(self.gate).reshape(-1)[:1].to(torch.int64))
         else:
             self.step_dev.add_(1)
-        check(lib().vm_adam_step_dev(ptr(a.flat), ptr(a.gflat), ptr(self.m), ptr(self.v), ptr(a.shadow_flat), a.numel,
-                                     g["lr"], b1, b2, g["eps"], g["weight_decay"], int(g["decoupled_weight_decay"]),
-                                     1 - b1 ** self.steps, 1 - b2 ** self.steps, self.grad_scale,
-                                     ptr(self.lr_dev), ptr(self.step_dev), ptr(self.gate) if self.gate is not None else None, stream()),
-              "vm_adam_step_dev")
+        wire, self.grad_wire = self.grad_wire, None
+        fn, grads = (lib().vm_adam_step_dev, a.gflat) if wire is None else (lib().vm_adam_step_wire, wire)
+        check(fn(ptr(a.flat), ptr(grads), ptr(self.m), ptr(self.v), ptr(a.shadow_flat), a.numel,
+                 g["lr"], b1, b2, g["eps"], g["weight_decay"], int(g["decoupled_weight_decay"]),
+                 1 - b1 ** self.steps, 1 - b2 ** self.steps, self.grad_scale,
+                 ptr(self.lr_dev), ptr(self.step_dev), ptr(self.gate) if self.gate is not None else None, stream()),
+              "vm_adam_step")
         a.mark_shadow_fresh()
 
     def sync_lr(self):

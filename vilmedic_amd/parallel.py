@@ -113,7 +113,7 @@ class ArenaDDP:
                 self.split_at = min(enc_offs)
                 model.split_backward = True
         # encoder buckets: {mark tag: arena offset where that layer's parameters start}; models may provide ``ddp_marks`` themselves
-        self._marks, self._live, self.mark_starts = {}, None, 0
+        self._marks, self._live, self.mark_starts, self._opt = {}, None, 0, None
         if self.split_at is not None and enc_buckets > 1:
             marks = getattr(model, "ddp_marks", None) or self._layer_marks(model)
             offs = sorted(o for o in marks.values() if self.split_at < o < self.arena.numel)
@@ -168,11 +168,30 @@ class ArenaDDP:
                 works.append((cs, ce, _avg_allreduce(g[cs:ce], self.dist, self.world, async_op=True)))
         return works
 
+    def attach_optimizer(self, optimizer):
+        """a FusedAdam that reads the averaged bf16 wire buffer itself (vm_adam_step_wire): the cast pass back into the fp32 gradient arena
+        is skipped, so after a reducing backward ``p.grad`` holds this rank's LOCAL gradients -- only for loops that do nothing with the
+        gradients between backward and step (no clipping, no inspection).  No-op for an fp32 wire or another optimizer."""
+        if self.bf16_wire and hasattr(optimizer, "grad_wire") and getattr(optimizer, "arena", None) is self.arena:
+            self._opt = optimizer
+
     def _wait(self, works):
+        fused = self.bf16_wire and self._opt is not None and self._covered(works)
         for cs, ce, w in works:
             w.wait()
-            if self.bf16_wire:
+            if self.bf16_wire and not fused:
                 self._ops.cast_to_f32(self._wire[cs:ce], self.arena.gflat[cs:ce])
+        if fused:
+            self._opt.grad_wire = self._wire
+
+    def _covered(self, works):
+        """the pending pieces tile the whole arena (a reducing backward / finish() always does; checked, not assumed)"""
+        at = 0
+        for cs, ce in sorted((cs, ce) for cs, ce, _ in works):
+            if cs > at:
+                return False
+            at = max(at, ce)
+        return at >= self.arena.numel
 
     def backward(self, loss, sync=True):
         """loss.backward() + gradient averaging, communication overlapped with the encoder's backward when possible.
