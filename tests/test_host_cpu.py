@@ -128,6 +128,28 @@ def test_rouge_l_and_reward_table():
     assert REWARD_COMPLIANT["rougel"][1] == 1
 
 
+def test_bit_parallel_lcs_equals_the_table():
+    """ROUGE-L's longest common subsequence runs bit-parallel on the host (the SCST reward of 2 x batch rollouts per step): same length
+    as the quadratic table on random token lists, empty and one-sided inputs included"""
+    import random
+    from vilmedic_amd.blocks.scorers import _lcs
+
+    def table(a, b):
+        prev = [0] * (len(b) + 1)
+        for x in a:
+            cur = [0]
+            for j, y in enumerate(b):
+                cur.append(prev[j] + 1 if x == y else max(prev[j + 1], cur[j]))
+            prev = cur
+        return prev[-1]
+    rng = random.Random(0)
+    for _ in range(400):
+        n, m, V = rng.randint(0, 140), rng.randint(0, 140), rng.choice([2, 3, 12, 60])
+        a, b = [str(rng.randrange(V)) for _ in range(n)], [str(rng.randrange(V)) for _ in range(m)]
+        assert _lcs(a, b) == table(a, b)
+    assert _lcs([], ["a"]) == 0 and _lcs(["a"], []) == 0 and _lcs(["a"] * 70, ["a"] * 65) == 65
+
+
 def test_out_of_scope_models_raise():
     import vilmedic_amd.models as M
     with pytest.raises(NotImplementedError):
