@@ -114,17 +114,17 @@ class SCST(nn.Module):
         sampled = trim_to_last_eos(out.sequences[B:], self.eos_token_id)
         if rollouts_only:
             return greedy, sampled
-        reward_greedy, _, _ = self.get_reward(greedy.detach(), input_ids)
-        return self._policy_gradient(sampled, input_ids, attention_mask, enc_s, mask_s, reward_greedy), reward_greedy
+        reward_greedy, _, refs = self.get_reward(greedy.detach(), input_ids)
+        return self._policy_gradient(sampled, input_ids, attention_mask, enc_s, mask_s, reward_greedy, ref_list=refs), reward_greedy
 
-    def pg_weights(self, seq, input_ids, reward_greedy, pad_to=None):
+    def pg_weights(self, seq, input_ids, reward_greedy, pad_to=None, ref_list=None):
         """rewards of the sampled rollout (host: tokenizer + scorers) -> (seq [B, T], row weights [B, T], bookkeeping).  Row (b, t) predicts
         seq[b, t + 1] with weight mask * (r_sample - r_greedy) / sum(mask) (ref:...SCST.py:14-45).  ``pad_to``: T is padded to this length
         with pad tokens of weight 0 -- the static shape of the graph-captured step; the loss does not change (weight-0 rows contribute 0,
         the causal mask keeps the pad positions out of every weighted row)."""
         dev = seq.device
         sampled_ids = seq[:, 1:].contiguous()
-        reward_sampling, hyp_list, _ = self.get_reward(sampled_ids, input_ids)
+        reward_sampling, hyp_list, _ = self.get_reward(sampled_ids, input_ids, ref_list=ref_list)
         weights = self.scores_weights[-len(self.scorers):]
         delta = [torch.tensor(rs, device=dev, dtype=torch.float32) - torch.tensor(rg, device=dev, dtype=torch.float32)
                  for rs, rg in zip(reward_sampling, reward_greedy)]
@@ -147,7 +147,7 @@ class SCST(nn.Module):
                             encoder_attention_mask=encoder_attention_mask, labels=seq, return_logits=False,
                             row_weight=row_w, banned=banned, top_k=self.top_k)["loss"]
 
-    def _policy_gradient(self, seq, input_ids, attention_mask, encoder_hidden_states, encoder_attention_mask, reward_greedy):
+    def _policy_gradient(self, seq, input_ids, attention_mask, encoder_hidden_states, encoder_attention_mask, reward_greedy, ref_list=None):
         """seq [B, T] with bos at 0 = the sampled rollout -> SCST loss through one teacher-forced pass (ref:...SCST.py:14-45,159-185)"""
         dev = encoder_hidden_states.device
         nll_loss = None
@@ -155,15 +155,26 @@ class SCST(nn.Module):
             nll_loss = self.decoder(input_ids=input_ids.to(dev), attention_mask=attention_mask.to(dev),
                                     encoder_hidden_states=encoder_hidden_states, encoder_attention_mask=encoder_attention_mask,
                                     labels=input_ids.to(dev), return_logits=False)["loss"]
-        seq, row_w, (delta_reward, delta_reward_per_metric, reward_sampling, hyp_list) = self.pg_weights(seq, input_ids, reward_greedy)
+        seq, row_w, (delta_reward, delta_reward_per_metric, reward_sampling, hyp_list) = self.pg_weights(seq, input_ids, reward_greedy, ref_list=ref_list)
         loss = self.pg_loss(seq, row_w, encoder_hidden_states, encoder_attention_mask)
         if self.use_nll:
             loss = loss + self.scores_weights[0] * nll_loss
         return loss, delta_reward, delta_reward_per_metric, reward_sampling, hyp_list
 
-    def get_reward(self, rollout_input_ids, input_ids):
-        hyp_list = [self.tokenizer.decode(h, skip_special_tokens=True, clean_up_tokenization_spaces=False) for h in rollout_input_ids]
-        ref_list = [self.tokenizer.decode(r, skip_special_tokens=True, clean_up_tokenization_spaces=False) for r in input_ids]
+    def _decode_texts(self, ids):
+        """token ids [B, T] -> texts: ONE device-to-host copy for the batch (iterating a device tensor row by row synchronises once per
+        row), the tokenizer's batch decode when it has one"""
+        rows = ids.tolist() if isinstance(ids, torch.Tensor) else [list(r) for r in ids]
+        kw = dict(skip_special_tokens=True, clean_up_tokenization_spaces=False)
+        batch = getattr(self.tokenizer, "batch_decode", None)
+        return list(batch(rows, **kw)) if batch is not None else [self.tokenizer.decode(r, **kw) for r in rows]
+
+    def get_reward(self, rollout_input_ids, input_ids, ref_list=None):
+        """``ref_list``: the decoded references when the caller already has them (the greedy and the sampled rollout of a step score against
+        the same ones)"""
+        hyp_list = self._decode_texts(rollout_input_ids)
+        if ref_list is None:
+            ref_list = self._decode_texts(input_ids)
         reward = [scorer(ref_list, hyp_list)[idx] for scorer, idx in zip(self.scorers, self.scorers_index)]
         return reward, hyp_list, ref_list
 

@@ -76,8 +76,8 @@ class RRG_SCST(nn.Module):
             enc_s = self.model.encode(images, None)              # (= the features the captured pass recomputes: no dropout in this encoder)
             greedy, sampled = self.scst.forward_rollouts(input_ids=input_ids, attention_mask=attention_mask, greedy_encoder=enc_g,
                                                          sampling_encoder=enc_s, rollouts_only=True)
-        reward_greedy, _, _ = self.scst.get_reward(greedy.detach(), input_ids)
-        seq, row_w, (delta_reward, _, reward_sampling, _) = self.scst.pg_weights(sampled, input_ids, reward_greedy, pad_to=self.scst.max_length)
+        reward_greedy, _, refs = self.scst.get_reward(greedy.detach(), input_ids)
+        seq, row_w, (delta_reward, _, reward_sampling, _) = self.scst.pg_weights(sampled, input_ids, reward_greedy, pad_to=self.scst.max_length, ref_list=refs)
         if g is None:
             from ...graph import GraphedTrainStep
 
