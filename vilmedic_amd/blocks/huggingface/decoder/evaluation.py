@@ -44,7 +44,7 @@ def evaluation(models, config, dl, **kwargs):
                 encoder_outputs, encoder_attention_mask = models[0].encode(**batch)
                 hyps = hf_model.generate(input_ids=start, encoder_hidden_states=encoder_outputs,
                                          encoder_attention_mask=encoder_attention_mask, **gen)
-            for h, r in zip(hyps, batch[ref_str]):
+            for h, r in zip(hyps.tolist(), batch[ref_str].tolist()):      # one device-to-host copy each, not one per row
                 hyp_list.append(tokenizer.decode(h, skip_special_tokens=True, clean_up_tokenization_spaces=False))
                 ref_list.append(tokenizer.decode(r, skip_special_tokens=True, clean_up_tokenization_spaces=False))
     return {"refs": ref_list, "hyps": hyp_list}

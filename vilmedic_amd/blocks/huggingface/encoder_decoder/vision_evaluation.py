@@ -25,7 +25,7 @@ def evaluation(models, config, dl, **kwargs):
             B = enc.shape[0]
             out = vedm.decoder.generate(input_ids=torch.full((B, 1), bos, dtype=torch.long, device=enc.device),
                                         encoder_hidden_states=enc, encoder_attention_mask=enc_mask, **gen)
-            for h, r in zip(out, batch["input_ids"]):
+            for h, r in zip(out.tolist(), batch["input_ids"].tolist()):      # one device-to-host copy each, not one per row
                 hyps.append(tokenizer.decode(h, skip_special_tokens=True, clean_up_tokenization_spaces=False))
                 refs.append(tokenizer.decode(r, skip_special_tokens=True, clean_up_tokenization_spaces=False))
     return {"refs": refs, "hyps": hyps}
