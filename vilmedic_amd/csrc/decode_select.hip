@@ -66,15 +66,34 @@ __global__ __launch_bounds__(256) void select_tokens_kernel(const SelArgs p) {
         const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);            // (0, 1)
         return -__logf(-__logf(u));
     };
+    // one pass over the row: 16-B loads, two per thread in flight (a row is 120 KB read by ONE workgroup -- with 4-B loads the launch was
+    // 39 us of dependent round trips); every element is visited exactly once, so what the passes compute does not depend on the order
+    const bool vec = (((uintptr_t)lr) & 15) == 0;
+    auto visit = [&](auto&& fn) {
+        int done = 0;
+        if (vec) {
+            const int nq = p.V >> 2;
+            const float4* l4 = reinterpret_cast<const float4*>(lr);
+            int q = tid;
+            for (; q + 256 < nq; q += 512) {
+                const float4 a = l4[q], b = l4[q + 256];
+                fn(4 * q, a.x); fn(4 * q + 1, a.y); fn(4 * q + 2, a.z); fn(4 * q + 3, a.w);
+                fn(4 * q + 1024, b.x); fn(4 * q + 1025, b.y); fn(4 * q + 1026, b.z); fn(4 * q + 1027, b.w);
+            }
+            if (q < nq) { const float4 a = l4[q]; fn(4 * q, a.x); fn(4 * q + 1, a.y); fn(4 * q + 2, a.z); fn(4 * q + 3, a.w); }
+            done = nq << 2;
+        }
+        for (int c = done + tid; c < p.V; c += 256) fn(c, lr[c]);
+    };
     float bv = -INFINITY; int bi = 0x7fffffff;
     if (!sample) {
-        for (int c = tid; c < p.V; c += 256) sel_better(bv, bi, lr[c], c);
+        visit([&](int c, float v) { sel_better(bv, bi, v, c); });
     } else if (p.top_k <= 0 || p.top_k >= p.V - p.n_banned) {
-        for (int c = tid; c < p.V; c += 256) if (!banned(c)) sel_better(bv, bi, lr[c] + gumbel(c), c);
+        visit([&](int c, float v) { if (!banned(c)) sel_better(bv, bi, v + gumbel(c), c); });
     } else {
         // (1) lower bound L of the k-th largest live logit: the k-th largest of the per-thread maxima
         float mx = -INFINITY;
-        for (int c = tid; c < p.V; c += 256) if (!banned(c)) mx = fmaxf(mx, lr[c]);
+        visit([&](int c, float v) { if (!banned(c)) mx = fmaxf(mx, v); });
         s_max[tid] = mx;
         if (tid == 0) s_n = 0;
         __syncthreads();
@@ -85,13 +104,12 @@ __global__ __launch_bounds__(256) void select_tokens_kernel(const SelArgs p) {
         __syncthreads();
         const float L = s_thr;
         // (2) every live logit >= L (at least k of them; normally a few dozen)
-        for (int c = tid; c < p.V; c += 256) {
-            const float v = lr[c];
+        visit([&](int c, float v) {
             if (!banned(c) && v >= L) {
                 const int at = atomicAdd(&s_n, 1);
                 if (at < SEL_CAND) { c_val[at] = v; c_idx[at] = c; }
             }
-        }
+        });
         __syncthreads();
         const int n = min(s_n, SEL_CAND);
         // (3) the exact threshold: the candidate that has exactly k - 1 candidates above it (ties by index); a row with fewer than k
