@@ -277,18 +277,34 @@ extern "C" int vm_ce_smooth_fwd_bwd(const float* logits, const int64_t* target, 
 }
 
 // ------------------------------------------------------------------ decode helpers (fp32)
+// thread tid visits columns tid, tid + 256, ... IN THAT ORDER (the sums below depend on it), eight loads requested before the first is
+// used: a vocabulary row is read by one workgroup, and with one 4-byte load per round trip these kernels were pure latency
+template <class F>
+__device__ __forceinline__ void row_strided8(const float* __restrict__ x, int V, int tid, F&& fn) {
+    int c = tid;
+    for (; c + 7 * 256 < V; c += 8 * 256) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = x[c + 256 * u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) fn(c + 256 * u, v[u]);
+    }
+    for (; c < V; c += 256) fn(c, x[c]);
+}
+
 __global__ __launch_bounds__(256) void logsoftmax_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int V) {
     __shared__ float sh[4];
     const float* r = x + (int64_t)blockIdx.x * ldx;
+    const int tid = threadIdx.x;
     float mx = -INFINITY;
-    for (int c = threadIdx.x; c < V; c += 256) mx = fmaxf(mx, r[c]);
+    row_strided8(r, V, tid, [&](int, float v) { mx = fmaxf(mx, v); });
     mx = block_reduce_max(mx, sh);
     float se = 0.f;
-    for (int c = threadIdx.x; c < V; c += 256) se += expf(r[c] - mx);
+    row_strided8(r, V, tid, [&](int, float v) { se += expf(v - mx); });
     se = block_reduce_sum(se, sh);
     const float lse = mx + logf(se);
     float* o = out + (int64_t)blockIdx.x * V;
-    for (int c = threadIdx.x; c < V; c += 256) o[c] = r[c] - lse;
+    row_strided8(r, V, tid, [&](int c, float v) { o[c] = v - lse; });
 }
 extern "C" int vm_logsoftmax_f32(const float* logits, int64_t ldl, float* out, int rows, int V, void* stream) {
     VM_REQUIRE(logits && out && rows > 0 && V > 0 && ldl >= V, "vm_logsoftmax_f32: bad arguments");
@@ -321,18 +337,19 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict_
     for (int r = 0; r < nb; ++r) {
         const float* x = logits + (int64_t)(b * nb + r) * ldl;
         float mx = -INFINITY;
-        for (int c = tid; c < V; c += 256) mx = fmaxf(mx, x[c]);
+        row_strided8(x, V, tid, [&](int, float v) { mx = fmaxf(mx, v); });
         mx = block_reduce_max(mx, sh);
         float se = 0.f;
-        for (int c = tid; c < V; c += 256) se += expf(x[c] - mx);
+        row_strided8(x, V, tid, [&](int, float v) { se += expf(v - mx); });
         se = block_reduce_sum(se, sh);
         lse[r] = mx + logf(se);
         sc[r] = scores[b * nb + r];
     }
-    auto value = [&](int r, int c) { return (logits[(int64_t)(b * nb + r) * ldl + c] - lse[r]) + sc[r]; };
     float best = -INFINITY;
-    for (int r = 0; r < nb; ++r)
-        for (int c = tid; c < V; c += 256) best = fmaxf(best, value(r, c));
+    for (int r = 0; r < nb; ++r) {
+        const float lr_ = lse[r], sr = sc[r];
+        row_strided8(logits + (int64_t)(b * nb + r) * ldl, V, tid, [&](int, float v) { best = fmaxf(best, (v - lr_) + sr); });
+    }
     s_max[tid] = best;
     if (tid == 0) s_n = 0;
     __syncthreads();
@@ -341,14 +358,16 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict_
     if (rank == keep - 1) s_thr = best;
     __syncthreads();
     const float L = s_thr;
-    for (int r = 0; r < nb; ++r)
-        for (int c = tid; c < V; c += 256) {
-            const float v = value(r, c);
+    for (int r = 0; r < nb; ++r) {
+        const float lr_ = lse[r], sr = sc[r];
+        row_strided8(logits + (int64_t)(b * nb + r) * ldl, V, tid, [&](int c, float x) {
+            const float v = (x - lr_) + sr;
             if (v >= L) {
                 const int at = atomicAdd(&s_n, 1);
                 if (at < BT_CAND) { c_val[at] = v; c_idx[at] = r * V + c; }
             }
-        }
+        });
+    }
     __syncthreads();
     const int n = min(s_n, BT_CAND);
     // rank of every candidate among the candidates (value descending, flat index ascending): ranks 0 .. keep - 1 are the answer
@@ -377,10 +396,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ x
     __shared__ int si[256];
     const float* r = x + (int64_t)blockIdx.x * ldx;
     float best = -INFINITY; int bi = 0x7fffffff;
-    for (int c = threadIdx.x; c < cols; c += 256) {
-        const float v = r[c];
-        if (v > best || (v == best && c < bi)) { best = v; bi = c; }
-    }
+    row_strided8(r, cols, threadIdx.x, [&](int c, float v) { if (v > best || (v == best && c < bi)) { best = v; bi = c; } });
     sv[threadIdx.x] = best; si[threadIdx.x] = bi;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
