@@ -109,7 +109,7 @@ def run_decode(args):
         return
     dev = torch.device("cuda")
     dec = bench.build_model(dev).eval().dec.decoder
-    B, S, T = 64, 197, 65
+    B, S, T = int(os.environ.get("VM_DECODE_BENCH_BATCH", "64")), 197, 65
     enc = torch.randn(B, S, 768, device=dev).bfloat16()
     mask = torch.ones(B, S, dtype=torch.bool, device=dev)
     start = torch.zeros(B, 1, dtype=torch.long, device=dev)
