@@ -126,12 +126,14 @@ typedef struct {
 } vm_decode_gemm_args;
 int vm_decode_gemm(const vm_decode_gemm_args* args, void* stream);
 
-/* Beam-search candidates of one step in one launch (hf:generation/utils.py _beam_search :3208-3520, driven by
+/* Beam-search candidates of one step (hf:generation/utils.py _beam_search :3208-3520, driven by
  * ref:vilmedic/blocks/huggingface/decoder/evaluation.py:73-78): for every sample the ``keep`` (= 2 x num_beams) best of
  * log_softmax(logits[b * num_beams + r, :]) + running_scores[b * num_beams + r] over (r, token), sorted by value (ties: flat index
- * r * V + token ascending).  logits fp32 [B * num_beams, ldl]; out_values fp32 [B, keep], out_indices int64 [B, keep]; num_beams <= 8. */
+ * r * V + token ascending).  logits fp32 [B * num_beams, ldl]; out_values fp32 [B, keep], out_indices int64 [B, keep]; num_beams <= 8.
+ * Two launches: one workgroup per row leaves the row's ``keep`` best in ``ws`` (vm_beam_topk_ws bytes, caller-provided), one per sample merges. */
+size_t vm_beam_topk_ws(int B, int num_beams, int keep);
 int vm_beam_topk(const float* logits, int64_t ldl, int B, int num_beams, int V, const float* running_scores, int keep,
-                 float* out_values, int64_t* out_indices, void* stream);
+                 float* out_values, int64_t* out_indices, void* ws, size_t ws_bytes, void* stream);
 /* Token selection of one decode step in one launch (csrc/decode_select.hip; hf:generation/utils.py _sample :2783-2975 with
  * NoBadWordsLogitsProcessor + TopKLogitsWarper, as driven by ref:vilmedic/blocks/rl/SCST.py:112-174 and
  * ref:vilmedic/blocks/huggingface/decoder/evaluation.py:73-78).  logits fp32 [rows, ldl].  Rows < greedy_rows: arg-max of the raw logits

@@ -280,7 +280,8 @@ def test_beam_topk_equals_logsoftmax_plus_torch_topk(B, nb, V):
     keep = 2 * nb
     val = torch.empty(B, keep, dtype=torch.float32, device=dev())
     idx = torch.empty(B, keep, dtype=torch.long, device=dev())
-    check(lib().vm_beam_topk(ptr(logits), ldl, B, nb, V, ptr(scores), keep, ptr(val), ptr(idx), stream()), "vm_beam_topk")
+    ws = torch.empty(lib().vm_beam_topk_ws(B, nb, keep), dtype=torch.uint8, device=dev())
+    check(lib().vm_beam_topk(ptr(logits), ldl, B, nb, V, ptr(scores), keep, ptr(val), ptr(idx), ptr(ws), ws.numel(), stream()), "vm_beam_topk")
     ref = (log_softmax_f32(logits[:, :V].contiguous()).view(B, nb, V) + scores[:, :, None]).view(B, nb * V)
     rv, ri = torch.topk(ref, keep)
     torch.cuda.synchronize()

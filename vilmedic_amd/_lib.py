@@ -106,7 +106,8 @@ SIGNATURES = {
     "vm_logsoftmax_f32": (_I, [_P, _L, _P, _I, _I, _P]),
     "vm_argmax_f32": (_I, [_P, _L, _P, _P, _I, _I, _P]),
     "vm_decode_gemm": (_I, [C.POINTER(DecodeGemmArgs), _P]),
-    "vm_beam_topk": (_I, [_P, _L, _I, _I, _I, _P, _I, _P, _P, _P]),
+    "vm_beam_topk": (_I, [_P, _L, _I, _I, _I, _P, _I, _P, _P, _P, _SZ, _P]),
+    "vm_beam_topk_ws": (_SZ, [_I, _I, _I]),
     "vm_select_tokens": (_I, [_P, _L, _I, _I, _I, C.POINTER(C.c_int32), _I, _I, _U64, _P, _P, _L, _I, _P, _I, _I, _P]),
     "vm_gemm_f32": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _I, _P, _L, _P]),
     "vm_layernorm_f32": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),

@@ -317,76 +317,93 @@ extern "C" int vm_logsoftmax_f32(const float* logits, int64_t ldl, float* out, i
 // ------------------------------------------------------------------ beam search: log-softmax + running score + top-k in one launch
 // hf:generation/utils.py _beam_search (:3208-3520): log_probs = log_softmax(logits.float()) + running_beam_scores[:, :, None], flattened
 // over (beam, token), then topk(2 * num_beams).  Round 2 ran it as vm_logsoftmax_f32 (a second [rows, V] fp32 matrix written and re-read)
-// + torch's multi-block radix top-k + gather (~300 us per step at 64 x 4 beams); here one workgroup per SAMPLE reads its beams' logits
-// four times from L2 and writes 2 x num_beams candidates.  The arithmetic is vm_logsoftmax_f32's, bit for bit (same strides, same
+// + torch's multi-block radix top-k + gather (~300 us per step at 64 x 4 beams); here one workgroup per ROW reads its logits four times from
+// L2 and leaves the row's best 2 x num_beams in a workspace, and one small workgroup per sample merges its rows' candidates (one
+// workgroup per SAMPLE walking all its rows measured 110 us at 64 x 4 rows: 64 workgroups of dependent round trips).  The arithmetic is vm_logsoftmax_f32's, bit for bit (same strides, same
 // reduction helpers): lse = max + log(sum exp(x - max)), value = (x - lse) + score.  The k best of the nb x V values are found exactly
 // through the k-th largest of the 256 per-thread maxima (a lower bound L of the k-th value: k values >= L exist) and a candidate list in
 // LDS (csrc/decode_select.hip uses the same idea); output sorted by value, ties by flat index (beam * V + token) ascending.
 #define BT_CAND 1024
 #define BT_MAXB 8
-__global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict__ logits, int64_t ldl, int nb, int V, const float* __restrict__ scores,
-                                                        int keep, float* __restrict__ out_val, int64_t* __restrict__ out_idx) {
+// one workgroup per (sample, beam) ROW: lse of the row, then the row's `keep` best values (x - lse) + score -- the sample's `keep` best all
+// rank below `keep` inside their own row -- written to ws[row][rank] as (value, flat index beam * V + token); padded with (-inf, INT_MAX)
+__global__ __launch_bounds__(256) void beam_rows_kernel(const float* __restrict__ logits, int64_t ldl, int nb, int V, const float* __restrict__ scores,
+                                                        int keep, float* __restrict__ ws_val, int* __restrict__ ws_idx) {
     __shared__ float sh[4];
     __shared__ float s_max[256];
     __shared__ float c_val[BT_CAND];
     __shared__ int c_idx[BT_CAND];
     __shared__ int s_n;
     __shared__ float s_thr;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    float lse[BT_MAXB], sc[BT_MAXB];
-    for (int r = 0; r < nb; ++r) {
-        const float* x = logits + (int64_t)(b * nb + r) * ldl;
-        float mx = -INFINITY;
-        row_strided8(x, V, tid, [&](int, float v) { mx = fmaxf(mx, v); });
-        mx = block_reduce_max(mx, sh);
-        float se = 0.f;
-        row_strided8(x, V, tid, [&](int, float v) { se += expf(v - mx); });
-        se = block_reduce_sum(se, sh);
-        lse[r] = mx + logf(se);
-        sc[r] = scores[b * nb + r];
-    }
+    const int row = blockIdx.x, r = row % nb, tid = threadIdx.x;
+    const float* x = logits + (int64_t)row * ldl;
+    float mx = -INFINITY;
+    row_strided8(x, V, tid, [&](int, float v) { mx = fmaxf(mx, v); });
+    mx = block_reduce_max(mx, sh);
+    float se = 0.f;
+    row_strided8(x, V, tid, [&](int, float v) { se += expf(v - mx); });
+    se = block_reduce_sum(se, sh);
+    const float lse = mx + logf(se), sc = scores[row];
+    const int kr = min(keep, V);
     float best = -INFINITY;
-    for (int r = 0; r < nb; ++r) {
-        const float lr_ = lse[r], sr = sc[r];
-        row_strided8(logits + (int64_t)(b * nb + r) * ldl, V, tid, [&](int, float v) { best = fmaxf(best, (v - lr_) + sr); });
-    }
+    row_strided8(x, V, tid, [&](int, float v) { best = fmaxf(best, (v - lse) + sc); });
     s_max[tid] = best;
     if (tid == 0) s_n = 0;
+    for (int a = tid; a < keep; a += 256) { ws_val[(int64_t)row * keep + a] = -INFINITY; ws_idx[(int64_t)row * keep + a] = 0x7fffffff; }
     __syncthreads();
     int rank = 0;
     for (int j = 0; j < 256; ++j) { const float o = s_max[j]; rank += (o > best || (o == best && j < tid)) ? 1 : 0; }
-    if (rank == keep - 1) s_thr = best;
+    if (rank == min(kr, 256) - 1) s_thr = best;
     __syncthreads();
     const float L = s_thr;
-    for (int r = 0; r < nb; ++r) {
-        const float lr_ = lse[r], sr = sc[r];
-        row_strided8(logits + (int64_t)(b * nb + r) * ldl, V, tid, [&](int c, float x) {
-            const float v = (x - lr_) + sr;
-            if (v >= L) {
-                const int at = atomicAdd(&s_n, 1);
-                if (at < BT_CAND) { c_val[at] = v; c_idx[at] = r * V + c; }
-            }
-        });
-    }
+    row_strided8(x, V, tid, [&](int c, float xv) {
+        const float v = (xv - lse) + sc;
+        if (v >= L) {
+            const int at = atomicAdd(&s_n, 1);
+            if (at < BT_CAND) { c_val[at] = v; c_idx[at] = r * V + c; }
+        }
+    });
     __syncthreads();
     const int n = min(s_n, BT_CAND);
-    // rank of every candidate among the candidates (value descending, flat index ascending): ranks 0 .. keep - 1 are the answer
     for (int a = tid; a < n; a += 256) {
         const float v = c_val[a]; const int ia = c_idx[a];
         int above = 0;
         for (int j = 0; j < n; ++j) { const float o = c_val[j]; above += (o > v || (o == v && c_idx[j] < ia)) ? 1 : 0; }
+        if (above < kr) { ws_val[(int64_t)row * keep + above] = v; ws_idx[(int64_t)row * keep + above] = ia; }
+    }
+}
+// one workgroup per sample: rank of every row candidate among the sample's nb * keep (value descending, flat index ascending)
+__global__ __launch_bounds__(256) void beam_merge_kernel(const float* __restrict__ ws_val, const int* __restrict__ ws_idx, int nb, int keep,
+                                                         float* __restrict__ out_val, int64_t* __restrict__ out_idx) {
+    extern __shared__ __attribute__((aligned(16))) char bm_smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, n = nb * keep;
+    float* cv = reinterpret_cast<float*>(bm_smem);
+    int* ci = reinterpret_cast<int*>(cv + n);
+    for (int a = tid; a < n; a += 256) { cv[a] = ws_val[(int64_t)b * n + a]; ci[a] = ws_idx[(int64_t)b * n + a]; }
+    __syncthreads();
+    for (int a = tid; a < n; a += 256) {
+        const float v = cv[a]; const int ia = ci[a];
+        if (ia == 0x7fffffff) continue;
+        int above = 0;
+        for (int j = 0; j < n; ++j) { const float o = cv[j]; above += (o > v || (o == v && ci[j] < ia)) ? 1 : 0; }
         if (above < keep) { out_val[(int64_t)b * keep + above] = v; out_idx[(int64_t)b * keep + above] = ia; }
     }
 }
 
+extern "C" size_t vm_beam_topk_ws(int B, int num_beams, int keep) { return (size_t)B * num_beams * keep * (sizeof(float) + sizeof(int)); }
+
 extern "C" int vm_beam_topk(const float* logits, int64_t ldl, int B, int num_beams, int V, const float* running_scores, int keep,
-                            float* out_values, int64_t* out_indices, void* stream) {
+                            float* out_values, int64_t* out_indices, void* ws, size_t ws_bytes, void* stream) {
     VM_REQUIRE(logits && running_scores && out_values && out_indices && B > 0 && V > 0 && ldl >= V, "vm_beam_topk: bad arguments");
     VM_REQUIRE(num_beams >= 1 && num_beams <= BT_MAXB && keep >= 1 && keep <= 256 && (int64_t)keep <= (int64_t)num_beams * V,
                "vm_beam_topk: 1 <= num_beams <= %d, 1 <= keep <= 256", BT_MAXB);
+    VM_REQUIRE(ws && ws_bytes >= vm_beam_topk_ws(B, num_beams, keep), "vm_beam_topk: workspace of vm_beam_topk_ws(B, num_beams, keep) bytes required");
     hipStream_t s = (hipStream_t)stream;
     VmProfScope prof(VM_FAM_DECODE, 16.0 * B * num_beams * (double)V, s, "beam_topk_B%d_nb%d_V%d", B, num_beams, V);
-    hipLaunchKernelGGL(beam_topk_kernel, dim3(B), dim3(256), 0, s, logits, ldl, num_beams, V, running_scores, keep, out_values, out_indices);
+    float* wv = reinterpret_cast<float*>(ws);
+    int* wi = reinterpret_cast<int*>(wv + (size_t)B * num_beams * keep);
+    hipLaunchKernelGGL(beam_rows_kernel, dim3(B * num_beams), dim3(256), 0, s, logits, ldl, num_beams, V, running_scores, keep, wv, wi);
+    hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(256), (size_t)num_beams * keep * 8, s, wv, wi, num_beams, keep, out_values, out_indices);
     return vm_check_launch("vm_beam_topk");
 }
 

@@ -445,12 +445,13 @@ def beam_search(decoder, input_ids, enc, enc_mask, *, max_length, eos_token_id, 
     row_base = (torch.arange(B, device=dev) * nb)[:, None]
     topk_lp = torch.empty(B, keep, dtype=torch.float32, device=dev)
     topk_idx = torch.empty(B, keep, dtype=torch.long, device=dev)
+    topk_ws = torch.empty(max(16, lib().vm_beam_topk_ws(B, min(nb, 8), keep)), dtype=torch.uint8, device=dev)
     cur = prompt
     while True:
         logits = st.step(running[:, :, cur - 1].reshape(-1), cur - 1)
-        if nb <= 8:           # log-softmax + running scores + top-2nb in one launch (csrc/loss.hip beam_topk_kernel)
-            check(lib().vm_beam_topk(ptr(logits), logits.stride(0), B, nb, V, ptr(running_scores), keep, ptr(topk_lp), ptr(topk_idx), stream()),
-                  "vm_beam_topk")
+        if nb <= 8:           # log-softmax + running scores + top-2nb: a per-row and a per-sample launch (csrc/loss.hip vm_beam_topk)
+            check(lib().vm_beam_topk(ptr(logits), logits.stride(0), B, nb, V, ptr(running_scores), keep, ptr(topk_lp), ptr(topk_idx),
+                                     ptr(topk_ws), topk_ws.numel(), stream()), "vm_beam_topk")
         else:
             logp = log_softmax_f32(logits.contiguous()).view(B, nb, V)
             logp = (logp + running_scores[:, :, None]).view(B, nb * V)
