@@ -31,9 +31,18 @@ def _digest():
     return h.hexdigest()
 
 
+def _stale():
+    """a source newer than the library: the stamp (a tracked file) can be restored by a checkout that also rewrote sources, and would then
+    vouch for a library built from other code"""
+    t = os.path.getmtime(LIB)
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    files.append(os.path.join(CSRC, "..", "..", "include", "vmhip.h"))
+    return any(os.path.getmtime(f) > t for f in files)
+
+
 def build(force=False, verbose=True):
     dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read() == dig:
+    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read() == dig and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
