@@ -15,6 +15,46 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 #define SK_NW 8        // waves per workgroup: the contraction is split 8 ways
 #define SK_D 4         // register ring: operand fragments of 4 k-steps in flight per wave
 
+// sum of the SK_NW waves' partial fragments (in wave order) + epilogue; wave w finishes fragments w, w + SK_NW, ...
+template <int MF>
+__device__ __forceinline__ void skinny_finish(const GemmArgs& p, const float* red, int wave, int lane, int m0, int n0) {
+    const int g = lane >> 4, c = lane & 15;
+    const vm_gemm_epilogue& e = p.e;
+    const float alpha = e.alpha_dev ? e.alpha * (*e.alpha_dev) : e.alpha;
+    const int gn = n0 + 4 * g;
+    for (int i = wave; i < MF; i += SK_NW) {                              // wave w finishes fragments w, w + SK_NW, ...
+        const int gm = m0 + 16 * i + c;
+        float4_t s = reinterpret_cast<const float4_t*>(red)[(0 * MF + i) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < SK_NW; ++w) {
+            const float4_t t = reinterpret_cast<const float4_t*>(red)[(w * MF + i) * 64 + lane];
+            s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+        }
+        if (gm >= p.M || gn >= p.N) continue;
+        float v[4] = {s[0] * alpha, s[1] * alpha, s[2] * alpha, s[3] * alpha};
+        const int nvalid = min(4, p.N - gn);
+        if (e.bias) for (int r = 0; r < nvalid; ++r) v[r] += e.bias[gn + r];
+        if (e.act == 1) for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+        if (e.residual) {
+            const bf16_t* rp = reinterpret_cast<const bf16_t*>(e.residual) + (int64_t)gm * e.ldr + gn;
+            for (int r = 0; r < nvalid; ++r) v[r] += bf16_to_f32(rp[r]);
+        }
+        const int64_t off = (int64_t)gm * p.ldc + gn;
+        if (e.out_dtype == VM_BF16) {
+            bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + off;
+            if (nvalid == 4 && (p.ldc & 3) == 0) {
+                uint2 u; u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<uint2*>(cp) = u;
+            } else for (int r = 0; r < nvalid; ++r) cp[r] = f32_to_bf16(v[r]);
+        } else {
+            float* cp = reinterpret_cast<float*>(p.C) + off;
+            if (e.accumulate) for (int r = 0; r < nvalid; ++r) cp[r] += v[r];
+            else if (nvalid == 4 && (p.ldc & 3) == 0) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+            else for (int r = 0; r < nvalid; ++r) cp[r] = v[r];
+        }
+    }
+}
+
 template <int MF>   // MF = number of 16-row fragments (M <= 16 * MF)
 __global__ __launch_bounds__(SK_NW * 64) void gemm_skinny_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) float red[];          // [SK_NW waves][MF][64 lanes][4]
@@ -57,39 +97,58 @@ __global__ __launch_bounds__(SK_NW * 64) void gemm_skinny_kernel(const GemmArgs 
 #pragma unroll
     for (int i = 0; i < MF; ++i) mine[i * 64] = acc[i];
     __syncthreads();
-    const vm_gemm_epilogue& e = p.e;
-    const float alpha = e.alpha_dev ? e.alpha * (*e.alpha_dev) : e.alpha;
-    const int gn = n0 + 4 * g;
-    for (int i = wave; i < MF; i += SK_NW) {                              // wave w finishes fragments w, w + SK_NW, ...
-        const int gm = m0 + 16 * i + c;
-        float4_t s = reinterpret_cast<const float4_t*>(red)[(0 * MF + i) * 64 + lane];
+    skinny_finish<MF>(p, red, wave, lane, m0, n0);
+}
+
+// The wide-output form (LM head: N = 30522 columns of K = 768): 1908 column blocks, and with one workgroup per block the 64-row operand
+// (98 KB) is re-read from L2 1908 times (the weights once).  Here a workgroup walks column blocks blockIdx.x, + gridDim.x, ... with its
+// waves' row fragments RESIDENT in registers (K <= 768: 3 k-steps x 4 fragments per wave), the next block's weight fragments requested
+// before the current block's reduction, and the LDS partials double-buffered (one barrier per block).  Same K split, same reduction
+// order: bit-identical to gemm_skinny_kernel.
+#define SKC_STEPS 3
+__global__ __launch_bounds__(SK_NW * 64) void gemm_skinny_cols_kernel(const GemmArgs p) {
+    constexpr int MF = 4;
+    extern __shared__ __attribute__((aligned(16))) float red[];          // 2 x [SK_NW waves][MF][64 lanes][4]
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * (16 * MF);
+    const int ksteps = p.K >> 5, per = (ksteps + SK_NW - 1) / SK_NW;
+    const int ks0 = wave * per, ks1 = min(ksteps, ks0 + per);
+    const int col_blocks = (p.N + 15) >> 4;
+    bf16x8_t aq[SKC_STEPS][MF], bq[SKC_STEPS], bn[SKC_STEPS];
 #pragma unroll
-        for (int w = 1; w < SK_NW; ++w) {
-            const float4_t t = reinterpret_cast<const float4_t*>(red)[(w * MF + i) * 64 + lane];
-            s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+    for (int d = 0; d < SKC_STEPS; ++d)
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const bf16_t* arow = p.A + (int64_t)min(m0 + 16 * i + c, p.M - 1) * p.lda + g * 8;
+            if (ks0 + d < ks1) aq[d][i] = *reinterpret_cast<const bf16x8_t*>(arow + (ks0 + d) * 32);
         }
-        if (gm >= p.M || gn >= p.N) continue;
-        float v[4] = {s[0] * alpha, s[1] * alpha, s[2] * alpha, s[3] * alpha};
-        const int nvalid = min(4, p.N - gn);
-        if (e.bias) for (int r = 0; r < nvalid; ++r) v[r] += e.bias[gn + r];
-        if (e.act == 1) for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
-        if (e.residual) {
-            const bf16_t* rp = reinterpret_cast<const bf16_t*>(e.residual) + (int64_t)gm * e.ldr + gn;
-            for (int r = 0; r < nvalid; ++r) v[r] += bf16_to_f32(rp[r]);
-        }
-        const int64_t off = (int64_t)gm * p.ldc + gn;
-        if (e.out_dtype == VM_BF16) {
-            bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + off;
-            if (nvalid == 4 && (p.ldc & 3) == 0) {
-                uint2 u; u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]);
-                *reinterpret_cast<uint2*>(cp) = u;
-            } else for (int r = 0; r < nvalid; ++r) cp[r] = f32_to_bf16(v[r]);
-        } else {
-            float* cp = reinterpret_cast<float*>(p.C) + off;
-            if (e.accumulate) for (int r = 0; r < nvalid; ++r) cp[r] += v[r];
-            else if (nvalid == 4 && (p.ldc & 3) == 0) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-            else for (int r = 0; r < nvalid; ++r) cp[r] = v[r];
-        }
+    auto load_b = [&](int cb, bf16x8_t (&b_)[SKC_STEPS]) {
+        const bf16_t* brow = p.B + (int64_t)min(cb * 16 + c, p.N - 1) * p.ldb + g * 8;
+#pragma unroll
+        for (int d = 0; d < SKC_STEPS; ++d) if (ks0 + d < ks1) b_[d] = *reinterpret_cast<const bf16x8_t*>(brow + (ks0 + d) * 32);
+    };
+    int cb = blockIdx.x, it = 0;
+    if (cb < col_blocks) load_b(cb, bq);
+    for (; cb < col_blocks; cb += gridDim.x, ++it) {
+        if (cb + (int)gridDim.x < col_blocks) load_b(cb + gridDim.x, bn);
+        float4_t acc[MF];
+#pragma unroll
+        for (int i = 0; i < MF; ++i) acc[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < SKC_STEPS; ++d)
+            if (ks0 + d < ks1) {
+#pragma unroll
+                for (int i = 0; i < MF; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[d], aq[d][i], acc[i], 0, 0, 0);
+            }
+        float* buf = red + (it & 1) * (SK_NW * MF * 64 * 4);
+        float4_t* mine = reinterpret_cast<float4_t*>(buf) + (wave * MF) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) mine[i * 64] = acc[i];
+        __syncthreads();           // (a wave reaches the next block's barrier only after it finished reading this buffer: two buffers suffice)
+        skinny_finish<MF>(p, buf, wave, lane, m0, cb * 16);
+#pragma unroll
+        for (int d = 0; d < SKC_STEPS; ++d) bq[d] = bn[d];
     }
 }
 
@@ -119,6 +178,18 @@ int vm_skinny_rows_per_wg(int M, int N, int max_mf) {
 // eligibility is decided by the caller (gemm.hip): row-major A and B (K contiguous), K % 32 == 0, M <= 256, no split-K,
 // no z side output / gelu' multiply / dropout
 int vm_gemm_skinny_dispatch(const GemmArgs& a, hipStream_t s) {
+    if (a.N >= 4096 && a.K <= 32 * SK_NW * SKC_STEPS) {          // wide output, short contraction: resident row fragments
+        const int row_blocks = (a.M + 63) / 64, col_blocks = (a.N + 15) / 16;
+        int gx = 512 / row_blocks; if (gx > col_blocks) gx = col_blocks; if (gx < 1) gx = 1;
+        const size_t lds = (size_t)2 * SK_NW * 4 * 64 * sizeof(float4_t);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_cols_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gemm_skinny_cols_kernel, dim3(gx, row_blocks), dim3(SK_NW * 64), lds, s, a);
+        return vm_check_launch("vm_gemm_bf16(skinny, column walk)");
+    }
     switch (vm_skinny_rows_per_wg(a.M, a.N, 8)) {
         case 1: return launch_skinny<1>(a, s);
         case 2: return launch_skinny<2>(a, s);
