@@ -237,6 +237,89 @@ __global__ __launch_bounds__(DG_NW * 64) void decode_gemm_kernel(const DgArgs p)
     }
 }
 
+// The wide-output form (the fp32 LM head: N = 30522 columns of K = 768; gemm_skinny.hip has the bf16 one): a workgroup walks column
+// blocks blockIdx.x, + gridDim.x, ... with the 64-row operand RESIDENT in its waves' registers (6 k-steps x 4 fragments per wave at
+// K = 768) instead of being re-read from L2 by each of 1908 workgroups; next block's weight fragments requested before the current
+// block's reduction; LDS partials double-buffered (one barrier per block).  Plain + bias only.  K split and reduction order are
+// decode_gemm_kernel's: bit-identical.
+#define DGC_STEPS 6
+template <bool F32>
+__global__ __launch_bounds__(DG_NW * 64) void decode_gemm_cols_kernel(const DgArgs p) {
+    typedef DgT<F32> T;
+    typedef typename T::elem elem;
+    typedef typename T::frag frag;
+    constexpr int MF = 4;
+    extern __shared__ __attribute__((aligned(16))) float red[];          // 2 x [DG_NW][MF][64 lanes][4]
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * (16 * MF);
+    const int ksteps = p.K / T::STEP, per = (ksteps + DG_NW - 1) / DG_NW;
+    const int ks0 = wave * per, ks1 = min(ksteps, ks0 + per);
+    const int col_blocks = (p.N + 15) >> 4;
+    frag aq[DGC_STEPS][MF], wq[DGC_STEPS], wn[DGC_STEPS];
+#pragma unroll
+    for (int d = 0; d < DGC_STEPS; ++d)
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const elem* arow = reinterpret_cast<const elem*>(p.A) + (int64_t)min(m0 + 16 * i + c, p.M - 1) * p.lda + g * T::PER_LANE;
+            if (ks0 + d < ks1) aq[d][i] = *reinterpret_cast<const frag*>(arow + (ks0 + d) * T::STEP);
+        }
+    auto load_w = [&](int cb, frag (&w_)[DGC_STEPS]) {
+        const elem* wrow = reinterpret_cast<const elem*>(p.W) + (int64_t)min(cb * 16 + c, p.N - 1) * p.ldw + g * T::PER_LANE;
+#pragma unroll
+        for (int d = 0; d < DGC_STEPS; ++d) if (ks0 + d < ks1) w_[d] = *reinterpret_cast<const frag*>(wrow + (ks0 + d) * T::STEP);
+    };
+    int cb = blockIdx.x, it = 0;
+    if (cb < col_blocks) load_w(cb, wq);
+    for (; cb < col_blocks; cb += gridDim.x, ++it) {
+        if (cb + (int)gridDim.x < col_blocks) load_w(cb + gridDim.x, wn);
+        const int gn = cb * 16 + 4 * g;
+        float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && wave < MF) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias4[r] = p.bias[min(gn + r, p.N - 1)];
+        }
+        float4_t acc[MF];
+#pragma unroll
+        for (int i = 0; i < MF; ++i) acc[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < DGC_STEPS; ++d)
+            if (ks0 + d < ks1) {
+#pragma unroll
+                for (int i = 0; i < MF; ++i) T::mma(wq[d], aq[d][i], acc[i]);
+            }
+        float* buf = red + (it & 1) * (DG_NW * MF * 64 * 4);
+        float4_t* mine = reinterpret_cast<float4_t*>(buf) + (wave * MF) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) mine[i * 64] = acc[i];
+        __syncthreads();           // (a wave reaches the next block's barrier only after it finished reading this buffer: two buffers suffice)
+        if (wave < MF) {
+            const int i = wave, gm = m0 + 16 * i + c;
+            float4_t sres = reinterpret_cast<const float4_t*>(buf)[(0 * MF + i) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < DG_NW; ++w) {
+                const float4_t t = reinterpret_cast<const float4_t*>(buf)[(w * MF + i) * 64 + lane];
+                sres[0] += t[0]; sres[1] += t[1]; sres[2] += t[2]; sres[3] += t[3];
+            }
+            if (gm < p.M && gn < p.N) {
+                const float v[4] = {sres[0] + bias4[0], sres[1] + bias4[1], sres[2] + bias4[2], sres[3] + bias4[3]};
+                const int nvalid = min(4, p.N - gn);
+                elem* cp = reinterpret_cast<elem*>(p.C) + (int64_t)gm * p.ldc + gn;
+                const bool vec = nvalid == 4 && ((p.ldc & 3) == 0);
+                if constexpr (F32) {
+                    if (vec) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                    else for (int r = 0; r < nvalid; ++r) cp[r] = v[r];
+                } else {
+                    if (vec) { uint2 u; u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]); *reinterpret_cast<uint2*>(cp) = u; }
+                    else for (int r = 0; r < nvalid; ++r) cp[r] = f32_to_bf16(v[r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DGC_STEPS; ++d) wq[d] = wn[d];
+    }
+}
+
 int vm_skinny_rows_per_wg(int M, int N, int max_mf);      // gemm_skinny.hip
 
 template <bool F32, int MF, bool LN>
@@ -285,6 +368,18 @@ extern "C" int vm_decode_gemm(const vm_decode_gemm_args* x, void* stream) {
     // rows per workgroup: at least one workgroup per CU (gemm_skinny.hip), at most 64 rows -- measured at 256 rows (beam 4) on the step's
     // shapes: 64-row blocks 14.9 / 15.3 / 17.8 us (N = 2304 / 3072 / 768 x K = 3072) against 18.4 / 18.8 / 28.3 us for 128-row blocks and
     // 15.0 / 17.5 / 20.3 us for 32-row blocks; fp32 likewise (26.0 / 26.8 / 32.6 vs 33.3 / 33.9 / 56.6 us)
+    if (f32 && !ln && !x->residual && !x->act && !x->c2 && x->N >= 4096 && x->K / step <= DG_NW * DGC_STEPS) {      // wide output: column walk
+        const int row_blocks = (x->M + 63) / 64, col_blocks = (x->N + 15) / 16;
+        int gx = 512 / row_blocks; if (gx > col_blocks) gx = col_blocks; if (gx < 1) gx = 1;
+        const size_t lds = (size_t)2 * DG_NW * 4 * 64 * sizeof(float4_t);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_gemm_cols_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((decode_gemm_cols_kernel<true>), dim3(gx, row_blocks), dim3(DG_NW * 64), lds, s, a);
+        return vm_check_launch("vm_decode_gemm(column walk)");
+    }
     int mf = vm_skinny_rows_per_wg(x->M, x->N, ln ? 2 : 4);
     if (!ln && mf == 2 && x->M > 128 && ((x->N + 15) / 16) * ((x->M + 63) / 64) >= 192) mf = 4;
     if (f32) return ln ? dg_dispatch<true, true>(a, mf, s) : dg_dispatch<true, false>(a, mf, s);
