@@ -162,7 +162,7 @@ class DecodeState:
                 self._step(self.tok, t)
             cur.wait_stream(warm)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with ops.capture(graph):
                 out = self._step(self.tok, t)
             entry = self.graphs[t] = (graph, out)
         entry[0].replay()

@@ -52,7 +52,7 @@ class GraphedTrainStep:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             steps0 = getattr(self.optimizer, "steps", None)
-            with torch.cuda.graph(g):
+            with ops.capture(g):
                 self._one()
             if steps0 is not None:
                 self.optimizer.steps = steps0      # capturing is not a step

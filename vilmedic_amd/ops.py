@@ -26,6 +26,29 @@ BF16 = torch.bfloat16
 _seed_state = {"base": 0x1234ABCD, "counter": 0}
 
 
+# HIP-graph captures (generation.DecodeState, graph.GraphedTrainStep) are checked per THREAD: in the default "global" mode an event query of
+# another thread -- the watchdog of an RCCL process group polls its collectives' events all the time -- invalidates a capture that happens
+# to be open ("operation not permitted when stream is capturing"), i.e. a validation decode inside a data-parallel run aborted at random.
+CAPTURE_MODE = "thread_local"
+
+
+@contextlib.contextmanager
+def capture(graph):
+    """``torch.cuda.graph(graph)`` for this package's captures: per-thread error mode (above), and the cyclic garbage collector held off while
+    the stream is capturing -- a collection that happens to run inside the capture and finds an OLD CUDAGraph (the decode graphs of a model
+    that went out of scope) destroys it there, which HIP rejects ("operation not permitted when stream is capturing", raised from
+    ~CUDAGraph: the process aborts).  torch.cuda.graph collects once before the capture begins; this keeps it that way until it ends."""
+    import gc
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, capture_error_mode=CAPTURE_MODE):
+            yield
+    finally:
+        if was:
+            gc.enable()
+
+
 def manual_seed(seed):
     _seed_state["base"] = int(seed) & 0xFFFFFFFF
     _seed_state["counter"] = 0
