@@ -158,11 +158,39 @@ def _tiny_trainor(tmp_path, tag, extra=()):
         if "loss" in out and tr.model.training:
             losses.append(out["loss"].detach().float().reshape(()).clone())
         return out
-    tr.model.forward = recording
+    if getattr(tr, "graph_any", False):            # replayed iterations do not call forward(): record what the graphed iteration returns
+        gi = tr._graphed_iteration
+
+        def graphed(batch):
+            loss = gi(batch)
+            losses.append(loss.detach().float().reshape(()).clone())
+            return loss
+        tr._graphed_iteration = graphed
+    else:
+        tr.model.forward = recording
     tr.start()
     torch.cuda.synchronize()
     from vilmedic_amd.arena import arena_of
     return tr, torch.stack(losses).cpu(), arena_of(tr.model).flat.clone(), tr.evaluator.scores
+
+
+def test_trainor_graph_step_replays_the_eager_iterations(tmp_path):
+    """trainor.graph_step for a model without its own graphed_step: every iteration of ``Trainor.start()`` (forward, backward, fused Adam
+    with the device-side NaN gate) is replayed from the HIP graph captured for the batch's shapes after two eager iterations.  Without
+    dropout the loss trajectory and the final parameters are those of the eager loop; validation and checkpointing run as before."""
+    extra = ["model.decoder.hidden_dropout_prob=0.0", "model.decoder.attention_probs_dropout_prob=0.0", "trainor.epochs=2"]
+    t0, l0, p0, s0 = _tiny_trainor(tmp_path, "eager", extra)
+    t1, l1, p1, s1 = _tiny_trainor(tmp_path, "graph", extra + ["trainor.graph_step=true"])
+    assert t1.graph_any and not t0.graph_any and len(t1._graphs) == 1
+    g = next(iter(t1._graphs.values()))
+    assert g.graph is not None                                    # 12 iterations: 2 eager, then captured and replayed
+    assert l0.shape == l1.shape and l0.numel() == 12            # (epochs 0 .. 2 of 4 iterations each, as the reference counts them)
+    dl, dp = (l0 - l1).abs().max().item(), _rel(p1, p0)
+    print(f"[parity] Trainor.start() with graph_step: max |loss_t - loss_t(eager)| {dl:.3e}, rel L2 of the final parameters {dp:.3e}; "
+          f"validation {s1[0]} vs {s0[0]}", flush=True)
+    assert dl <= 1e-5 and dp <= 1e-5
+    assert s1[0] == s0[0]
+    assert int(t1.optimizer.state_dict()["steps"]) == 12
 
 
 @pytest.mark.parametrize("wire", ["fp32", "bf16"])

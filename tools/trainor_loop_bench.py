@@ -5,6 +5,7 @@ same YAML as bin/train.py) on the C2 config under four input conditions and prin
     loader      the training loader alone (no model)
     fixed       Trainor.start() over ONE resident device batch, repeated (the loop without an input pipeline: what bench.py times)
     prefetch    Trainor.start() over the PrefetchLoader (the shipped default)
+    graph       the same with trainor.graph_step (iterations replayed from a captured HIP graph)
     plain       Trainor.start() over the bare DataLoader (prefetch: 0 -- what round 1 shipped)
 
     python tools/trainor_loop_bench.py [iters=100] [num_samples=3200]
@@ -77,6 +78,9 @@ def main():
 
     run("fixed", [fixed], iters)
     run("prefetch", create_data_loader(tcfg, "train", logger), iters)
+    tr.graph_any = True          # trainor.graph_step: every iteration replayed from the HIP graph captured for the batch's shapes
+    run("graph", create_data_loader(tcfg, "train", logger), iters)
+    tr.graph_any = False
     tcfg["prefetch"] = 0
     run("plain", create_data_loader(tcfg, "train", logger), max(30, iters // 3))
     for k, v in res.items():

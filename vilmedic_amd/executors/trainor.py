@@ -73,8 +73,13 @@ class Trainor(object):
             self.ddp.attach_optimizer(self.optimizer)      # the optimizer reads the averaged bf16 wire buffer itself (no cast pass back)
         # trainor.graph_step: true -- models that can replay their whole update (rollouts aside) from one captured graph do so
         # (BASELINE configs[4]: RRG + SCST with a HIP-graph-captured step); single process, one micro-batch per step, no clipping
-        self.graph_step = bool(config.get("graph_step")) and hasattr(self.model, "graphed_step") and self.ddp is None and \
-            self.grad_accu == 1 and self.clip is None and hasattr(self.optimizer, "gate")
+        graphable = bool(config.get("graph_step")) and self.ddp is None and self.grad_accu == 1 and self.clip is None and \
+            hasattr(self.optimizer, "gate")
+        self.graph_step = graphable and hasattr(self.model, "graphed_step")
+        # ... and every other model has its whole iteration (forward, backward, fused Adam with the device-side NaN gate) captured per batch
+        # shape by vilmedic_amd.graph.GraphedTrainStep: the host enqueues one graph launch per iteration, the rate no longer depends on it
+        self.graph_any = graphable and not self.graph_step
+        self._graphs = {}
         self.eval_start = int(config.get("eval_start") or 0)
         self.evaluator = Validator(config.validator_view, [self.model], self.dl, seed, True, self.logger, self.rank, self.world) \
             if config.get("validator_view") is not None else None
@@ -110,6 +115,28 @@ class Trainor(object):
         self._zero_grad()
         self.training_scheduler.iteration_step(epoch + float(iteration) / max(len(self.dl), 1))      # frac_epoch, trainor.py:125-126,152-153
 
+    def _graphed_iteration(self, batch):
+        """one iteration replayed from the HIP graph captured for this batch's tensor shapes (two eager iterations, then the capture); None
+        when the batch carries something that is neither a tensor (a static input of the graph) nor a None / scalar constant (part of the graph's
+        key) -- the caller then runs it eagerly"""
+        from ..graph import GraphedTrainStep
+        tensors = {k: v.cuda() for k, v in batch.items() if isinstance(v, torch.Tensor)}
+        consts = {k: v for k, v in batch.items() if not isinstance(v, torch.Tensor)}
+        if not all(v is None or isinstance(v, (bool, int, float, str)) for v in consts.values()):
+            return None
+        key = tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(tensors.items())) + tuple(sorted((k, repr(v)) for k, v in consts.items()))
+        g = self._graphs.get(key)
+        if g is None:
+            def step_fn(**tb):
+                loss = self.model(**tb, **consts)["loss"].mean()
+                self._zero_grad()
+                self.optimizer.gate = loss.detach()          # NaN / Inf loss: the update is skipped on the device (trainor.py:109-112)
+                loss.backward()
+                self.optimizer.step()
+                return loss
+            g = self._graphs[key] = GraphedTrainStep(step_fn, tensors, optimizer=self.optimizer, warmup=2)
+        return g(**tensors)
+
     def start(self):
         cfg = self.config
         early_stop_start = int(cfg.get("early_stop_start") or 0)
@@ -124,6 +151,15 @@ class Trainor(object):
                     self.training_scheduler.iteration_step(epoch + float(iteration) / max(len(self.dl), 1))
                     losses.append(out["loss"].detach().clone())
                     continue
+                if self.graph_any:
+                    loss = self._graphed_iteration(batch)
+                    if loss is None:
+                        self._zero_grad()                # (a graphed iteration leaves its gradients behind: it zeroes them before its backward)
+                    else:
+                        self.training_scheduler.iteration_step(epoch + float(iteration) / max(len(self.dl), 1))
+                        losses.append(loss.detach().clone())
+                        out = {"loss": loss}
+                        continue
                 out = self.model(**batch, epoch=epoch, iteration=iteration)
                 if "loss" not in out:
                     continue
