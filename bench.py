@@ -508,6 +508,26 @@ def main():
             secondary = secondary_metrics(model, device)
         except Exception as e:      # the headline line must survive a failing side measurement; the failure is reported, not hidden
             secondary = {"error": f"{type(e).__name__}: {e}"}
+        if ddp is None and isinstance(secondary, dict):
+            # the other launch mode of the SAME step, after the timed region: 10 iterations replayed from one captured HIP graph when the
+            # timed steps were eager launches (and the reverse) -- the rate that does not depend on the host, next to the one that does
+            try:
+                from vilmedic_amd.graph import GraphedTrainStep
+                if args.graph:
+                    other, name = eager_step, "eager"
+                else:
+                    g2 = GraphedTrainStep(eager_step, dict(input_ids=ids, attention_mask=am, images=images), optimizer=opt, warmup=1)
+                    other, name = (lambda: g2(input_ids=ids, attention_mask=am, images=images)), "hip-graph replay"
+                for _ in range(3):
+                    other()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    other()
+                torch.cuda.synchronize()
+                secondary["other_launch_mode"] = {"launch_mode": name, "ms_per_step": round((time.perf_counter() - t0) * 100.0, 3), "steps": 10}
+            except Exception as e:
+                secondary["other_launch_mode"] = {"error": f"{type(e).__name__}: {e}"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
