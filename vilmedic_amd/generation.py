@@ -194,11 +194,12 @@ class DecodeState:
         check(lib().vm_decode_gemm(C_.byref(g), stream()), "vm_decode_gemm")
 
     def _dgl(self, s, ln, x, W, C, M, N, K, **kw):
-        """projection of LN(s), with x = LN(s) kept for the residual.  Up to 64 rows (fp32) / 32 rows (bf16) the LayerNorm rides on the
+        """projection of LN(s), with x = LN(s) kept for the residual.  Up to 16 rows (fp32) / 32 rows (bf16) the LayerNorm rides on the
         projection's operand load (one launch); beyond, every one of the 144-192 workgroups recomputing the statistics of all rows costs
         more than the separate LayerNorm launch (measured per step, fused vs separate -- bf16: 16 rows 0.686 vs 0.751 ms, 32 rows 0.799 vs
-        0.816, 64 rows 0.951 vs 0.904; fp32: 1.021 vs 1.238, 1.181 vs 1.333, 1.486 vs 1.54; 256 rows 3.8 vs 2.1 ms)."""
-        if M <= (64 if self.f32 else 32):
+        0.816, 64 rows 0.951 vs 0.904; fp32, with the single-read vm_layernorm_f32: 16 rows 1.032 vs 1.078, 64 rows 1.468 vs 1.34;
+        256 rows 3.8 vs 2.1 ms)."""
+        if M <= (16 if self.f32 else 32):
             return self._dg(s, W, C, M, N, K, ln=ln, ln_out=x, **kw)
         if self.f32:
             check(lib().vm_layernorm_f32(ptr(s), ptr(ln.weight), ptr(ln.bias), ptr(x), M, K, self.cfg.layer_norm_eps, stream()), "vm_layernorm_f32")
