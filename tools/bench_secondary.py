@@ -7,10 +7,10 @@
   mvqa              training images/s and inference images/s    (config/MVQA/vqa-synthetic.yml, batch 256)
   rrs               summarisation training step, pairs/s        (config/RRS/rrs-synthetic.yml, batch 64)
   scst              RRG + SCST step (two rollouts + policy gradient), pairs/s   (config/RRG/rrg-scst-synthetic.yml, batch 32)
-  decode            greedy and beam-4 decode of the RRG decoder, tokens/s       (B = 64, 64 new tokens)
+  decode            greedy and beam-4 decode of the RRG decoder, tokens/s       (B = 64 or VM_DECODE_BENCH_BATCH, 64 new tokens)
 
 Prints one JSON object per measurement.  ``--dry`` builds every dataset and model on the CPU and stops (what can be checked without
-a GPU).  Written at the end of round 1 after the GPU budget was spent: the timed part has not run yet."""
+a GPU)."""
 import argparse
 import json
 import logging
