@@ -150,8 +150,8 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 def stream():
     """raw hipStream_t of torch's current stream on the current device (the C accessor: no Stream object per launch)"""
     if _raw_stream is not None:
-        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return _raw_stream(torch.cuda.current_device())          # (a plain int: ctypes converts it for a c_void_p parameter itself)
+    return torch.cuda.current_stream().cuda_stream
 
 
 def ptr(t):
@@ -159,4 +159,4 @@ def ptr(t):
         return None
     if not t.is_cuda:
         raise VmHipError("vilmedic_amd ops need device tensors: the HIP path has no CPU fallback")
-    return C.c_void_p(t.data_ptr())
+    return t.data_ptr() or None          # (a plain int -- ctypes converts it for a c_void_p parameter or field; address 0 -> NULL)

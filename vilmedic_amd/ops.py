@@ -82,23 +82,23 @@ def gemm(A, a_layout, B, b_layout, C_out, M, N, K, *, lda=None, ldb=None, ldc=No
          mul_gelu_z=None, dropout_p=0.0, dropout_seed=0, residual=None, ldr=None, alpha=1.0, alpha_dev=None, accumulate=False,
          split_k=1):
     e = GemmEpilogue()
-    e.bias = ptr(bias).value if bias is not None else None
+    e.bias = ptr(bias) if bias is not None else None
     e.act = act
-    e.aux_out = ptr(aux_out).value if aux_out is not None else None
-    e.mul_gelu_z = ptr(mul_gelu_z).value if mul_gelu_z is not None else None
+    e.aux_out = ptr(aux_out) if aux_out is not None else None
+    e.mul_gelu_z = ptr(mul_gelu_z) if mul_gelu_z is not None else None
     e.dropout_p = dropout_p
     e.dropout_seed = dropout_seed
     e.dropout_seed_dev = seed_dev(C_out.device).data_ptr() if dropout_p > 0 else None
-    e.residual = ptr(residual).value if residual is not None else None
+    e.residual = ptr(residual) if residual is not None else None
     e.ldr = ldr if ldr is not None else (residual.stride(0) if residual is not None else 0)
     e.alpha = alpha
-    e.alpha_dev = ptr(alpha_dev).value if alpha_dev is not None else None
+    e.alpha_dev = ptr(alpha_dev) if alpha_dev is not None else None
     e.out_dtype = VM_F32 if C_out.dtype == torch.float32 else VM_BF16
     e.accumulate = 1 if accumulate else 0
     e.split_k = split_k
     if split_k > 1:
         ws = _workspace(split_k * M * (ldc if ldc is not None else C_out.stride(0)) * 4, C_out.device)
-        e.workspace = ptr(ws).value
+        e.workspace = ptr(ws)
         e.workspace_bytes = ws.numel()
     lda = lda if lda is not None else A.stride(0)
     ldb = ldb if ldb is not None else B.stride(0)
