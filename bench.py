@@ -422,7 +422,9 @@ def main():
         return out["loss"]
 
     step = eager_step
-    if args.graph and ddp is None:
+    # (under data parallelism the capture holds the RCCL collectives too: the decoder range and the mark-started encoder buckets keep their
+    # side-stream fork / join inside the graph -- what a multi-GPU node replays is one graph launch per step and rank)
+    if args.graph:
         from vilmedic_amd.graph import GraphedTrainStep
         graphed = GraphedTrainStep(eager_step, dict(input_ids=ids, attention_mask=am, images=images), optimizer=opt, warmup=min(3, max(1, args.warmup - 1)))
         step = lambda: graphed(input_ids=ids, attention_mask=am, images=images)
@@ -508,7 +510,7 @@ def main():
             secondary = secondary_metrics(model, device)
         except Exception as e:      # the headline line must survive a failing side measurement; the failure is reported, not hidden
             secondary = {"error": f"{type(e).__name__}: {e}"}
-        if ddp is None and isinstance(secondary, dict):
+        if isinstance(secondary, dict):
             # the other launch mode of the SAME step, after the timed region: 10 iterations replayed from one captured HIP graph when the
             # timed steps were eager launches (and the reverse) -- the rate that does not depend on the host, next to the one that does
             try:
@@ -545,7 +547,7 @@ def main():
                                    "bf16, 224x224 images, 128-token reports, dropout 0.1, fwd+bwd+Adam",
                        "per_gpu_batch": B, "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}"},
             "model_tflops_per_s": round(step_flops * args.steps / elapsed / 1e12 * world, 1),
-            "launch_mode": "hip-graph replay" if (args.graph and ddp is None) else "eager",
+            "launch_mode": "hip-graph replay" if args.graph else "eager",
             "final_loss": round(final_loss, 4),
             "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,
         }

@@ -79,7 +79,9 @@ int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void* B, int64_
  * no separate reduce / column-sum kernels.  What autograd computes for nn.Linear weight / bias in the reference's backward
  * (hf:models/bert_generation/modeling_bert_generation.py:104-106,264-291; hf:models/vit/modeling_vit.py:192-251).
  * alpha_i: optional DEVICE scalar (upstream dL/dloss).  Returns VM_EUNSUPPORTED (nothing launched) unless every problem has
- * rows % 64 == 0, leading dims % 8 == 0 and 16-byte aligned pointers -- the caller then uses vm_gemm_bf16 + vm_colsum_bf16. */
+ * rows % 64 == 0, leading dims % 8 == 0 and 16-byte aligned pointers -- the caller then uses vm_gemm_bf16 + vm_colsum_bf16.
+ * Launches whose problems all have k_in % 256 == 0 and that hold at least 64 tiles of 256 x 256 run on the wide-tile kernel (csrc/gemm_p8w.hip:
+ * one 8-wave workgroup per CU, 16 problems per launch; VM_WGRAD_P8=0 switches it off), the others on 128 x 128 tiles, 8 problems per launch. */
 typedef struct {
     const void* dY; int64_t ld_dy;      /* bf16 [rows, n_out]  */
     const void* X; int64_t ld_x;        /* bf16 [rows, k_in]   */
@@ -87,6 +89,8 @@ typedef struct {
     float* db;                          /* fp32 [n_out] accumulated, or NULL */
     int rows, n_out, k_in;
     const float* alpha_dev;
+    int overwrite;                      /* 1: dW (and db) hold nothing yet -- this is their first contribution since the gradients were zeroed --
+                                           so the kernel may STORE instead of read-add-write (only the 256 x 256-tile kernel uses it; 0 is always correct) */
 } vm_wgrad_problem;
 int vm_wgrad_grouped(const vm_wgrad_problem* problems, int n, void* stream);
 /* n independent products C_i[M_i,N_i] (+)= A_i B_i of ONE operand layout (vm_gemm_bf16's a_layout / b_layout; NT, NN or TN) with the plain

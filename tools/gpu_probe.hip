@@ -219,7 +219,86 @@ static void bench_ab(int M, int N, int K, int la, int lb, int flags, int split) 
     hipFree(dbias); if (ws) hipFree(ws);
 }
 
+// grouped weight gradients: the 128 x 128-tile kernel (VM_WGRAD_P8=0) against the 256 x 256-tile kernel (2 / 4 barrier pairs per K-tile) on the
+// linears of `layers` transformer layers: results compared element by element (same MFMA, same K order: expected bit-identical), then timed
+static int bench_wgrad(int rows, const std::vector<std::pair<int, int>>& lin, int layers, int overwrite, const char* tag) {
+    std::vector<vm_wgrad_problem> pr;
+    std::vector<void*> frees;
+    std::vector<std::pair<float*, size_t>> outs;      // (dW | db, floats)
+    uint32_t x = 777u;
+    for (int l = 0; l < layers; ++l) for (auto& nk : lin) {
+        const int n_out = nk.first, k_in = nk.second;
+        const int64_t ld_dy = (n_out + 7) / 8 * 8;
+        std::vector<uint16_t> hy((size_t)rows * ld_dy), hx((size_t)rows * k_in);
+        for (auto& v : hy) { x = x * 1664525u + 1013904223u; v = f2bf((((x >> 8) & 0xffff) / 32768.f - 1.f) * 0.05f); }
+        for (auto& v : hx) { x = x * 1664525u + 1013904223u; v = f2bf(((x >> 8) & 0xffff) / 32768.f - 1.f); }
+        void *dY, *dX; float *dW, *db;
+        hipMalloc(&dY, hy.size() * 2); hipMalloc(&dX, hx.size() * 2); hipMalloc((void**)&dW, (size_t)n_out * k_in * 4); hipMalloc((void**)&db, (size_t)n_out * 4);
+        hipMemcpy(dY, hy.data(), hy.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dX, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
+        frees.push_back(dY); frees.push_back(dX); frees.push_back(dW); frees.push_back(db);
+        outs.push_back({dW, (size_t)n_out * k_in}); outs.push_back({db, (size_t)n_out});
+        vm_wgrad_problem q = {}; q.dY = dY; q.ld_dy = ld_dy; q.X = dX; q.ld_x = k_in; q.dW = dW; q.ld_dw = k_in; q.db = db; q.rows = rows; q.n_out = n_out; q.k_in = k_in;
+        q.alpha_dev = nullptr; q.overwrite = overwrite;
+        pr.push_back(q);
+    }
+    auto fill = [&](float v) { for (auto& o : outs) { std::vector<float> h(o.second, v); hipMemcpy(o.first, h.data(), o.second * 4, hipMemcpyHostToDevice); } };
+    auto fetch = [&]() { std::vector<std::vector<float>> r; for (auto& o : outs) { std::vector<float> h(o.second); hipMemcpy(h.data(), o.first, o.second * 4, hipMemcpyDeviceToHost); r.push_back(h); } return r; };
+    const int modes[3] = {0, 2, 4};
+    std::vector<std::vector<float>> ref;
+    int bad = 0;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int mode : modes) {
+        { char pb[4]; snprintf(pb, 4, "%d", mode); setenv("VM_WGRAD_P8", pb, 1); vm_reload_env(); }
+        fill(overwrite ? 123.f : 0.25f);                       // overwrite must erase the old contents; accumulate must keep them
+        int rc = vm_wgrad_grouped(pr.data(), (int)pr.size(), nullptr);
+        if (rc) { printf("wgrad rc=%d %s\n", rc, vm_last_error()); return 1; }
+        hipDeviceSynchronize();
+        auto got = fetch();
+        if (mode == 0) {
+            if (overwrite) for (auto& v : got) for (auto& e : v) e -= 123.f;      // the old kernel always accumulates
+            ref = got;
+        } else {
+            size_t nd = 0; double md = 0;
+            for (size_t t = 0; t < got.size(); ++t) for (size_t e = 0; e < got[t].size(); ++e) {
+                const double d = fabs((double)got[t][e] - ref[t][e]);
+                if (d > 0) ++nd;
+                if (d > md) md = d;
+                if (d > 1e-3 + 1e-4 * fabs(ref[t][e])) ++bad;
+            }
+            printf("wgrad %s p8w(%d) vs 128-tile kernel: %zu differing elements, max |diff| %.3g\n", tag, mode, nd, md);
+        }
+        double flop = 0; for (auto& q : pr) flop += 2.0 * q.rows * (double)q.n_out * q.k_in;
+        hipEventRecord(a, nullptr);
+        const int it = 6;
+        for (int i = 0; i < it; ++i) vm_wgrad_grouped(pr.data(), (int)pr.size(), nullptr);
+        hipEventRecord(b, nullptr); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b); ms /= it;
+        printf("wgrad %s rows=%d problems=%zu overwrite=%d VM_WGRAD_P8=%d: %8.1f us  %7.1f TFLOP/s\n", tag, rows, pr.size(), overwrite, mode, ms * 1e3, flop / ms * 1e-9);
+    }
+    for (void* f : frees) hipFree(f);
+    printf("wgrad %s: bad=%d %s\n", tag, bad, bad ? "FAIL" : "ok");
+    return bad != 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 2 && !strcmp(argv[1], "wgrad")) {
+        int fails = 0;
+        const std::vector<std::pair<int, int>> enc = {{2304, 768}, {768, 768}, {3072, 768}, {768, 3072}};
+        const std::vector<std::pair<int, int>> dec = {{2304, 768}, {768, 768}, {768, 768}, {768, 768}, {3072, 768}, {768, 3072}};
+        fails += bench_wgrad(12608, enc, 2, 0, "enc2");
+        fails += bench_wgrad(12608, enc, 2, 1, "enc2");
+        fails += bench_wgrad(8192, dec, 2, 0, "dec2");
+        fails += bench_wgrad(8192, dec, 2, 1, "dec2");
+        fails += bench_wgrad(12608, enc, 1, 1, "enc1");
+        fails += bench_wgrad(12608, enc, 4, 1, "enc4");
+        fails += bench_wgrad(8192, {{30522, 768}}, 1, 0, "lmhead");
+        fails += bench_wgrad(12608, {{18432, 768}}, 1, 1, "crosskv");
+        setenv("VM_WGRAD_P8_MIN", "1", 1);
+        fails += bench_wgrad(320, {{1000, 512}, {520, 256}}, 2, 0, "ragged");
+        fails += bench_wgrad(64, {{256, 256}, {130, 256}}, 1, 1, "tiny");
+        printf("wgrad fails=%d\n", fails);
+        return fails;
+    }
     if (argc >= 8 && !strcmp(argv[1], "one")) {     // gpu_probe.bin one M N K la lb split     (production kernel only: rocprofv3 --pmc workload)
         bench_gemm(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]));
         return 0;
@@ -275,7 +354,8 @@ int main(int argc, char** argv) {
             {12608, 768, 768, 0, 1, 0}, {8192, 768, 768, 0, 1, 0}, {12608, 768, 3072, 0, 1, 0}, {12608, 768, 2304, 0, 1, 0}, {12608, 1536, 768, 0, 0, 1},
             {8192, 2304, 768, 0, 0, 1}, {8192, 768, 3072, 0, 0, 49}, {12608, 2304, 768, 0, 1, 0},
         };
-        for (auto& c : cs) for (int variant = 0; variant <= 4; variant += 4) {
+        const int variants[] = {0, 4, 8, 9};
+        for (auto& c : cs) for (int variant : variants) {
             { char b[4]; snprintf(b, 4, "%d", variant); setenv("VM_GEMM_VARIANT", b, 1); vm_reload_env(); }
             printf("v%d ", variant);
             bench_gemm2(c.M, c.N, c.K, c.la, c.lb, c.flags, 6);

@@ -25,7 +25,7 @@ class GemmEpilogue(C.Structure):
 
 class WgradProblem(C.Structure):
     _fields_ = [("dY", C.c_void_p), ("ld_dy", C.c_int64), ("X", C.c_void_p), ("ld_x", C.c_int64), ("dW", C.c_void_p), ("ld_dw", C.c_int64),
-                ("db", C.c_void_p), ("rows", C.c_int), ("n_out", C.c_int), ("k_in", C.c_int), ("alpha_dev", C.c_void_p)]
+                ("db", C.c_void_p), ("rows", C.c_int), ("n_out", C.c_int), ("k_in", C.c_int), ("alpha_dev", C.c_void_p), ("overwrite", C.c_int)]
 
 
 class GemmProblem(C.Structure):

@@ -134,6 +134,8 @@ class ParamArena:
 
     def zero_grad(self):
         self.gflat.zero_()
+        from . import ops
+        ops.grads_zeroed(self.gflat)           # every gradient view is clean: the next weight-gradient GEMM into one may store
         for p, _ in self._layout:
             if p.requires_grad:
                 p.grad = p._vm_grad_view

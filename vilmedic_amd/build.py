@@ -14,7 +14,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libvmhip.so")
 STAMP = os.path.join(CSRC, ".build_stamp")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value",
-         "-Wno-unused-result"]
+         "-Wno-unused-result", "-Wno-inline-asm"]
 
 
 def _sources():

@@ -127,6 +127,9 @@ struct VmEnv {
     int gemm_variant;      // VM_GEMM_VARIANT: force a tile variant (-1: cost model)
     int gemm_debug;        // VM_GEMM_DEBUG: 1 skip the epilogue, 2 one K-tile only (timing breakdowns)
     int gemm_groupw;       // VM_GEMM_GROUPW: column-group width of the tile order (0: heuristic)
+    int gemm_p8_mf;        // VM_GEMM_P8_MF: A fragments per wave of the wide-tile kernel (4..8; 0: cost model)
+    int wgrad_p8_min;      // VM_WGRAD_P8_MIN: fewest 256 x 256 tiles in a launch for the wide-tile kernel (default 64)
+    int wgrad_p8;          // VM_WGRAD_P8: grouped weight gradients on 256 x 256 tiles: 0 off, 2 / 4 barrier pairs per K-tile (default 2)
     bool gemm_generic;     // VM_GEMM_GENERIC: register-staged fallback kernel only
     bool gemm_no_skinny;   // VM_GEMM_NO_SKINNY: never take the M <= 256 decode-step kernel
     bool attn_tile;        // VM_ATTN_TILE: tile-streaming attention kernels instead of the head-resident ones

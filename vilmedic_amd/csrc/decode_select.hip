@@ -63,8 +63,12 @@ __global__ __launch_bounds__(256) void select_tokens_kernel(const SelArgs p) {
     const DropKey key = drop_key(p.seed + ((uint64_t)p.cur << 32) + (uint64_t)row * 0x9E3779B97F4A7C15ull);
     auto gumbel = [&](int c) {
         const uint32_t h = sel_hash((uint32_t)c, key.s0, key.s1);
-        const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);            // (0, 1)
-        return -__logf(-__logf(u));
+        // 23 random bits: (h >> 9) + 0.5 is exact in fp32 and u stays strictly inside (0, 1).  With 24 bits the + 0.5 is not representable above
+        // 2^23 and 16777215.5 rounds to 2^24, i.e. u == 1 with probability 2^-24 per column: -log(-log 1) = +inf made that column win whatever
+        // its logit (about V / 2^24 = 0.18 % of the sampled rows per step at V = 30522).  The inner log is the accurate one: near u = 1 the
+        // fast __logf loses the relative accuracy the outer log needs.
+        const float u = ((float)(h >> 9) + 0.5f) * (1.0f / 8388608.0f);
+        return -__logf(-logf(u));
     };
     // one pass over the row: 16-B loads, two per thread in flight (a row is 120 KB read by ONE workgroup -- with 4-B loads the launch was
     // 39 us of dependent round trips); every element is visited exactly once, so what the passes compute does not depend on the order

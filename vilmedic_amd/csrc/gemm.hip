@@ -305,6 +305,25 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
         // tile variant: 256x128 3-stage ring when it still yields enough workgroups (1 per CU), else 128x128 2-stage
         int variant = 0;
         const int force = vm_env().gemm_variant;
+        // wide-tile kernel (gemm_p8.hip): (32 MF) x 256 tiles, one 8-wave workgroup per CU; 8 = one tile per workgroup, 9 = persistent
+        if ((force == 8 || force == 9) && a_layout == 0) {       // 8: four barrier pairs per K-tile, 9: two
+            int mf = vm_env().gemm_p8_mf;
+            if (mf < 5 || mf > 8) {      // rounds of the 256 CUs x rows per tile, ties to the larger tile
+                int64_t best = -1;
+                for (int m = 8; m >= 5; --m) {
+                    const int64_t t = (int64_t)((M + 32 * m - 1) / (32 * m)) * ((N + 255) / 256) * split;
+                    const int64_t cost = (t + 255) / 256 * m;
+                    if (best < 0 || cost < best) { best = cost; mf = m; }
+                }
+            }
+            a.tiles_m = (M + 32 * mf - 1) / (32 * mf);
+            a.tiles_n = (N + 255) / 256;
+            a.group_w = a.tiles_n >= 12 ? 4 : a.tiles_n;
+            if (vm_env().gemm_groupw > 0) a.group_w = vm_env().gemm_groupw;
+            int rc = vm_gemm_p8_dispatch(a, a_layout, b_layout, mf, force == 9 ? 2 : 4, a.tiles_m * a.tiles_n * split, s);
+            if (rc == VM_OK && split > 1) rc = vm_gemm_splitk_reduce(a, split, s);
+            return rc;
+        }
         const int tiles_m256 = (M + 255) / 256;
         if (force >= 0) variant = force;
         else if (K >= 4096 && (int64_t)tiles_m256 * a.tiles_n * split >= 1024) variant = 1;   // measured: only huge square-ish problems gain
@@ -359,7 +378,35 @@ extern "C" int vm_wgrad_grouped(const vm_wgrad_problem* pr, int n, void* stream)
     }
     double work = 0;
     for (int i = 0; i < n; ++i) work += 2.0 * pr[i].rows * (double)pr[i].n_out * pr[i].k_in;
-    VmProfScope prof(VM_FAM_GEMM, work, s, "wgrad_grouped_n%d_rows%d", n, pr[0].rows);
+    // wide-tile path: every problem in whole 256-column tiles, and enough 256 x 256 tiles in the launch to be worth one workgroup per CU
+    bool p8w = vm_env().wgrad_p8 != 0;
+    int tiles256 = 0;
+    for (int i = 0; i < n && p8w; ++i) {
+        p8w = (pr[i].k_in % 256) == 0 && (pr[i].n_out + 7) / 8 * 8 <= pr[i].ld_dy;      // (the last 8-column piece of dY is read whole)
+        tiles256 += ((pr[i].n_out + 255) / 256) * (pr[i].k_in / 256);
+    }
+    p8w = p8w && tiles256 >= vm_env().wgrad_p8_min;
+    VmProfScope prof(VM_FAM_GEMM, work, s, p8w ? "wgrad_p8w_n%d_rows%d" : "wgrad_grouped_n%d_rows%d", n, pr[0].rows);
+    if (p8w) {
+        for (int base = 0; base < n; base += P8W_MAX_GROUP) {
+            P8wArgs ga = {};
+            ga.n = n - base < P8W_MAX_GROUP ? n - base : P8W_MAX_GROUP;
+            int tiles = 0;
+            for (int i = 0; i < ga.n; ++i) {
+                const vm_wgrad_problem& q = pr[base + i];
+                P8wProblem& a = ga.g[i];
+                a.A = (const bf16_t*)q.dY; a.B = (const bf16_t*)q.X; a.C = q.dW; a.bias_grad = q.db; a.alpha_dev = q.alpha_dev;
+                a.lda = q.ld_dy; a.ldb = q.ld_x; a.ldc = q.ld_dw;
+                a.M = q.n_out; a.N = q.k_in; a.ktiles = q.rows / 64; a.tiles_n = q.k_in / 256; a.accumulate = q.overwrite ? 0 : 1;
+                ga.tile_start[i] = tiles;
+                tiles += ((a.M + 255) / 256) * a.tiles_n;
+            }
+            for (int i = ga.n; i <= P8W_MAX_GROUP; ++i) ga.tile_start[i] = tiles;
+            const int rc = vm_wgrad_p8w_launch(ga, vm_env().wgrad_p8 == 2 ? 2 : 4, s);
+            if (rc != VM_OK) return rc;
+        }
+        return VM_OK;
+    }
     for (int base = 0; base < n; base += VM_GEMM_MAX_GROUP) {
         GemmGroupArgs ga = {};
         ga.n = n - base < VM_GEMM_MAX_GROUP ? n - base : VM_GEMM_MAX_GROUP;

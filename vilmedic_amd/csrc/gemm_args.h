@@ -27,6 +27,22 @@ int vm_gemm_grouped_launch(const GemmGroupArgs& ga, int nblocks, int a_layout, i
 int vm_gemm_splitk_reduce(const GemmArgs& a, int nsplit, hipStream_t s);
 void vm_gemm_variant_tile(int variant, int a_layout, int* bm, int* bn);
 int vm_gemm_fast_dispatch(const GemmArgs& a, int a_layout, int b_layout, int nblocks, int variant, hipStream_t s);
+// wide-tile path (gemm_p8.hip): (32 mf) x 256 tiles, 8 waves, one workgroup per CU; row-major A
+int vm_gemm_p8_dispatch(const GemmArgs& a, int a_layout, int b_layout, int mf, int phases, int total, hipStream_t s);
+// grouped weight gradients on 256 x 256 tiles (gemm_p8w.hip): dW[M, N] (+)= alpha * A^T B over `ktiles` 64-row steps, A = dY [rows, M] (lda),
+// B = X [rows, N] (ldb), C = dW fp32 (ldc); tile_start[i] = first tile of problem i, tile_start[P8W_MAX_GROUP] = all tiles
+#define P8W_MAX_GROUP 16
+struct P8wProblem {
+    const bf16_t* A; const bf16_t* B; void* C; float* bias_grad; const float* alpha_dev;
+    int64_t lda, ldb, ldc;
+    int M, N, ktiles, tiles_n, accumulate, pad_;
+};
+struct P8wArgs {
+    int n;
+    int tile_start[P8W_MAX_GROUP + 1];
+    P8wProblem g[P8W_MAX_GROUP];
+};
+int vm_wgrad_p8w_launch(const P8wArgs& ga, int phases, hipStream_t s);
 // skinny path (gemm_skinny.hip): M <= 256 rows (the decode step), K % 32 == 0, row-major A and B, plain / bias / gelu / residual epilogue
 int vm_skinny_rows_per_wg(int M, int N, int max_mf);
 int vm_gemm_skinny_dispatch(const GemmArgs& a, hipStream_t s);

@@ -37,6 +37,9 @@ static void load_env() {
     g_env.gemm_variant = (v = getenv("VM_GEMM_VARIANT")) ? atoi(v) : -1;
     g_env.gemm_debug = (v = getenv("VM_GEMM_DEBUG")) ? atoi(v) : 0;
     g_env.gemm_groupw = (v = getenv("VM_GEMM_GROUPW")) ? atoi(v) : 0;
+    g_env.gemm_p8_mf = (v = getenv("VM_GEMM_P8_MF")) ? atoi(v) : 0;
+    g_env.wgrad_p8 = (v = getenv("VM_WGRAD_P8")) ? atoi(v) : 2;
+    g_env.wgrad_p8_min = (v = getenv("VM_WGRAD_P8_MIN")) ? atoi(v) : 64;
     g_env.gemm_generic = getenv("VM_GEMM_GENERIC") != nullptr;
     g_env.gemm_no_skinny = getenv("VM_GEMM_NO_SKINNY") != nullptr;
     g_env.attn_tile = getenv("VM_ATTN_TILE") != nullptr;

@@ -73,13 +73,15 @@ class Trainor(object):
             self.ddp.attach_optimizer(self.optimizer)      # the optimizer reads the averaged bf16 wire buffer itself (no cast pass back)
         # trainor.graph_step: true -- models that can replay their whole update (rollouts aside) from one captured graph do so
         # (BASELINE configs[4]: RRG + SCST with a HIP-graph-captured step); single process, one micro-batch per step, no clipping
-        graphable = bool(config.get("graph_step")) and self.ddp is None and self.grad_accu == 1 and self.clip is None and \
-            hasattr(self.optimizer, "gate")
-        self.graph_step = graphable and hasattr(self.model, "graphed_step")
+        # (under data parallelism the captured step holds the RCCL collectives too -- ArenaDDP.backward and the MIN all-reduce of the
+        # finiteness flag are stream work like everything else)
+        graphable = bool(config.get("graph_step")) and self.grad_accu == 1 and self.clip is None and hasattr(self.optimizer, "gate")
+        self.graph_step = graphable and self.ddp is None and hasattr(self.model, "graphed_step")
         # ... and every other model has its whole iteration (forward, backward, fused Adam with the device-side NaN gate) captured per batch
         # shape by vilmedic_amd.graph.GraphedTrainStep: the host enqueues one graph launch per iteration, the rate no longer depends on it
         self.graph_any = graphable and not self.graph_step
         self._graphs = {}
+        self.max_graphs = int(config.get("graph_cache") or 8)     # captured batch signatures kept (each owns its activation pool)
         self.eval_start = int(config.get("eval_start") or 0)
         self.evaluator = Validator(config.validator_view, [self.model], self.dl, seed, True, self.logger, self.rank, self.world) \
             if config.get("validator_view") is not None else None
@@ -118,7 +120,8 @@ class Trainor(object):
     def _graphed_iteration(self, batch):
         """one iteration replayed from the HIP graph captured for this batch's tensor shapes (two eager iterations, then the capture); None
         when the batch carries something that is neither a tensor (a static input of the graph) nor a None / scalar constant (part of the graph's
-        key) -- the caller then runs it eagerly"""
+        key) -- the caller then runs it eagerly.  The captured forward is called WITHOUT ``epoch`` / ``iteration`` (the eager path passes them): a
+        model whose forward depends on them must not set ``graph_step``."""
         from ..graph import GraphedTrainStep
         tensors = {k: v.cuda() for k, v in batch.items() if isinstance(v, torch.Tensor)}
         consts = {k: v for k, v in batch.items() if not isinstance(v, torch.Tensor)}
@@ -126,16 +129,38 @@ class Trainor(object):
             return None
         key = tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(tensors.items())) + tuple(sorted((k, repr(v)) for k, v in consts.items()))
         g = self._graphs.get(key)
+        if g is False:                                       # this signature failed to capture once (a forward that reads the device): eager
+            return None
+        if g is None and len(self._graphs) >= self.max_graphs:
+            # every captured signature owns a private pool of activations: variable-length batches must not grow memory without bound.  The
+            # least recently replayed graph goes (its pool is released with it); under data parallelism every rank sees the same sequence of
+            # signatures only if the loaders pad alike, so there the cache is simply not grown past the cap
+            if self.ddp is not None:
+                return None
+            old = next(iter(self._graphs))
+            del self._graphs[old]
+        if g is not None:
+            self._graphs[key] = self._graphs.pop(key)        # most recently used last
         if g is None:
             def step_fn(**tb):
                 loss = self.model(**tb, **consts)["loss"].mean()
                 self._zero_grad()
-                self.optimizer.gate = loss.detach()          # NaN / Inf loss: the update is skipped on the device (trainor.py:109-112)
-                loss.backward()
+                self._gate(loss)                             # NaN / Inf loss: the update is skipped on the device (trainor.py:109-112), on every rank
+                if self.ddp is not None:
+                    self.ddp.backward(loss)
+                else:
+                    loss.backward()
                 self.optimizer.step()
                 return loss
             g = self._graphs[key] = GraphedTrainStep(step_fn, tensors, optimizer=self.optimizer, warmup=2)
-        return g(**tensors)
+        try:
+            return g(**tensors)
+        except RuntimeError as e:                            # capture failed (nothing of this batch has run yet): this signature stays eager
+            if g.graph is not None:
+                raise                                        # a replay error is a real error
+            self.logger.warning("graph_step: capture failed for this batch signature ({}); running it eagerly".format(str(e).splitlines()[0]))
+            self._graphs[key] = False
+            return None
 
     def start(self):
         cfg = self.config
@@ -159,6 +184,9 @@ class Trainor(object):
                         self.training_scheduler.iteration_step(epoch + float(iteration) / max(len(self.dl), 1))
                         losses.append(loss.detach().clone())
                         out = {"loss": loss}
+                        if iteration % 50 == 0 and self.rank == 0:
+                            self.logger.info("Epoch {}, iter {}, lr {:.2e}, loss {:.4f} (hip-graph replay)".format(
+                                epoch + 1, iteration, self.optimizer.param_groups[0]["lr"], float(torch.nanmean(torch.stack(losses[-50:]).float()))))
                         continue
                 out = self.model(**batch, epoch=epoch, iteration=iteration)
                 if "loss" not in out:

@@ -178,6 +178,18 @@ class DecodeState:
         return a.f32_group(params) if self.f32 else a.shadow_group(params)
 
     def _dg(self, A, W, C, M, N, K, *, bias=None, act=0, residual=None, ln=None, ln_out=None, c2=None, ldc2=0, split_n=0):
+        """one vm_decode_gemm launch.  The kernel's domain is M <= 256 rows and K a multiple of 32 (bf16) / 16 (fp32), K <= 1024 with
+        LayerNorm-on-load: more rows (64 samples x 8 beams, an SCST rollout of more than 128 samples) run as 256-row blocks, other
+        widths through the general GEMMs with a separate LayerNorm."""
+        step = 16 if self.f32 else 32
+        if K % step or (ln is not None and K > 1024):
+            return self._dg_general(A, W, C, M, N, K, bias=bias, act=act, residual=residual, ln=ln, ln_out=ln_out, c2=c2, ldc2=ldc2, split_n=split_n)
+        if M > 256:
+            for r0 in range(0, M, 256):
+                rows = min(256, M - r0)
+                self._dg(A[r0:], W, C[r0:], rows, N, K, bias=bias, act=act, residual=None if residual is None else residual[r0:], ln=ln,
+                         ln_out=None if ln_out is None else ln_out[r0:], c2=None if c2 is None else c2[r0 * (ldc2 // c2.stride(0)):], ldc2=ldc2, split_n=split_n)
+            return
         g = DecodeGemmArgs()
         g.dtype = VM_F32 if self.f32 else VM_BF16
         g.A, g.lda, g.W, g.ldw, g.C, g.ldc = A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0), C.data_ptr(), C.stride(0)
@@ -192,6 +204,27 @@ class DecodeState:
             if ln_out is not None:
                 g.ln_out, g.ln_out_ld = ln_out.data_ptr(), ln_out.stride(0)
         check(lib().vm_decode_gemm(C_.byref(g), stream()), "vm_decode_gemm")
+
+    def _dg_general(self, A, W, C, M, N, K, *, bias, act, residual, ln, ln_out, c2, ldc2, split_n):
+        """the same projection through vm_gemm_bf16 / vm_gemm_f32 (any K that is a multiple of 8 / any K) + a separate LayerNorm"""
+        if ln is not None:
+            xn = ln_out if ln_out is not None else torch.empty(M, K, dtype=self.act, device=A.device)
+            if self.f32:
+                check(lib().vm_layernorm_f32(ptr(A), ptr(ln.weight), ptr(ln.bias), ptr(xn), M, K, self.cfg.layer_norm_eps, stream()), "vm_layernorm_f32")
+            else:
+                check(lib().vm_layernorm_fwd(ptr(A), ptr(ln.weight), ptr(ln.bias), ptr(xn), ptr(self.buf_stat), ptr(self.buf_stat[M:]), M, K,
+                                             self.cfg.layer_norm_eps, stream()), "vm_layernorm_fwd")
+            A = xn
+
+        def run(Wp, bp, out, ldc, n):
+            if self.f32:
+                _gemm32(A, Wp, bp, out, M, n, K, ldc=ldc, act=act, residual=residual)
+            else:
+                ops.gemm(A, 0, Wp, 0, out, M, n, K, ldc=ldc, bias=bp, act=act, residual=residual)
+        if c2 is None:
+            return run(W, bias, C, C.stride(0), N)
+        run(W, bias, C, C.stride(0), split_n)                       # Q -> C, K|V of the new token -> its cache row
+        run(W[split_n:], None if bias is None else bias[split_n:], c2, ldc2, N - split_n)
 
     def _dgl(self, s, ln, x, W, C, M, N, K, **kw):
         """projection of LN(s), with x = LN(s) kept for the residual.  Up to 16 rows (fp32) / 32 rows (bf16) the LayerNorm rides on the

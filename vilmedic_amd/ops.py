@@ -10,6 +10,7 @@ Design notes
   * dropout masks are regenerated from a counter-based RNG (seed per call site), never stored;
   * there is NO CPU fallback: every op raises on non-device tensors.
 """
+import bisect
 import contextlib
 import ctypes as C
 import math
@@ -284,8 +285,52 @@ def backward_mark(x, tag):
 # still overlaps the activation-gradient chain.  Flushed at the latest when the backward pass ends, before a gradient
 # all-reduce starts (ArenaDDP) and before the optimizer reads the gradients.
 GROUP_WGRAD = os.environ.get("VM_WGRAD_GROUP", "1") != "0"
-GROUP_TILES = int(os.environ.get("VM_WGRAD_GROUP_TILES", "400"))      # flush threshold in 128 x 128 output tiles (512 resident workgroups)
+# flush threshold in 128 x 128 output tiles.  The wide-tile kernel (csrc/gemm_p8w.hip: 256 x 256 tiles, one workgroup per CU, up to 16 problems per
+# launch) wants ONE full round of the 256 CUs: the linears of two transformer layers (encoder 2 x 432 = 864 -> 216 tiles of 256 x 256, decoder
+# 2 x 504 = 1008 -> 252); the 128 x 128-tile kernel 400 (512 resident workgroups, VM_WGRAD_P8=0)
+GROUP_TILES = int(os.environ.get("VM_WGRAD_GROUP_TILES", "400" if os.environ.get("VM_WGRAD_P8", "2") == "0" else "840"))
 _pg = {"items": [], "tiles": 0, "ptrs": set()}
+# first-touch tracking: a gradient buffer that no kernel has written since its arena zeroed the gradients may be STORED instead of accumulated
+# (vm_wgrad_problem.overwrite: the read half of 0.9 GB of fp32 read-modify-write per step).  ``touched``: buffers written since then;
+# ``shared``: buffers other kernels add into (the tied word embedding: vm_embedding_bwd) -- always accumulated; ``ranges``: arenas whose gradients
+# have been zeroed through ParamArena.zero_grad at least once (before that nothing is known about a buffer's contents).
+_touch = {"lo": [], "hi": [], "shared": [], "ranges": []}      # touched intervals (sorted, disjoint starts) / shared intervals / tracked arenas
+
+
+def _span(t):
+    lo = t.data_ptr()
+    return lo, lo + t.numel() * t.element_size()
+
+
+def grads_zeroed(gflat):
+    """ParamArena.zero_grad() just zeroed ``gflat``: every gradient view inside it is clean again"""
+    lo, hi = _span(gflat)
+    if (lo, hi) not in _touch["ranges"]:
+        _touch["ranges"] = [r for r in _touch["ranges"] if r[1] <= lo or r[0] >= hi] + [(lo, hi)]
+    keep = [(a, b) for a, b in zip(_touch["lo"], _touch["hi"]) if b <= lo or a >= hi]
+    _touch["lo"], _touch["hi"] = [a for a, _ in keep], [b for _, b in keep]
+
+
+def mark_touched(t):
+    """``t`` (a gradient buffer) has been or will be written by something else than an overwriting weight-gradient GEMM"""
+    lo, hi = _span(t)
+    i = bisect.bisect_left(_touch["lo"], lo)
+    _touch["lo"].insert(i, lo)
+    _touch["hi"].insert(i, hi)
+
+
+def _first_touch(t):
+    """True at most once per zeroing, for a buffer inside a tracked arena that overlaps nothing written since (intervals, not start pointers:
+    a fused Q|K|V gradient view and the view of K alone are the same memory)"""
+    lo, hi = _span(t)
+    los, his = _touch["lo"], _touch["hi"]
+    i = bisect.bisect_right(los, lo)
+    clean = not ((i > 0 and his[i - 1] > lo) or (i < len(los) and los[i] < hi))
+    if clean:
+        clean = not any(a < hi and lo < b for a, b in _touch["shared"])
+    los.insert(i, lo)
+    his.insert(i, hi)
+    return clean and any(a <= lo and hi <= b for a, b in _touch["ranges"])
 
 
 def _eligible(dY, X, dW, ld_dy, ld_x):
@@ -305,7 +350,11 @@ def param_grads(dY, X, dW, db=None, *, ld_dy=None, ld_x=None, alpha_dev=None, co
         if dW.data_ptr() in _pg["ptrs"]:            # the same parameter twice in one backward graph: never in one launch (two owners of a tile)
             flush_param_grads()
         K = X.shape[1]
-        _pg["items"].append((dY, X, dW, db, ld_dy, ld_x, alpha_dev, N, K))
+        fw = _first_touch(dW)
+        fb = _first_touch(db) if db is not None else True
+        if not (fw and fb):                         # one flag for both outputs of a problem; accumulating into a clean buffer is always right
+            fw = False
+        _pg["items"].append((dY, X, dW, db, ld_dy, ld_x, alpha_dev, N, K, fw))
         _pg["ptrs"].add(dW.data_ptr())
         _pg["tiles"] += ((N + 127) // 128) * ((K + 127) // 128)
         if _pg["tiles"] >= GROUP_TILES:
@@ -313,6 +362,9 @@ def param_grads(dY, X, dW, db=None, *, ld_dy=None, ld_x=None, alpha_dev=None, co
         else:
             _ensure_end_of_backward_flush()
         return
+    for t in (dW, db):
+        if t is not None:
+            mark_touched(t)
     with on_side(*(t for t in (dY, X, alpha_dev) if t is not None)):
         if dW is not None:
             wgrad(dY, X, dW[:N] if dW.shape[0] != N else dW, ld_dy=ld_dy, ld_x=ld_x, alpha_dev=alpha_dev, n_out=N)
@@ -345,10 +397,11 @@ def flush_param_grads():
     _pg["items"], _pg["tiles"], _pg["ptrs"] = [], 0, set()
     arr = (_lib.WgradProblem * len(items))()
     tensors = []
-    for q, (dY, X, dW, db, ld_dy, ld_x, alpha_dev, N, K) in zip(arr, items):
+    for q, (dY, X, dW, db, ld_dy, ld_x, alpha_dev, N, K, first) in zip(arr, items):
         q.dY, q.ld_dy, q.X, q.ld_x = dY.data_ptr(), ld_dy, X.data_ptr(), ld_x
         q.dW, q.ld_dw, q.db = dW.data_ptr(), dW.stride(0), (db.data_ptr() if db is not None else None)
         q.rows, q.n_out, q.k_in = dY.shape[0], N, K
+        q.overwrite = 1 if first else 0
         q.alpha_dev = alpha_dev.data_ptr() if alpha_dev is not None else None
         tensors += [t for t in (dY, X, alpha_dev) if t is not None]
     with on_side(*tensors):
@@ -800,6 +853,10 @@ class EmbeddingFn(Fn):
         check(lib().vm_embedding_fwd(ptr(ids), ptr(word), ptr(pos), ptr(out), B, L, D, past_len, stream()), "vm_embedding_fwd")
         ctx.save_for_backward(ids)
         ctx.meta = (padding_idx, g_word, g_pos, D, past_len)
+        if g_word is not None:
+            sp = _span(g_word)
+            if sp not in _touch["shared"]:
+                _touch["shared"].append(sp)                 # the scatter-add of the backward pass shares this buffer with the tied LM head's weight gradient
         return out
 
     @staticmethod
@@ -810,6 +867,7 @@ class EmbeddingFn(Fn):
         if g_word is not None:
             d_out = d_out.contiguous()
             gp = g_pos[past_len:] if past_len else g_pos
+            mark_touched(g_word)
             # parameter gradients only: side stream, which also orders this scatter-add after the tied LM-head wgrad that
             # accumulates into the same g_word there (same stream -> no race, and the main stream never waits)
             with on_side(d_out, ids):
