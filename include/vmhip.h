@@ -31,6 +31,7 @@ typedef enum { VM_BF16 = 1, VM_F32 = 0 } vm_dtype;
 
 const char* vm_last_error(void);
 int vm_version(void);
+const char* vm_build_digest(void);   /* sha256 of the sources the library was built from (vilmedic_amd/build.py compares it, not file times) */
 
 /* ---- lightweight per-family profiler (HIP events on the launch stream; bench.py roofline) */
 int vm_prof_enable(int on);

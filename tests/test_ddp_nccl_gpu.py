@@ -136,11 +136,11 @@ def test_bf16_wire_error_on_the_c2_model(nccl):
 # VM_FORCE_DDP=1 makes a ONE-rank group take every collective path (vilmedic_amd/parallel.py: active / force_collectives), so the RCCL
 # calls of the training loop, of the contrastive-negatives all-gather and of the GLoRIA gather execute on the GPU box's communicator.
 # With one rank every collective is the identity, so the results must equal the run without a process group.
-def _tiny_trainor(tmp_path, tag, extra=()):
+def _tiny_trainor(tmp_path, tag, extra=(), yml="rrg-vit-synthetic.yml"):
     from vilmedic_amd.config import executor_view, get_config
     from vilmedic_amd.executors import Trainor
     os.makedirs(tmp_path / tag, exist_ok=True)
-    cfg = get_config(os.path.join(os.path.dirname(__file__), "..", "config", "RRG", "rrg-vit-synthetic.yml"),
+    cfg = get_config(os.path.join(os.path.dirname(__file__), "..", "config", "RRG", yml),
                      ["dataset.num_samples=16", "dataset.image_size=32", "dataset.vocab_size=97", "dataset.tokenizer_max_len=16",
                       "model.decoder.hidden_size=128", "model.decoder.num_attention_heads=2", "model.decoder.intermediate_size=256",
                       "model.decoder.num_hidden_layers=2", "model.decoder.max_position_embeddings=64",
@@ -216,6 +216,27 @@ def test_trainor_start_on_rccl_equals_single_process(nccl, tmp_path, monkeypatch
     else:
         assert err_l <= 5e-2 and err_p <= 2e-2
     assert len([f for f in os.listdir(tmp_path / ("ddp_" + wire)) if f.endswith(".pth")]) == 1
+
+
+def test_rrg_scst_trainor_on_rccl_equals_single_process(nccl, tmp_path, monkeypatch):
+    """BASELINE configs[4] as it is worded -- RRG + SCST under data parallelism (ref: vilmedic/models/rrg/RRG_SCST.py:59-85 driven by
+    trainor_accelerate.py:111-156): ``Trainor.start()`` on config/RRG/rrg-scst-synthetic.yml (tiny sizes) once without a process group and once
+    with VM_FORCE_DDP on the 1-rank RCCL group.  RRG_SCST forwards enc / dec / split_backward to ArenaDDP, so the policy-gradient step takes
+    the two-phase backward (decoder range reduced while the ViT backward runs, encoder buckets started from the backward marks); same seeds ->
+    same rollouts -> the same loss trajectory and parameters (fp32 wire)."""
+    extra = ["model.decoder.hidden_dropout_prob=0.0", "model.decoder.attention_probs_dropout_prob=0.0", "trainor.optim_params.lr=0.0003",
+             "model.top_k=8"]
+    monkeypatch.delenv("VM_FORCE_DDP", raising=False)
+    tr0, l0, p0, _ = _tiny_trainor(tmp_path, "scst_plain", extra, yml="rrg-scst-synthetic.yml")
+    assert tr0.ddp is None
+    monkeypatch.setenv("VM_FORCE_DDP", "1")
+    tr1, l1, p1, _ = _tiny_trainor(tmp_path, "scst_ddp", extra + ["trainor.ddp_wire=fp32"], yml="rrg-scst-synthetic.yml")
+    assert tr1.ddp is not None and tr1.ddp.split_at is not None and tr1.model.split_backward and tr1.ddp.mark_starts >= 1
+    assert l0.numel() == l1.numel() and l0.numel() >= 4
+    err_l, err_p = (l1 - l0).abs().max().item(), _rel(p1, p0)
+    print(f"[parity] RRG_SCST Trainor.start() on 1-rank RCCL (two-phase backward): max |loss_t - loss_t(single)| {err_l:.3e} over {l0.numel()} steps, "
+          f"rel L2 of the final parameters {err_p:.3e}", flush=True)
+    assert err_l <= 2e-4 and err_p <= 2e-3
 
 
 def test_convirt_forward_all_gathers_negatives_on_rccl(nccl, monkeypatch):

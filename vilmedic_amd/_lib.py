@@ -52,6 +52,7 @@ _P, _I, _L, _F, _U64, _SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint6
 SIGNATURES = {
     "vm_last_error": (C.c_char_p, []),
     "vm_version": (_I, []),
+    "vm_build_digest": (C.c_char_p, []),
     "vm_prof_enable": (_I, [_I]),
     "vm_prof_reset": (_I, []),
     "vm_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -23,7 +23,7 @@ def _sources():
 
 def _digest():
     h = hashlib.sha256()
-    for f in _sources() + sorted(f for f in os.listdir(CSRC) if f.endswith(".h")):
+    for f in _sources() + sorted(f for f in os.listdir(CSRC) if f.endswith(".h")):       # (build_digest.inc, the generated file, is not part of it)
         h.update(f.encode())
         h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(open(os.path.join(CSRC, "..", "..", "include", "vmhip.h"), "rb").read())
@@ -31,19 +31,30 @@ def _digest():
     return h.hexdigest()
 
 
-def _stale():
-    """a source newer than the library: the stamp (a tracked file) can be restored by a checkout that also rewrote sources, and would then
-    vouch for a library built from other code"""
-    t = os.path.getmtime(LIB)
-    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
-    files.append(os.path.join(CSRC, "..", "..", "include", "vmhip.h"))
-    return any(os.path.getmtime(f) > t for f in files)
+DIGEST_INC = os.path.join(CSRC, "build_digest.inc")      # generated: the digest the library is built from, compiled into runtime.hip
+MARK = b"VMDIGEST:"
+
+
+def _lib_digest():
+    """the source digest compiled into libvmhip.so (``vm_build_digest()``), read from the file's bytes -- no loading, no mtimes: a copy or a
+    checkout that does not preserve timestamps (the gpurun snapshot) cannot make a matching library look stale, and a stamp file restored
+    next to a library built from other sources cannot vouch for it"""
+    try:
+        blob = open(LIB, "rb").read()
+    except OSError:
+        return None
+    i = blob.find(MARK)
+    return blob[i + len(MARK):i + len(MARK) + 64].decode("ascii", "replace") if i >= 0 else None
 
 
 def build(force=False, verbose=True):
     dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read() == dig and not _stale():
+    if not force and _lib_digest() == dig:
+        if not (os.path.exists(STAMP) and open(STAMP).read() == dig):
+            open(STAMP, "w").write(dig)
         return LIB
+    with open(DIGEST_INC, "w") as f:
+        f.write('#define VM_BUILD_DIGEST "%s"\n' % dig)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []

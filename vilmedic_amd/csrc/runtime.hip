@@ -52,6 +52,15 @@ const VmEnv& vm_env() {
 }
 extern "C" void vm_reload_env(void) { load_env(); }
 extern "C" int vm_version(void) { return 100; }
+// the digest of the sources this library was built from (vilmedic_amd/build.py writes build_digest.inc before compiling); build.py finds the
+// marker in the file's bytes to decide whether the library is current
+#if __has_include("build_digest.inc")
+#include "build_digest.inc"
+#endif
+#ifndef VM_BUILD_DIGEST
+#define VM_BUILD_DIGEST "unknown"
+#endif
+extern "C" const char* vm_build_digest(void) { return "VMDIGEST:" VM_BUILD_DIGEST + 9; }
 extern "C" int vm_sizeof_gemm_epilogue(void) { return (int)sizeof(vm_gemm_epilogue); }
 
 // ---------------------------------------------------------------- profiler

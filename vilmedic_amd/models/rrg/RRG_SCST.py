@@ -37,6 +37,18 @@ class RRG_SCST(nn.Module):
         self.scst = SCST(decoder=self.model.dec.decoder, dl=dl, scores=scores, scores_args=scores_args,
                          scores_weights=scores_weights, use_nll=use_nll, top_k=top_k)
         self.eval_func = evaluation
+        # data parallelism (ArenaDDP): the same two-phase backward as RRG -- the policy-gradient loss consumes a DETACHED copy of the train-mode
+        # image features, so the decoder's gradient range is reduced while the encoder's backward still runs
+        self.split_backward = False
+        self._split = None
+
+    @property
+    def enc(self):
+        return self.model.enc
+
+    @property
+    def dec(self):
+        return self.model.dec
 
     def forward(self, input_ids, attention_mask, images, images_mask=None, encoder_outputs=None, **kwargs):
         with torch.no_grad():                                   # 1. the greedy baseline's encoder pass (eval mode, as the reference)
@@ -44,6 +56,10 @@ class RRG_SCST(nn.Module):
             enc_g = self.model.encode(images.cuda(), images_mask, **kwargs)
         self.model.train()                                      # 2. the sampling rollout's encoder pass (train mode, differentiated)
         enc, enc_mask = self.model.encode(images.cuda(), images_mask, **kwargs)
+        if self.split_backward and torch.is_grad_enabled() and enc.requires_grad:
+            leaf = enc.detach().requires_grad_(True)
+            self._split = (enc, leaf)
+            enc = leaf
         # 3. both rollouts in one decode loop (greedy rows on the eval features, sampled rows on the train features), rewards, policy
         #    gradient -- the reference's forward_greedy + forward_sampling (RRG_SCST.py:53-75) without a second 128-step decode
         (loss, delta_reward, _, reward_sampling, _), _ = self.scst.forward_rollouts(
@@ -61,11 +77,18 @@ class RRG_SCST(nn.Module):
         Falls back to forward() + backward() + optimizer.step() when the step cannot be replayed (use_nll, a different batch shape,
         an encoder whose train-mode features are random)."""
         images = images.cuda()
-        key = (tuple(images.shape), tuple(input_ids.shape))
+        key = tuple(images.shape)            # (input_ids only feed the host-side reward: their padded length is not part of the captured graph)
         g = getattr(self, "_graphed", None)
-        if self.scst.use_nll or images_mask is not None or float(getattr(getattr(self.model.enc, "dropout_out", None), "p", 0.0) or 0.0) > 0 or (g is not None and g[0] != key):
+        # the graph recomputes the train-mode encoder pass the rollouts already ran once under no_grad: an encoder with batch statistics
+        # (BatchNorm running means) or with random train-mode features (dropout) would be updated twice / disagree with the rollout
+        if getattr(self, "_enc_replayable", None) is None:
+            self._enc_replayable = not any(isinstance(m, nn.modules.batchnorm._BatchNorm) for m in self.model.enc.modules()) and \
+                not float(getattr(getattr(self.model.enc, "dropout_out", None), "p", 0.0) or 0.0) > 0
+        if self.scst.use_nll or images_mask is not None or not self._enc_replayable or (g is not None and g[0] != key):
             out = self(input_ids=input_ids, attention_mask=attention_mask, images=images, images_mask=images_mask, **kwargs)
             optimizer.zero_grad()
+            if hasattr(optimizer, "gate"):
+                optimizer.gate = out["loss"].detach()        # (never the static loss of an earlier replay)
             out["loss"].backward()
             optimizer.step()
             return out
