@@ -62,7 +62,10 @@ __device__ __forceinline__ float wave_max(float v) { VM_WAVE_REDUCE(fmaxf) retur
 struct GeluParts { float cdf, pdf; };
 __device__ __forceinline__ GeluParts gelu_parts(float z) {
     const float x = fabsf(z) * 0.70710678118654752f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * x);
+    // v_rcp_f32 (1 ulp), not __frcp_rn: the correctly rounded reciprocal compiles to the full division sequence (2 v_div_scale, v_rcp, 4 FMAs,
+    // v_div_fmas, v_div_fixup + hazard s_nops: 10 of the 26 instructions per element of the GELU epilogues, which run with the MFMA pipe idle --
+    // 30 us of a 100 us MLP-up launch); 1 ulp in t moves erf by ~1e-7, far below the bf16 rounding of every consumer
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);
     const float e = __expf(-x * x);                                  // = exp(-z^2 / 2)
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float erf_abs = 1.0f - poly * e;                           // erf(|z|/sqrt2)

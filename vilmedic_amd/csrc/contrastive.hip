@@ -124,6 +124,13 @@ __device__ __forceinline__ ContrOperands contr_operands(const ContrArgs& a) {
     o.A = contr_uni(a.A); o.B = contr_uni(a.B); o.R = contr_uni(a.R); o.C = contr_uni(a.C); o.D = contr_uni(a.D); o.inv_tau = contr_uni(a.inv_tau);
     return o;
 }
+// [r4] D % 64 == 0 (every model's embedding width): the operand chunks go HBM / L2 -> LDS by LDS-DMA into a 2-slot ring of un-padded 128-B rows,
+// XOR-swizzled on the DMA source (chunk ^= row & 7, the layout-0 image of gemm_fast.hip), the next chunk requested before the current one's
+// MFMAs -- the register-staged pipeline below kept ONE 64-deep chunk in flight per workgroup and paid an exposed L2 round trip per chunk
+// (24.6 us for the 6.4 GFLOP of the B = 2048 forward tiles).  Rows past R / C re-read the last valid row: they only feed S entries nobody reads.
+__device__ __forceinline__ void contr_dma16(const bf16_t* src, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
 __device__ __forceinline__ void contr_s_tile(const ContrOperands p, char* smem, int m0, int n0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     float4_t acc[4][4];
@@ -131,6 +138,48 @@ __device__ __forceinline__ void contr_s_tile(const ContrOperands p, char* smem, 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    if ((p.D & 63) == 0) {
+        const int wv = __builtin_amdgcn_readfirstlane(wave), g = lane >> 4, c = lane & 15;
+        const bf16_t* srcA[4];
+        const bf16_t* srcB[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * (wv * 4 + i) + (lane >> 3), lc = (lane & 7) ^ (row & 7);
+            srcA[i] = p.A + (int64_t)min(m0 + row, p.R - 1) * p.D + lc * 8;
+            srcB[i] = p.B + (int64_t)min(n0 + row, p.C - 1) * p.D + lc * 8;
+        }
+        constexpr int SLOT = 2 * CT * 128;                 // A chunk [128][64] + B chunk [128][64], bf16
+        auto stage = [&](int buf) {
+            char* d = smem + buf * SLOT;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                contr_dma16(srcA[i], d + (wv * 4 + i) * 1024); srcA[i] += 64;
+                contr_dma16(srcB[i], d + CT * 128 + (wv * 4 + i) * 1024); srcB[i] += 64;
+            }
+        };
+        const int ktiles = p.D >> 6;
+        stage(0);
+        for (int kt = 0; kt < ktiles; ++kt) {
+            __syncthreads();                               // (the compiler adds vmcnt(0)): chunk kt landed for every wave, the other slot is drained
+            if (kt + 1 < ktiles) stage((kt + 1) & 1);
+            const char* sa = smem + (kt & 1) * SLOT;
+            const char* sb = sa + CT * 128;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                c_bf16x8_t fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    fa[i] = *reinterpret_cast<const c_bf16x8_t*>(sa + (wm * 64 + i * 16 + c) * 128 + (((kk * 4 + g) ^ (c & 7)) << 4));
+                    fb[i] = *reinterpret_cast<const c_bf16x8_t*>(sb + (wn * 64 + i * 16 + c) * 128 + (((kk * 4 + g) ^ (c & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                   // every wave is done with the ring: the S tile is staged over it
+    } else {
     uint4 ra[4], rb[4];
     auto load = [&](int k0) {
 #pragma unroll
@@ -172,6 +221,7 @@ __device__ __forceinline__ void contr_s_tile(const ContrOperands p, char* smem, 
         }
         if (kt + 1 < ktiles) store(smem + ((kt + 1) & 1) * (2 * CT * CT_KS * 2));
         __syncthreads();
+    }
     }
     // stage S tile (fp32, scaled): C/D layout col = lane & 15, row = (lane >> 4) * 4 + reg
     float* cs = reinterpret_cast<float*>(smem);

@@ -306,7 +306,12 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
         int variant = 0;
         const int force = vm_env().gemm_variant;
         // wide-tile kernel (gemm_p8.hip): (32 MF) x 256 tiles, one 8-wave workgroup per CU; 8 = one tile per workgroup, 9 = persistent
-        if ((force == 8 || force == 9) && a_layout == 0) {       // 8: four barrier pairs per K-tile, 9: two
+        // (cost model: only very wide row-major outputs with many rounds of 256 x 256 tiles -- the LM head, 8192 x 30522 x 768: 15 rounds,
+        //  measured 383-421 us against 427-438 us on the 128-row kernels; everywhere else the lockstep prologue / epilogue bursts of one
+        //  workgroup per CU cost more than the faster main loop gains, profiles/r04_a_gemm_p8_probe.txt)
+        const bool p8_auto = force < 0 && a_layout == 0 && b_layout == 0 && split == 1 && N >= 16384 && M >= 4096 && K <= 1024 &&
+                             (int64_t)((M + 255) / 256) * ((N + 255) / 256) >= 12 * 256;
+        if (((force == 8 || force == 9) && a_layout == 0) || p8_auto) {       // 8: four barrier pairs per K-tile, 9 / auto: two
             int mf = vm_env().gemm_p8_mf;
             if (mf < 5 || mf > 8) {      // rounds of the 256 CUs x rows per tile, ties to the larger tile
                 int64_t best = -1;
@@ -320,7 +325,7 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
             a.tiles_n = (N + 255) / 256;
             a.group_w = a.tiles_n >= 12 ? 4 : a.tiles_n;
             if (vm_env().gemm_groupw > 0) a.group_w = vm_env().gemm_groupw;
-            int rc = vm_gemm_p8_dispatch(a, a_layout, b_layout, mf, force == 9 ? 2 : 4, a.tiles_m * a.tiles_n * split, s);
+            int rc = vm_gemm_p8_dispatch(a, a_layout, b_layout, mf, force == 8 ? 4 : 2, a.tiles_m * a.tiles_n * split, s);
             if (rc == VM_OK && split > 1) rc = vm_gemm_splitk_reduce(a, split, s);
             return rc;
         }

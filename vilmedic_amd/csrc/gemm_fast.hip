@@ -405,24 +405,54 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs& p, const int bid,
     const bf16_t* rsrc = reinterpret_cast<const bf16_t*>(e.residual);
     const bool vec = nvalid == 8;
     const DropKey dkey = drop_key(eff_seed(e.dropout_seed, e.dropout_seed_dev));
-#pragma unroll 1
-    for (int ps = 0; ps < NPASS; ++ps) {
-    uint4 zq[ITEMS], rq[ITEMS];
+    // gfx950 has ONE in-order counter for loads and stores: a wait for ANY load issued after the first pass's stores also waits for those stores
+    // (measured on the 256-row kernel of gemm_p8.hip: 8 us per tile of store round trips).  With two passes (the 160-row tile) the operand
+    // loads of BOTH passes are therefore issued -- and, with the bias, waited for -- before the first store, the pass loop is unrolled, and its
+    // barriers are raw s_barrier + lgkmcnt(0) (a __syncthreads() in front of pending loads waits vmcnt(0)): pass 2 no longer starts with
+    // the drain of pass 1's stores.
+    uint4_t zq[NPASS][ITEMS], rq[NPASS][ITEMS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) { zq[ps][it] = (uint4_t){0u, 0u, 0u, 0u}; rq[ps][it] = (uint4_t){0u, 0u, 0u, 0u}; }
     if (zsrc && vec) {
 #pragma unroll
-        for (int it = 0; it < ITEMS; ++it) {
-            const int gm = min(m0 + ps * RPP + row_t + it * RSTEP, p.M - 1);
-            zq[it] = *reinterpret_cast<const uint4*>(zsrc + (int64_t)gm * p.ldc + gn);
-        }
+        for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int gm = min(m0 + ps * RPP + row_t + it * RSTEP, p.M - 1);
+                zq[ps][it] = *reinterpret_cast<const uint4_t*>(zsrc + (int64_t)gm * p.ldc + gn);
+            }
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) asm volatile("" : "+v"(zq[ps][it]));
     }
     if (rsrc && vec) {
 #pragma unroll
-        for (int it = 0; it < ITEMS; ++it) {
-            const int gm = min(m0 + ps * RPP + row_t + it * RSTEP, p.M - 1);
-            rq[it] = *reinterpret_cast<const uint4*>(rsrc + (int64_t)gm * e.ldr + gn);
-        }
+        for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int gm = min(m0 + ps * RPP + row_t + it * RSTEP, p.M - 1);
+                rq[ps][it] = *reinterpret_cast<const uint4_t*>(rsrc + (int64_t)gm * e.ldr + gn);
+            }
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) asm volatile("" : "+v"(rq[ps][it]));
     }
-    __syncthreads();                                // operand buffers / previous pass fully consumed by every wave
+#pragma unroll
+    for (int r = 0; r < 8; ++r) asm volatile("" : "+v"(bias8[r]));
+    auto epi_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+    };
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+    epi_barrier();                                  // operand buffers / previous pass fully consumed by every wave
     if (wm * WR >= ps * RPP && wm * WR < (ps + 1) * RPP) {
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
@@ -435,7 +465,7 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs& p, const int bid,
             }
         }
     }
-    __syncthreads();
+    epi_barrier();
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const int row = row_t + it * RSTEP;
@@ -466,7 +496,7 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs& p, const int bid,
         }
         if (zsrc) {
             float zf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (vec) unpack8(zq[it], zf);
+            if (vec) unpack8(make_uint4(zq[ps][it][0], zq[ps][it][1], zq[ps][it][2], zq[ps][it][3]), zf);
             else for (int r = 0; r < nvalid; ++r) zf[r] = bf16_to_f32(zsrc[off + r]);
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] *= gelu_grad_f(zf[r]);
@@ -479,7 +509,7 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs& p, const int bid,
         }
         if (rsrc) {
             float rf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (vec) unpack8(rq[it], rf);
+            if (vec) unpack8(make_uint4(rq[ps][it][0], rq[ps][it][1], rq[ps][it][2], rq[ps][it][3]), rf);
             else for (int r = 0; r < nvalid; ++r) rf[r] = bf16_to_f32(rsrc[(int64_t)gm * e.ldr + gn + r]);
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] += rf[r];

@@ -7,7 +7,8 @@
 // loop of the 256 x 256 tile measured 6.6 TFLOP/s per CU against 3.6 for the 128 x 128 tiles of gemm_grouped_kernel (profiles/r04_*):
 //   * one 8-wave workgroup per CU, two wave groups (rows 0-127 / 128-255 of the tile) in ping-pong on the SIMDs they share: while one
 //     group issues its MFMAs the other reads its fragments (ds_read_b64_tr_b16: both operands are contraction-major) and stages;
-//   * LDS-DMA half-tiles [64 k][128], A one K-tile ahead, B two, one counted s_waitcnt vmcnt(4) per K-tile (see gemm_p8.hip);
+//   * LDS-DMA half-tiles [64 k][128], BOTH operands two K-tiles ahead (A ring of three K-tiles, B ring of two), one counted
+//     s_waitcnt vmcnt(8) per K-tile; the epilogue stages through the idle A ring (see gemm_p8.hip for the hazards);
 //   * a workgroup owns its output tile (no split of the contraction: the launches are sized to fill the chip by grouping the linears of
 //     two transformer layers), so accumulation into dW needs no atomics.  ``accumulate == 0`` (the caller knows this is the first
 //     contribution to dW since the gradients were zeroed -- ops.param_grads tracks it) stores; otherwise the epilogue reads, adds and
@@ -37,9 +38,11 @@ __device__ __forceinline__ int pw_xcd_remap(int orig, int nwg) {
 #define PW_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } while (0)
 
 constexpr int PW_HALF = 128 * 128;                 // bytes of a half-tile: [64 k][128] bf16
-constexpr int PW_SLOT = 4 * PW_HALF;               // A_lo, A_hi, B_lo, B_hi
-constexpr int PW_EPI = 32 * 256 * 4;
-constexpr int PW_LDS = 2 * PW_SLOT + PW_EPI;       // 160 KiB
+constexpr int PW_KT = 2 * PW_HALF;                 // one operand's K-tile: lo and hi half
+constexpr int PW_A0 = 0, PW_NA = 3;                // A ring: THREE K-tiles (both operands are requested two K-tiles ahead: a weight-gradient
+constexpr int PW_B0 = PW_NA * PW_KT, PW_NB = 2;    //   launch streams its operands from HBM / MALL, and one K-tile of lead -- 1.7 us -- did not cover
+constexpr int PW_LDS = PW_B0 + PW_NB * PW_KT;      //   that latency); B ring: two (its registers free the slot after the first phase).  160 KiB.
+constexpr int PW_EPI = 32 * 256 * 4;               // the epilogue stages through the (then idle) A ring
 
 template <int NPH>
 __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const P8wArgs ga) {
@@ -93,19 +96,19 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const P8wArgs ga) {
         stepA = (int64_t)64 * p.lda; stepB = (int64_t)64 * p.ldb;
     };
     auto stageA = [&](int slot, int h) {
-        const uint32_t dst = lds0 + slot * PW_SLOT + h * PW_HALF;
+        const uint32_t dst = lds0 + PW_A0 + slot * PW_KT + h * PW_HALF;
 #pragma unroll
         for (int i = 0; i < 2; ++i) pw_glds16(pA, offA[h][i], dst + (wave + 8 * i) * 1024);
     };
     auto stageB = [&](int slot, int h) {
-        const uint32_t dst = lds0 + slot * PW_SLOT + 2 * PW_HALF + h * PW_HALF;
+        const uint32_t dst = lds0 + PW_B0 + slot * PW_KT + h * PW_HALF;
 #pragma unroll
         for (int i = 0; i < 2; ++i) pw_glds16(pB, offB[h][i], dst + (wave + 8 * i) * 1024);
     };
-    auto prologue = [&](int nk) {
+    auto prologue = [&](int nk) {                          // K-tiles 0 and 1 of both operands; the first wait leaves the second in flight
         stageA(0, 0); stageA(0, 1); pA += stepA;
         stageB(0, 0); stageB(0, 1); pB += stepB;
-        if (nk > 1) { stageB(1, 0); stageB(1, 1); pB += stepB; }
+        if (nk > 1) { stageA(1, 0); stageA(1, 1); pA += stepA; stageB(1, 0); stageB(1, 1); pB += stepB; }
     };
 
     for (int work = (int)blockIdx.x; work < total; work += (int)gridDim.x) {
@@ -126,19 +129,20 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const P8wArgs ga) {
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[j][i] = (float4_t){0.f, 0.f, 0.f, 0.f};
-        if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PW_BARRIER();
 
         bf16x8_t fa[2][4], fb[2][4];
         const short8_t ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
         const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
 
-        // one K-tile; HA / HB: there is an A(t+1) / a B(t+2) to request; BG: this workgroup also sums the rows of A
-        auto ktile = [&](int t, auto ha_c, auto hb_c, auto bg_c) {
-            constexpr bool HA = decltype(ha_c)::value, HB = decltype(hb_c)::value, BG = decltype(bg_c)::value;
+        // one K-tile t; sa = t % 3 (its A slot), H2: there is a K-tile t + 2 to request; BG: this workgroup also sums the rows of A
+        auto ktile = [&](int t, int sa, auto h2_c, auto bg_c) {
+            constexpr bool H2 = decltype(h2_c)::value, BG = decltype(bg_c)::value;
             const int s = t & 1;
-            const char* As = smem + s * PW_SLOT + wm * PW_HALF;
-            const char* Bs = smem + s * PW_SLOT + 2 * PW_HALF + (wn >> 1) * PW_HALF;
+            const int sa2 = sa == 0 ? 2 : sa - 1;           // (t + 2) % 3: the slot K-tile t - 1 was read from
+            const char* As = smem + PW_A0 + sa * PW_KT + wm * PW_HALF;
+            const char* Bs = smem + PW_B0 + s * PW_KT + (wn >> 1) * PW_HALF;
             auto mfma_rows = [&](auto i0_c, auto j_lo, auto j_hi) {       // A fragments i0..i0+3 (in fa) x B fragments [j_lo, j_hi)
                 constexpr int i0 = decltype(i0_c)::value, JL = decltype(j_lo)::value, JH = decltype(j_hi)::value;
                 __builtin_amdgcn_s_setprio(1);
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const P8wArgs ga) {
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) fa[kk][i] = read1(As, 0, i, kk);
-                if constexpr (HA) { stageA(s ^ 1, 0); stageA(s ^ 1, 1); pA += stepA; }
+                if constexpr (H2) { stageA(sa2, 0); stageA(sa2, 1); pA += stepA; }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 PW_BARRIER();
                 mfma_rows(I0{}, I0{}, I4{});
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const P8wArgs ga) {
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) fa[kk][i] = read1(As, 0, 4 + i, kk);
-                if constexpr (HB) { stageB(s, 0); stageB(s, 1); pB += stepB; asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                if constexpr (H2) { stageB(s, 0); stageB(s, 1); pB += stepB; asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }      // K-tile t + 2 (8 pieces) may be in flight
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 PW_BARRIER();
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const P8wArgs ga) {
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) fa[kk][i] = read1(As, 0, i, kk);
-                if constexpr (HA) stageA(s ^ 1, 0);
+                if constexpr (H2) stageA(sa2, 0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 PW_BARRIER();
                 mfma_rows(I0{}, I0{}, I2{});
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const P8wArgs ga) {
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                     for (int j = 2; j < 4; ++j) fb[kk][j] = read1(Bs, b_rb, j, kk);
-                if constexpr (HA) { stageA(s ^ 1, 1); pA += stepA; }
+                if constexpr (H2) { stageA(sa2, 1); pA += stepA; }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 PW_BARRIER();
                 mfma_rows(I0{}, I2{}, I4{});
@@ -223,13 +227,13 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const P8wArgs ga) {
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) fa[kk][i] = read1(As, 0, 4 + i, kk);
-                if constexpr (HB) stageB(s, 0);
+                if constexpr (H2) stageB(s, 0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 PW_BARRIER();
                 mfma_rows(I4{}, I2{}, I4{});
                 mfma_bias(1);
                 PW_BARRIER();
-                if constexpr (HB) { stageB(s, 1); pB += stepB; asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                if constexpr (H2) { stageB(s, 1); pB += stepB; asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 PW_BARRIER();
                 mfma_rows(I4{}, I0{}, I2{});
@@ -237,10 +241,9 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const P8wArgs ga) {
             }
         };
         auto kloop = [&](auto bg_c) {
-            int t = 0;
-            for (; t + 2 < nk; ++t) ktile(t, std::true_type{}, std::true_type{}, bg_c);
-            if (t + 1 < nk) { ktile(t, std::true_type{}, std::false_type{}, bg_c); ++t; }
-            ktile(t, std::false_type{}, std::false_type{}, bg_c);
+            int t = 0, sa = 0;
+            for (; t + 2 < nk; ++t) { ktile(t, sa, std::true_type{}, bg_c); sa = sa == 2 ? 0 : sa + 1; }
+            for (; t < nk; ++t) { ktile(t, sa, std::false_type{}, bg_c); sa = sa == 2 ? 0 : sa + 1; }
         };
         if (wm == 1) PW_BARRIER();                         // group 1 runs one barrier behind group 0
         if (bias_wg) kloop(std::true_type{}); else kloop(std::false_type{});
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const P8wArgs ga) {
         // ---- epilogue: 8 chunks of 32 rows (fragment row i of both groups) through the fp32 stage; whole 1-KiB rows to HBM
         float alpha = has_alpha ? *p.alpha_dev : 1.0f;
         asm volatile("" : "+v"(alpha));
-        float* cs = reinterpret_cast<float*>(smem + 2 * PW_SLOT);
+        float* cs = reinterpret_cast<float*>(smem + PW_A0);          // the A ring is idle: nothing is in flight behind the last K-tile's vmcnt(0)
         int tid_e = tid, c_e = c, g_e = g;
         asm volatile("" : "+v"(tid_e), "+v"(c_e), "+v"(g_e));
         const int q = tid_e & 31, row_t = tid_e >> 5;

@@ -187,6 +187,22 @@ def side_context(device, defer_join=None):
 
 
 @contextlib.contextmanager
+def collective_context(device):
+    """where ArenaDDP enqueues its gradient all-reduces.  Eagerly: the side stream (side_context), so the collectives are ordered behind the
+    weight-gradient GEMMs without the main stream waiting for them.  While a HIP graph is being captured: the capturing stream itself, after it
+    has joined the side stream -- a collective issued from a forked side stream inside a capture crashes at capture_end on this stack
+    (ROCm 7.0 / RCCL 2.26; tools/ddp_graph_probe.py: sync, async and bf16 AVG all-reduces capture fine from the origin stream, any of them from the
+    side stream segfaults); RCCL's own stream is still forked from and joined into the graph by the async work handle, so the all-reduce
+    overlaps whatever the capturing stream enqueues after it."""
+    if torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing():
+        join_side()
+        yield
+        return
+    with side_context(device):
+        yield
+
+
+@contextlib.contextmanager
 def on_side(*inputs):
     """launch the enclosed kernels on the side stream, after everything enqueued on the current stream so far.
     ``inputs`` are the tensors those kernels read: they are recorded on the side stream so the caching allocator does

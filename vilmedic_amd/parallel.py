@@ -152,7 +152,7 @@ class ArenaDDP:
             return
         ops = self._ops
         ops.flush_param_grads()                          # the queued weight / LayerNorm gradients of the layers behind the mark
-        with ops.side_context(self.arena.flat.device):
+        with ops.collective_context(self.arena.flat.device):
             st["pending"] += self._start(off, st["hi"], 1)
         st["hi"] = off
         self.mark_starts += 1
@@ -219,14 +219,14 @@ class ArenaDDP:
         try:
             loss.backward()                              # decoder graph only (features were detached)
             ops.flush_param_grads()                      # the decoder's queued weight gradients, before their range is reduced
-            with ops.side_context(dev):
+            with ops.collective_context(dev):
                 pending = self._start(0, self.split_at, max(1, self.chunks // 2))
             self._live = {"hi": n, "pending": pending}   # the encoder's backward marks start the buckets behind them (_on_mark)
             if leaf.grad is not None:
                 feats.backward(leaf.grad)                # encoder graph, overlapping the decoder's (and its own rear buckets') all-reduce
             hi, self._live = self._live["hi"], None
             ops.flush_param_grads()
-            with ops.side_context(dev):
+            with ops.collective_context(dev):
                 pending += self._start(self.split_at, hi, 1 if hi < n else max(1, self.chunks // 2))
                 self._wait(pending)
         finally:
