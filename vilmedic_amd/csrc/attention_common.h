@@ -24,9 +24,13 @@ struct AttnArgs {
     float dropout_p; uint64_t seed; const uint64_t* seed_dev; uint32_t thresh; float drop_scale;
 };
 
+// 16 B of a row, or zeros for a lane whose row does not exist.  A PREDICATED load (exec-masked: dead lanes keep the zeros), not "load from a safe
+// address, then select": the select consumed the loaded value at once, so hipcc waited for every such load right behind its issue -- the
+// next-group prefetches of the head kernels never overlapped anything (ISA of round 3: "LD LD W(1) W(0)" at the head of the group loop).
 __device__ __forceinline__ bf16x8_t ld_frag_global(const bf16_t* p, const bf16_t* safe, bool ok) {
-    uint4 v = *reinterpret_cast<const uint4*>(ok ? p : safe);
-    if (!ok) v = make_uint4(0, 0, 0, 0);
+    (void)safe;
+    uint4_t v = {0u, 0u, 0u, 0u};
+    if (ok) v = *reinterpret_cast<const uint4_t*>(p);
     return __builtin_bit_cast(bf16x8_t, v);
 }
 __device__ __forceinline__ bf16x8_t pack_b_operand(const float4_t& a, const float4_t& b) {

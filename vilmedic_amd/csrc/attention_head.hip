@@ -340,6 +340,11 @@ __global__ __launch_bounds__(256, 3) void attn_head_fwd_kernel(const AttnArgs p)
 #pragma unroll
             for (int i = 0; i < NG; ++i) load_q(grp0 + 4 * NG + 4 * i, qn[i]);
         }
+        // [r4] the next group's queries (requested a whole group of math ago) are made complete HERE, before this group's stores: loads and
+        // stores retire through one in-order counter, and the compiler's own wait for them sat at the top of the next iteration, behind the
+        // stores -- vmcnt(0): every group began with the round trip of the previous group's stores (ISA: "LD LD W(1) W(0)" at the loop head)
+#pragma unroll
+        for (int i = 0; i < NG; ++i) { head_pin(qn[i][0]); head_pin(qn[i][1]); }
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             if (grp0 + 4 * i < ngroups && qrow[i] < p.Lq) {
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(256, 3) void attn_head_dq_kernel(const AttnArgs p) 
     const DropKey dkey = drop_key(eff_seed(p.seed, p.seed_dev));
     const uint32_t lk_even = (uint32_t)((p.Lk + 1) & ~1);
     const float c2 = p.scale * LOG2E_F;
-    struct Own { bf16x8_t qf[2], dof[2], of[2]; float m, inv_l; };      // of: the forward output rows (for delta = rowsum(dO * O))
+    struct Own { bf16x8_t qf[2], dof[2], of[2]; float m, inv_l; };      // of: the forward output rows (for delta = rowsum(dO * O)); inv_l holds l until the group starts
     auto load_own = [&](int grp, Own& w) {
         const int qrow = qc0 + grp * 16 + c;
         const bool ok = qrow < p.Lq && grp < ngroups;
@@ -386,9 +391,13 @@ __global__ __launch_bounds__(256, 3) void attn_head_dq_kernel(const AttnArgs p) 
             w.dof[kk] = ld_frag_global(dop + kk * 32 + g * 8, p.d_o, ok);
             w.of[kk] = ld_frag_global(op + kk * 32 + g * 8, p.o, ok);
         }
-        const int64_t si = ok ? (int64_t)(b * p.H + h) * p.Lq + qrow : 0;
-        const float mm = p.stats[si * 2], ll = p.stats[si * 2 + 1];
-        w.m = ok ? mm : 0.f; w.inv_l = ok ? 1.0f / ll : 0.f;
+        // predicated loads, and NO arithmetic on the loaded values here: anything that consumes them makes hipcc wait for the loads at once
+        float mm = 0.f, ll = 0.f;
+        if (ok) {
+            const float2 st = *reinterpret_cast<const float2*>(p.stats + ((int64_t)(b * p.H + h) * p.Lq + qrow) * 2);
+            mm = st.x; ll = st.y;
+        }
+        w.m = mm; w.inv_l = ll;                  // l, inverted by the consumer
     };
     Own nx;
     load_own(wave, nx);
@@ -412,7 +421,8 @@ __global__ __launch_bounds__(256, 3) void attn_head_dq_kernel(const AttnArgs p) 
     for (int grp = wave; grp < ngroups; grp += 4) {
         const int q0 = qc0 + grp * 16, qrow = q0 + c;
         const bool qok = qrow < p.Lq;
-        const Own w = nx;
+        Own w = nx;
+        w.inv_l = w.inv_l > 0.f ? 1.0f / w.inv_l : 0.f;      // (load_own leaves l there; 0 for dead queries)
         if (!stage.precise) load_own(grp + 4, nx);
         const float nm = fmaf(-w.m, LOG2E_F, __builtin_amdgcn_logf(w.inv_l));   // log2 of exp(-m)/l; -inf for dead queries
         // delta = rowsum(dO * O) of the lane's query: 16 of the 64 columns per lane, summed over the 4 lane groups; saved for dK/dV
@@ -513,6 +523,9 @@ __global__ __launch_bounds__(256, 3) void attn_head_dq_kernel(const AttnArgs p) 
             }
         }
         if (stage.precise) { stage.precise = false; load_own(grp + 4, nx); }      // the first group ran beside the DMA burst
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) { head_pin(nx.qf[kk]); head_pin(nx.dof[kk]); head_pin(nx.of[kk]); }      // complete before the stores (see the forward kernel)
+        head_pin(nx.m); head_pin(nx.inv_l);
         if (qok && g == 0) p.delta[(int64_t)(b * p.H + h) * p.Lq + qrow] = delta;
         if (qok) hstore_t_acc(p.dq + (int64_t)(b * p.Lq + qrow) * p.lddq + h * 64, dq, p.scale, lane);
     }
@@ -570,7 +583,8 @@ __global__ __launch_bounds__(256, 3) void attn_head_dkv_kernel(const AttnArgs p)
         const bf16_t* vp = p.v + (int64_t)(b * p.Lk + key) * p.ldv + h * 64;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) { w.kf[kk] = ld_frag_global(kp + kk * 32 + g * 8, p.k, ok); w.vf[kk] = ld_frag_global(vp + kk * 32 + g * 8, p.v, ok); }
-        const uint8_t mk = (ok && p.key_mask) ? p.key_mask[(int64_t)b * p.Lk + key] : (uint8_t)1;
+        uint8_t mk = 1;
+        if (ok && p.key_mask) mk = p.key_mask[(int64_t)b * p.Lk + key];
         w.keep = mk != 0;
     };
     // one half (16 tile rows = fragment F) of a transposed A operand
@@ -600,9 +614,10 @@ __global__ __launch_bounds__(256, 3) void attn_head_dkv_kernel(const AttnArgs p)
     for (int grp = wave; grp < ngroups; grp += 4) {
         const int k0 = kc0 + grp * 16, key = k0 + c;
         const bool kok = key < p.Lk;
-        Own w;                      // (no next-group prefetch here: the kernel is at its VGPR budget for 3 waves/SIMD)
-        if (stage.precise) w = w0;
-        else load_own(grp, w);
+        // (no prefetch behind the math here: the kernel is at its VGPR budget for 3 waves/SIMD.  The next group's keys / values are requested
+        // at the END of a group, when only dK / dV are live, and completed before the group's stores -- requested behind the stores, their wait
+        // also covered the round trip of those eight stores)
+        const Own w = w0;
         float4_t dk[4], dv[4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) { dk[f] = (float4_t){0.f, 0.f, 0.f, 0.f}; dv[f] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
@@ -715,6 +730,14 @@ __global__ __launch_bounds__(256, 3) void attn_head_dkv_kernel(const AttnArgs p)
             }
         }
         stage.precise = false;
+        load_own(grp + 4, w0);
+        {
+            int kp = w0.keep ? 1 : 0;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) { head_pin(w0.kf[kk]); head_pin(w0.vf[kk]); }
+            head_pin(kp);
+            w0.keep = kp != 0;
+        }
         if (kok) {
             hstore_t_acc(p.dk + (int64_t)(b * p.Lk + key) * p.lddk + h * 64, dk, p.scale, lane);
             hstore_t_acc(p.dv + (int64_t)(b * p.Lk + key) * p.lddv + h * 64, dv, 1.0f, lane);

@@ -19,70 +19,43 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     if (step_dev) { const float t = (float)(*step_dev); bc1 = 1.0f - powf(b1, t); bc2 = 1.0f - powf(b2, t); }
     const float step = lr / bc1;
     const float inv_sqrt_bc2 = rsqrtf(bc2);
-    // Software pipeline: the NEXT iteration's 16-B loads are issued before this iteration's stores.  gfx950 retires loads and stores through one
-    // in-order counter, so a wait for loads issued AFTER a store also waits for that store's round trip; with the loads ahead of the stores the
-    // wait at their first use only covers older loads (vmcnt counts the younger stores as still outstanding).
-    const int64_t stride = (int64_t)gridDim.x * 1024;
-    struct Quad { float4 p, g, m, v; };
-    auto load = [&](int64_t i, Quad& q) {
-        q.p = *reinterpret_cast<const float4*>(p + i);
-        if (GB) {
-            const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(gv) + i);
-            q.g = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
-        } else {
-            q.g = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(gv) + i);
-        }
-        q.m = *reinterpret_cast<const float4*>(m + i);
-        q.v = *reinterpret_cast<const float4*>(v + i);
-    };
-    auto update = [&](int64_t i, const Quad& q) {
-        float P[4] = {q.p.x, q.p.y, q.p.z, q.p.w}, G[4] = {q.g.x, q.g.y, q.g.z, q.g.w};
-        float M[4] = {q.m.x, q.m.y, q.m.z, q.m.w}, V[4] = {q.v.x, q.v.y, q.v.z, q.v.w};
+    // (round 4 measured a software-pipelined form -- the next iteration's loads issued ahead of this iteration's stores, counted waits in the ISA --
+    //  and dropped it: 1.45 ms against 1.21-1.36 ms for this loop; the kernel is bandwidth-, not latency-bound, at 8 blocks per CU)
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+        if (i + 4 <= n) {
+            float4 pp = *reinterpret_cast<float4*>(p + i), gg;
+            if (GB) {
+                const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(gv) + i);
+                gg = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+            } else {
+                gg = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(gv) + i);
+            }
+            float4 mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+            float P[4] = {pp.x, pp.y, pp.z, pp.w}, G[4] = {gg.x, gg.y, gg.z, gg.w}, M[4] = {mm.x, mm.y, mm.z, mm.w}, V[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float gr = G[j] * gscale;
-            if (decoupled) P[j] *= 1.f - lr * wd; else gr += wd * P[j];
-            M[j] = b1 * M[j] + (1.f - b1) * gr;
-            V[j] = b2 * V[j] + (1.f - b2) * gr * gr;
-            P[j] -= step * M[j] / (sqrtf(V[j]) * inv_sqrt_bc2 + eps);
-        }
-        *reinterpret_cast<float4*>(p + i) = make_float4(P[0], P[1], P[2], P[3]);
-        *reinterpret_cast<float4*>(m + i) = make_float4(M[0], M[1], M[2], M[3]);
-        *reinterpret_cast<float4*>(v + i) = make_float4(V[0], V[1], V[2], V[3]);
-        if (shadow) {
-            uint2 u; u.x = pack_bf16x2(P[0], P[1]); u.y = pack_bf16x2(P[2], P[3]);
-            *reinterpret_cast<uint2*>(shadow + i) = u;
-        }
-    };
-    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    Quad qa, qb;
-    if (i + 4 <= n) load(i, qa);
-    // two full quads per trip, ONE basic block (so that hipcc counts the waits instead of draining: vmcnt(0) at a block merge): B requested,
-    // A updated and stored, A of the next trip requested, B updated and stored
-    while (i + 2 * stride + 4 <= n) {
-        load(i + stride, qb);
-        update(i, qa);
-        load(i + 2 * stride, qa);
-        update(i + stride, qb);
-        i += 2 * stride;
-    }
-    if (i + stride + 4 <= n) {                    // two full quads left
-        load(i + stride, qb);
-        update(i, qa);
-        update(i + stride, qb);
-        i += 2 * stride;
-    } else if (i + 4 <= n) {                      // one
-        update(i, qa);
-        i += stride;
-    }
-    if (i < n && i + 4 > n) {                     // the ragged tail of the arena (at most one thread)
-        for (int64_t k = i; k < n; ++k) {
-            float gr = (GB ? bf16_to_f32(reinterpret_cast<const bf16_t*>(gv)[k]) : reinterpret_cast<const float*>(gv)[k]) * gscale, pv = p[k];
-            if (decoupled) pv *= 1.f - lr * wd; else gr += wd * pv;
-            const float mk = b1 * m[k] + (1.f - b1) * gr, vk = b2 * v[k] + (1.f - b2) * gr * gr;
-            pv -= step * mk / (sqrtf(vk) * inv_sqrt_bc2 + eps);
-            p[k] = pv; m[k] = mk; v[k] = vk;
-            if (shadow) shadow[k] = f32_to_bf16(pv);
+            for (int j = 0; j < 4; ++j) {
+                float gr = G[j] * gscale;
+                if (decoupled) P[j] *= 1.f - lr * wd; else gr += wd * P[j];
+                M[j] = b1 * M[j] + (1.f - b1) * gr;
+                V[j] = b2 * V[j] + (1.f - b2) * gr * gr;
+                P[j] -= step * M[j] / (sqrtf(V[j]) * inv_sqrt_bc2 + eps);
+            }
+            *reinterpret_cast<float4*>(p + i) = make_float4(P[0], P[1], P[2], P[3]);
+            *reinterpret_cast<float4*>(m + i) = make_float4(M[0], M[1], M[2], M[3]);
+            *reinterpret_cast<float4*>(v + i) = make_float4(V[0], V[1], V[2], V[3]);
+            if (shadow) {
+                uint2 u; u.x = pack_bf16x2(P[0], P[1]); u.y = pack_bf16x2(P[2], P[3]);
+                *reinterpret_cast<uint2*>(shadow + i) = u;
+            }
+        } else {
+            for (int64_t k = i; k < n; ++k) {
+                float gr = (GB ? bf16_to_f32(reinterpret_cast<const bf16_t*>(gv)[k]) : reinterpret_cast<const float*>(gv)[k]) * gscale, pv = p[k];
+                if (decoupled) pv *= 1.f - lr * wd; else gr += wd * pv;
+                const float mk = b1 * m[k] + (1.f - b1) * gr, vk = b2 * v[k] + (1.f - b2) * gr * gr;
+                pv -= step * mk / (sqrtf(vk) * inv_sqrt_bc2 + eps);
+                p[k] = pv; m[k] = mk; v[k] = vk;
+                if (shadow) shadow[k] = f32_to_bf16(pv);
+            }
         }
     }
 }
