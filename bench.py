@@ -447,6 +447,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    enqueue = time.perf_counter() - t0          # the host's share: Python / ctypes time to enqueue the K steps (no synchronisation inside)
     barrier()
     elapsed = time.perf_counter() - t0
     gc.unfreeze()
@@ -542,6 +543,7 @@ def main():
         line = {
             "metric": "image-report pairs/sec training (RRG, 224px x 128tok)", "value": round(value, 2), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "host_enqueue_ms_per_step": round(1e3 * enqueue / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "config/RRG: ViT-B/16 + 12-layer BERT-generation decoder (d=768, h=12, ff=3072, V=30522), "
                                    "bf16, 224x224 images, 128-token reports, dropout 0.1, fwd+bwd+Adam",

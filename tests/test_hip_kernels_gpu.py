@@ -128,6 +128,8 @@ def _attn_ref(q, k, v, H, key_mask, causal):
     (2, 4, 128, 197, False, True),     # cross-attention with a key-padding mask
     (1, 1, 1, 300, False, True),       # single query row (decode step), > 4 key tiles
     (2, 2, 70, 64, False, False),
+    (1, 2, 256, 256, True, False),     # the longest head-resident sequence: every kernel of the three needs > 64 KiB of dynamic LDS
+    (1, 2, 250, 256, False, False),
 ])
 def test_attention_fwd_bwd(case):
     from vilmedic_amd import ops

@@ -351,6 +351,20 @@ int main(int argc, char** argv) {
         for (auto& c : cs) bench_ab(c.M, c.N, c.K, c.la, c.lb, c.flags, c.split);
         return fails;
     }
+    if (argc >= 2 && !strcmp(argv[1], "epiab")) {      // epilogue operands requested in front of the last K-tile (0) vs behind the main loop (VM_GEMM_DEBUG=4)
+        struct { int M, N, K, la, lb, flags; } cs[] = {
+            {12608, 3072, 768, 0, 1, 8}, {8192, 3072, 768, 0, 1, 8}, {12608, 3072, 768, 0, 0, 7}, {8192, 3072, 768, 0, 0, 7},
+            {12608, 768, 3072, 0, 0, 33}, {12608, 768, 768, 0, 0, 33}, {8192, 768, 768, 0, 0, 49}, {8192, 768, 3072, 0, 0, 49},
+            {12608, 2304, 768, 0, 0, 1}, {8192, 2304, 768, 0, 0, 1}, {12608, 768, 2304, 0, 1, 0}, {8192, 768, 768, 0, 1, 0},
+        };
+        for (int rep = 0; rep < 2; ++rep)
+            for (auto& c : cs) for (int dbg : {0, 4}) {
+                { char b[4]; snprintf(b, 4, "%d", dbg); setenv("VM_GEMM_DEBUG", b, 1); vm_reload_env(); }
+                printf("dbg%d ", dbg);
+                bench_gemm2(c.M, c.N, c.K, c.la, c.lb, c.flags, 6);
+            }
+        return 0;
+    }
     if (argc >= 2 && !strcmp(argv[1], "epi")) {
         struct { int M, N, K, la, lb, flags; } cs[] = {
             {12608, 3072, 768, 0, 0, 0}, {12608, 3072, 768, 0, 0, 1}, {12608, 3072, 768, 0, 0, 3}, {12608, 3072, 768, 0, 0, 7}, {12608, 3072, 768, 0, 0, 5},

@@ -750,10 +750,16 @@ __global__ __launch_bounds__(256, 3) void attn_head_dkv_kernel(const AttnArgs p)
 // =============================================================================== host
 template <typename K>
 static void launch_head(K kernel, dim3 grid, size_t lds, hipStream_t s, const AttnArgs& a) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * HB + 4096);
-        attr_set = true;
+    // (the three kernels of this file have the same C++ type, so this template is ONE function and a single "done" flag would cover only
+    // the first kernel launched: the kernels already prepared are kept by address.  Matters for L in (240, 256]: > 64 KiB of LDS)
+    static const void* ready[8];
+    static int nready = 0;
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    bool seen = false;
+    for (int i = 0; i < nready; ++i) seen = seen || ready[i] == fn;
+    if (!seen) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * HB + 4096);
+        if (nready < 8) ready[nready++] = fn;
     }
     hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, a);
 }

@@ -10,7 +10,7 @@ struct GemmArgs {
     int group_w;             // fast path: tile columns per column group of the block-id -> tile map (>= tiles_n: plain row-major)
     vm_gemm_epilogue e;
     uint32_t drop_thresh; float drop_scale;
-    int dbg;                 // VM_GEMM_DEBUG experiments (0 in production): 1 skip epilogue, 2 single K-tile
+    int dbg;                 // VM_GEMM_DEBUG experiments (0 in production): 1 skip epilogue, 2 single K-tile, 4 epilogue operands requested late
     float* slabs;            // split-K partial slabs [split][M][ldc] fp32 (fast path), or null
     float* bias_grad;        // grouped weight-gradient launch: fp32 [M] += alpha * sum_k A(m, k), or null
 };

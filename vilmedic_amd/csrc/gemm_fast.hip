@@ -163,6 +163,58 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs& p, const int bid,
     for (int i = 0; i < (BG ? MF : 1); ++i) accb[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
     const bool bias_wg = BG && p.bias_grad != nullptr && tn == 0 && split == 0;
 
+    // ---- epilogue geometry, and the epilogue's global operands.  Every thread owns a fixed group of 8 columns (q) and rows
+    // tid / QPR + it * (NT / QPR) of each staged pass: the per-column operand (bias) is loaded once, the per-element operands (residual,
+    // gelu'(z) input) of ALL of the tile's items by issue_operands() -- called in front of the LAST K-tile's MFMAs (round 4), so that their
+    // round trip runs under the main loop's tail instead of in front of the epilogue: with every workgroup of a round finishing at the same
+    // time these reads were an exposed burst (26 us of the 102 us FC2-dgrad launch, and it was not the gelu' arithmetic: storing the
+    // derivative in the forward pass and multiplying it in as is bought 5 us).
+    const vm_gemm_epilogue& e = p.e;
+    constexpr int RING_BYTES = STAGES * F_STAGE;
+    constexpr int LDS_BYTES = RING_BYTES >= WR * FBN * 4 ? RING_BYTES : WR * FBN * 4;   // at least one wave-row of fp32 staging
+    constexpr int RPP_RAW = LDS_BYTES / (FBN * 4);
+    constexpr int RPP = RPP_RAW >= FBM ? FBM : (RPP_RAW / WR) * WR;   // rows staged per pass (multiple of a wave's WR rows)
+    static_assert(FBM % RPP == 0 && (RPP * (FBN / 8)) % NT == 0, "epilogue pass geometry");
+    constexpr int NPASS = FBM / RPP;
+    constexpr int QPR = FBN / 8;                                     // 8-column items per row
+    constexpr int ITEMS = RPP * QPR / NT;
+    static_assert(NT % QPR == 0, "column group must be thread-invariant");
+    constexpr int RSTEP = NT / QPR;
+    const int q = tid % QPR, row_t = tid / QPR;
+    const int gn = n0 + q * 8;
+    const bool col_ok = gn < p.N;
+    const int nvalid = min(8, p.N - gn);
+    const bool vec = nvalid == 8;
+    const bf16_t* zsrc = p.slabs ? nullptr : reinterpret_cast<const bf16_t*>(e.mul_gelu_z);
+    const bf16_t* rsrc = p.slabs ? nullptr : reinterpret_cast<const bf16_t*>(e.residual);
+    // The loads are inline asm: written as C++ loads, hipcc merged them with their first use and sank them behind the main loop (ISA: the
+    // eight global_load_dwordx4 sat between the last MFMA and the staging barrier).  Invisible to the compiler's waitcnt pass, they are
+    // completed by the explicit s_waitcnt vmcnt(0) at the head of the epilogue.
+    uint4_t bq[2] = {(uint4_t){0u, 0u, 0u, 0u}, (uint4_t){0u, 0u, 0u, 0u}};
+    // ONE per-element operand array: gelu'(z) input and residual never meet in a launch of the step (if they do, the residual is read in place)
+    uint4_t oq[NPASS][ITEMS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) oq[ps][it] = (uint4_t){0u, 0u, 0u, 0u};
+    auto ldg16 = [](const void* src, uint4_t& dst) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src)); };
+    const bool bias_vec = e.bias && col_ok && !p.slabs && vec;
+    const bool late_ops = p.dbg == 4;          // VM_GEMM_DEBUG=4: operands requested behind the main loop, as before round 4 (A/B)
+    const bf16_t* osrc = zsrc ? zsrc : rsrc;
+    const int64_t ldo = zsrc ? p.ldc : e.ldr;
+    auto issue_operands = [&]() {
+        if (bias_vec) { ldg16(e.bias + gn, bq[0]); ldg16(e.bias + gn + 4, bq[1]); }
+        if (osrc && vec) {
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+                for (int it = 0; it < ITEMS; ++it) {
+                    const int gm = min(m0 + ps * RPP + row_t + it * RSTEP, p.M - 1);
+                    ldg16(osrc + (int64_t)gm * ldo + gn, oq[ps][it]);
+                }
+        }
+    };
+
     auto compute = [&](int buf) {
         const char* sa = smem + buf * F_STAGE;
         const char* sb = sa + F_OPER_A;
@@ -306,11 +358,14 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs& p, const int bid,
                 mfma_half(K0{});
                 slot_reads();
                 mid_tile_barrier();
+                if (!late_ops) issue_operands();                    // (behind the loop's last vmcnt wait: 1.5 K-tiles of MFMAs to land under)
+                __builtin_amdgcn_sched_barrier(0);
                 read_half(nxt, K0{});
                 mfma_half(K1{});
                 slot_reads();
                 ++t;
             }
+            if (nk == 1 && !late_ops) issue_operands();
             {                                                       // last tile
                 const char* cur = smem + (t & 1) * F_STAGE;
                 read_half(cur, K1{});
@@ -327,12 +382,15 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs& p, const int bid,
         }
     } else if (STAGES == 2) {
         stage(0);
-        for (int kt = kt_begin; kt < kt_end; ++kt) {
+        for (int kt = kt_begin; kt + 1 < kt_end; ++kt) {
             const int buf = (kt - kt_begin) & 1;
             __syncthreads();                   // (compiler adds vmcnt(0)): tile kt landed for every wave; buf^1 is free
-            if (kt + 1 < kt_end) stage(buf ^ 1);
+            stage(buf ^ 1);
             compute(buf);
         }
+        __syncthreads();                       // last K-tile (peeled): nothing left to request, the epilogue's operands go out instead
+        if (!late_ops) issue_operands();
+        compute((kt_end - 1 - kt_begin) & 1);
     } else {
         // STAGES-deep ring, STAGES-1 tiles in flight.  Each wave issues NLD = NA_I + NB_I DMA instructions per tile, so
         // "tile kt has landed" == at most NLD * (tiles issued after kt) of this wave's loads are still outstanding.
@@ -352,7 +410,9 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs& p, const int bid,
             buf = buf == STAGES - 1 ? 0 : buf + 1;
             nbuf = nbuf == STAGES - 1 ? 0 : nbuf + 1;
         }
+        if (!late_ops) issue_operands();
     }
+    if (late_ops) issue_operands();
 
     // ---- epilogue.  The accumulators (lane: row m = c, 4 consecutive columns) are staged through LDS as fp32 with a
     // 16-B-chunk XOR swizzle (conflict-free ds_write_b128), then every thread handles 8 consecutive columns of a row so
@@ -360,7 +420,6 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs& p, const int bid,
     // residual / gelu'(z) operands are read with the same coalesced pattern.  (Storing straight from the MFMA layout
     // -- 8-B pieces scattered over 16 rows per instruction -- measured 2.4x slower end to end on K = 768 GEMMs.)
     if (p.dbg == 1 && acc[0][0][0] != 12345.678f) return;
-    const vm_gemm_epilogue& e = p.e;
     const float alpha = e.alpha_dev ? e.alpha * (*e.alpha_dev) : e.alpha;
     if constexpr (BG != 0) {
         if (bias_wg && wn == 0 && g == 0) {         // one owner per output row (tile column 0, no split): plain read-modify-write
@@ -372,77 +431,31 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs& p, const int bid,
         }
     }
     float* cs = reinterpret_cast<float*>(smem);     // [RPP][FBN] fp32, 16-B chunks XOR-swizzled by row
-    constexpr int RING_BYTES = STAGES * F_STAGE;
-    constexpr int LDS_BYTES = RING_BYTES >= WR * FBN * 4 ? RING_BYTES : WR * FBN * 4;   // at least one wave-row of fp32 staging
-    constexpr int RPP_RAW = LDS_BYTES / (FBN * 4);
-    constexpr int RPP = RPP_RAW >= FBM ? FBM : (RPP_RAW / WR) * WR;   // rows staged per pass (multiple of a wave's WR rows)
-    static_assert(FBM % RPP == 0 && (RPP * (FBN / 8)) % NT == 0, "epilogue pass geometry");
-    constexpr int NPASS = FBM / RPP;
-    constexpr int QPR = FBN / 8;                                     // 8-column items per row
-    constexpr int ITEMS = RPP * QPR / NT;
     auto load8 = [&](int row, int q, float* v) {     // 8 consecutive columns 8q..8q+7 of staged row
         const float4 lo = *reinterpret_cast<const float4*>(cs + row * FBN + (((2 * q) ^ (row & 7)) << 2));
         const float4 hi = *reinterpret_cast<const float4*>(cs + row * FBN + (((2 * q + 1) ^ (row & 7)) << 2));
         v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
     };
-    // every thread owns a fixed group of 8 columns (q) and rows  tid / QPR + it * (NT / QPR): the per-column operands
-    // (bias) are loaded once, and the per-element operands (residual, z) of ALL of a pass's items are requested before
-    // the LDS staging barriers so their HBM latency is off the critical path.
-    static_assert(NT % QPR == 0, "column group must be thread-invariant");
-    constexpr int RSTEP = NT / QPR;
-    const int q = tid % QPR, row_t = tid / QPR;
-    const int gn = n0 + q * 8;
-    const bool col_ok = gn < p.N;
-    const int nvalid = min(8, p.N - gn);
-    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (e.bias && col_ok) {
-        if (nvalid == 8) {
-            const float4 b0 = *reinterpret_cast<const float4*>(e.bias + gn), b1 = *reinterpret_cast<const float4*>(e.bias + gn + 4);
-            bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
-        } else for (int r = 0; r < nvalid; ++r) bias8[r] = e.bias[gn + r];
-    }
-    const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(e.mul_gelu_z);
-    const bf16_t* rsrc = reinterpret_cast<const bf16_t*>(e.residual);
-    const bool vec = nvalid == 8;
     const DropKey dkey = drop_key(eff_seed(e.dropout_seed, e.dropout_seed_dev));
     // gfx950 has ONE in-order counter for loads and stores: a wait for ANY load issued after the first pass's stores also waits for those stores
-    // (measured on the 256-row kernel of gemm_p8.hip: 8 us per tile of store round trips).  With two passes (the 160-row tile) the operand
-    // loads of BOTH passes are therefore issued -- and, with the bias, waited for -- before the first store, the pass loop is unrolled, and its
-    // barriers are raw s_barrier + lgkmcnt(0) (a __syncthreads() in front of pending loads waits vmcnt(0)): pass 2 no longer starts with
-    // the drain of pass 1's stores.
-    uint4_t zq[NPASS][ITEMS], rq[NPASS][ITEMS];
+    // (measured on the 256-row kernel of gemm_p8.hip: 8 us per tile of store round trips).  The operand loads of BOTH passes (the 160-row tile
+    // has two) were therefore issued up front (issue_operands, in front of the last K-tile's MFMAs) and are -- with the bias -- complete before
+    // the first store; the pass loop is unrolled, and its barriers are raw s_barrier + lgkmcnt(0) (a __syncthreads() in front of pending
+    // loads waits vmcnt(0)): pass 2 no longer starts with the drain of pass 1's stores.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps)
 #pragma unroll
-        for (int it = 0; it < ITEMS; ++it) { zq[ps][it] = (uint4_t){0u, 0u, 0u, 0u}; rq[ps][it] = (uint4_t){0u, 0u, 0u, 0u}; }
-    if (zsrc && vec) {
+        for (int it = 0; it < ITEMS; ++it) asm volatile("" : "+v"(oq[ps][it]));
+    asm volatile("" : "+v"(bq[0]));
+    asm volatile("" : "+v"(bq[1]));
+    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (bias_vec) {
 #pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps)
-#pragma unroll
-            for (int it = 0; it < ITEMS; ++it) {
-                const int gm = min(m0 + ps * RPP + row_t + it * RSTEP, p.M - 1);
-                zq[ps][it] = *reinterpret_cast<const uint4_t*>(zsrc + (int64_t)gm * p.ldc + gn);
-            }
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps)
-#pragma unroll
-            for (int it = 0; it < ITEMS; ++it) asm volatile("" : "+v"(zq[ps][it]));
+        for (int r = 0; r < 4; ++r) { bias8[r] = __uint_as_float(bq[0][r]); bias8[4 + r] = __uint_as_float(bq[1][r]); }
+    } else if (e.bias && col_ok && !p.slabs) {
+        for (int r = 0; r < nvalid; ++r) bias8[r] = e.bias[gn + r];
     }
-    if (rsrc && vec) {
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps)
-#pragma unroll
-            for (int it = 0; it < ITEMS; ++it) {
-                const int gm = min(m0 + ps * RPP + row_t + it * RSTEP, p.M - 1);
-                rq[ps][it] = *reinterpret_cast<const uint4_t*>(rsrc + (int64_t)gm * e.ldr + gn);
-            }
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps)
-#pragma unroll
-            for (int it = 0; it < ITEMS; ++it) asm volatile("" : "+v"(rq[ps][it]));
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) asm volatile("" : "+v"(bias8[r]));
     auto epi_barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -496,7 +509,7 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs& p, const int bid,
         }
         if (zsrc) {
             float zf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (vec) unpack8(make_uint4(zq[ps][it][0], zq[ps][it][1], zq[ps][it][2], zq[ps][it][3]), zf);
+            if (vec) unpack8(make_uint4(oq[ps][it][0], oq[ps][it][1], oq[ps][it][2], oq[ps][it][3]), zf);
             else for (int r = 0; r < nvalid; ++r) zf[r] = bf16_to_f32(zsrc[off + r]);
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] *= gelu_grad_f(zf[r]);
@@ -509,7 +522,8 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs& p, const int bid,
         }
         if (rsrc) {
             float rf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (vec) unpack8(make_uint4(rq[ps][it][0], rq[ps][it][1], rq[ps][it][2], rq[ps][it][3]), rf);
+            if (vec && !zsrc) unpack8(make_uint4(oq[ps][it][0], oq[ps][it][1], oq[ps][it][2], oq[ps][it][3]), rf);
+            else if (vec) unpack8(*reinterpret_cast<const uint4*>(rsrc + (int64_t)gm * e.ldr + gn), rf);
             else for (int r = 0; r < nvalid; ++r) rf[r] = bf16_to_f32(rsrc[(int64_t)gm * e.ldr + gn + r]);
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] += rf[r];
