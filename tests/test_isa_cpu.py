@@ -64,7 +64,9 @@ def test_pipelined_k_tile_schedule_is_present(gemm_fast_asm):
     assert len(mfma) == 32, len(mfma)
     reads_between = [i for i, (o, _) in enumerate(ops) if o.startswith("ds_read") and mfma[0] < i < mfma[-1]]
     assert len(reads_between) >= 8, len(reads_between)
-    assert sum(1 for o, l in ops if o == "s_waitcnt" and "lgkmcnt(0)" in l) <= 2
+    # (besides the barrier's own "vmcnt(0) lgkmcnt(0)": since the last K-tile is peeled -- the epilogue operands go out in front of it --
+    # the barrier, the DMA issue and the MFMAs are one basic block)
+    assert sum(1 for o, l in ops if o == "s_waitcnt" and "lgkmcnt(0)" in l and "vmcnt" not in l) <= 2
 
 
 @pytest.mark.parametrize("name,n_mfma", [
