@@ -251,17 +251,19 @@ int vm_ce_smooth_fwd_bwd(const float* logits, const int64_t* target, int R, int 
  * GLoRIALoss.py:54-75): with S[R,C] = n(a) n(b)^T * inv_tau (n = x / max(|x|, eps) when ``normalize``, identity otherwise) and row i
  * paired with column i + diag_offset (the local rows of a rank against all gathered columns):
  *     loss_rows[i] = log sum_j exp(S_ij) - S_{i,i+off}      loss_cols[j] = log sum_i exp(S_ij) - S_{j-off,j}
- * (the paired term is dropped for a row / column without a partner).  S never reaches HBM.
+ * (the paired term is dropped for a row / column without a partner).
  * vm_contrastive_loss_fwd: three short dependent launches -- normalise + cast both matrices (a_hat [R,D], b_hat [C,D] bf16, the norms),
- *   one workgroup per 128 x 128 tile of S on the MFMA writing per-tile (max, sum exp) partials, one thread per row / column merging them
- *   into lse_rows / lse_cols and the losses.
- * vm_contrastive_loss_bwd: two launches -- G tiles
+ *   one workgroup per 128 x 128 tile of S on the MFMA writing per-tile (max, sum exp) partials and the fp32 tile itself into ``ws``, one
+ *   thread per row / column merging the partials into lse_rows / lse_cols and the losses.
+ * vm_contrastive_loss_bwd: three launches -- a streaming pass over the stored S:
  *   G_ij = g_rows[i] softmax_row(S)_ij + g_cols[j] softmax_col(S)_ij - [j == i+off](g_rows[i] + g_cols[j])  (bf16, in ``ws``, with the
- *   partial sums of G.S that the normalisation backward needs), then 64 x 96 tiles of
- *   da = d/da (sum_i g_rows[i] loss_rows[i] + sum_j g_cols[j] loss_cols[j]) and db likewise (fp32 [R,D] / [C,D]), the L2-normalisation
- *   backward applied in the GEMM epilogue.  ``ws``: vm_contrastive_ws(R, C) bytes, 256-B aligned; the backward recomputes S, so it does
- *   not need the forward's buffer.  (A single persistent backward launch with in-kernel hand-offs was built first and measured slower:
- *   every release / acquire hand-off costs more than a kernel boundary on this chip -- csrc/contrastive.hip.)
+ *   sums of G.S that the normalisation backward needs); the two gradient products G b_hat / tau and G^T a_hat / tau as tiles of the
+ *   library's GEMM main loop (R and C multiples of 64; 64 x 96 register-staged tiles otherwise) into
+ *   da = d/da (sum_i g_rows[i] loss_rows[i] + sum_j g_cols[j] loss_cols[j]) and db likewise (fp32 [R,D] / [C,D]); the L2-normalisation
+ *   backward as a row pass over both, in place.  ``ws``: vm_contrastive_ws(R, C) bytes, 256-B aligned, and THE SAME buffer, untouched, for
+ *   the forward call and its backward call (it carries S; until round 4 the backward recomputed S).  (A single persistent backward launch
+ *   with in-kernel hand-offs was built first and measured slower: every release / acquire hand-off costs more than a kernel boundary on
+ *   this chip -- csrc/contrastive.hip.)
  * vm_rownorm_cast: the normalise + cast of one matrix on its own (GLoRIA's global embeddings share it). */
 int vm_rownorm_cast(const float* x /* [rows,D] */, void* out_bf16, float* norms /* [rows] or NULL */, int rows, int D,
                     int normalize /* 1: x/max(|x|,eps) (ConVIRT cosine)  0: plain cast (InfoNCE) */, float eps, void* stream);

@@ -367,7 +367,8 @@ def _sim_ref(a, b, normalize, inv_tau, off):
 
 
 @pytest.mark.parametrize("R,C,D,off,normalize", [(2048, 2048, 768, 0, True), (256, 2048, 768, 512, True), (300, 1000, 96, 37, True),
-                                                  (77, 50, 40, -5, False), (1000, 300, 264, 0, True)])
+                                                  (77, 50, 40, -5, False), (1000, 300, 264, 0, True),
+                                                  (192, 320, 136, 64, False), (320, 192, 72, -64, True)])      # multiples of 64 that are not tiles of 128: the GEMM-tile gradient path's edges
 def test_similarity_loss_kernels_rectangular_ragged_offset(R, C, D, off, normalize):
     """csrc/contrastive.hip through _SimilarityLossFn: square (BASELINE configs[2]), a rank's row block of the global similarity
     (256 local rows against 2048 gathered columns, paired column = row + 512), ragged tile edges in every dimension, a negative offset,
@@ -400,4 +401,4 @@ def test_similarity_loss_kernels_rectangular_ragged_offset(R, C, D, off, normali
     torch.cuda.synchronize()
     assert torch.equal(lr2, lr) and torch.equal(lc2, lc)
     gerr = max(rel_l2(ad2.grad, ad.grad), rel_l2(bd2.grad, bd.grad))
-    assert gerr == 0.0, gerr                         # no atomics, no order-dependent reduction anywhere in the five launches
+    assert gerr == 0.0, gerr                         # no atomics, no order-dependent reduction anywhere in the six launches

@@ -2,9 +2,10 @@
 
 ref: vilmedic/blocks/losses/selfsup/ConVIRTLoss.py:5-38, InfoNCELoss.py:5-24, GLoRIALoss.py:5-170.
 
-The [B,B] similarity S = n(a) n(b)^T / tau is computed tile by tile on the MFMA and never reaches HBM: row / column
-log-sum-exp and the diagonal in the forward pass, the gradient matrix G from recomputed tiles in the backward pass
-(csrc/contrastive.hip); dA = G B / tau and dB = G^T A / tau are tiles of one launch with the normalisation backward in their epilogue.  When torch.distributed is initialised with world_size > 1 the text / image embeddings are
+The [B,B] similarity S = n(a) n(b)^T / tau is computed tile by tile on the MFMA: row / column log-sum-exp and the diagonal in the
+forward pass, which also parks the fp32 tiles in the workspace; the backward pass streams them once into the gradient matrix G
+(csrc/contrastive.hip), forms dA = G B / tau and dB = G^T A / tau as GEMM tiles of one launch and applies the normalisation backward as a
+row pass.  When torch.distributed is initialised with world_size > 1 the text / image embeddings are
 all-gathered first (RCCL), so every rank sees the GLOBAL batch of negatives (SURVEY §8e -- a capability the reference
 lacks: under DDP it contrasts within the local shard only, conVIRT.py:97-100).
 """
@@ -24,8 +25,8 @@ def _pad8(n):
 class _SimilarityLossFn(torch.autograd.Function):
     """(a [R,D], b [C,D]) -> per-row losses  row_i = lse_j S_ij - S_{i,i+off},  col_i = lse_j S_{j,i+off} - S_{i,i+off}  with
     S = n(a) n(b)^T * inv_tau  (n = L2 normalisation when ``normalize``); ``diag_offset`` = off pairs row i with column i + off
-    (a rank's local rows against the gathered columns).  Two C-ABI calls, five short kernel launches forward + backward
-    (csrc/contrastive.hip): the [R, C] matrix never reaches HBM and the normalisation backward is the epilogue of the gradient GEMMs."""
+    (a rank's local rows against the gathered columns).  Two C-ABI calls, six short kernel launches forward + backward
+    (csrc/contrastive.hip); the workspace carries the fp32 similarity from the forward call to the backward call."""
 
     @staticmethod
     def forward(ctx, a, b, normalize, inv_tau, eps, diag_offset=0):

@@ -1,11 +1,12 @@
 // contrastive.hip -- the image-text contrastive losses (ConVIRT / InfoNCE / GLoRIA-global) on the [B,B] similarity S = a_hat b_hat^T / tau:
 //   vm_rownorm_cast      x fp32 [R,D] -> x/max(|x|,eps) as bf16 (+ the norms), or a plain cast (InfoNCE)
-//   vm_contrastive_fwd   row / column log-sum-exp and the diagonal of S, tile by tile on the MFMA (S never reaches HBM)
-//   vm_contrastive_bwd   G = g_row_i softmax_row(S)_ij + g_col_j softmax_col(S)_ij - [i==j](g_row_i+g_col_i)  -> bf16, from recomputed tiles
+//   vm_contrastive_fwd   row / column log-sum-exp and the diagonal of S, tile by tile on the MFMA (the fp32 tiles are kept in the workspace)
+//   vm_contrastive_bwd   G = g_row_i softmax_row(S)_ij + g_col_j softmax_col(S)_ij - [i==j](g_row_i+g_col_i)  -> bf16, from the stored tiles
 // (round 1 materialised S in fp32 and made three scalar passes over it: 0.314 vs 0.147 ms of kernel time at B = 2048, 1.45 vs 0.80 ms
 // at B = 8192 -- profiles/r02_l_contrastive_bench.txt -- that path and its kernels are gone.)
 // ref: vilmedic/blocks/losses/selfsup/ConVIRTLoss.py:12-31, InfoNCELoss.py:11-19, GLoRIALoss.py:54-75.
 #include "common.h"
+#include "gemm_args.h"
 
 __global__ __launch_bounds__(256) void rownorm_cast_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, float* __restrict__ norms,
                                                            int rows, int D, int normalize, float eps) {
@@ -31,17 +32,25 @@ extern "C" int vm_rownorm_cast(const float* x, void* out_bf16, float* norms, int
 
 
 
-// ------------------------------------------------------------------ the similarity loss in five short launches: S never reaches HBM
+// ------------------------------------------------------------------ the similarity loss in six short launches
 //   forward   contr_prep_kernel    both embedding matrices in ONE launch: x/max(|x|,eps) -> bf16 (or a plain cast), the norms; zeroes the
 //                                  paired-diagonal buffer
-//             contr_fwd_kernel     one workgroup per 128 x 128 tile of S = A^ B^^T * inv_tau (bf16 MFMA, fp32 accumulate, the tile staged in
-//                                  LDS as fp32): per-row / per-column (max, sum exp) partials + the paired-diagonal entries
+//             contr_fwd_kernel     one workgroup per 128 x 128 tile of S = A^ B^^T * inv_tau (bf16 MFMA through an LDS-DMA ring, fp32
+//                                  accumulate, the tile staged in LDS as fp32): per-row / per-column (max, sum exp) partials, the
+//                                  paired-diagonal entries, and [r4] the tile itself into the workspace for the backward pass
 //             contr_merge_kernel   one thread per row / column: log-sum-exp over the per-tile partials, the per-row losses
-//   backward  contr_g_kernel       a recomputed S tile -> G = g_r softmax_row + g_c softmax_col - [paired](g_r + g_c) as bf16 (8 MB at
-//                                  B = 2048: L2 / MALL resident) and the partial sums p_i = sum_j G_ij S_ij, q_j = sum_i G_ij S_ij
-//                                  (the a^.da^ / b^.db^ projections of the normalisation backward)
-//             contr_grad_kernel    64 x BN output tiles of dA = G B^ / tau and dB = G^T A^ / tau, the L2-normalisation backward applied in
-//                                  the epilogue: dx = (dx^ - x^ (x^ . dx^)) / |x| -- no cross-tile reduction is left because x^ . dx^ = p.
+//   backward  contr_g_rows_kernel  [r4] streaming pass over whole rows of the stored S: G = g_r softmax_row + g_c softmax_col -
+//                                  [paired](g_r + g_c) as bf16 and the sums p_i = sum_j G_ij S_ij (complete), q_j = sum_i G_ij S_ij
+//                                  (one partial per row block) = the a^.da^ / b^.db^ projections of the normalisation backward
+//             gemm_pair_kernel     [r4] dA^ = G B^ / tau and dB^ = G^T A^ / tau as 128 x 128 tiles of the library's LDS-DMA GEMM main loop
+//                                  (gemm_fast.hip; R, C multiples of 64 -- else contr_grad_kernel, the 64 x BN register-staged tiles)
+//             contr_norm_bwd_kernel [r4] row pass over both results: dx = (dx^ - x^ (x^ . dx^)) / |x|, x^ . dx^ from p / the q partials
+// Round 4 (profiles/r04_*_contrastive_bench.txt), B = 2048 / 8192: the G pass recomputed every S tile on the MFMA (32.6 / 269 us) -> reads the
+// stored tiles (13.7 / 108 us; the first streaming version read the tile by tile layout -- 512-B row segments at a power-of-two stride -- and
+// took 20 us, a 16-wave tile form 31 us); the gradient products on 64 x 96 register-staged tiles with ONE chunk in flight (47.3 / 535 us) ->
+// GEMM tiles (30.4 / 276 us; a 2-way K split of the 192 tiles bought 4 us and cost 3 in the row pass: not kept) + the row pass (11.8 / 38 us:
+// one wave per row summing 512 column partials 4 B at a time took 17.7 us; 8 rows per workgroup read them 32 B at a time).
+// Kernel time forward + backward 121 -> 96 us at B = 2048, 1036 -> 661 us at B = 8192 (0.187 of the MFMA peak).
 // History (profiles/r03_*): round 2 ran this as six library launches + a dozen torch glue kernels (147 us + ~50 us of kernels, 0.34 ms wall at
 // B = 2048; the two gradient GEMMs alone took 61 us because 2048 x 768 outputs are 96 tiles of 128 x 128 on 256 CUs).  Round 3 first built it
 // as ONE persistent backward launch pulling tiles from a device queue with agent-scope release / acquire hand-offs between the phases, and a
@@ -71,6 +80,8 @@ struct ContrArgs {
     // backward
     const float* lse_r; const float* lse_c; const float* g_r; const float* g_c; bf16_t* G; int64_t ldg;
     float* p_part; float* q_part;                    // [tiles_n][R], [tiles_m][C]
+    int nparts_p, nparts_q;                          // partial sums per row of p_part / per column of q_part
+    float* S; int64_t ldS;                           // the scaled similarity, fp32 [R][ldS]: written by the forward tiles, read by the G tiles
     const float* a32; const float* b32; const float* na; const float* nb; float* da; float* db;
     int normalize, bn, items_a, items_da, items_db; float eps;
 };
@@ -255,18 +266,6 @@ __device__ __forceinline__ float contr_merge_lse(const float* part, int64_t n, i
     }
     return M + __logf(L);
 }
-__device__ __forceinline__ float contr_sum_parts(const float* part, int64_t n, int x, int nt) {
-    float s = 0.f;
-    for (int t0 = 0; t0 < nt; t0 += 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (t0 + u < nt) ? part[(int64_t)(t0 + u) * n + x] : 0.f;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
-    }
-    return s;
-}
-
 __global__ __launch_bounds__(256, 2) void contr_fwd_kernel(const ContrArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -275,6 +274,22 @@ __global__ __launch_bounds__(256, 2) void contr_fwd_kernel(const ContrArgs p) {
     contr_s_tile(contr_operands(p), smem, m0, n0);
     const float* cs = reinterpret_cast<const float*>(smem);
     const int rows = min(CT, p.R - m0), cols = min(CT, p.C - n0);
+    {   // [r4] the tile goes to the workspace (fp32, 32 contiguous bytes per lane: whole 512-B row segments per 16 lanes): the backward pass
+        // reads it back instead of recomputing it on the MFMA (16 MB at B = 2048: L2 / MALL resident between the two launches)
+        const int c0 = (tid & 15) * 8;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = (tid >> 4) + 16 * it;
+            if (r < rows && c0 < cols) {
+                float* o = p.S + (int64_t)(m0 + r) * p.ldS + n0 + c0;
+                const float* src = cs + r * CT_CS + c0;
+                if (c0 + 8 <= cols) {
+                    *reinterpret_cast<float4*>(o) = *reinterpret_cast<const float4*>(src);
+                    *reinterpret_cast<float4*>(o + 4) = *reinterpret_cast<const float4*>(src + 4);
+                } else for (int j = 0; j < cols - c0; ++j) o[j] = src[j];
+            }
+        }
+    }
     if (tid < CT) {                        // threads 0..127: one row each
         const int r = tid;
         if (r < rows) {
@@ -341,80 +356,91 @@ __device__ __forceinline__ float quarters_sum(float v) {      // over lanes l, l
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-// one tile of G (+ the projection partials)
-struct ContrGTile {         // the fields phase A uses, in SGPRs
-    int R, C, diag_offset, tiles_m, tiles_n; int64_t ldg;
-    const float* lse_r; const float* lse_c; const float* g_r; const float* g_c; bf16_t* G; float* p_part; float* q_part;
-};
-__device__ __noinline__ void contr_g_tile(const ContrArgs& pa, char* smem, int tm, int tn) {
+// G and the projection sums from the forward's S, as a STREAMING pass over row blocks (round 4; the tile form re-ran the S product on the MFMA,
+// 32.6 us at B = 2048).  One workgroup = RB whole rows of S: a lane owns 8 consecutive columns of every row of the block (32 B of S in, 16 B
+// of G out per row: whole rows are contiguous kilobytes -- the first version read the stored S tile by tile, 128 row segments of 512 B at a
+// power-of-two stride per workgroup, and took 20 us for 24 MB), so
+//   p_i = sum_j G_ij S_ij   is complete inside the workgroup (lanes, then waves through LDS: one value per row, no partials), and
+//   q_j = sum_i G_ij S_ij   leaves one partial per row block and column, owned by one lane (no cross-lane step): q_part[block][C],
+//                            summed by the consumer's waves (contr_norm_bwd_kernel).
+template <int RB>
+__global__ __launch_bounds__(256) void contr_g_rows_kernel(const ContrArgs p) {
+    __shared__ float red[4][RB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = tm * CT, n0 = tn * CT;
-    const ContrOperands ops = contr_operands(pa);
-    ContrGTile p;
-    p.R = ops.R; p.C = ops.C; p.diag_offset = contr_uni(pa.diag_offset); p.tiles_m = contr_uni(pa.tiles_m); p.tiles_n = contr_uni(pa.tiles_n);
-    p.ldg = (int64_t)contr_uni((int)pa.ldg);
-    p.lse_r = contr_uni(pa.lse_r); p.lse_c = contr_uni(pa.lse_c); p.g_r = contr_uni(pa.g_r); p.g_c = contr_uni(pa.g_c); p.G = contr_uni(pa.G);
-    p.p_part = contr_uni(pa.p_part); p.q_part = contr_uni(pa.q_part);
-    contr_s_tile(ops, smem, m0, n0);
-    const float* cs = reinterpret_cast<const float*>(smem);
-    float* red = reinterpret_cast<float*>(smem + CT_RED_OFF);
-    const int rows = min(CT, p.R - m0), cols = min(CT, p.C - n0);
-    const int c0 = (tid & 15) * 8;
-    float colacc[8];
-    float gcj[8], lcj[8];
+    const int rb = blockIdx.x, m0 = rb * RB;
+    const int rows = min(RB, p.R - m0);
+    float gr[RB], lr[RB], rs[RB];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int gc = n0 + c0 + j;
-        colacc[j] = 0.f;
-        gcj[j] = (c0 + j < cols) ? p.g_c[gc] : 0.f;
-        lcj[j] = (c0 + j < cols) ? p.lse_c[gc] : 0.f;
+    for (int i = 0; i < RB; ++i) {
+        const int r = min(m0 + i, p.R - 1);
+        gr[i] = p.g_r[r]; lr[i] = p.lse_r[r]; rs[i] = 0.f;
     }
-    float gr8[8], lr8[8];                  // the 8 rows' upstream gradient and log-sum-exp, requested together (not one round trip per row)
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int r = (tid >> 4) + 16 * it;
-        gr8[it] = r < rows ? p.g_r[m0 + r] : 0.f;
-        lr8[it] = r < rows ? p.lse_r[m0 + r] : 0.f;
-    }
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {       // 8 consecutive columns of a row per thread: 16-B bf16 stores, whole 256-B rows per 16 lanes
-        const int r = (tid >> 4) + 16 * it;
-        const int gr = m0 + r;
-        const bool rok = r < rows;
-        const float gri = gr8[it], lri = lr8[it];
-        float v[8], rs = 0.f;
+    const bool vec4 = (p.C & 3) == 0;
+    for (int cb = 0; cb < p.C; cb += 2048) {
+        const int c0 = cb + tid * 8;
+        if (c0 >= p.C) continue;
+        const int nv = min(8, p.C - c0);
+        float gc[8], lc[8], colacc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float g = 0.f;
-            if (rok && c0 + j < cols) {
-                const float sv = cs[r * CT_CS + c0 + j];
-                g = gri * __expf(sv - lri) + gcj[j] * __expf(sv - lcj[j]);
-                if (n0 + c0 + j == gr + p.diag_offset) g -= gri + gcj[j];
-                rs += g * sv;
-                colacc[j] += g * sv;
-            }
-            v[j] = g;
+            const int c = min(c0 + j, p.C - 1);
+            gc[j] = p.g_c[c]; lc[j] = p.lse_c[c]; colacc[j] = 0.f;
         }
-        rs = row16_sum(rs);
-        if (rok) {
-            if ((tid & 15) == 0) p.p_part[(int64_t)tn * p.R + gr] = rs;
-            if (c0 < cols) {
-                bf16_t* o = p.G + (int64_t)gr * p.ldg + n0 + c0;
-                if (c0 + 8 <= cols) *reinterpret_cast<uint4*>(o) = pack8(v);
-                else for (int j = 0; j < cols - c0; ++j) o[j] = f32_to_bf16(v[j]);
+        float sv[RB][8];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {           // every row's 32 B requested before the first exp
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sv[i][j] = 0.f;
+            if (i < rows) {
+                const float* src = p.S + (int64_t)(m0 + i) * p.ldS + c0;
+                if (nv == 8) {
+                    const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+                    sv[i][0] = lo.x; sv[i][1] = lo.y; sv[i][2] = lo.z; sv[i][3] = lo.w; sv[i][4] = hi.x; sv[i][5] = hi.y; sv[i][6] = hi.z; sv[i][7] = hi.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (j < nv) sv[i][j] = src[j];
+                }
             }
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            if (i >= rows) continue;
+            const int grow = m0 + i;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float g = 0.f;
+                if (j < nv) {
+                    const float x = sv[i][j];
+                    g = gr[i] * __expf(x - lr[i]) + gc[j] * __expf(x - lc[j]);
+                    if (c0 + j == grow + p.diag_offset) g -= gr[i] + gc[j];
+                    rs[i] += g * x;
+                    colacc[j] += g * x;
+                }
+                v[j] = g;
+            }
+            bf16_t* o = p.G + (int64_t)grow * p.ldg + c0;
+            if (nv == 8) *reinterpret_cast<uint4*>(o) = pack8(v);
+            else for (int j = 0; j < nv; ++j) o[j] = f32_to_bf16(v[j]);
+        }
+        float* qo = p.q_part + (int64_t)rb * p.C + c0;
+        if (nv == 8 && vec4) {
+            *reinterpret_cast<float4*>(qo) = make_float4(colacc[0], colacc[1], colacc[2], colacc[3]);
+            *reinterpret_cast<float4*>(qo + 4) = make_float4(colacc[4], colacc[5], colacc[6], colacc[7]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (j < nv) qo[j] = colacc[j];
         }
     }
-    // column partials: the 4 row groups of a wave (lanes l, l^16, l^32, l^48), then the 4 waves through LDS
 #pragma unroll
-    for (int j = 0; j < 8; ++j) colacc[j] = quarters_sum(colacc[j]);
-    if (lane < 16) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) red[wave * CT + lane * 8 + j] = colacc[j];
+    for (int i = 0; i < RB; ++i) {
+        const float t = wave_sum(rs[i]);
+        if (lane == 0) red[wave][i] = t;
     }
     __syncthreads();
-    if (tid < cols) p.q_part[(int64_t)tm * p.C + n0 + tid] = red[tid] + red[CT + tid] + red[2 * CT + tid] + red[3 * CT + tid];
+    if (tid < rows) p.p_part[m0 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
+static int contr_rb(int R) { return R > 2048 ? 16 : 4; }      // rows per workgroup of the G pass: >= 512 workgroups from R = 2048 on
 
 // gradient tiles: out[m0.., n0..] (64 x BN, fp32) = sum_k P[m][k] X^[k][n] / tau, normalisation backward in the epilogue.
 //   PT = false (dA): P[m][k] = G[m0 + m][k],  X^ = B^,  K = C;    PT = true (dB): P[m][k] = G[k][m0 + m],  X^ = A^,  K = R
@@ -424,20 +450,11 @@ template <int NB, bool PT>
 __device__ __noinline__ void contr_grad_tile(const ContrArgs& pa, char* smem, int m0, int n0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave >> 1, wm = wave & 1;
     constexpr int BN = NB * 32;                       // NB 16-column blocks per wave x 2 waves
-    struct { int R, C, D, normalize; int64_t ldg; float inv_tau, eps; const bf16_t* G; } p;      // in SGPRs (see contr_uni)
-    p.R = contr_uni(pa.R); p.C = contr_uni(pa.C); p.D = contr_uni(pa.D); p.normalize = contr_uni(pa.normalize); p.ldg = (int64_t)contr_uni((int)pa.ldg);
-    p.inv_tau = contr_uni(pa.inv_tau); p.eps = contr_uni(pa.eps); p.G = contr_uni((const bf16_t*)pa.G);
+    struct { int R, C, D; int64_t ldg; float inv_tau; const bf16_t* G; } p;      // in SGPRs (see contr_uni)
+    p.R = contr_uni(pa.R); p.C = contr_uni(pa.C); p.D = contr_uni(pa.D); p.ldg = (int64_t)contr_uni((int)pa.ldg);
+    p.inv_tau = contr_uni(pa.inv_tau); p.G = contr_uni((const bf16_t*)pa.G);
     const int M = PT ? p.C : p.R, K = PT ? p.R : p.C;
     const bf16_t* X = contr_uni(PT ? pa.A : pa.B);
-    // the projections x^ . dx^ = sum over the G tiles' partial sums for this lane's two output rows: requested NOW (independent loads, two
-    // memory round trips) so that they have landed long before the epilogue needs them
-    const float* part = contr_uni(PT ? pa.q_part : pa.p_part);
-    const int nparts = contr_uni(PT ? pa.tiles_m : pa.tiles_n);
-    float proj_j[2] = {0.f, 0.f};
-    if (p.normalize) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) proj_j[j] = contr_sum_parts(part, M, min(m0 + wm * 32 + j * 16 + (lane & 15), M - 1), nparts);
-    }
     float4_t acc[NB][2];
 #pragma unroll
     for (int i = 0; i < NB; ++i) { acc[i][0] = (float4_t){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
@@ -497,46 +514,24 @@ __device__ __noinline__ void contr_grad_tile(const ContrArgs& pa, char* smem, in
         if (kt + 1 < ktiles) store(smem + ((kt + 1) & 1) * CB_STAGE);
         __syncthreads();
     }
-    // epilogue: lane holds out[m][n .. n + 3], m = m0 + wm 32 + j 16 + (lane & 15), n = n0 + wn BN/2 + i 16 + (lane >> 4) 4
-    const float* x32 = contr_uni(PT ? pa.b32 : pa.a32);
-    const float* nrm = contr_uni(PT ? pa.nb : pa.na);
+    // epilogue: lane holds out[m][n .. n + 3], m = m0 + wm 32 + j 16 + (lane & 15), n = n0 + wn BN/2 + i 16 + (lane >> 4) 4; the plain product
+    // (the L2-normalisation backward is contr_norm_bwd_kernel's row pass, for this path and the GEMM-tile path alike)
     float* out = contr_uni(PT ? pa.db : pa.da);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int m = m0 + wm * 32 + j * 16 + (lane & 15);
         if (m >= M) continue;
-        float proj = 0.f, d = 1.f;
-        bool unit = false;
-        if (p.normalize) {
-            proj = proj_j[j];
-            const float nm = nrm[m];
-            d = fmaxf(nm, p.eps);
-            unit = nm > p.eps;
-        }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int n = n0 + wn * (BN / 2) + i * 16 + (lane >> 4) * 4;
             if (n >= p.D) continue;
-            float4 o;
-            float* ov = reinterpret_cast<float*>(&o);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ov[r] = acc[i][j][r] * p.inv_tau;
-            if (p.normalize) {
-                const float4 xv = *reinterpret_cast<const float4*>(x32 + (int64_t)m * p.D + n);
-                const float* xs = reinterpret_cast<const float*>(&xv);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ov[r] = (ov[r] - (unit ? xs[r] / d * proj : 0.f)) / d;
-            }
-            *reinterpret_cast<float4*>(out + (int64_t)m * p.D + n) = o;
+            *reinterpret_cast<float4*>(out + (int64_t)m * p.D + n) =
+                make_float4(acc[i][j][0] * p.inv_tau, acc[i][j][1] * p.inv_tau, acc[i][j][2] * p.inv_tau, acc[i][j][3] * p.inv_tau);
         }
     }
     __syncthreads();                 // the LDS stages are reused by the next item
 }
 
-__global__ __launch_bounds__(256, 2) void contr_g_kernel(const ContrArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    contr_g_tile(p, smem, blockIdx.x / p.tiles_n, blockIdx.x % p.tiles_n);
-}
 // items [0, items_da): tiles of dA; [items_da, items_da + items_db): tiles of dB (dependent launch behind contr_g_kernel)
 __global__ __launch_bounds__(256, 2) void contr_grad_kernel(const ContrArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -549,6 +544,87 @@ __global__ __launch_bounds__(256, 2) void contr_grad_kernel(const ContrArgs p) {
     else            { if (isb) contr_grad_tile<4, true>(p, smem, m0, n0); else contr_grad_tile<4, false>(p, smem, m0, n0); }
 }
 
+// [r4] R and C multiples of 64: the two gradient products run on the library's 128 x 128 LDS-DMA GEMM main loop (vm_gemm_pair_launch, fp32
+// output scaled by 1 / tau) -- the 64 x 96 register-staged tiles above kept ONE 64-deep chunk in flight and filled 335 MB of LDS for 13 GFLOP
+// (47 us at B = 2048) -- and the L2-normalisation backward is this row pass over the two results, in place:
+// dx = (dx^ - x^ (x^ . dx^)) / |x| with x^ . dx^ = the G tiles' partial sums (one wave per row).
+#define CN_ROWS 8
+__global__ __launch_bounds__(256) void contr_norm_bwd_kernel(const ContrArgs p) {
+    __shared__ float sacc[32][CN_ROWS + 1];
+    __shared__ float sk[CN_ROWS], sd[CN_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int base = blockIdx.x * CN_ROWS;
+    // (1) x^ . dx^ of the block's 8 rows: thread (group tq of 32, row c of 8) adds the partials t = tq, tq + 32, ... -- 8 adjacent rows per
+    // partial line (one wave per row read 4 B out of every 128-B line: 134 MB of L2 traffic for the 4 MB of column partials at B = 2048)
+    if (p.normalize) {
+        const int c = tid & (CN_ROWS - 1), tq = tid / CN_ROWS;
+        const int row = base + c;
+        float acc = 0.f;
+        if (row < p.R + p.C) {
+            const bool first = row < p.R;
+            const int r = first ? row : row - p.R, M = first ? p.R : p.C, nparts = first ? p.nparts_p : p.nparts_q;
+            const float* part = (first ? p.p_part : p.q_part) + r;
+            for (int t = tq; t < nparts; t += 128) {      // four independent loads per step; fixed order
+                const float v0 = part[(int64_t)t * M], v1 = t + 32 < nparts ? part[(int64_t)(t + 32) * M] : 0.f;
+                const float v2 = t + 64 < nparts ? part[(int64_t)(t + 64) * M] : 0.f, v3 = t + 96 < nparts ? part[(int64_t)(t + 96) * M] : 0.f;
+                acc += (v0 + v1) + (v2 + v3);
+            }
+        }
+        sacc[tq][c] = acc;
+        __syncthreads();
+        if (tid < CN_ROWS) {
+            float proj = 0.f;
+#pragma unroll
+            for (int t = 0; t < 32; ++t) proj += sacc[t][tid];
+            const int row2 = base + tid;
+            float k = 0.f, d = 1.f;
+            if (row2 < p.R + p.C) {
+                const float nm = row2 < p.R ? p.na[row2] : p.nb[row2 - p.R];
+                d = fmaxf(nm, p.eps);
+                k = nm > p.eps ? proj / d : 0.f;
+            }
+            sk[tid] = k; sd[tid] = d;
+        }
+        __syncthreads();
+    }
+    // (2) the rows themselves, two per wave: dx = (dx^ - x^ (x^ . dx^)) / |x| in place, every load of a row requested before its first use
+#pragma unroll
+    for (int i = 0; i < CN_ROWS / 4; ++i) {
+        const int lr = wave * (CN_ROWS / 4) + i, row = base + lr;
+        if (row >= p.R + p.C) continue;
+        const bool first = row < p.R;
+        const int r = first ? row : row - p.R;
+        const float k = p.normalize ? sk[lr] : 0.f, d = p.normalize ? sd[lr] : 1.f;
+        const float* x = (first ? p.a32 : p.b32) + (int64_t)r * p.D;
+        float* o = (first ? p.da : p.db) + (int64_t)r * p.D;
+        for (int c0 = lane * 4; c0 < p.D; c0 += 1024) {
+            float4 g[4], xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + 256 * u;
+                g[u] = make_float4(0.f, 0.f, 0.f, 0.f); xv[u] = g[u];
+                if (c < p.D) {
+                    g[u] = *reinterpret_cast<const float4*>(o + c);
+                    if (p.normalize) xv[u] = *reinterpret_cast<const float4*>(x + c);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + 256 * u;
+                if (c < p.D) *reinterpret_cast<float4*>(o + c) = make_float4((g[u].x - xv[u].x * k) / d, (g[u].y - xv[u].y * k) / d, (g[u].z - xv[u].z * k) / d, (g[u].w - xv[u].w * k) / d);
+            }
+        }
+    }
+}
+static GemmArgs contr_gemm_args(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, float alpha) {
+    GemmArgs a = {};
+    a.A = A; a.B = B; a.C = C; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+    a.tiles_m = (M + 127) / 128; a.tiles_n = (N + 127) / 128; a.ktiles = K / 64; a.ktiles_per_split = a.ktiles; a.group_w = a.tiles_n;
+    a.e.alpha = alpha; a.e.out_dtype = VM_F32; a.e.split_k = 1;
+    a.drop_scale = 1.0f;
+    return a;
+}
+
 static int contr_common(const char* fn, const void* a, const void* b, int R, int C, int D) {
     VM_REQUIRE(a && b && R > 0 && C > 0 && D > 0 && (D % 8) == 0, "%s: bad arguments (R=%d C=%d D=%d, D must be a multiple of 8)", fn, R, C, D);
     VM_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0, "%s: operands must be 16-byte aligned", fn);
@@ -558,13 +634,12 @@ static void contr_attr() {
     static bool set = false;
     if (set) return;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&contr_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CT_LDS_ALL);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&contr_g_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CT_LDS_ALL);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&contr_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CT_LDS_ALL);
     set = true;
 }
 // workspace layout (bytes, every block 256-B aligned): diag [R] | row_part [tn][R][2] | col_part [tm][C][2] | p_part [tn][R] | q_part [tm][C] |
-// G bf16 [R][ldg]
-struct ContrWs { size_t diag, row_part, col_part, p_part, q_part, G, total; int64_t ldg; };
+// G bf16 [R][ldg] | S fp32 [R][ldS] (forward -> backward)
+struct ContrWs { size_t diag, row_part, col_part, p_part, q_part, G, S, total; int64_t ldg, ldS; };
 static ContrWs contr_ws_layout(int R, int C) {
     const size_t tm = (R + CT - 1) / CT, tn = (C + CT - 1) / CT;
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
@@ -575,8 +650,10 @@ static ContrWs contr_ws_layout(int R, int C) {
     w.col_part = w.row_part + up(tn * (size_t)R * 8);
     w.p_part = w.col_part + up(tm * (size_t)C * 8);
     w.q_part = w.p_part + up(tn * (size_t)R * 4);
-    w.G = w.q_part + up(tm * (size_t)C * 4);
-    w.total = w.G + up((size_t)R * w.ldg * 2);
+    w.G = w.q_part + up((size_t)((R + contr_rb(R) - 1) / contr_rb(R)) * (size_t)C * 4);
+    w.ldS = (C + 7) / 8 * 8;
+    w.S = w.G + up((size_t)R * w.ldg * 2);
+    w.total = w.S + up((size_t)R * w.ldS * 4);
     return w;
 }
 extern "C" size_t vm_contrastive_ws(int R, int C) { return (R > 0 && C > 0) ? contr_ws_layout(R, C).total : 0; }
@@ -588,6 +665,7 @@ static void contr_fill(ContrArgs& p, const void* ah, const void* bh, int R, int 
     p.row_part = (float*)(ws + w.row_part); p.col_part = (float*)(ws + w.col_part);
     p.p_part = (float*)(ws + w.p_part); p.q_part = (float*)(ws + w.q_part);
     p.G = (bf16_t*)(ws + w.G); p.ldg = w.ldg;
+    p.S = (float*)(ws + w.S); p.ldS = w.ldS;
 }
 
 extern "C" int vm_contrastive_loss_fwd(const float* a, const float* b, int R, int C, int D, int normalize, float eps, float inv_tau, int diag_offset,
@@ -643,13 +721,28 @@ extern "C" int vm_contrastive_loss_bwd(const float* a, const float* b, const voi
     p.items_db = ((C + CB_M - 1) / CB_M) * nbt;
     contr_attr();
     if (w.ldg != C) hipMemsetAsync(p.G, 0, (size_t)R * w.ldg * 2, s);      // ragged C: the pad columns of G are read as zeros
+    const int rb = contr_rb(R);
+    p.nparts_p = 1; p.nparts_q = (R + rb - 1) / rb;
     {
-        VmProfScope prof(VM_FAM_LOSS, 2.0 * R * (double)C * D, s, "contrastive_g_R%d_C%d_D%d", R, C, D);
-        hipLaunchKernelGGL(contr_g_kernel, dim3(p.items_a), dim3(256), CT_LDS_ALL, s, p);
+        VmProfScope prof(VM_FAM_LOSS, 12.0 * R * (double)C, s, "contrastive_g_R%d_C%d_D%d", R, C, D);
+        if (rb == 4) hipLaunchKernelGGL(contr_g_rows_kernel<4>, dim3(p.nparts_q), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(contr_g_rows_kernel<16>, dim3(p.nparts_q), dim3(256), 0, s, p);
     }
     {
         VmProfScope prof(VM_FAM_LOSS, 4.0 * R * (double)C * D, s, "contrastive_grad_R%d_C%d_D%d", R, C, D);
-        hipLaunchKernelGGL(contr_grad_kernel, dim3(p.items_da + p.items_db), dim3(256), CT_LDS_ALL, s, p);
+        if ((R % 64) == 0 && (C % 64) == 0 && !vm_env().gemm_generic) {
+            // dA^ [R, D] = G [R, C] (row-major) . B^ [C, D] (k-major);  dB^ [C, D] = G^T (G is its k-major form) . A^ [R, D] (k-major)
+            const GemmArgs ga = contr_gemm_args(p.G, p.ldg, p.B, D, da, D, R, D, C, inv_tau);
+            const GemmArgs gb = contr_gemm_args(p.G, p.ldg, p.A, D, db, D, C, D, R, inv_tau);
+            const int rc2 = vm_gemm_pair_launch(ga, gb, s);
+            if (rc2) return rc2;
+        } else {                                   // ragged sizes: the register-staged 64 x BN tiles (plain products: the normalisation follows)
+            hipLaunchKernelGGL(contr_grad_kernel, dim3(p.items_da + p.items_db), dim3(256), CT_LDS_ALL, s, p);
+        }
+    }
+    if (normalize) {
+        VmProfScope prof(VM_FAM_LOSS, 12.0 * (R + C) * (double)D, s, "contrastive_norm_R%d_C%d_D%d", R, C, D);
+        hipLaunchKernelGGL(contr_norm_bwd_kernel, dim3((R + C + CN_ROWS - 1) / CN_ROWS), dim3(256), 0, s, p);
     }
     return vm_check_launch("vm_contrastive_loss_bwd");
 }

@@ -27,6 +27,8 @@ int vm_gemm_grouped_launch(const GemmGroupArgs& ga, int nblocks, int a_layout, i
 int vm_gemm_splitk_reduce(const GemmArgs& a, int nsplit, hipStream_t s);
 void vm_gemm_variant_tile(int variant, int a_layout, int* bm, int* bn);
 int vm_gemm_fast_dispatch(const GemmArgs& a, int a_layout, int b_layout, int nblocks, int variant, hipStream_t s);
+// two GEMMs of different operand layouts in one launch of 128 x 128 tiles (a0: row-major A x k-major B, a1: k-major A x k-major B)
+int vm_gemm_pair_launch(const GemmArgs& a0, const GemmArgs& a1, hipStream_t s);
 // wide-tile path (gemm_p8.hip): (32 mf) x 256 tiles, 8 waves, one workgroup per CU; row-major A
 int vm_gemm_p8_dispatch(const GemmArgs& a, int a_layout, int b_layout, int mf, int phases, int total, hipStream_t s);
 // grouped weight gradients on 256 x 256 tiles (gemm_p8w.hip): dW[M, N] (+)= alpha * A^T B over `ktiles` 64-row steps, A = dY [rows, M] (lda),

@@ -586,6 +586,28 @@ static int launch_fast(const GemmArgs& a, int nblocks, hipStream_t s) {
     return vm_check_launch("vm_gemm_bf16(fast)");
 }
 
+// Two independent GEMMs of DIFFERENT operand layouts in one launch (the two gradient products of the similarity losses, csrc/contrastive.hip:
+// dA = G B^ and dB = G^T A^): a workgroup runs one of the two main loops (uniform branch on the block id), 128 x 128 tiles, PIPE 4.
+template <int LA0, int LB0, int LA1, int LB1>
+__global__ __launch_bounds__(256, 2) void gemm_pair_kernel(const GemmArgs a0, const GemmArgs a1, const int tiles0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bid = blockIdx.x;
+    if (bid < tiles0) gemm_fast_body<LA0, LB0, 2, 2, 2, 64, 4, 4, 0>(a0, bid, smem);
+    else gemm_fast_body<LA1, LB1, 2, 2, 2, 64, 4, 4, 0>(a1, bid - tiles0, smem);
+}
+// a0: A row-major x B k-major, a1: A k-major x B k-major; both with K % 64 == 0, tiles_m / tiles_n counted in 128 x 128 tiles, no split
+int vm_gemm_pair_launch(const GemmArgs& a0, const GemmArgs& a1, hipStream_t s) {
+    constexpr int LDS = 2 * (128 + 128) * 64 * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pair_kernel<0, 1, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    const int t0 = a0.tiles_m * a0.tiles_n, t1 = a1.tiles_m * a1.tiles_n;
+    hipLaunchKernelGGL((gemm_pair_kernel<0, 1, 1, 1>), dim3(t0 + t1), dim3(256), LDS, s, a0, a1, t0);
+    return vm_check_launch("vm_gemm_pair");
+}
+
 // C[m, 0:N] (+)= sum_s slabs[s][m, 0:N]
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C, int M, int N, int64_t ldc,
                                                             int nsplit, int accumulate) {
