@@ -50,7 +50,9 @@ extern "C" int vm_rownorm_cast(const float* x, void* out_bf16, float* norms, int
 // took 20 us, a 16-wave tile form 31 us); the gradient products on 64 x 96 register-staged tiles with ONE chunk in flight (47.3 / 535 us) ->
 // GEMM tiles (30.4 / 276 us; a 2-way K split of the 192 tiles bought 4 us and cost 3 in the row pass: not kept) + the row pass (11.8 / 38 us:
 // one wave per row summing 512 column partials 4 B at a time took 17.7 us; 8 rows per workgroup read them 32 B at a time).
-// Kernel time forward + backward 121 -> 96 us at B = 2048, 1036 -> 661 us at B = 8192 (0.187 of the MFMA peak).
+// Kernel time forward + backward 121 -> 96 us at B = 2048, 1036 -> 661 us at B = 8192 (0.187 of the MFMA peak).  Measured and dropped: a
+// 4-slot LDS-DMA ring with counted waits (three chunks in flight, one workgroup per CU) for the forward tiles, 28.8 vs 25.6 us -- the twelve
+// K chunks are ~8 us of that launch, the tail (tile store, the two partial passes) and the launch itself are the rest.
 // History (profiles/r03_*): round 2 ran this as six library launches + a dozen torch glue kernels (147 us + ~50 us of kernels, 0.34 ms wall at
 // B = 2048; the two gradient GEMMs alone took 61 us because 2048 x 768 outputs are 96 tiles of 128 x 128 on 256 CUs).  Round 3 first built it
 // as ONE persistent backward launch pulling tiles from a device queue with agent-scope release / acquire hand-offs between the phases, and a
