@@ -35,7 +35,7 @@ DEC_12L = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, in
                vocab_size=30522, max_position_embeddings=514, layer_norm_eps=1e-5, bos_token_id=0, pad_token_id=1,
                eos_token_id=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, initializer_range=0.02)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_PROFILE = "profiles/r03_k_pmc_gemm.txt"      # separate rocprofv3 --pmc passes of the dominant shapes (traffic is not measurable in-process)
+PMC_PROFILE = "profiles/r04_pmc_gemm.txt"      # separate rocprofv3 --pmc passes of the dominant shapes (traffic is not measurable in-process)
 
 
 def flops_per_pair_fwd(S=197, L=128, d=768, V=30522, layers=12):
@@ -49,7 +49,7 @@ def flops_per_pair_fwd(S=197, L=128, d=768, V=30522, layers=12):
 def dominant_shape_roofline(dump_path):
     """the single largest forward GEMM shape (QKV projection of the ViT, 12608 x 2304 x 768, bias epilogue): achieved rate from
     this run's per-launch HIP events, HBM-side traffic per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2
-    gfx950 correction + WRITE_SIZE, profiles/r03_k_pmc_gemm.txt; round 2: r02_n_pmc_gemm.txt)."""
+    gfx950 correction + WRITE_SIZE, profiles/r04_pmc_gemm.txt; rounds 2 / 3: r02_n_pmc_gemm.txt, r03_k_pmc_gemm.txt)."""
     tag, M, N, K = "M12608_N2304_K768_l00", 12608, 2304, 768
     ms = n = 0.0
     try:
@@ -61,7 +61,9 @@ def dominant_shape_roofline(dump_path):
         return None
     if n == 0:
         return None
-    traffic = None                  # HBM-side bytes need rocprofv3 --pmc passes (tools/pmc_kernels.sh); the latest are under profiles/
+    # HBM-side bytes need rocprofv3 --pmc passes (tools/pmc_kernels.sh, not possible in-process): the value of the committed pass over this kernel
+    # and shape on the round-4 build -- FETCH_SIZE x 2 (gfx950 correction) 89.9 MB + WRITE_SIZE 55.5 MB
+    traffic = 145.4e6
     dur = ms / n * 1e-3
     algo = 2.0 * (M * K + N * K + M * N)
     return {"kernel": "gemm_fast_kernel<0,0,...> C[12608,2304] = A[12608,768] . B[2304,768]^T + bias (ViT QKV projection)",
@@ -480,12 +482,14 @@ def main():
                 fam[name] = (ms.value, work.value, n.value)
             gms, gwork, gn = fam["gemm"]
             ach = gwork / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
-            roof = {"bound": "mfma", "kernel": "gemm_fast_kernel<LA,LB,...> + gemm_grouped_kernel (every forward / dgrad launch of vm_gemm_bf16 and the "
-                                             "grouped weight + bias gradient launches of vm_wgrad_grouped)", "achieved": round(ach, 1),
+            roof = {"bound": "mfma", "kernel": "gemm_fast_kernel<LA,LB,...> (every forward / dgrad launch of vm_gemm_bf16; the LM head on gemm_p8_kernel) + "
+                                             "gemm_p8w_kernel (the grouped weight + bias gradient launches of vm_wgrad_grouped, 256 x 256 tiles)",
+                    "achieved": round(ach, 1),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                    "traffic_note": "family of ~30 shapes, not measurable in-process; separate rocprofv3 --pmc passes of the dominant shape on the final "
-                                    "round-3 build: 12608x2304x768 forward FETCH_SIZE x2 88.6 MB + WRITE_SIZE 55.4 MB = 144.0 MB per launch at the "
-                                    "fabric vs 81.0 MB algorithmic (round 2: 144.6 MB; its dgrad 118.1 MB, profiles/r02_n_pmc_gemm.txt) in " + PMC_PROFILE,
+                    "traffic_note": "family of ~30 shapes, not measurable in-process; separate rocprofv3 --pmc passes on the round-4 build in " + PMC_PROFILE +
+                                    ": 12608x2304x768 forward FETCH_SIZE x2 89.9 MB + WRITE_SIZE 55.5 MB = 145.4 MB per launch at the fabric vs 81.0 MB "
+                                    "algorithmic (1.79x, as in rounds 2-3), its dgrad 116.4 MB (1.44x); a grouped weight-gradient launch of two encoder "
+                                    "layers on gemm_p8w_kernel 918.8 + 58.6 = 977 MB vs 677 MB algorithmic (1.44x)",
                     "launches_per_step": gn // 2, "avg_launch_ms": round(gms / max(gn, 1), 4),
                     "family_ms_per_step": {k: round(v[0] / 2, 3) for k, v in fam.items()}}
             dump = os.environ.get("VM_PROF_DUMP") or os.path.join(tempfile.gettempdir(), f"vm_prof_{os.getpid()}.txt")
