@@ -309,7 +309,9 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
         // (cost model: only very wide row-major outputs with many rounds of 256 x 256 tiles -- the LM head, 8192 x 30522 x 768: 15 rounds,
         //  measured 383-421 us against 427-438 us on the 128-row kernels; everywhere else the lockstep prologue / epilogue bursts of one
         //  workgroup per CU cost more than the faster main loop gains, profiles/r04_a_gemm_p8_probe.txt)
-        const bool p8_auto = force < 0 && a_layout == 0 && b_layout == 0 && split == 1 && N >= 16384 && M >= 4096 && K <= 1024 &&
+        // (whole 256-row tiles only: the cross K|V projection of all layers, 12608 x 18432 x 768, runs 192-row tiles there and measured
+        //  410-436 us against 397 us on the 160-row kernel, profiles/r04_g_shape_table.txt vs r03_b_kernel_shape_breakdown.txt)
+        const bool p8_auto = force < 0 && a_layout == 0 && b_layout == 0 && split == 1 && N >= 16384 && M >= 4096 && (M % 256) == 0 && K <= 1024 &&
                              (int64_t)((M + 255) / 256) * ((N + 255) / 256) >= 12 * 256;
         if (((force == 8 || force == 9) && a_layout == 0) || p8_auto) {       // 8: four barrier pairs per K-tile, 9 / auto: two
             int mf = vm_env().gemm_p8_mf;
