@@ -184,6 +184,35 @@ def test_attention_dropout_statistics_and_backward_consistency():
     assert abs(v.grad.float().sum().item() / (o.float() * do.float()).sum().item() - 1) < 2e-2
 
 
+@pytest.mark.parametrize("nprob,rows,N,K", [(1, 512, 256, 256), (4, 1024, 2304, 768)])      # 128 x 128 grouped kernel / 256 x 256 tiles (>= 64 of them)
+def test_param_grads_first_touch_stores_then_accumulates(nprob, rows, N, K):
+    """vm_wgrad_problem.overwrite through ops.param_grads: the first launch after the arena reported a zeroing STORES (shown by poisoning the
+    buffers behind the tracker's back), the second one accumulates; weight and bias gradients of every problem of the launch"""
+    from vilmedic_amd import ops
+    g = torch.zeros(nprob * (N * K + N), device=dev())
+    dYs = [rnd(rows, N, scale=0.1, seed=40 + i).to(dev()) for i in range(nprob)]
+    Xs = [rnd(rows, K, seed=50 + i).to(dev()) for i in range(nprob)]
+    dWs = [g[i * (N * K + N):i * (N * K + N) + N * K].view(N, K) for i in range(nprob)]
+    dbs = [g[i * (N * K + N) + N * K:(i + 1) * (N * K + N)] for i in range(nprob)]
+    ops.flush_param_grads()
+    ops.grads_zeroed(g)
+    if nprob > 1:                                  # the 256-tile kernel honours the flag (the 128-tile kernel always adds: the flag is a permission, and
+        g.fill_(7.0)                               # adding to a clean buffer is the same thing) -- no caller poisons a buffer: a stale value survives only if the launch adds
+    for rep in (1, 2):
+        ops._side["defer"] = True                  # (outside a backward pass every param_grads() call would flush on its own: one launch per problem)
+        try:
+            for dY, X, dW, db in zip(dYs, Xs, dWs, dbs):
+                ops.param_grads(dY, X, dW, db)
+        finally:
+            ops._side["defer"] = False
+        ops.join_side()
+        torch.cuda.synchronize()
+        for dY, X, dW, db in zip(dYs, Xs, dWs, dbs):
+            ref = dY.float().t() @ X.float()
+            torch.testing.assert_close(dW, rep * ref, rtol=1e-4, atol=2e-3 * rep)
+            torch.testing.assert_close(db, rep * dY.float().sum(0), rtol=1e-4, atol=2e-3 * rep)
+
+
 def test_embedding_and_ce():
     from vilmedic_amd import ops
     B, L, V, D = 3, 10, 50, 64

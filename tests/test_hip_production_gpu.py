@@ -134,7 +134,7 @@ def _run_gemm_case(M, N, K, la, lb, epi, split, seed=0):
     return err.max().item(), (err / (ref.abs() + 1e-2)).max().item()
 
 
-@pytest.mark.parametrize("variant", [None, 0, 4, 1])
+@pytest.mark.parametrize("variant", [None, 0, 4, 1, 5])
 def test_gemm_forward_shapes_every_tile_variant(variant, gemm_variant):
     """forward (row-major x row-major) launches of the step, cost-model choice and every forced tile variant"""
     gemm_variant(variant)
@@ -146,7 +146,7 @@ def test_gemm_forward_shapes_every_tile_variant(variant, gemm_variant):
     report(f"gemm fwd variant={variant}", shapes=len(cases), max_rel_err=worst)
 
 
-@pytest.mark.parametrize("variant", [None, 0, 4])
+@pytest.mark.parametrize("variant", [None, 0, 4, 5])
 def test_gemm_dgrad_shapes(variant, gemm_variant):
     gemm_variant(variant)
     worst = 0.0

@@ -334,6 +334,9 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
         const int tiles_m256 = (M + 255) / 256;
         if (force >= 0) variant = force;
         else if (K >= 4096 && (int64_t)tiles_m256 * a.tiles_n * split >= 1024) variant = 1;   // measured: only huge square-ish problems gain
+        else if (a_layout == 0 && K <= 768 && (int64_t)((M + 127) / 128) * a.tiles_n * split <= 384 && (int64_t)((M + 63) / 64) * a.tiles_n * split <= 768)
+            variant = 5;    // [r4] less than one round of 128-row tiles and a short K: 64-row tiles, three workgroups per CU (8192 x 768 x 768: 19.3 -> 17.7 us,
+                            // its dgrad 16.7 -> 15.7; slower on every larger shape, profiles/r04_i_gemm_64row_tiles_ab.txt)
         else if (a_layout == 0) {
             // 512 workgroup slots (256 CUs x 2 resident workgroups): compare rounds x rows-per-tile of the 128- and the
             // 160-row tile -- e.g. M = 12608, N = 768: 594 tiles = 2 rounds of 128 rows vs 474 tiles = 1 round of 160 rows

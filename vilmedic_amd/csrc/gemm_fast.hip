@@ -282,7 +282,7 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs& p, const int bid,
         static_assert(STAGES == 2 && BKT == 64, "cross-tile register pipeline: 2 LDS slots of 64-wide k-tiles");
         constexpr int NLD = NA_I + NB_I, RA = LA == 0 ? 1 : 2, RB = LB == 0 ? 1 : 2;
         constexpr int NRD = MF * RA + 4 * RB;                       // LDS read instructions per k-half
-        static_assert(NRD <= 4 * MF, "one read slot per MFMA");
+        static_assert(NRD <= 8 * MF, "at most two read slots per MFMA");
         const int nk = kt_end - kt_begin;
         bf16x8_t fa[2][MF], fb[2][4];
         auto read_half = [&](const char* sa, auto kk_c) {
@@ -320,12 +320,26 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs& p, const int bid,
                 }
             };
             auto slot_reads = [&]() {                               // NRD reads behind the first MFMAs, then the remaining MFMAs
+                if constexpr (NRD <= NMF) {
 #pragma unroll
-                for (int n = 0; n < NRD; ++n) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    for (int n = 0; n < NRD; ++n) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
+                } else {                                            // (the 64-row tile with a transposed operand: 10 reads for 8 MFMAs) two reads per slot
+                    constexpr int PAIRS = NRD / 2;                  // (constant arguments only: PAIRS slots of two reads, one odd read, the rest)
+#pragma unroll
+                    for (int n = 0; n < PAIRS; ++n) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+                    if constexpr (NRD & 1) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, NMF - PAIRS - (NRD & 1), 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
             };
             stage(0);
             if (nk > 1) {
@@ -664,6 +678,8 @@ int vm_gemm_fast_dispatch(const GemmArgs& a0, int a_layout, int b_layout, int nb
     }
     if (variant == 4 && a_layout == 0)
         return b_layout == 0 ? launch_fast<0, 0, 2, 2, 2, 64, 5, 1>(a0, nblocks, s) : launch_fast<0, 1, 2, 2, 2, 64, 5, 4>(a0, nblocks, s);
+    if (variant == 5 && a_layout == 0)       // 64 x 128 (two A fragments per wave): three workgroups per CU for problems of less than one round of 128-row tiles
+        return b_layout == 0 ? launch_fast<0, 0, 2, 2, 2, 64, 2, 1>(a0, nblocks, s) : launch_fast<0, 1, 2, 2, 2, 64, 2, 4>(a0, nblocks, s);
     if (a_layout == 0 && b_layout == 0) return launch_fast<0, 0, 2, 2, 2, 64, 4, 1>(a0, nblocks, s);
     if (a_layout == 0 && b_layout == 1) return launch_fast<0, 1, 2, 2, 2, 64, 4, 4>(a0, nblocks, s);
     if (a_layout == 1 && b_layout == 0) return launch_fast<1, 0, 2, 2, 2, 64, 4, 4>(a0, nblocks, s);
@@ -673,7 +689,7 @@ int vm_gemm_fast_dispatch(const GemmArgs& a0, int a_layout, int b_layout, int nb
 // the tile a variant runs for these layouts (strided A falls back to the 128-row tile)
 void vm_gemm_variant_tile(int variant, int a_layout, int* bm, int* bn) {
     if (variant == 1) { *bm = 256; *bn = 128; return; }
-    *bm = (variant == 4 && a_layout == 0) ? 160 : 128;
+    *bm = (variant == 4 && a_layout == 0) ? 160 : (variant == 5 && a_layout == 0) ? 64 : 128;
     *bn = 128;
 }
 

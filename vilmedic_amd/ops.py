@@ -323,29 +323,53 @@ def grads_zeroed(gflat):
     lo, hi = _span(gflat)
     if (lo, hi) not in _touch["ranges"]:
         _touch["ranges"] = [r for r in _touch["ranges"] if r[1] <= lo or r[0] >= hi] + [(lo, hi)]
-    keep = [(a, b) for a, b in zip(_touch["lo"], _touch["hi"]) if b <= lo or a >= hi]
+    keep = []
+    for a, b in zip(_touch["lo"], _touch["hi"]):          # (an interval that reaches beyond the arena keeps its outside parts)
+        if b <= lo or a >= hi:
+            keep.append((a, b))
+        else:
+            if a < lo:
+                keep.append((a, lo))
+            if b > hi:
+                keep.append((hi, b))
     _touch["lo"], _touch["hi"] = [a for a, _ in keep], [b for _, b in keep]
+
+
+def _touch_insert(lo, hi):
+    """add [lo, hi) to the touched set, kept as SORTED DISJOINT intervals (overlapping ones are merged: a view nested in an earlier, larger
+    one must not hide that one from a later neighbour test)"""
+    los, his = _touch["lo"], _touch["hi"]
+    i = bisect.bisect_left(los, lo)
+    if i > 0 and his[i - 1] > lo:
+        i -= 1
+        lo, hi = los[i], max(hi, his[i])
+        del los[i], his[i]
+    while i < len(los) and los[i] < hi:
+        hi = max(hi, his[i])
+        del los[i], his[i]
+    los.insert(i, lo)
+    his.insert(i, hi)
+
+
+def _touch_overlaps(lo, hi):
+    los, his = _touch["lo"], _touch["hi"]
+    i = bisect.bisect_right(los, lo)
+    return (i > 0 and his[i - 1] > lo) or (i < len(los) and los[i] < hi)
 
 
 def mark_touched(t):
     """``t`` (a gradient buffer) has been or will be written by something else than an overwriting weight-gradient GEMM"""
-    lo, hi = _span(t)
-    i = bisect.bisect_left(_touch["lo"], lo)
-    _touch["lo"].insert(i, lo)
-    _touch["hi"].insert(i, hi)
+    _touch_insert(*_span(t))
 
 
 def _first_touch(t):
     """True at most once per zeroing, for a buffer inside a tracked arena that overlaps nothing written since (intervals, not start pointers:
     a fused Q|K|V gradient view and the view of K alone are the same memory)"""
     lo, hi = _span(t)
-    los, his = _touch["lo"], _touch["hi"]
-    i = bisect.bisect_right(los, lo)
-    clean = not ((i > 0 and his[i - 1] > lo) or (i < len(los) and los[i] < hi))
+    clean = not _touch_overlaps(lo, hi)
     if clean:
         clean = not any(a < hi and lo < b for a, b in _touch["shared"])
-    los.insert(i, lo)
-    his.insert(i, hi)
+    _touch_insert(lo, hi)
     return clean and any(a <= lo and hi <= b for a, b in _touch["ranges"])
 
 
