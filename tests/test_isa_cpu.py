@@ -91,3 +91,44 @@ def test_cross_tile_register_pipeline_keeps_the_dma_in_flight(gemm_fast_asm, nam
     assert not any(o == "s_waitcnt" and "vmcnt" in l for o, l in ops[max(dma):]), [l for o, l in ops[max(dma):] if o == "s_waitcnt"]
     mf = [i for i, o in enumerate(names) if o.startswith("v_mfma")]
     assert sum(1 for i, o in enumerate(names) if o.startswith("ds_read") and mf[0] < i < mf[-1]) >= 16
+
+
+def _asm_of(tmp_path_factory, src):
+    if not shutil.which(HIPCC):
+        pytest.skip("hipcc not available")
+    from vilmedic_amd.build import FLAGS
+    out = tmp_path_factory.mktemp("isa") / (src + ".s")
+    cmd = [HIPCC, *FLAGS, "-S", "--cuda-device-only", os.path.join(ROOT, "vilmedic_amd", "csrc", src + ".hip"), "-o", str(out)]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    return out.read_text()
+
+
+def test_wide_tile_weight_gradient_kernel_keeps_two_k_tiles_in_flight(tmp_path_factory):
+    """gemm_p8w_kernel<2> (round 4: the grouped weight gradients of the step): 256 x 256 tile = 64 MFMAs per wave and K-tile, both operands by
+    LDS-DMA (8 requests per wave and K-tile), ONE counted wait per K-tile that leaves the two younger K-tiles in flight (a vmcnt(0) here is
+    what the compiler's own waits looked like: every K-tile then waited for the tile just requested), no register spilled anywhere"""
+    asm = _asm_of(tmp_path_factory, "gemm_p8w")
+    name = next(k for k in _kernel_meta(asm) if "gemm_p8w_kernelILi2E" in k)
+    m = _kernel_meta(asm)[name]
+    assert m["vgpr_spill_count"] == 0 and m["vgpr_count"] <= 256, m
+    ops = _loop(asm, name)
+    names = [o for o, _ in ops]
+    assert sum(o.startswith("v_mfma") for o in names) == 64
+    assert sum(o.startswith("global_load_lds") for o in names) == 8
+    assert names.count("s_barrier") == 4                                   # two barrier pairs per K-tile (the two wave groups run one apart)
+    vm = [l for o, l in ops if o == "s_waitcnt" and "vmcnt" in l]
+    assert vm == ["s_waitcnt vmcnt(8)"], vm
+    assert not any(o.startswith("scratch_") for o in names)
+
+
+def test_wide_tile_forward_kernel_main_loop_is_clean(tmp_path_factory):
+    """gemm_p8_kernel<0, 0, 8, 2> (the LM head): the K loop holds its 64 MFMAs, one counted wait, no scratch access (the kernel as a whole
+    parks 6 VGPRs of the epilogue in scratch -- outside the loop; stated in DESIGN section 10)"""
+    asm = _asm_of(tmp_path_factory, "gemm_p8")
+    name = next(k for k in _kernel_meta(asm) if "gemm_p8_kernelILi0ELi0ELi8ELi2E" in k)
+    assert _kernel_meta(asm)[name]["vgpr_spill_count"] <= 8
+    ops = _loop(asm, name)
+    names = [o for o, _ in ops]
+    assert sum(o.startswith("v_mfma") for o in names) == 64
+    assert [l for o, l in ops if o == "s_waitcnt" and "vmcnt" in l] == ["s_waitcnt vmcnt(4)"]
+    assert not any(o.startswith("scratch_") for o in names)
