@@ -351,6 +351,10 @@ int main(int argc, char** argv) {
         for (auto& c : cs) bench_ab(c.M, c.N, c.K, c.la, c.lb, c.flags, c.split);
         return fails;
     }
+    if (argc >= 8 && !strcmp(argv[1], "onef")) {    // gpu_probe.bin onef M N K la lb flags   (one shape with epilogue options: rocprofv3 --pmc workload)
+        bench_gemm2(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), 6);
+        return 0;
+    }
     if (argc >= 2 && !strcmp(argv[1], "epiab")) {      // epilogue operands requested in front of the last K-tile (0) vs behind the main loop (VM_GEMM_DEBUG=4)
         struct { int M, N, K, la, lb, flags; } cs[] = {
             {12608, 3072, 768, 0, 1, 8}, {8192, 3072, 768, 0, 1, 8}, {12608, 3072, 768, 0, 0, 7}, {8192, 3072, 768, 0, 0, 7},
