@@ -401,7 +401,9 @@ def main():
     opt = FusedAdam(model, lr=1e-4)
     dist, wire = None, None
     if world > 1 or os.environ.get("VM_FORCE_DDP"):
-        wire = torch.empty(opt.arena.numel, dtype=torch.bfloat16, device=device)     # bf16 staging of the gradient all-reduce      # VM_FORCE_DDP: exercise the RCCL path on a single GPU
+        from vilmedic_amd.parallel import default_bf16_wire           # fp32 wire by default (exact mean); VM_DDP_WIRE=bf16 opts into the compressed wire
+        if default_bf16_wire():
+            wire = torch.empty(opt.arena.numel, dtype=torch.bfloat16, device=device)     # bf16 staging of the gradient all-reduce      # VM_FORCE_DDP: exercise the RCCL path on a single GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -551,7 +553,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "config/RRG: ViT-B/16 + 12-layer BERT-generation decoder (d=768, h=12, ff=3072, V=30522), "
                                    "bf16, 224x224 images, 128-token reports, dropout 0.1, fwd+bwd+Adam",
-                       "per_gpu_batch": B, "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}"},
+                       "per_gpu_batch": B, "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}",
+                       "ddp_wire": (("bf16" if ddp.bf16_wire else "fp32") if ddp is not None else None)},
             "model_tflops_per_s": round(step_flops * args.steps / elapsed / 1e12 * world, 1),
             "launch_mode": "hip-graph replay" if args.graph else "eager",
             "final_loss": round(final_loss, 4),

@@ -214,6 +214,20 @@ int vm_embedding_fwd(const int64_t* ids, const float* word, const float* pos, vo
 /* scatter-add d_out into fp32 grads; rows with id==padding_idx get no word gradient (nn.Embedding(padding_idx)) */
 int vm_embedding_bwd(const int64_t* ids, const void* d_out, float* d_word, float* d_pos,
                      int B, int L, int D, int padding_idx, void* stream);
+/* BERT / RoBERTa embeddings behind a pretrained `proto` (ref:vilmedic/blocks/huggingface/encoder/encoder_model.py:19-22,
+ * decoder/decoder_model.py:17-21 -> hf:models/bert/modeling_bert.py BertEmbeddings, hf:models/roberta/modeling_roberta.py:55-155):
+ *   out[row] = (word[ids[row]] + type_row) + pos[pos_ids ? pos_ids[row] : row % L + past_len]
+ * pos_ids (NULL or int64 [B*L]): explicit position ids (RoBERTa: cumsum(ids != pad) * (ids != pad) + pad, made by the caller);
+ * type_row (NULL or fp32 [D]): the token-type embedding of type 0 (the reference never passes token_type_ids); out bf16 or fp32. */
+int vm_embedding_fwd_ex(const int64_t* ids, const int64_t* pos_ids, const float* word, const float* pos, const float* type_row,
+                        void* out, int out_dtype /* VM_BF16 / VM_F32 */, int B, int L, int D, int past_len, void* stream);
+/* its backward: d_word[ids] += d_out (not for id == padding_idx); d_pos[pos id] += d_out (not for pos id == pos_padding_idx, -1: none;
+ * without pos_ids the position of column t is t + pos_offset); d_type (NULL or fp32 [D]) += sum of all rows.  fp32 atomics. */
+int vm_embedding_bwd_ex(const int64_t* ids, const int64_t* pos_ids, const void* d_out, float* d_word, float* d_pos, float* d_type,
+                        int B, int L, int D, int padding_idx, int pos_offset, int pos_padding_idx, void* stream);
+/* dz = dy * gelu'(z), bf16, n % 8 == 0: backward of the dense -> GELU -> LayerNorm transform of the BERT / RoBERTa LM heads
+ * (hf:models/roberta/modeling_roberta.py RobertaLMHead, hf:models/bert/modeling_bert.py BertPredictionHeadTransform) */
+int vm_gelu_bwd_bf16(const void* dy, const void* z, void* dz, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------ ViT patch assembly
  * hf:models/vit/modeling_vit.py:60,69 (conv as GEMM), :146-157 (cls + position embeddings). */
@@ -223,6 +237,12 @@ int vm_vit_assemble(const void* patches /* bf16 [B*n, D] */, const float* cls /*
                     void* out /* bf16 [B,(n+1),D] */, int B, int n, int D, void* stream);
 int vm_vit_assemble_bwd(const void* d_out /* bf16 [B,(n+1),D] */, void* d_patches /* bf16 [B*n,D] */,
                         float* d_cls /* += [D] */, float* d_pos /* += [(n+1),D] */, int B, int n, int D, void* stream);
+/* the same with ns (1..4) special tokens in front of the patches: DeiT = [CLS], distillation token
+ * (ref:vilmedic/blocks/vision/visual_encoder.py:59-61 -> hf:models/deit/modeling_deit.py DeiTEmbeddings.forward) */
+int vm_vit_assemble_ex(const void* patches /* bf16 [B*n, D] */, const float* special /* [ns,D] */, const float* pos /* [(n+ns),D] */,
+                       void* out /* bf16 [B,(n+ns),D] */, int B, int n, int ns, int D, void* stream);
+int vm_vit_assemble_bwd_ex(const void* d_out /* bf16 [B,(n+ns),D] */, void* d_patches /* bf16 [B*n,D] */,
+                           float* d_special /* += [ns,D] */, float* d_pos /* += [(n+ns),D] */, int B, int n, int ns, int D, void* stream);
 
 /* ------------------------------------------------------------------ losses
  * Shifted causal-LM cross-entropy (hf:loss/loss_utils.py:49-72; labels = input_ids, pads included,

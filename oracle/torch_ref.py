@@ -99,7 +99,13 @@ def vit_forward(images, state, cfg, prefix=""):
     eps = cfg.get("layer_norm_eps", 1e-12)
     x = vit_patch_embed(images, state, prefix, cfg["patch_size"])
     cls = state[prefix + "embeddings.cls_token"].expand(x.shape[0], -1, -1)
-    x = torch.cat([cls, x], dim=1) + state[prefix + "embeddings.position_embeddings"]
+    if prefix + "embeddings.distillation_token" in state:
+        # HF DeiTModel (ref:vilmedic/blocks/vision/visual_encoder.py:59-61; hf:models/deit/modeling_deit.py DeiTEmbeddings.forward):
+        # [CLS], distillation token, patches; the rest of the stack is the ViT one
+        dist = state[prefix + "embeddings.distillation_token"].expand(x.shape[0], -1, -1)
+        x = torch.cat([cls, dist, x], dim=1) + state[prefix + "embeddings.position_embeddings"]
+    else:
+        x = torch.cat([cls, x], dim=1) + state[prefix + "embeddings.position_embeddings"]
     for i in range(cfg["num_hidden_layers"]):
         p = f"{prefix}encoder.layer.{i}."
         h = layer_norm(x, state, p + "layernorm_before", eps)
@@ -239,10 +245,40 @@ def bert_embeddings(input_ids, state, prefix, eps, past_len=0, pad_token_id=None
     return layer_norm(x, state, prefix + "LayerNorm", eps)
 
 
-def decoder_hidden(input_ids, attention_mask, enc, enc_mask, state, cfg, prefix="bert."):
+def roberta_position_ids(input_ids, padding_idx, past_len=0):
+    """hf:models/roberta/modeling_roberta.py:142-155 create_position_ids_from_input_ids"""
+    mask = input_ids.ne(padding_idx).int()
+    return ((torch.cumsum(mask, dim=1).type_as(mask) + past_len) * mask).long() + padding_idx
+
+
+def text_embeddings(input_ids, state, prefix, cfg, past_len=0, position_ids=None):
+    """Embeddings of the three text architectures the reference reaches (``cfg["model_type"]``):
+      bert-generation (default)  LN(word + pos[arange])                     hf:...bert_generation.py:394-426
+      bert                       LN((word + type[0]) + pos[arange])         hf:models/bert/modeling_bert.py BertEmbeddings.forward
+      roberta                    LN((word + type[0]) + pos[cumsum ids])     hf:models/roberta/modeling_roberta.py:55-155
+    The reference never passes token_type_ids (ref:...encoder_model.py:44-56, decoder_model.py:42-47): type row 0 everywhere.
+    ``position_ids`` overrides the default numbering (HF generate() passes 0..t for models whose forward accepts position_ids)."""
+    mt = cfg.get("model_type", "bert-generation")
+    if mt == "bert-generation":
+        return bert_embeddings(input_ids, state, prefix, cfg["layer_norm_eps"], past_len=past_len, pad_token_id=cfg.get("pad_token_id"))
+    pad = cfg.get("pad_token_id")
     L = input_ids.shape[1]
-    x = bert_embeddings(input_ids, state, prefix + "embeddings.", cfg["layer_norm_eps"],
-                        pad_token_id=cfg.get("pad_token_id"))
+    x = F.embedding(input_ids, state[prefix + "word_embeddings.weight"], padding_idx=pad)
+    x = x + state[prefix + "token_type_embeddings.weight"][0]
+    if position_ids is None:
+        position_ids = roberta_position_ids(input_ids, pad, past_len) if mt == "roberta" else torch.arange(past_len, past_len + L)[None].expand_as(input_ids)
+    x = x + F.embedding(position_ids, state[prefix + "position_embeddings.weight"], padding_idx=pad if mt == "roberta" else None)
+    return layer_norm(x, state, prefix + "LayerNorm", cfg["layer_norm_eps"])
+
+
+def _base_prefix(cfg):
+    return "roberta." if cfg.get("model_type") == "roberta" else "bert."
+
+
+def decoder_hidden(input_ids, attention_mask, enc, enc_mask, state, cfg, prefix=None, position_ids=None):
+    L = input_ids.shape[1]
+    prefix = _base_prefix(cfg) if prefix is None else prefix
+    x = text_embeddings(input_ids, state, prefix + "embeddings.", cfg, position_ids=position_ids)
     self_mask = causal_padding_mask(attention_mask, L)
     cross_mask = key_padding_mask(enc_mask)
     for i in range(cfg["num_hidden_layers"]):
@@ -250,8 +286,18 @@ def decoder_hidden(input_ids, attention_mask, enc, enc_mask, state, cfg, prefix=
     return x
 
 
-def lm_logits(hidden, state):
-    """Tied LM head (hf:...bert_generation.py:590-610): word-embedding weight + lm_head.bias."""
+def lm_logits(hidden, state, cfg=None):
+    """Tied LM head: word-embedding weight + bias (hf:...bert_generation.py:590-610); RoBERTa / BERT causal-LM heads first apply
+    dense -> erf-GELU -> LayerNorm (hf:models/roberta/modeling_roberta.py RobertaLMHead, hf:models/bert/modeling_bert.py
+    BertPredictionHeadTransform + BertLMPredictionHead)."""
+    mt = (cfg or {}).get("model_type", "bert-generation")
+    if mt == "roberta":
+        h = layer_norm(F.gelu(linear(hidden, state, "lm_head.dense")), state, "lm_head.layer_norm", cfg["layer_norm_eps"])
+        return F.linear(h, state["roberta.embeddings.word_embeddings.weight"], state["lm_head.bias"])
+    if mt == "bert":
+        h = layer_norm(F.gelu(linear(hidden, state, "cls.predictions.transform.dense")), state, "cls.predictions.transform.LayerNorm",
+                       cfg["layer_norm_eps"])
+        return F.linear(h, state["bert.embeddings.word_embeddings.weight"], state["cls.predictions.bias"])
     return F.linear(hidden, state["bert.embeddings.word_embeddings.weight"], state["lm_head.bias"])
 
 
@@ -265,7 +311,7 @@ def causal_lm_loss(logits, labels):
 def decoder_forward(input_ids, attention_mask, enc, enc_mask, state, cfg):
     """DecoderModel.forward -> (loss, logits)  (ref:...decoder_model.py:39-49)."""
     h = decoder_hidden(input_ids, attention_mask, enc, enc_mask, state, cfg)
-    logits = lm_logits(h, state)
+    logits = lm_logits(h, state, cfg)
     return causal_lm_loss(logits, input_ids), logits
 
 
@@ -286,8 +332,7 @@ def bert_pooler(x, state, prefix):
 def text_encoder_forward(input_ids, attention_mask, state, cfg, prefix=""):
     """EncoderModel(proto=None) = BertGenerationEncoder (+BertPooler)
     (ref:vilmedic/blocks/huggingface/encoder/encoder_model.py:44-62)."""
-    x = bert_embeddings(input_ids, state, prefix + "embeddings.", cfg["layer_norm_eps"],
-                        pad_token_id=cfg.get("pad_token_id"))
+    x = text_embeddings(input_ids, state, prefix + "embeddings.", cfg)
     x = bert_encoder_forward(x, state, cfg, prefix + "encoder.", attention_mask)
     return x
 
@@ -420,13 +465,17 @@ def decoder_step_logits(ids, enc, enc_mask, state, cfg):
     Ensemble decoding: ``state`` (and ``enc`` / ``enc_mask`` / ``cfg``) may be LISTS, one entry per model; the models'
     next-token logits are SUMMED before the log-softmax
     (ref:vilmedic/blocks/huggingface/decoder/beam_search.py:243-262, bin/ensemble.py:72-80)."""
+    # generate() numbers the positions 0..t for every architecture whose forward accepts ``position_ids`` (BERT, RoBERTa:
+    # hf:generation/utils.py _prepare_position_ids_for_generation) -- for RoBERTa that is NOT the pad-offset numbering of its training forward
+    def pos(c):
+        return torch.arange(ids.shape[1])[None].expand_as(ids) if c.get("model_type", "bert-generation") != "bert-generation" else None
     if isinstance(state, (list, tuple)):
         cfgs = cfg if isinstance(cfg, (list, tuple)) else [cfg] * len(state)
-        logits = sum(lm_logits(decoder_hidden(ids, None, e, m, st, c)[:, -1], st).float()
+        logits = sum(lm_logits(decoder_hidden(ids, None, e, m, st, c, position_ids=pos(c))[:, -1], st, c).float()
                      for e, m, st, c in zip(enc, enc_mask, state, cfgs))
         return torch.log_softmax(logits, dim=-1)
-    h = decoder_hidden(ids, None, enc, enc_mask, state, cfg)
-    return torch.log_softmax(lm_logits(h[:, -1], state).float(), dim=-1)
+    h = decoder_hidden(ids, None, enc, enc_mask, state, cfg, position_ids=pos(cfg))
+    return torch.log_softmax(lm_logits(h[:, -1], state, cfg).float(), dim=-1)
 
 
 def greedy_decode(enc, enc_mask, state, cfg, bos, eos, pad, max_length):
@@ -458,7 +507,7 @@ def beam_decode(enc, enc_mask, state, cfg, bos, eos, pad, max_length, num_beams,
         enc_b = [e.repeat_interleave(nb, 0) for e in enc]
         mask_b = [m.repeat_interleave(nb, 0) if m is not None else None for m in enc_mask]
     else:
-        B, V = enc.shape[0], state["lm_head.bias"].shape[0]
+        B, V = enc.shape[0], cfg["vocab_size"]
         enc_b = enc.repeat_interleave(nb, 0)
         mask_b = enc_mask.repeat_interleave(nb, 0) if enc_mask is not None else None
 

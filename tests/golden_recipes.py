@@ -73,6 +73,57 @@ def bert_embedding_shapes(cfg, prefix):
     }
 
 
+def deit_shapes(cfg, prefix=""):
+    """HF DeiTModel(add_pooling_layer=False): the ViT tree + ``embeddings.distillation_token`` and n + 2 positions"""
+    s = vit_shapes(cfg)
+    n = (cfg["image_size"] // cfg["patch_size"]) ** 2
+    s["embeddings.distillation_token"] = (1, 1, cfg["hidden_size"])
+    s["embeddings.position_embeddings"] = (1, n + 2, cfg["hidden_size"])
+    return {prefix + k: v for k, v in s.items()}
+
+
+def text_model_shapes(cfg, prefix="", pooler=True, cross=False):
+    """HF BertModel / RobertaModel: embeddings (word, position, token_type, LayerNorm) + encoder.layer.* (+ pooler.dense)"""
+    d = cfg["hidden_size"]
+    s = bert_embedding_shapes(cfg, "embeddings.")
+    s["embeddings.token_type_embeddings.weight"] = (cfg["type_vocab_size"], d)
+    for i in range(cfg["num_hidden_layers"]):
+        s.update(bert_layer_shapes(cfg, f"encoder.layer.{i}.", cross=cross))
+    if pooler:
+        s["pooler.dense.weight"], s["pooler.dense.bias"] = (d, d), (d,)
+    return {prefix + k: v for k, v in s.items()}
+
+
+def causal_lm_shapes(cfg, model_type):
+    """RobertaForCausalLM / BertLMHeadModel with cross-attention (the tied ``*.decoder.weight`` / ``.bias`` aliases are not generated)"""
+    d, V = cfg["hidden_size"], cfg["vocab_size"]
+    s = text_model_shapes(cfg, model_type + ".", pooler=False, cross=True)
+    if model_type == "roberta":
+        s.update({"lm_head.bias": (V,), "lm_head.dense.weight": (d, d), "lm_head.dense.bias": (d,),
+                  "lm_head.layer_norm.weight": (d,), "lm_head.layer_norm.bias": (d,)})
+    else:
+        s.update({"cls.predictions.bias": (V,), "cls.predictions.transform.dense.weight": (d, d), "cls.predictions.transform.dense.bias": (d,),
+                  "cls.predictions.transform.LayerNorm.weight": (d,), "cls.predictions.transform.LayerNorm.bias": (d,)})
+    return s
+
+
+def write_proto_dir(path, model_type, cfg, state, architectures=None):
+    """a local pretrained-checkpoint directory (config.json + model.safetensors) holding ``state`` -- what ``proto: <dir>`` of
+    EncoderModel / DecoderModel points at.  Written from the recipe so that fixtures stay small; make_golden.py loads the SAME
+    directory through the reference's ``AutoModel.from_pretrained`` / ``AutoModelForCausalLM.from_pretrained``."""
+    import json
+    import os
+    from safetensors.torch import save_file
+    os.makedirs(path, exist_ok=True)
+    c = dict(cfg, model_type=model_type, hidden_act="gelu", position_embedding_type="absolute")
+    if architectures:
+        c["architectures"] = architectures
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(c, f, indent=1, sort_keys=True)
+    save_file({k: v.contiguous() for k, v in state.items()}, os.path.join(path, "model.safetensors"))
+    return path
+
+
 def decoder_shapes(cfg, prefix=""):
     """BertGenerationDecoder with cross-attention; LM head tied to word embeddings
     (``lm_head.decoder.weight`` is an alias and is not generated)."""
@@ -158,6 +209,16 @@ DEC_TINY = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, int
 DEC_768_2L = dict(hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=3072,
                   vocab_size=1000, max_position_embeddings=514, layer_norm_eps=1e-5,
                   bos_token_id=0, pad_token_id=1, eos_token_id=2)
+# pretrained-`proto` towers (ref:encoder_model.py:19-22, decoder_model.py:17-21): RoBERTa-shaped (pad 1, one token type, 1e-5) and
+# BERT-shaped (pad 0, two token types, 1e-12) tiny checkpoints
+ROBERTA_TINY = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=97,
+                    max_position_embeddings=66, type_vocab_size=1, layer_norm_eps=1e-5, bos_token_id=0, pad_token_id=1, eos_token_id=2,
+                    hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+BERT_TINY = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=97,
+                 max_position_embeddings=64, type_vocab_size=2, layer_norm_eps=1e-12, pad_token_id=0,
+                 hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+DEIT_TINY = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                 image_size=32, patch_size=8, num_channels=3, layer_norm_eps=1e-12)
 MVQA_TINY = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=192,
                  layer_norm_eps=1e-12)
 TXT_TINY = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,

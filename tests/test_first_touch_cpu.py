@@ -67,3 +67,42 @@ def test_buffers_outside_tracked_arenas_and_two_arenas(fresh):
     ops.grads_zeroed(g1)                                 # zeroing one arena leaves the other's history alone
     assert not ops._first_touch(g2[10:20])
     assert ops._first_touch(g1[0:10])
+
+
+def test_span_of_a_column_slice_covers_its_row_strides():
+    """a [rows, 64] column slice of a [rows, 256] matrix spans (rows - 1) * 256 + 64 elements, not rows * 64"""
+    from vilmedic_amd import ops
+    t = torch.zeros(8, 256)
+    lo, hi = ops._span(t[:, 64:128])
+    assert lo == t.data_ptr() + 64 * 4 and hi - lo == ((8 - 1) * 256 + 64) * 4
+    assert ops._span(t) == (t.data_ptr(), t.data_ptr() + t.numel() * 4)
+    assert ops._span(torch.zeros(0)) [1] == ops._span(torch.zeros(0))[0]
+
+
+def test_forget_range_and_reset_host_state():
+    """records about a freed arena's memory are dropped (ParamArena's finalizer), and an aborted graph capture leaves no queued launches
+    and no buffer that still counts as clean (graph.GraphedTrainStep's except path)"""
+    from vilmedic_amd import ops
+    saved = {k: (list(v) if isinstance(v, list) else v) for k, v in ops._touch.items()}
+    try:
+        g = torch.zeros(1024)
+        ops._touch.update(lo=[], hi=[], shared=[], ranges=[])
+        ops.grads_zeroed(g)
+        assert ops._first_touch(g[:128]) is True and ops._first_touch(g[:128]) is False
+        ops._touch["shared"].append(ops._span(g[512:640]))
+        ops.forget_range(*ops._span(g))
+        assert ops._touch["ranges"] == [] and ops._touch["shared"] == [] and ops._touch["lo"] == []
+        assert ops._first_touch(g[128:256]) is False             # untracked memory is never "clean"
+        ops.grads_zeroed(g)
+        ops._pg["items"].append("stale"), ops._pg["ptrs"].add(1), ops._lnq["items"].append("stale")
+        ops._side["pending"] = True
+        ops.reset_host_state()
+        assert ops._pg["items"] == [] and ops._pg["ptrs"] == set() and ops._pg["tiles"] == 0 and ops._lnq["items"] == []
+        assert ops._side["pending"] is False and ops._side["callback_queued"] is False
+        assert ops._first_touch(g[256:384]) is False             # after an aborted capture nothing stores until the next zero_grad
+        ops.grads_zeroed(g)
+        assert ops._first_touch(g[256:384]) is True
+    finally:
+        ops._touch.update(saved)
+        ops._pg.update(items=[], tiles=0, ptrs=set())
+        ops._lnq.update(items=[], ptrs=set())

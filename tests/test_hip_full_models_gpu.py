@@ -333,6 +333,70 @@ def test_bench_model_end_to_end_vs_oracle():
     assert worst_cos >= 0.999 and worst_rel <= 3e-2
 
 
+def test_bench_model_B64_vs_oracle():
+    """The configuration bench.py times -- BASELINE configs[1]: ViT-B/16 + 12-layer decoder, V = 30522, B = 64, L = 128 (M = 12608 / 8192 token
+    rows: the multi-round XCD-remapped GEMM grids, the 256-row weight-gradient tiles with first-touch stores in real autograd order, the side
+    stream) -- end to end against the fp32 CPU oracle: loss, logits, seven gradients spread over both towers, then an Adam step on both
+    sides and the loss of the second step (dropout 0; same tolerances as the B = 2 case)."""
+    import bench
+    from oracle import torch_ref as O
+    from vilmedic_amd.optim import FusedAdam
+    model = bench.build_model(dev())
+    for mod in model.modules():
+        if hasattr(mod, "cfg") and hasattr(mod.cfg, "hidden_dropout_prob"):
+            mod.cfg.hidden_dropout_prob = mod.cfg.attention_probs_dropout_prob = 0.0
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("bias") or "LayerNorm" in n or "layernorm" in n:
+                p.add_(0.02 * torch.randn_like(p))
+    model.train()
+    B, L, lr = 64, 128, 1e-4
+    images, ids, am = bench.synthetic_batch(B, L, bench.DEC_12L["vocab_size"], dev(), seed=5)
+    st = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()
+          if "lm_head.decoder" not in k}
+    vcfg, dcfg = dict(bench.VIT_B16), {k: v for k, v in bench.DEC_12L.items() if "dropout" not in k}
+    ref_opt = torch.optim.Adam([v for v in st.values() if v.requires_grad], lr=lr)
+    opt = FusedAdam(model, lr=lr)
+    names = ["dec.decoder.bert.encoder.layer.11.output.dense.weight", "dec.decoder.bert.encoder.layer.5.crossattention.self.key.weight",
+             "dec.decoder.bert.encoder.layer.0.attention.self.query.weight", "dec.decoder.bert.embeddings.word_embeddings.weight",
+             "enc.model.encoder.layer.11.intermediate.dense.weight", "enc.model.encoder.layer.0.attention.attention.value.weight",
+             "enc.model.embeddings.patch_embeddings.projection.weight"]
+    named = dict(model.named_parameters())
+    losses = []
+    for step in range(2):
+        ref_opt.zero_grad()
+        ref_loss, ref_logits = O.rrg_vit_forward(images.cpu(), ids.cpu(), am.cpu(), st, vcfg, dcfg)
+        ref_loss.backward()
+        opt.zero_grad()
+        out = model(input_ids=ids, attention_mask=am, images=images)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        losses.append((out["loss"].item(), ref_loss.item()))
+        if step == 0:
+            ref_d = ref_logits.detach().to(dev())
+            lerr = (out["logits"].float() - ref_d).abs()
+            lmax, lmean, labs = lerr.max().item(), lerr.mean().item(), ref_d.abs().max().item()
+            del lerr, ref_d
+            worst_cos, worst_rel = 1.0, 0.0
+            for n in names:
+                gg, gr = named[n].grad.float().cpu(), st[n].grad
+                worst_cos, worst_rel = min(worst_cos, cosine(gg, gr)), max(worst_rel, rel_l2(gg, gr))
+        del ref_logits, out
+        ref_opt.step()
+        opt.step()
+    torch.cuda.synchronize()
+    drift = max(rel_l2(named[n].detach().float().cpu(), st[n].detach()) for n in names)
+    report("bench model B=64 L=128 (the benched configuration)", loss0=losses[0][0], ref_loss0=losses[0][1], loss1=losses[1][0], ref_loss1=losses[1][1],
+           logits_max_err=lmax, logits_mean_err=lmean, logits_absmax=labs, grad_cos_min=worst_cos, grad_rel_l2_max=worst_rel,
+           params_rel_l2_after_2_adam_steps=drift)
+    for got, ref in losses:
+        assert abs(got - ref) <= 1e-3 * max(1.0, abs(ref)), losses
+    assert losses[1][1] < losses[0][1]                          # (the step did something)
+    assert lmean <= 1e-2 and lmax <= 3e-2 + 3e-2 * labs
+    assert worst_cos >= 0.999 and worst_rel <= 3e-2
+    assert drift <= 1e-4                 # Adam's first steps move every element by ~lr: the parameters agree to a fraction of that
+
+
 def test_c1_at_its_true_size_vs_oracle():
     """BASELINE configs[0] exactly: HF ResNet-18 (64-128-256-512 channels) + visual projection + 2-layer d = 768 decoder, B = 4, 224 x 224
     images, 64-token reports, V = 4000, train-mode BatchNorm: loss, logits and gradients in both towers"""

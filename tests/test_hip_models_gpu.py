@@ -217,6 +217,27 @@ def test_greedy_and_beam_decode_bit_exact_vs_golden(golden):
         assert err <= 1e-4
 
 
+def test_greedy_with_output_scores_and_bad_words_takes_the_library_argmax_loop(golden):
+    """generation.sample's second loop (callers: ``output_scores=True``, a greedy call with ``bad_words_ids``): same ids as the one-kernel
+    selection, one fp32 score tensor per emitted position whose arg-max is that token; a greedy call with a banned token never emits it;
+    sampling outside vm_select_tokens' domain raises instead of falling back to torch sampling"""
+    g, cfg, dec, st, enc, start, common = _g7_setup(golden)
+    enc_d, mask_d = enc.to(dev()), g["enc_mask"].to(dev())
+    ref = g["beams1_lp1.0"]["sequences"]
+    out = dec.generate(input_ids=start, encoder_hidden_states=enc_d, encoder_attention_mask=mask_d, output_scores=True,
+                       return_dict_in_generate=True, **common)
+    assert torch.equal(out.sequences.cpu(), ref)
+    assert len(out.scores) == ref.shape[1] - 1 and out.scores[0].shape == (g["B"], cfg["vocab_size"])
+    assert torch.equal(out.scores[0].argmax(-1).cpu(), ref[:, 1])
+    banned = int(ref[0, 1])
+    ids = dec.generate(input_ids=start, encoder_hidden_states=enc_d, encoder_attention_mask=mask_d, bad_words_ids=[[banned]], **common).cpu()
+    assert int(ids[0, 1]) != banned and not bool((ids[:, 1:] == banned).any())
+    with pytest.raises(NotImplementedError):
+        dec.generate(input_ids=start, encoder_hidden_states=enc_d, encoder_attention_mask=mask_d, do_sample=True, top_k=1000, **common)
+    with pytest.raises(NotImplementedError):
+        dec.generate(input_ids=start, encoder_hidden_states=enc_d, encoder_attention_mask=mask_d, do_sample=True, output_scores=True, **common)
+
+
 def test_bf16_decode_step_stays_within_margin_of_fp32_oracle(golden):
     """the training-precision decode step (decode_dtype="bf16": SCST rollouts, throughput runs): every emitted token is an
     fp32-oracle arg-max of ITS OWN prefix up to a margin, where the margin is what bf16 activations can move a logit gap by

@@ -132,3 +132,132 @@ def test_wide_tile_forward_kernel_main_loop_is_clean(tmp_path_factory):
     assert sum(o.startswith("v_mfma") for o in names) == 64
     assert [l for o, l in ops if o == "s_waitcnt" and "vmcnt" in l] == ["s_waitcnt vmcnt(4)"]
     assert not any(o.startswith("scratch_") for o in names)
+
+
+def _vregs(tok):
+    """VGPR numbers named by one operand token: v7 -> {7}, v[12:15] -> {12..15}"""
+    out = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", tok):
+        out |= set(range(int(a), int(b) + 1))
+    out |= {int(x) for x in re.findall(r"\bv(\d+)\b", tok)}
+    return out
+
+
+def _blocks(body):
+    """basic blocks of one function's assembly: {label: (instructions, successor labels)}; the entry block is labelled None"""
+    blocks, order, cur = {}, [], None
+    blocks[cur] = []
+    order.append(cur)
+    for raw in body.splitlines():
+        l = raw.strip()
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            cur = m.group(1)
+            blocks[cur] = []
+            order.append(cur)
+            continue
+        if l.startswith(";;#ASM"):
+            blocks[cur].append(l)                       # inline-asm markers: only loads inside them are the hand-placed ones
+            continue
+        if not l or l.startswith((";", ".", "//")):
+            continue
+        blocks[cur].append(l)
+    succ = {}
+    for k, lab in enumerate(order):
+        ins = blocks[lab]
+        nxt = order[k + 1] if k + 1 < len(order) else None
+        out, falls = [], True
+        for l in ins:
+            op = l.split()[0]
+            if op.startswith("s_cbranch"):
+                out.append(l.split()[-1])
+            elif op == "s_branch":
+                out.append(l.split()[-1])
+                falls = False
+            elif op == "s_endpgm":
+                falls = False
+        if falls and nxt is not None:
+            out.append(nxt)
+        succ[lab] = out
+    return blocks, succ, order
+
+
+def _reads(l):
+    """VGPRs an instruction READS: every vector operand but the destination (stores, compares and AGPR writes have no VGPR destination;
+    accumulating ops read theirs)"""
+    op, _, rest = l.partition(" ")
+    ops = [o.strip() for o in rest.split(",")]
+    if not ops or not ops[0]:
+        return set()
+    no_dst = op.startswith(("global_store", "scratch_store", "ds_write", "ds_store", "buffer_store", "flat_store", "v_cmp", "v_accvgpr_write",
+                            "v_readlane", "v_readfirstlane", "global_atomic", "v_swap"))
+    reads_dst = any(t in op for t in ("mac", "dot2c", "v_swap", "v_permlane"))
+    srcs = ops if (no_dst or reads_dst or not ops[0].startswith("v")) else ops[1:]
+    out = set()
+    for o in srcs:
+        out |= _vregs(o)
+    return out
+
+
+def _check_pending_loads(name, body):
+    """forward may-analysis over the CFG: the set of VGPRs that are destinations of an inline-asm global_load_dwordx4 still in flight (no
+    vmcnt(0) since).  Any instruction that READS such a register -- a copy, a spill, an AGPR move, an address computation, an ALU operand --
+    would see stale data.  (A plain redefinition ends the register's pending state: the kernels have several mutually exclusive issue
+    sites -- one K-tile / peeled last K-tile / late operands -- that reuse the same registers, and the analysis does not correlate branches.)"""
+    blocks, succ, order = _blocks(body)
+    entry = {lab: None for lab in order}              # None = not reached yet
+    entry[None] = frozenset()
+    work, n_loads = [None], 0
+    seen_loads = set()
+    while work:
+        lab = work.pop()
+        pending = dict.fromkeys(entry[lab], "")
+        in_asm = False
+        for l in blocks[lab]:
+            if l.startswith(";;#ASM"):
+                in_asm = l.startswith(";;#ASMSTART")
+                continue
+            op = l.split()[0]
+            if op == "s_waitcnt" and "vmcnt(0)" in l:
+                pending.clear()
+                continue
+            if in_asm and op.startswith("global_load_dwordx4") and l.rstrip().endswith("off") and "lds" not in op:
+                dst, rest = l.split(None, 1)[1].split(",", 1)
+                assert not (_vregs(rest) & set(pending)), (name, lab, l, "address built from an in-flight destination")
+                for r in _vregs(dst):
+                    pending[r] = l
+                if (lab, l) not in seen_loads:
+                    seen_loads.add((lab, l))
+                    n_loads += 1
+                continue
+            if pending and not op.startswith("s_"):
+                hit = _reads(l) & set(pending)
+                assert not hit, (name, lab, l, "reads a register whose load is still in flight", pending[next(iter(hit))])
+                for r in _vregs(l.partition(" ")[2].split(",")[0]) if l.partition(" ")[2].strip().startswith("v") else ():
+                    pending.pop(r, None)
+        out = frozenset(pending)
+        for t in succ[lab]:
+            if t not in entry:
+                continue
+            new = out if entry[t] is None else (entry[t] | out)
+            if new != entry[t]:
+                entry[t] = new
+                work.append(t)
+    return n_loads
+
+
+def test_early_epilogue_operand_loads_are_not_touched_before_their_wait(gemm_fast_asm):
+    """The epilogue operands (bias, residual, gelu' input) are requested by inline-asm ``global_load_dwordx4`` in front of the last K-tile and
+    completed by an explicit ``s_waitcnt vmcnt(0)`` at the head of the epilogue (gemm_fast.hip).  The compiler believes the destination
+    registers are defined when the asm returns: a copy, a spill or a move to an AGPR placed between the request and the wait would read
+    stale data.  For EVERY gemm_fast_kernel / gemm_grouped_kernel / gemm_pair_kernel instantiation: no VGPR spill, and on no path of the
+    control-flow graph does an instruction name a destination register of such a load before the next vmcnt(0)."""
+    meta = _kernel_meta(gemm_fast_asm)
+    names = [k for k in meta if re.match(r"_Z(16gemm_fast_kernel|19gemm_grouped_kernel|16gemm_pair_kernel)", k)]
+    assert len(names) >= 9, names
+    total = 0
+    for name in names:
+        assert meta[name]["vgpr_spill_count"] == 0, (name, meta[name])
+        start = gemm_fast_asm.index(name + ":")
+        total += _check_pending_loads(name, gemm_fast_asm[start:gemm_fast_asm.index(".Lfunc_end", start)])
+    assert total >= 2 * len(names), total

@@ -397,3 +397,102 @@ def test_g22_ensemble_decode_summed_logits_bit_exact(golden):
     # and the sum matters: model 0 alone decodes something else
     alone = O.greedy_decode(encs[0], masks[0], states[0], cfg, 0, 2, 1, g["max_len"])
     assert torch.equal(alone, g["model0_alone_greedy"]) and not torch.equal(alone, ids)
+
+
+# ----------------------------------------------------------------------------- G23 / G24: pretrained `proto` towers, DeiT
+def _thin(g):
+    return g[::4] if (g.dim() == 2 and g.shape[0] >= 128) else g
+
+
+def proto_enc_case(g, mt):
+    e = g[mt + "_enc"]
+    cfg = dict(e["cfg"], model_type=mt)
+    st = R.rand_state(R.text_model_shapes(e["cfg"]), e["seed"])
+    assert abs(R.state_checksum(st) - e["checksum"]) < 1e-6 * e["checksum"]
+    ids, am = R.make_reports(e["B"], e["L"], cfg["vocab_size"], seed=e["seed"], **e["specials"])
+    return e, cfg, st, ids, am
+
+
+def proto_dec_case(g, mt):
+    d = g[mt + "_dec"]
+    cfg = dict(d["cfg"], model_type=mt)
+    st = R.rand_state(R.causal_lm_shapes(d["cfg"], mt), d["seed"], **d["recipe"])
+    st["lm_head.bias" if mt == "roberta" else "cls.predictions.bias"][d["specials"]["sep"]] += d["eos_bias"]
+    assert abs(R.state_checksum(st) - d["checksum"]) < 1e-6 * d["checksum"]
+    ids, am = R.make_reports(d["B"], d["L"], cfg["vocab_size"], seed=d["seed"] - 1, **d["specials"])
+    gen = torch.Generator().manual_seed(d["seed"] + 1)
+    enc = torch.randn(d["B"], d["S"], cfg["hidden_size"], generator=gen)
+    enc[~d["enc_mask"]] = 0.0
+    return d, cfg, st, ids, am, enc
+
+
+@pytest.mark.parametrize("mt", ["roberta", "bert"])
+def test_g23_proto_encoder_tower(golden, mt):
+    """EncoderModel(proto=<dir>) -> AutoModel.from_pretrained (ref:encoder_model.py:19-22): hidden states of every layer, the built-in
+    pooler, and the gradients of the three embedding tables (RoBERTa: position ids from the pad mask, no gradient into the pad rows)"""
+    e, cfg, st, ids, am = proto_enc_case(golden("g23_proto_towers"), mt)
+    assert e["cls_name"] == ("RobertaModel" if mt == "roberta" else "BertModel")
+    st = {k: v.requires_grad_(True) for k, v in st.items()}
+    x = O.text_embeddings(ids, st, "embeddings.", cfg)
+    hs = [x]
+    m = O.key_padding_mask(am)
+    for i in range(cfg["num_hidden_layers"]):
+        x = O.bert_layer(x, st, f"encoder.layer.{i}.", cfg, m)
+        hs.append(x)
+    close(torch.stack(hs), e["hidden_states"])
+    close(O.text_encoder_forward(ids, am, st, cfg), e["last_hidden_state"])
+    pooled = O.bert_pooler(x, st, "pooler")
+    close(pooled, e["pooler_output"])
+    gen = torch.Generator().manual_seed(e["seed"] + 5)
+    wl, wp = torch.randn(x.shape, generator=gen), torch.randn(pooled.shape, generator=gen)
+    ((x * wl * am[..., None]).sum() + (pooled * wp).sum()).backward()
+    for n, ref in e["grads"].items():
+        close(_thin(st[n].grad), ref, rtol=1e-3, atol=1e-5)
+    if mt == "roberta":          # nn.Embedding(padding_idx): the pad rows of BOTH tables get no gradient
+        assert float(st["embeddings.position_embeddings.weight"].grad[cfg["pad_token_id"]].abs().sum()) == 0.0
+    assert float(st["embeddings.word_embeddings.weight"].grad[cfg["pad_token_id"]].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("mt", ["roberta", "bert"])
+def test_g23_proto_decoder_loss_grads_and_decode_ids(golden, mt):
+    """DecoderModel(proto=<dir>) -> AutoModelForCausalLM.from_pretrained(is_decoder, add_cross_attention) (ref:decoder_model.py:17-21):
+    loss / logits / gradients, and greedy + beam-4 token ids of HF generate() on it (bit-exact)"""
+    d, cfg, st, ids, am, enc = proto_dec_case(golden("g23_proto_towers"), mt)
+    assert d["cls_name"] == ("RobertaForCausalLM" if mt == "roberta" else "BertLMHeadModel")
+    stg = {k: v.clone().requires_grad_(True) for k, v in st.items()}
+    encg = enc.clone().requires_grad_(True)
+    loss, logits = O.decoder_forward(ids, am, encg, d["enc_mask"], stg, cfg)
+    close(loss, d["loss"])
+    close(logits, d["logits"], rtol=1e-3, atol=1e-4)
+    loss.backward()
+    for n, ref in d["grads"].items():
+        close(_thin(stg[n].grad), ref, rtol=2e-3, atol=1e-6)
+    close(encg.grad, d["enc_grad"], rtol=2e-3, atol=1e-7)
+    sp = d["specials"]
+    with torch.no_grad():
+        seq = O.greedy_decode(enc, d["enc_mask"], st, cfg, sp["cls"], sp["sep"], sp["pad"], d["max_len"])
+        assert torch.equal(seq, d["beams1"]["sequences"]), (seq.tolist(), d["beams1"]["sequences"].tolist())
+        seqs, scores = O.beam_decode(enc, d["enc_mask"], st, cfg, sp["cls"], sp["sep"], sp["pad"], d["max_len"], 4)
+        assert torch.equal(seqs, d["beams4"]["sequences"]), (seqs.tolist(), d["beams4"]["sequences"].tolist())
+        close(scores, d["beams4"]["scores"], rtol=1e-4, atol=1e-5)
+
+
+def test_g24_deit_visual_encoder_and_rrg_hf(golden):
+    g = golden("g24_deit")
+    assert g["cls_name"] == "DeiTModel"
+    cfg = g["cfg"]
+    st = R.rand_state(R.deit_shapes(cfg), g["seed"])
+    assert abs(R.state_checksum(st) - g["checksum"]) < 1e-6 * g["checksum"]
+    images = R.make_images(g["B"], cfg["image_size"], seed=g["seed"])
+    feats, mask = O.visual_encode(O.vit_forward(images, st, cfg), {})
+    assert feats.shape[1] == (cfg["image_size"] // cfg["patch_size"]) ** 2 + 2
+    close(feats, g["features"])
+    assert torch.equal(mask, g["mask"])
+    dst = R.rand_state(R.decoder_shapes(g["dec_cfg"]), g["seed"] + 1)
+    assert abs(R.state_checksum(dst) - g["dec_checksum"]) < 1e-6 * g["dec_checksum"]
+    full = {"model.encoder." + k: v for k, v in st.items()}
+    full.update({"model.decoder." + k: v for k, v in dst.items()})
+    ids, am = R.make_reports(g["B"], g["L"], g["dec_cfg"]["vocab_size"], seed=g["seed"])
+    loss, logits = O.rrg_hf_forward(images, ids, am, full, cfg, g["dec_cfg"])
+    close(loss, g["loss4"])
+    close(logits, g["logits4"], rtol=1e-3, atol=1e-4)

@@ -1,9 +1,12 @@
 """north_star: "config/RRG, config/MVQA and config/SELFSUP YAMLs run unchanged".  Every YAML the REFERENCE ships for those three
 task families is loaded by this repo's config loader (includes resolved the reference's way) and its ``model:`` sub-tree is
 constructed through the plugin surface -- ``eval(proto)(**model_cfg, dl=dl)`` as vilmedic/executors/utils.py:97-110 does -- with a
-stand-in data loader.  A YAML whose sub-tree names a pretrained checkpoint (``proto: allenai/biomed_roberta_base`` ...) must fail
-with the documented NotImplementedError (there is no network in this image; the module that would be built is the same class);
-a YAML that spells its architecture out must build.  Skipped where /root/reference does not exist (the GPU box)."""
+stand-in data loader.  A YAML whose sub-tree names a hub checkpoint (``proto: allenai/biomed_roberta_base`` ...) must fail with the
+documented NotImplementedError while that checkpoint is not on disk (there is no network in this image, and the package never
+downloads) and must BUILD -- through the reference's ``from_pretrained`` path, blocks/huggingface/pretrained.py -- once ``proto``
+points at a local checkpoint directory of that architecture (a RobertaForMaskedLM checkpoint saved by the installed transformers at
+RoBERTa-base width, which is what the named hub checkpoints are); a YAML that spells its architecture out must build as is, DeiT
+included.  Skipped where /root/reference does not exist (the GPU box)."""
 import copy
 import glob
 import os
@@ -21,6 +24,7 @@ class _Tok:
     """what the models read from ``dl.dataset(.seq).tokenizer``: vocab_size, special-token vocabulary, max length"""
     vocab_size = 977
     cls_token, sep_token, pad_token = "[CLS]", "[SEP]", "[PAD]"
+    cls_token_id, pad_token_id, sep_token_id, unk_token_id = 0, 1, 2, 3          # (read by RRG_HF: ref:models/rrg/RRG_HF.py:73-79)
     vocab = {"[CLS]": 0, "[PAD]": 1, "[SEP]": 2, "[UNK]": 3, "[MASK]": 4}
 
     def get_vocab(self):
@@ -39,6 +43,23 @@ def _fake_dl():
     ds = types.SimpleNamespace(seq=seq, tokenizer=tok, tokenizer_max_len=32, tgt_tokenizer=tok, tgt_tokenizer_max_len=32, label=label,
                                num_labels=330)
     return types.SimpleNamespace(dataset=ds)
+
+
+_CKPT = {}
+
+
+def _roberta_base_like_checkpoint():
+    if "dir" not in _CKPT:
+        import tempfile
+        import torch
+        import transformers
+        torch.manual_seed(0)
+        cfg = transformers.RobertaConfig(vocab_size=977, hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=3072,
+                                         max_position_embeddings=514, type_vocab_size=1, layer_norm_eps=1e-5)
+        d = tempfile.mkdtemp(prefix="vm_roberta_base_like_")
+        transformers.RobertaForMaskedLM(cfg).save_pretrained(d)
+        _CKPT["dir"] = d
+    return _CKPT["dir"]
 
 
 def _pretrained_names(tree):
@@ -74,20 +95,24 @@ def test_reference_yaml_model_subtree_constructs(path, monkeypatch):
     for sub in ("decoder", "encoder", "transformer"):
         if isinstance(mcfg.get(sub), dict) and mcfg[sub].get("num_hidden_layers"):
             mcfg[sub].update(shrink)
-    unsupported_hf = proto == "RRG_HF" and (mcfg["vision"].get("proto_model") != "vit" or mcfg["decoder"].get("proto_model") != "bert-generation")
+    unsupported_hf = proto == "RRG_HF" and (mcfg["vision"].get("proto_model") not in ("vit", "deit") or mcfg["decoder"].get("proto_model") != "bert-generation")
     if hub or unsupported_hf or proto == "RRS_HF":
+        monkeypatch.setenv("HF_HUB_OFFLINE", "1")
         with pytest.raises(NotImplementedError):
             getattr(M, proto)(**copy.deepcopy(mcfg), dl=_fake_dl(), logger=None, from_training=True)
         if not hub:
             return
-        # the SAME sub-tree with the checkpoint name replaced by the architecture that checkpoint has (BERT-base / RoBERTa-base:
-        # 768 / 12 heads / 3072, one layer here) must build: everything but the download is exercised
-        base = dict(proto=None, hidden_size=768, num_attention_heads=12, intermediate_size=3072, num_hidden_layers=1, vocab_size=977,
-                    max_position_embeddings=514, layer_norm_eps=1e-5, pad_token_id=1, bos_token_id=0, eos_token_id=2)
+        # the SAME sub-tree with the hub name replaced by a local checkpoint directory of the architecture that checkpoint has
+        # (RoBERTa-base: 768 / 12 heads / 3072 / 514 positions / one token type; one layer and a small vocabulary here) must build
+        # through the from_pretrained path: prefix stripping, dropped MLM head, fresh pooler / cross-attention, as HF does
+        ckpt = _roberta_base_like_checkpoint()
         for sub in ("decoder", "encoder"):
             if isinstance(mcfg.get(sub), dict) and isinstance(mcfg[sub].get("proto"), str) and "/" in mcfg[sub]["proto"]:
-                mcfg[sub].update(base)
+                mcfg[sub]["proto"] = ckpt
     model = getattr(M, proto)(**mcfg, dl=_fake_dl(), logger=None, from_training=True)
+    if hub:
+        towers = [m for m in model.modules() if hasattr(m, "_vm_missing_keys")]
+        assert towers and all(type(t).__name__ in ("RobertaModel", "RobertaForCausalLM") for t in towers)
     assert callable(model.eval_func)
     n = sum(p.numel() for p in model.parameters())
     assert n > 1_000_000, n

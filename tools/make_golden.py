@@ -820,9 +820,132 @@ def gen_ensemble_decode():
     print("model 0 alone", alone.tolist())
     save("g22_ensemble_decode", res)
 
+# ------------------------------------------------------------------ G23: pretrained `proto` towers (BERT / RoBERTa) from a local directory
+def _specials(mt):
+    return dict(cls=0, pad=1, sep=2) if mt == "roberta" else dict(cls=3, pad=0, sep=4)
+
+
+def _thin(g):
+    """weight-matrix gradients are stored every 4th row (fixture size); embedding tables and vectors whole"""
+    return g[::4].clone() if (g.dim() == 2 and g.shape[0] >= 128) else g.clone()
+
+
+def gen_proto_towers():
+    """The reference's two `proto` paths on local checkpoint directories written from the recipe (R.write_proto_dir):
+      EncoderModel(proto=dir)  -> AutoModel.from_pretrained (RobertaModel / BertModel, built-in pooler)     encoder_model.py:19-22
+      DecoderModel(proto=dir)  -> AutoModelForCausalLM.from_pretrained(config: is_decoder, add_cross_attention)  decoder_model.py:17-21
+    Pins oracle.text_embeddings (token-type row, RoBERTa position ids and their pad-row gradient rule), oracle.lm_logits' dense -> GELU ->
+    LayerNorm transform and, through HF generate() on the loaded decoder (evaluation.py:73-78), the position numbering of decode."""
+    import tempfile
+    from transformers import GenerationConfig
+    from transformers.cache_utils import DynamicCache, EncoderDecoderCache
+    out = {}
+    tmp = tempfile.mkdtemp()
+    for mt, cfg, seed in (("roberta", R.ROBERTA_TINY, 231), ("bert", R.BERT_TINY, 241)):
+        sp = _specials(mt)
+        # ---- encoder
+        st = R.rand_state(R.text_model_shapes(cfg), seed)
+        d = R.write_proto_dir(os.path.join(tmp, mt + "_enc"), mt, cfg, st)
+        e = em.EncoderModel(AttrDict(proto=d))
+        e.encoder.config._attn_implementation = "eager"
+        B, L = 4, 20
+        ids, am = R.make_reports(B, L, cfg["vocab_size"], seed=seed, **sp)
+        e.train()
+        o = e(input_ids=ids, attention_mask=am, output_hidden_states=True)
+        g = torch.Generator().manual_seed(seed + 5)
+        wl, wp = torch.randn(o.last_hidden_state.shape, generator=g), torch.randn(o.pooler_output.shape, generator=g)
+        ((o.last_hidden_state * wl * am[..., None]).sum() + (o.pooler_output * wp).sum()).backward()
+        named = dict(e.encoder.named_parameters())
+        gn = ["embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight", "embeddings.token_type_embeddings.weight",
+              "embeddings.LayerNorm.weight", "encoder.layer.0.attention.self.query.weight", "encoder.layer.1.output.dense.weight", "pooler.dense.weight"]
+        out[mt + "_enc"] = dict(cfg=cfg, seed=seed, B=B, L=L, specials=sp, checksum=R.state_checksum(st), cls_name=type(e.encoder).__name__,
+                                last_hidden_state=o.last_hidden_state.detach(), pooler_output=o.pooler_output.detach(),
+                                hidden_states=torch.stack([h.detach() for h in o.hidden_states]),
+                                grads={n: _thin(named[n].grad) for n in gn})
+        # ---- decoder (non-degenerate decode recipe of G7)
+        recipe = dict(std=0.6, emb_std=0.2, qk_std=0.15, pos_std=0.6)
+        eos_bias = float(os.environ.get("G23_EOS", 2.5))     # (the head's LayerNorm bounds the logits: G7's 6.0 ends every row at once)
+        dst = R.rand_state(R.causal_lm_shapes(cfg, mt), seed + 1, **recipe)
+        bias_key = "lm_head.bias" if mt == "roberta" else "cls.predictions.bias"
+        dst[bias_key][sp["sep"]] += eos_bias
+        dd = R.write_proto_dir(os.path.join(tmp, mt + "_dec"), mt, cfg, dst)
+        dec = dm.DecoderModel(AttrDict(proto=dd))
+        hf = dec.decoder
+        hf.config._attn_implementation = "eager"
+        assert hf.config.is_decoder and hf.config.add_cross_attention
+        S = 10
+        g = torch.Generator().manual_seed(seed + 2)
+        enc = torch.randn(B, S, cfg["hidden_size"], generator=g)
+        enc_mask = torch.ones(B, S, dtype=torch.bool)
+        enc_mask[1, 7:] = False
+        enc[~enc_mask] = 0.0
+        enc = enc.requires_grad_(True)
+        dec.train()
+        o = dec(input_ids=ids, attention_mask=am, encoder_outputs=enc, encoder_attention_mask=enc_mask)
+        o["loss"].backward()
+        named = dict(hf.named_parameters())
+        base = mt + "."
+        head = ["lm_head.dense.weight", "lm_head.layer_norm.weight", "lm_head.bias"] if mt == "roberta" else \
+            ["cls.predictions.transform.dense.weight", "cls.predictions.transform.LayerNorm.weight", "cls.predictions.bias"]
+        gn = [base + "embeddings.word_embeddings.weight", base + "embeddings.position_embeddings.weight", base + "embeddings.token_type_embeddings.weight",
+              base + "encoder.layer.0.crossattention.self.key.weight", base + "encoder.layer.1.intermediate.dense.weight"] + head
+        res = dict(cfg=cfg, seed=seed + 1, B=B, L=L, S=S, specials=sp, recipe=recipe, eos_bias=eos_bias, checksum=R.state_checksum(dst),
+                   cls_name=type(hf).__name__, enc_mask=enc_mask, loss=o["loss"].detach(), logits=o["logits"].detach(),
+                   grads={n: _thin(named[n].grad) for n in gn}, enc_grad=enc.grad.clone())
+        dec.eval()
+        max_len = 24
+        for nb in (1, 4):
+            args = dict(bos_token_id=sp["cls"], eos_token_id=sp["sep"], pad_token_id=sp["pad"], num_return_sequences=1, max_length=max_len,
+                        use_cache=True, num_beams=nb, length_penalty=1.0, return_dict_in_generate=True, output_scores=True)
+            with torch.no_grad():
+                og = hf.generate(input_ids=torch.ones((B, 1), dtype=torch.long) * sp["cls"], generation_config=GenerationConfig(**args),
+                                 encoder_hidden_states=enc.detach(), encoder_attention_mask=enc_mask,
+                                 past_key_values=EncoderDecoderCache(DynamicCache(config=hf.config), DynamicCache(config=hf.config)))
+            res[f"beams{nb}"] = dict(sequences=og.sequences, scores=getattr(og, "sequences_scores", None))
+            print(mt, "beams", nb, og.sequences.tolist())
+        res["max_len"] = max_len
+        out[mt + "_dec"] = res
+    save("g23_proto_towers", out)
+
+
+# ------------------------------------------------------------------ G24: DeiT through VisualEncoder and RRG_HF
+def gen_deit():
+    """``backbone: deit`` (visual_encoder.py:59-61: DeiTModel(DeiTConfig(**kwargs), add_pooling_layer=False)) through VisualEncoder.encode,
+    and the RRG_HF forward body on a VisionEncoderDecoderModel whose encoder is a DeiTModel (config/RRG/baseline-HF.yml:22)."""
+    import ast
+    from transformers import DeiTConfig, DeiTModel, VisionEncoderDecoderModel
+    cfg, seed, B = R.DEIT_TINY, 251, 3
+    enc = ve.VisualEncoder(backbone="deit", permute="no_permute", dropout_out=0.0, **cfg, attn_implementation="eager")
+    st = R.rand_state(R.deit_shapes(cfg), seed)
+    load_into(enc.model, st, vit_to_hf5)
+    enc.eval()
+    images = R.make_images(B, cfg["image_size"], seed=seed)
+    with torch.no_grad():
+        feats, mask = enc.encode(images)
+    res = dict(cfg=cfg, seed=seed, B=B, checksum=R.state_checksum(st), cls_name=type(enc.model).__name__, features=feats, mask=mask)
+    # RRG_HF.forward on a DeiT encoder (4-D images; same width as the decoder: no enc_to_dec_proj)
+    tree = ast.parse(open(REF + "models/rrg/RRG_HF.py").read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "RRG_HF"][0]
+    fn = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "forward"][0]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "RRG_HF.py", "exec"), ns)
+    dcfg, L = R.DEC_TINY, 14
+    deit = DeiTModel(DeiTConfig(**cfg, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, attn_implementation="eager"), add_pooling_layer=False)
+    load_into(deit, st, vit_to_hf5)
+    dec, dst = build_ref_decoder(dcfg, seed + 1)
+    model = VisionEncoderDecoderModel(encoder=deit, decoder=dec.decoder).eval()
+    if not hasattr(model.decoder.config, "cross_attention_hidden_size"):
+        model.decoder.config.cross_attention_hidden_size = None
+    assert not hasattr(model, "enc_to_dec_proj")
+    ids, am = R.make_reports(B, L, dcfg["vocab_size"], seed=seed)
+    with torch.no_grad():
+        o4 = ns["forward"](types.SimpleNamespace(model=model), ids, am, images)
+    res.update(dec_cfg=dcfg, L=L, dec_checksum=R.state_checksum(dst), loss4=o4["loss"].clone(), logits4=o4["logits"].clone())
+    save("g24_deit", res)
+
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs", "vicreg", "bleu", "vit_multi", "schedulers", "model_compositions", "scst_sampling", "rrg_hf", "gloria_model", "ensemble_decode"]
+    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs", "vicreg", "bleu", "vit_multi", "schedulers", "model_compositions", "scst_sampling", "rrg_hf", "gloria_model", "ensemble_decode", "proto_towers", "deit"]
     for w in which:
         globals()["gen_" + w]()

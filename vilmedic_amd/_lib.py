@@ -77,6 +77,11 @@ SIGNATURES = {
                               _I, _I, _I, _I, _I, _F, _I, _F, _U64, _P, _P, _P]),
     "vm_embedding_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "vm_embedding_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vm_embedding_fwd_ex": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "vm_embedding_bwd_ex": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "vm_gelu_bwd_bf16": (_I, [_P, _P, _P, _L, _P]),
+    "vm_vit_assemble_ex": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vm_vit_assemble_bwd_ex": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "vm_im2col_patches": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "vm_vit_assemble": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "vm_vit_assemble_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

@@ -64,6 +64,9 @@ class ParamArena:
                 p._vm_arena = self
                 p._vm_off = o
                 self.offsets[id(p)] = o
+        import weakref
+        lo = self.gflat.data_ptr()
+        weakref.finalize(self, ops.forget_range, lo, lo + self.gflat.numel() * 4)     # first-touch records die with the buffer they describe
         self._layout = layout
         self._views = {}
         self._version = -1

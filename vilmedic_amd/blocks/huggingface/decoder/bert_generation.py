@@ -85,6 +85,11 @@ class BertGenerationDecoder(nn.Module):
     def padded_vocab(self):
         return (self.config.vocab_size + 7) // 8 * 8
 
+    # (the names vilmedic_amd.generation reads; BertLMHeadModel / RobertaForCausalLM have a dense -> GELU -> LayerNorm transform here)
+    lm_bias = property(lambda self: self.lm_head.bias)
+    head_dense = None
+    head_ln = None
+
     def forward(self, input_ids=None, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None,
                 labels=None, return_logits=True, row_weight=None, banned=None, top_k=None, **kw):
         arena = arena_of(self)   # root the arena HERE (before the sub-module forward) so it covers lm_head.bias too

@@ -5,18 +5,21 @@ from .bert_generation import BertGenerationDecoder, decoder_config
 
 
 class DecoderModel(nn.Module):
-    """If ``proto`` is set the reference loads a pretrained HF checkpoint by name (needs network: unsupported
-    here, raises); otherwise builds a BertGenerationDecoder from the YAML dict with is_decoder +
-    add_cross_attention forced on (decoder_model.py:23-26)."""
+    """If ``proto`` is set: the reference's ``AutoModelForCausalLM.from_pretrained(proto, config=<is_decoder, add_cross_attention>)``
+    (decoder_model.py:17-21) -- a RobertaForCausalLM / BertLMHeadModel / BertGenerationDecoder on the HIP path, read from a local
+    checkpoint directory or the local HF cache (blocks/huggingface/pretrained.py; never downloads); the cross-attention blocks an
+    encoder checkpoint lacks are freshly initialised, as HF does.  Otherwise builds a BertGenerationDecoder from the YAML dict with
+    is_decoder + add_cross_attention forced on (decoder_model.py:23-26)."""
 
     def __init__(self, decoder, **kwargs):
         super().__init__()
         decoder = dict(decoder)
         proto = decoder.pop("proto", None)
         if proto is not None:
-            raise NotImplementedError(f"DecoderModel(proto={proto!r}): pretrained HF checkpoints cannot be fetched "
-                                      "(no network); build from a config dict (proto: null)")
-        self.decoder = BertGenerationDecoder(decoder_config(decoder))
+            from ..pretrained import auto_causal_lm
+            self.decoder = auto_causal_lm(proto)
+        else:
+            self.decoder = BertGenerationDecoder(decoder_config(decoder))
         self.generate = self.decoder.generate if hasattr(self.decoder, "generate") else None
         self.config = self.decoder.config
 

@@ -7,24 +7,29 @@ from ..decoder.bert_generation import BertGenerationEncoder
 
 
 class EncoderModel(nn.Module):
-    """``proto`` names a pretrained HF checkpoint in the reference (needs network -> unsupported here);
-    ``proto: null`` builds a random BertGenerationEncoder from the dict (bidirectional, no cross-attention) with an
-    optional BertPooler.  The output always carries ``pooler_output`` and supports both attribute and ``[...]`` access
-    (the reference sets it by ``setattr`` and reads it by key: SURVEY §2.1)."""
+    """``proto``: a pretrained checkpoint -- the reference's ``AutoModel.from_pretrained(proto)`` (encoder_model.py:19-22) -- built as a
+    BertModel / RobertaModel / BertGenerationEncoder on the HIP path from a local checkpoint directory or the local HF cache
+    (blocks/huggingface/pretrained.py; a hub name that is not cached raises: this package never downloads);
+    ``proto: null`` builds a random BertGenerationEncoder from the dict (bidirectional, no cross-attention).  ``add_pooling_layer`` puts
+    an extra BertPooler on top in both cases (encoder_model.py:28-29; "roberta already has a pooler layer").  The output always carries
+    ``pooler_output`` and supports both attribute and ``[...]`` access (the reference sets it by ``setattr`` and reads it by key:
+    SURVEY §2.1)."""
 
     def __init__(self, encoder, **kwargs):
         super().__init__()
         encoder = dict(encoder)
         proto = encoder.pop("proto", None)
-        if proto is not None:
-            raise NotImplementedError(f"EncoderModel(proto={proto!r}): pretrained HF checkpoints cannot be fetched "
-                                      "(no network); build from a config dict (proto: null)")
         add_pool = bool(encoder.pop("add_pooling_layer", False))
         encoder.pop("last_n_layers", None)
-        cfg = make_config(BERT_GEN_DEFAULTS, encoder)
-        cfg.is_decoder = False
-        cfg.add_cross_attention = False
-        self.encoder = BertGenerationEncoder(cfg)
+        if proto is not None:
+            from ..pretrained import auto_model
+            self.encoder = auto_model(proto)
+            cfg = self.encoder.config
+        else:
+            cfg = make_config(BERT_GEN_DEFAULTS, encoder)
+            cfg.is_decoder = False
+            cfg.add_cross_attention = False
+            self.encoder = BertGenerationEncoder(cfg)
         if add_pool:
             self.pooler = BertPooler(cfg)
 
@@ -34,7 +39,7 @@ class EncoderModel(nn.Module):
         out = self.encoder(input_ids=input_ids, attention_mask=attention_mask, output_hidden_states=bool(output_hidden_states))
         if hasattr(self, "pooler"):
             out.pooler_output = self.pooler(out.last_hidden_state, arena)
-        else:
+        elif getattr(out, "pooler_output", None) is None:
             out.pooler_output = out.last_hidden_state[:, 0].float()
         return out
 

@@ -21,7 +21,10 @@ def get_network(backbone, output_layer, pretrained, **kwargs):
     if "vit" in backbone.lower():
         kwargs = {k: v for k, v in kwargs.items() if k not in ("attn_implementation", "return_dict")}
         return ViTModel(make_config(VIT_DEFAULTS, kwargs))
-    if "deit" in backbone.lower() or "hfpoolformer" in backbone.lower() or "3d" in backbone.lower():
+    if "deit" in backbone.lower():                # visual_encoder.py:59-61: DeiTModel(DeiTConfig(**kwargs), add_pooling_layer=False)
+        kwargs = {k: v for k, v in kwargs.items() if k not in ("attn_implementation", "return_dict")}
+        return ViTModel(make_config(VIT_DEFAULTS, kwargs), distillation=True)
+    if "hfpoolformer" in backbone.lower() or "3d" in backbone.lower():
         raise NotImplementedError(f"backbone {backbone!r} is outside the MI355X hot path (SURVEY §8a)")
     return _cnn.build(backbone, output_layer, pretrained, **kwargs)
 

@@ -248,6 +248,116 @@ extern "C" int vm_embedding_bwd(const int64_t* ids, const void* d_out, float* d_
     return vm_check_launch("vm_embedding_bwd");
 }
 
+// ------------------------------------------------------------------ embeddings with explicit position ids and a token-type row
+// hf:models/bert/modeling_bert.py BertEmbeddings.forward (token_type_ids default to zeros: one constant row) and
+// hf:models/roberta/modeling_roberta.py:55-155 (position ids = cumsum(ids != pad) * (ids != pad) + pad, computed by the caller):
+//   out[row] = word[ids[row]] + pos[pos_ids ? pos_ids[row] : row % L + past_len] (+ type_row)
+template <typename OUT>
+__global__ __launch_bounds__(256) void embedding_fwd_ex_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ pos_ids,
+                                                               const float* __restrict__ word, const float* __restrict__ pos,
+                                                               const float* __restrict__ type_row, OUT* __restrict__ out,
+                                                               int rows, int L, int D, int past_len) {
+    const int lane = threadIdx.x & 63;
+    const int nch = D >> 3;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        const int64_t id = ids[row];
+        const int64_t t = pos_ids ? pos_ids[row] : (int64_t)(row % L + past_len);
+        const float* w = word + id * D;
+        const float* pp = pos + t * D;
+        for (int ch = lane; ch < nch; ch += 64) {
+            const float4 a0 = *reinterpret_cast<const float4*>(w + ch * 8), a1 = *reinterpret_cast<const float4*>(w + ch * 8 + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(pp + ch * 8), b1 = *reinterpret_cast<const float4*>(pp + ch * 8 + 4);
+            // (word + type) + pos: the order of hf's two additions
+            float f[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            if (type_row) {
+                const float4 c0 = *reinterpret_cast<const float4*>(type_row + ch * 8), c1 = *reinterpret_cast<const float4*>(type_row + ch * 8 + 4);
+                f[0] += c0.x; f[1] += c0.y; f[2] += c0.z; f[3] += c0.w; f[4] += c1.x; f[5] += c1.y; f[6] += c1.z; f[7] += c1.w;
+            }
+            f[0] += b0.x; f[1] += b0.y; f[2] += b0.z; f[3] += b0.w; f[4] += b1.x; f[5] += b1.y; f[6] += b1.z; f[7] += b1.w;
+            if constexpr (sizeof(OUT) == 2) {
+                *reinterpret_cast<uint4*>(out + (int64_t)row * D + ch * 8) = pack8(f);
+            } else {
+                *reinterpret_cast<float4*>(out + (int64_t)row * D + ch * 8) = make_float4(f[0], f[1], f[2], f[3]);
+                *reinterpret_cast<float4*>(out + (int64_t)row * D + ch * 8 + 4) = make_float4(f[4], f[5], f[6], f[7]);
+            }
+        }
+    }
+}
+// backward: one block per (column t of ids, column half) as embedding_bwd_kernel.  Rows whose position id is the regular one of the
+// column (t + pos_offset: every non-pad token of a right-padded batch) are summed in registers; the others go to d_pos one atomic at a time.
+// Every write to d_pos / d_type is an atomic add (another column's irregular row may target the same element).  Rows with
+// id == padding_idx get no word gradient and position pos_padding_idx gets no position gradient (nn.Embedding(padding_idx=...)).
+__global__ __launch_bounds__(256) void embedding_bwd_ex_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ pos_ids,
+                                                               const bf16_t* __restrict__ d_out, float* __restrict__ d_word,
+                                                               float* __restrict__ d_pos, float* __restrict__ d_type,
+                                                               int B, int L, int D, int padding_idx, int pos_offset, int pos_padding_idx) {
+    const int t = blockIdx.x;
+    const int half = D >> 1;
+    const int per = (half + gridDim.y - 1) / gridDim.y;
+    const int p_lo = blockIdx.y * per, p_hi = min(half, p_lo + per);
+    const int64_t regular = (int64_t)t + pos_offset;
+    for (int cp = p_lo + threadIdx.x; cp < p_hi; cp += 256) {
+        float a0 = 0.f, a1 = 0.f, s0 = 0.f, s1 = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const int64_t row = (int64_t)b * L + t;
+            const int64_t id = ids[row];
+            const int64_t pid = pos_ids ? pos_ids[row] : regular;
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(d_out + row * D + 2 * cp);
+            const float lo = __uint_as_float(v << 16), hi = __uint_as_float(v & 0xffff0000u);
+            s0 += lo; s1 += hi;
+            if (pid == regular) { a0 += lo; a1 += hi; }
+            else if (pid != pos_padding_idx) { atomicAdd(d_pos + pid * D + 2 * cp, lo); atomicAdd(d_pos + pid * D + 2 * cp + 1, hi); }
+            if (id != padding_idx) { atomicAdd(d_word + id * D + 2 * cp, lo); atomicAdd(d_word + id * D + 2 * cp + 1, hi); }
+        }
+        if (regular != pos_padding_idx) { atomicAdd(d_pos + regular * D + 2 * cp, a0); atomicAdd(d_pos + regular * D + 2 * cp + 1, a1); }
+        if (d_type) { atomicAdd(d_type + 2 * cp, s0); atomicAdd(d_type + 2 * cp + 1, s1); }
+    }
+}
+extern "C" int vm_embedding_fwd_ex(const int64_t* ids, const int64_t* pos_ids, const float* word, const float* pos, const float* type_row,
+                                   void* out, int out_dtype, int B, int L, int D, int past_len, void* stream) {
+    VM_REQUIRE(ids && word && pos && out && B > 0 && L > 0 && D > 0 && (D % 8) == 0 && (out_dtype == VM_BF16 || out_dtype == VM_F32),
+               "vm_embedding_fwd_ex: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    VmProfScope prof(VM_FAM_ELT, 10.0 * B * L * (double)D, s);
+    if (out_dtype == VM_BF16)
+        hipLaunchKernelGGL(embedding_fwd_ex_kernel<bf16_t>, dim3(grid_for(B * L, 4)), dim3(256), 0, s, ids, pos_ids, word, pos, type_row, (bf16_t*)out, B * L, L, D, past_len);
+    else
+        hipLaunchKernelGGL(embedding_fwd_ex_kernel<float>, dim3(grid_for(B * L, 4)), dim3(256), 0, s, ids, pos_ids, word, pos, type_row, (float*)out, B * L, L, D, past_len);
+    return vm_check_launch("vm_embedding_fwd_ex");
+}
+extern "C" int vm_embedding_bwd_ex(const int64_t* ids, const int64_t* pos_ids, const void* d_out, float* d_word, float* d_pos, float* d_type,
+                                   int B, int L, int D, int padding_idx, int pos_offset, int pos_padding_idx, void* stream) {
+    VM_REQUIRE(ids && d_out && d_word && d_pos && B > 0 && L > 0 && D > 0 && (D % 8) == 0, "vm_embedding_bwd_ex: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    VmProfScope prof(VM_FAM_ELT, 10.0 * B * L * (double)D, s);
+    const int ysplit = (D / 2 + 255) / 256 > 1 ? 2 : 1;
+    hipLaunchKernelGGL(embedding_bwd_ex_kernel, dim3(L, ysplit), dim3(256), 0, s, ids, pos_ids, (const bf16_t*)d_out, d_word, d_pos, d_type, B, L, D,
+                       padding_idx, pos_offset, pos_padding_idx);
+    return vm_check_launch("vm_embedding_bwd_ex");
+}
+
+// ------------------------------------------------------------------ erf-GELU backward as an elementwise pass: dz = dy * gelu'(z)
+// (the LM-head transform of BERT / RoBERTa: dense -> GELU -> LayerNorm, hf:models/roberta/modeling_roberta.py RobertaLMHead; inside the
+// MLP block the same product rides in the FC2 dgrad epilogue instead, vm_gemm_epilogue.mul_gelu_z)
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ z, bf16_t* __restrict__ dz, int64_t n) {
+    const int64_t nvec = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        float a[8], b[8];
+        unpack8(*reinterpret_cast<const uint4*>(dy + i * 8), a);
+        unpack8(*reinterpret_cast<const uint4*>(z + i * 8), b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] *= gelu_grad_f(b[j]);
+        *reinterpret_cast<uint4*>(dz + i * 8) = pack8(a);
+    }
+}
+extern "C" int vm_gelu_bwd_bf16(const void* dy, const void* z, void* dz, int64_t n, void* stream) {
+    VM_REQUIRE(dy && z && dz && n > 0 && (n % 8) == 0, "vm_gelu_bwd_bf16: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    VmProfScope prof(VM_FAM_ELT, 6.0 * n, s);
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)z, (bf16_t*)dz, n);
+    return vm_check_launch("vm_gelu_bwd_bf16");
+}
+
 // ------------------------------------------------------------------ ViT patches
 // out[(b*gh+py)*gw+px][c*p*p + ph*p + pw] = images[b][c][py*p+ph][px*p+pw]   (p % 8 == 0)
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int B, int C, int H, int W, int p) {
@@ -272,37 +382,38 @@ extern "C" int vm_im2col_patches(const float* images, void* out, int B, int C, i
     return vm_check_launch("vm_im2col_patches");
 }
 
+// ns special tokens in front of the n patches (ViT: [CLS]; DeiT: [CLS], distillation -- hf:models/deit/modeling_deit.py DeiTEmbeddings.forward)
 __global__ __launch_bounds__(256) void vit_assemble_kernel(const bf16_t* __restrict__ patches, const float* __restrict__ cls,
-                                                           const float* __restrict__ pos, bf16_t* __restrict__ out, int B, int n, int D) {
+                                                           const float* __restrict__ pos, bf16_t* __restrict__ out, int B, int n, int ns, int D) {
     const int nch = D >> 3;
-    const int64_t total = (int64_t)B * (n + 1) * nch;
+    const int64_t total = (int64_t)B * (n + ns) * nch;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int ch = (int)(i % nch);
         const int64_t row = i / nch;
-        const int t = (int)(row % (n + 1)), b = (int)(row / (n + 1));
+        const int t = (int)(row % (n + ns)), b = (int)(row / (n + ns));
         float f[8];
-        if (t == 0) {
+        if (t < ns) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = cls[ch * 8 + j];
+            for (int j = 0; j < 8; ++j) f[j] = cls[(int64_t)t * D + ch * 8 + j];
         } else {
-            unpack8(*reinterpret_cast<const uint4*>(patches + ((int64_t)b * n + t - 1) * D + ch * 8), f);
+            unpack8(*reinterpret_cast<const uint4*>(patches + ((int64_t)b * n + t - ns) * D + ch * 8), f);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] += pos[(int64_t)t * D + ch * 8 + j];
         *reinterpret_cast<uint4*>(out + row * D + ch * 8) = pack8(f);
     }
 }
-// d_patches = d_out[:,1:];  d_pos[t] += sum_b d_out[b,t];  d_cls += sum_b d_out[b,0]
+// d_patches = d_out[:,ns:];  d_pos[t] += sum_b d_out[b,t];  d_cls[t] += sum_b d_out[b,t] for t < ns
 __global__ __launch_bounds__(256) void vit_assemble_bwd_kernel(const bf16_t* __restrict__ d_out, bf16_t* __restrict__ d_patches,
-                                                               float* __restrict__ d_cls, float* __restrict__ d_pos, int B, int n, int D) {
+                                                               float* __restrict__ d_cls, float* __restrict__ d_pos, int B, int n, int ns, int D) {
     const int nch = D >> 3;
-    const int64_t total = (int64_t)(n + 1) * nch;
+    const int64_t total = (int64_t)(n + ns) * nch;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int ch = (int)(i % nch), t = (int)(i / nch);
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int b = 0; b < B; ++b) {
-            const uint4 raw = *reinterpret_cast<const uint4*>(d_out + ((int64_t)b * (n + 1) + t) * D + ch * 8);
-            if (t > 0) *reinterpret_cast<uint4*>(d_patches + ((int64_t)b * n + t - 1) * D + ch * 8) = raw;
+            const uint4 raw = *reinterpret_cast<const uint4*>(d_out + ((int64_t)b * (n + ns) + t) * D + ch * 8);
+            if (t >= ns) *reinterpret_cast<uint4*>(d_patches + ((int64_t)b * n + t - ns) * D + ch * 8) = raw;
             float f[8];
             unpack8(raw, f);
 #pragma unroll
@@ -311,23 +422,29 @@ __global__ __launch_bounds__(256) void vit_assemble_bwd_kernel(const bf16_t* __r
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             d_pos[(int64_t)t * D + ch * 8 + j] += acc[j];
-            if (t == 0) d_cls[ch * 8 + j] += acc[j];
+            if (t < ns) d_cls[(int64_t)t * D + ch * 8 + j] += acc[j];
         }
     }
 }
-extern "C" int vm_vit_assemble(const void* patches, const float* cls, const float* pos, void* out, int B, int n, int D, void* stream) {
-    VM_REQUIRE(patches && cls && pos && out && B > 0 && n > 0 && D > 0 && (D % 8) == 0, "vm_vit_assemble: bad arguments");
+extern "C" int vm_vit_assemble_ex(const void* patches, const float* special, const float* pos, void* out, int B, int n, int ns, int D, void* stream) {
+    VM_REQUIRE(patches && special && pos && out && B > 0 && n > 0 && ns >= 1 && ns <= 4 && D > 0 && (D % 8) == 0, "vm_vit_assemble_ex: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    VmProfScope prof(VM_FAM_ELT, 4.0 * B * (n + 1) * (double)D, s);
-    hipLaunchKernelGGL(vit_assemble_kernel, dim3(grid_for((int64_t)B * (n + 1) * D / 8)), dim3(256), 0, s, (const bf16_t*)patches, cls, pos, (bf16_t*)out, B, n, D);
+    VmProfScope prof(VM_FAM_ELT, 4.0 * B * (n + ns) * (double)D, s);
+    hipLaunchKernelGGL(vit_assemble_kernel, dim3(grid_for((int64_t)B * (n + ns) * D / 8)), dim3(256), 0, s, (const bf16_t*)patches, special, pos, (bf16_t*)out, B, n, ns, D);
     return vm_check_launch("vm_vit_assemble");
 }
-extern "C" int vm_vit_assemble_bwd(const void* d_out, void* d_patches, float* d_cls, float* d_pos, int B, int n, int D, void* stream) {
-    VM_REQUIRE(d_out && d_patches && d_cls && d_pos && B > 0 && n > 0 && D > 0 && (D % 8) == 0, "vm_vit_assemble_bwd: bad arguments");
+extern "C" int vm_vit_assemble_bwd_ex(const void* d_out, void* d_patches, float* d_special, float* d_pos, int B, int n, int ns, int D, void* stream) {
+    VM_REQUIRE(d_out && d_patches && d_special && d_pos && B > 0 && n > 0 && ns >= 1 && ns <= 4 && D > 0 && (D % 8) == 0, "vm_vit_assemble_bwd_ex: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    VmProfScope prof(VM_FAM_ELT, 4.0 * B * (n + 1) * (double)D, s);
-    hipLaunchKernelGGL(vit_assemble_bwd_kernel, dim3(grid_for((int64_t)(n + 1) * D / 8)), dim3(256), 0, s, (const bf16_t*)d_out, (bf16_t*)d_patches, d_cls, d_pos, B, n, D);
+    VmProfScope prof(VM_FAM_ELT, 4.0 * B * (n + ns) * (double)D, s);
+    hipLaunchKernelGGL(vit_assemble_bwd_kernel, dim3(grid_for((int64_t)(n + ns) * D / 8)), dim3(256), 0, s, (const bf16_t*)d_out, (bf16_t*)d_patches, d_special, d_pos, B, n, ns, D);
     return vm_check_launch("vm_vit_assemble_bwd");
+}
+extern "C" int vm_vit_assemble(const void* patches, const float* cls, const float* pos, void* out, int B, int n, int D, void* stream) {
+    return vm_vit_assemble_ex(patches, cls, pos, out, B, n, 1, D, stream);
+}
+extern "C" int vm_vit_assemble_bwd(const void* d_out, void* d_patches, float* d_cls, float* d_pos, int B, int n, int D, void* stream) {
+    return vm_vit_assemble_bwd_ex(d_out, d_patches, d_cls, d_pos, B, n, 1, D, stream);
 }
 
 // ------------------------------------------------------------------ dropout mask re-application (backward of the

@@ -318,6 +318,7 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
             if (mf < 5 || mf > 8) {      // rounds of the 256 CUs x rows per tile, ties to the larger tile
                 int64_t best = -1;
                 for (int m = 8; m >= 5; --m) {
+                    if (p8_auto && (M % (32 * m)) != 0) continue;   // the automatic choice never takes a ragged last row tile (the gate above admits M % 256 == 0: m = 8 always qualifies)
                     const int64_t t = (int64_t)((M + 32 * m - 1) / (32 * m)) * ((N + 255) / 256) * split;
                     const int64_t cost = (t + 255) / 256 * m;
                     if (best < 0 || cost < best) { best = cost; mf = m; }

@@ -54,14 +54,17 @@ class Trainor(object):
             import torch.distributed as dist
             from ..arena import arena_of
             from ..parallel import ArenaDDP
-            wire = torch.empty(arena_of(self.model).numel, dtype=torch.bfloat16, device=torch.device("cuda", self.local_rank))
+            from ..parallel import default_bf16_wire
+            # trainor.ddp_wire: "fp32" (default: the exact mean, all-reduced in place on the gradient arena) or "bf16" (half the bytes over
+            # xGMI, one rounding per gradient; also VM_DDP_WIRE=bf16)
+            bf16_wire = (str(config.get("ddp_wire")) == "bf16") if config.get("ddp_wire") else default_bf16_wire()
+            wire = torch.empty(arena_of(self.model).numel, dtype=torch.bfloat16, device=torch.device("cuda", self.local_rank)) if bf16_wire else None
             if not dist.is_initialized():
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 os.environ.setdefault("MASTER_PORT", "29534")
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local_rank))
             self.dist = dist
-            # trainor.ddp_wire: "bf16" (default: half the bytes over xGMI, one rounding per gradient) or "fp32" (exact mean)
-            self.ddp = ArenaDDP(self.model, self.dist, wire=wire, bf16_wire=str(config.get("ddp_wire") or "bf16") != "fp32")
+            self.ddp = ArenaDDP(self.model, self.dist, wire=wire, bf16_wire=bf16_wire)
         self.training_scheduler = create_training_scheduler(config, self.optimizer, self.logger, state_dict=self.state)
         self.saver = CheckpointSaver(self.ckpt_dir, self.logger, seed, ckpt=config.get("ckpt"))
         self.grad_accu = int(config.get("grad_accu") or 1)
@@ -79,7 +82,10 @@ class Trainor(object):
         self.graph_step = graphable and self.ddp is None and hasattr(self.model, "graphed_step")
         # ... and every other model has its whole iteration (forward, backward, fused Adam with the device-side NaN gate) captured per batch
         # shape by vilmedic_amd.graph.GraphedTrainStep: the host enqueues one graph launch per iteration, the rate no longer depends on it
-        self.graph_any = graphable and not self.graph_step
+        # (a model that brings its own captured step -- RRG_SCST: host-side rewards inside forward -- cannot be captured whole; under data
+        # parallelism, where its graphed_step is not used, it runs eagerly instead of wasting two warm-up iterations per batch signature
+        # on a capture that must fail)
+        self.graph_any = graphable and not self.graph_step and not hasattr(self.model, "graphed_step")
         self._graphs = {}
         self.max_graphs = int(config.get("graph_cache") or 8)     # captured batch signatures kept (each owns its activation pool)
         self.eval_start = int(config.get("eval_start") or 0)

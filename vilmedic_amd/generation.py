@@ -102,6 +102,9 @@ class DecodeState:
         self.T = max_length
         self.D = cfg.hidden_size
         self.H = cfg.num_attention_heads
+        if self.D // self.H not in ops.HEAD_DIMS:
+            raise NotImplementedError(f"the cached decode step needs head_dim in {ops.HEAD_DIMS} (got {self.D // self.H}: such heads train through "
+                                      "the zero-padded path of ops._attention_padded_heads, which the KV-cache kernels do not have)")
         dev = enc.device
         self.S = enc.shape[1]
         self.layers = decoder.bert.encoder.layer
@@ -120,6 +123,13 @@ class DecodeState:
         self.buf_h = torch.empty(self.M, ff, dtype=self.act, device=dev)
         self.buf_stat = torch.empty(2 * self.M, dtype=torch.float32, device=dev)
         self.graphs = {}
+        # BERT / RoBERTa decoders (blocks/huggingface/bert_models.py): the token-type row rides in a derived position table, and HF's
+        # generate() numbers the positions 0, 1, 2, ... for them too -- it builds ``position_ids`` from the attention mask because their
+        # forward accepts that argument (hf:generation/utils.py _prepare_position_ids_for_generation), which overrides RoBERTa's
+        # pad-offset numbering of the training forward.  Reproduced as is: the reference decodes through that call.
+        self.pos_table = None
+        if hasattr(decoder.bert.embeddings, "token_type_embeddings"):
+            self.pos_table = torch.empty_like(decoder.bert.embeddings.position_embeddings.weight)
         self.load_encoder(enc, enc_mask)
 
     def load_encoder(self, enc, enc_mask):
@@ -127,6 +137,10 @@ class DecodeState:
         beams of a sample), reset the row-index table.  Buffers keep their addresses, so captured graphs stay valid."""
         a = self.arena
         a.refresh()
+        if self.pos_table is not None:
+            e = self.dec.bert.embeddings
+            with torch.no_grad():
+                torch.add(e.position_embeddings.weight, e.token_type_embeddings.weight[0], out=self.pos_table)
         enc = enc.to(self.act).contiguous()
         enc2 = enc.view(self.B * self.S, enc.shape[2])
         if self.enc_mask is not None:
@@ -246,7 +260,8 @@ class DecodeState:
         emb = self.dec.bert.embeddings
         s, x, q = self.buf_s, self.buf_x, self.buf_q
         fn = lib().vm_embedding_fwd_f32 if self.f32 else lib().vm_embedding_fwd
-        check(fn(ptr(tokens.contiguous()), ptr(emb.word_embeddings.weight), ptr(emb.position_embeddings.weight), ptr(s), M, 1, D, t, stream()),
+        pos = self.pos_table if self.pos_table is not None else emb.position_embeddings.weight
+        check(fn(ptr(tokens.contiguous()), ptr(emb.word_embeddings.weight), ptr(pos), ptr(s), M, 1, D, t, stream()),
               "vm_embedding_fwd")
         ln = emb.LayerNorm                       # the LayerNorm that turns the running pre-LN sum ``s`` into the next sub-layer's input
         for li, layer in enumerate(self.layers):
@@ -280,14 +295,22 @@ class DecodeState:
             self._dgl(s, blk.LayerNorm, x, self._w([i.weight]), h, M, F, D, bias=i.bias, act=1)
             self._dg(h, self._w([o.weight]), s, M, D, F, bias=o.bias, residual=x)
             ln = layer.output.LayerNorm
+        hd, hl = self.dec.head_dense, self.dec.head_ln          # LM-head transform of BERT / RoBERTa decoders: dense -> GELU -> LayerNorm
         if self.f32:
             xl = _ln32(s, ln, cfg.layer_norm_eps)
+            if hd is not None:
+                self._dg(xl, self._w([hd.weight]), q, M, D, D, bias=hd.bias, act=1)
+                xl = _ln32(q, hl, cfg.layer_norm_eps)
             V = self.V
             logits = torch.empty(M, (V + 3) // 4 * 4, dtype=F32, device=s.device)
             # (the decode GEMM's 64-row blocks: 128- / 256-row blocks measured 285 us for this product at 256 rows)
-            self._dg(xl, emb.word_embeddings.weight, logits, M, V, D, bias=self.dec.lm_head.bias)
+            self._dg(xl, emb.word_embeddings.weight, logits, M, V, D, bias=self.dec.lm_bias)
             return logits[:, :V]
-        return ops.lm_logits_f32(_ln(s, ln, cfg.layer_norm_eps), self.emb_sh, self.dec.lm_head.bias, self.V)
+        xl = _ln(s, ln, cfg.layer_norm_eps)
+        if hd is not None:
+            self._dg(xl, self._w([hd.weight]), q, M, D, D, bias=hd.bias, act=1)
+            xl = _ln(q, hl, cfg.layer_norm_eps)
+        return ops.lm_logits_f32(xl, self.emb_sh, self.dec.lm_bias, self.V)
 
 
 class EnsembleState:
@@ -416,23 +439,19 @@ def sample(decoder, input_ids, enc, enc_mask, *, max_length, eos_token_id, pad_t
             cur += 1
             if cur % 8 == 0 and not bool(unf.any()):           # host sync only every 8 steps; trimmed exactly below
                 break
+    # The one selection kernel covers every call the reference makes (greedy; multinomial sampling with bad_words [[pad],[bos]] and an optional
+    # top_k: ref:blocks/rl/SCST.py:142-157).  What it does not return is the per-step score tensors: ``output_scores`` (and a greedy call
+    # with bad words) takes the loop below -- arg-max over the processed fp32 logits with the same library kernels (vm_argmax_f32), one
+    # launch more per step.  There is no torch-sampling twin of the kernel: sampling outside the kernel's domain raises.
+    if not fused and do_sample:
+        raise NotImplementedError("sampling runs in vm_select_tokens: at most 4 single-token bad words, top_k <= 256, no output_scores "
+                                  f"(got {len(bad)} bad words, top_k={top_k}, output_scores={output_scores})")
     unfinished = torch.ones(B, dtype=torch.bool, device=dev)
     while not fused and cur < max_length:
         logits = st.step(seq[:, cur - 1], cur - 1)
-        if do_sample and greedy_rows:
-            g = int(greedy_rows)
-            nxt = torch.empty(B, dtype=torch.long, device=dev)
-            nxt[:g] = argmax_f32(logits[:g].contiguous())
-            probs = torch.softmax(_process(logits[g:].clone(), bad, top_k), dim=-1)
-            nxt[g:] = torch.multinomial(probs, 1, generator=generator).squeeze(1)
-        else:
-            if do_sample or bad or output_scores:
-                logits = _process(logits.clone(), bad, top_k)
-            if do_sample:
-                probs = torch.softmax(logits, dim=-1)
-                nxt = torch.multinomial(probs, 1, generator=generator).squeeze(1)
-            else:
-                nxt = argmax_f32(logits.contiguous())
+        if bad or output_scores:
+            logits = _process(logits.clone(), bad, None)
+        nxt = argmax_f32(logits.contiguous())
         if output_scores:
             scores.append(logits)
         nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad_token_id))

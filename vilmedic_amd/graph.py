@@ -52,8 +52,18 @@ class GraphedTrainStep:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             steps0 = getattr(self.optimizer, "steps", None)
-            with ops.capture(g):
-                self._one()
+            try:
+                with ops.capture(g):
+                    self._one()
+            except BaseException:
+                # an aborted capture leaves host-side state behind that points into the dead capture: queued weight-gradient / LayerNorm
+                # reduce items (tensors of the aborted graph's pool), a pending side-stream join, gradient buffers already marked clean.
+                # Drop all of it, so that the eager iteration that follows starts from a clean slate (its first weight gradients then
+                # accumulate into freshly zeroed buffers instead of flushing stale queue entries with overwrite = 1)
+                ops.reset_host_state()
+                if steps0 is not None:
+                    self.optimizer.steps = steps0
+                raise
             if steps0 is not None:
                 self.optimizer.steps = steps0      # capturing is not a step
             self.graph = g                # (the capture itself executed nothing: this call's step is the replay below)

@@ -5,8 +5,9 @@ same forward (single 4-D image batch -> encoder_attention_mask=None, RRG_HF.py:1
 from ``images_mask``, :143), same parameter names as ``VisionEncoderDecoderModel`` (``model.encoder.*`` incl. the ViT
 pooler the HF class creates by default, ``model.decoder.bert.*`` / ``lm_head.*``, ``model.enc_to_dec_proj.*`` when the
 hidden sizes differ, :137-140), returning ``vars(decoder_outputs)``.  Built on the HIP path: vilmedic_amd.nn.ViTModel +
-BertGenerationDecoder.  Class lookup by HF mapping name is restricted to the two architectures of the hot path
-(``vit`` / ``bert-generation``); pretrained names (strings) need a download and raise."""
+BertGenerationDecoder.  Class lookup by HF mapping name is restricted to the architectures of the hot path
+(``vit`` / ``deit`` encoders -- both shipped RRG_HF YAMLs name ``deit``, ref:config/RRG/baseline-HF.yml:22 -- and the
+``bert-generation`` decoder); pretrained names (strings) need a download and raise."""
 import torch
 import torch.nn as nn
 
@@ -19,11 +20,11 @@ from ..utils import get_n_params
 
 
 class _ViTWithPooler(ViTModel):
-    """HF ``ViTModel(config)`` (add_pooling_layer=True): the pooler exists in the state dict but the encoder-decoder path
-    only reads ``last_hidden_state``."""
+    """HF ``ViTModel(config)`` / ``DeiTModel(config)`` (add_pooling_layer=True): the pooler exists in the state dict but the
+    encoder-decoder path only reads ``last_hidden_state``."""
 
-    def __init__(self, cfg):
-        super().__init__(cfg)
+    def __init__(self, cfg, distillation=False):
+        super().__init__(cfg, distillation=distillation)
         self.pooler = BertPooler(cfg)
 
 
@@ -48,10 +49,11 @@ class RRG_HF(nn.Module):
                                       "`decoder` as config dicts (proto_model / proto_config / proto_config_args)")
         vision, decoder = dict(vision), dict(decoder)
         assert "proto_model" in vision and "proto_config" in vision
-        if vision.pop("proto_model") != "vit" or vision.pop("proto_config") != "vit":
-            raise NotImplementedError("RRG_HF on the HIP path supports vision proto_model / proto_config 'vit'")
+        pm, pc = vision.pop("proto_model"), vision.pop("proto_config")
+        if pm != pc or pm not in ("vit", "deit"):
+            raise NotImplementedError("RRG_HF on the HIP path supports vision proto_model / proto_config 'vit' and 'deit'")
         enc_args = dict(vision.pop("proto_config_args", None) or {})
-        encoder = _ViTWithPooler(make_config(VIT_DEFAULTS, enc_args))
+        encoder = _ViTWithPooler(make_config(VIT_DEFAULTS, enc_args), distillation=(pm == "deit"))
         assert "proto_model" in decoder and "proto_config" in decoder
         if decoder.pop("proto_model") != "bert-generation" or decoder.pop("proto_config") != "bert-generation":
             raise NotImplementedError("RRG_HF on the HIP path supports decoder proto_model / proto_config 'bert-generation'")

@@ -46,9 +46,10 @@ def make_config(defaults, kwargs):
     cfg.update({k: v for k, v in dict(kwargs).items()})
     if cfg.hidden_act not in ("gelu",):
         raise ValueError(f"hidden_act={cfg.hidden_act!r} unsupported by the HIP path (erf-GELU only)")
-    if cfg.hidden_size % cfg.num_attention_heads or cfg.hidden_size // cfg.num_attention_heads not in (32, 64, 96, 128):
-        raise ValueError("the HIP attention kernels need head_dim in {32, 64, 96, 128} "
-                         f"(hidden_size={cfg.hidden_size}, heads={cfg.num_attention_heads})")
+    dh = cfg.hidden_size // cfg.num_attention_heads
+    if cfg.hidden_size % cfg.num_attention_heads or dh % 8 or dh > 128:
+        raise ValueError("the HIP attention kernels need head_dim to be a multiple of 8, at most 128 (32 / 64 / 96 / 128 run natively, other "
+                         f"widths zero-padded per head: ops._attention_padded_heads); got hidden_size={cfg.hidden_size}, heads={cfg.num_attention_heads}")
     return cfg
 
 
@@ -135,17 +136,33 @@ class ViTLayer(nn.Module):
                        grads=(arena.grad(i.weight), arena.grad(i.bias), arena.grad(o.weight), arena.grad(o.bias)), anchor=i.weight)
 
 
-class ViTModel(nn.Module):
-    """HF ViTModel(add_pooling_layer=False): forward(images fp32 [B,C,H,W]) -> last_hidden_state bf16 [B,1+n,D]."""
+class _ViTEmbeddings(nn.Module):
+    def arena_groups(self):
+        """DeiT: [CLS] and the distillation token adjacent in the arena -- one [2, D] operand of the assemble kernel"""
+        if hasattr(self, "distillation_token"):
+            return [[self.cls_token, self.distillation_token]]
+        return []
 
-    def __init__(self, cfg):
+
+class ViTModel(nn.Module):
+    """HF ViTModel(add_pooling_layer=False): forward(images fp32 [B,C,H,W]) -> last_hidden_state bf16 [B,1+n,D].
+    ``distillation=True``: HF DeiTModel (hf:models/deit/modeling_deit.py) -- the same pre-LN stack with a second special token
+    (``embeddings.distillation_token``) and ``n + 2`` position embeddings (ref:vilmedic/blocks/vision/visual_encoder.py:59-61)."""
+
+    def __init__(self, cfg, distillation=False):
         super().__init__()
         self.config = cfg
         d, p, c, s = cfg.hidden_size, cfg.patch_size, cfg.num_channels, cfg.initializer_range
         n = (cfg.image_size // p) ** 2
-        self.embeddings = _Holder()
-        self.embeddings.cls_token = nn.Parameter(torch.nn.init.trunc_normal_(torch.empty(1, 1, d), std=s))
-        self.embeddings.position_embeddings = nn.Parameter(torch.nn.init.trunc_normal_(torch.empty(1, n + 1, d), std=s))
+        self.n_special = 2 if distillation else 1
+        self.embeddings = _ViTEmbeddings()
+        if distillation:            # hf DeiTEmbeddings: zeros (not trunc_normal) for the three embedding parameters
+            self.embeddings.cls_token = nn.Parameter(torch.zeros(1, 1, d))
+            self.embeddings.distillation_token = nn.Parameter(torch.zeros(1, 1, d))
+            self.embeddings.position_embeddings = nn.Parameter(torch.zeros(1, n + 2, d))
+        else:
+            self.embeddings.cls_token = nn.Parameter(torch.nn.init.trunc_normal_(torch.empty(1, 1, d), std=s))
+            self.embeddings.position_embeddings = nn.Parameter(torch.nn.init.trunc_normal_(torch.empty(1, n + 1, d), std=s))
         self.embeddings.patch_embeddings = _Holder()
         self.embeddings.patch_embeddings.projection = Affine(d, c, p, p, std=s)
         self.encoder = _Holder()
@@ -162,10 +179,11 @@ class ViTModel(nn.Module):
         e = self.embeddings
         proj = e.patch_embeddings.projection
         images = images.contiguous().float()
+        special = [e.cls_token, e.distillation_token] if self.n_special == 2 else [e.cls_token]
         x = ops.patch_embed(proj.weight, images, arena.shadow(proj.weight).view(cfg.hidden_size, -1), proj.bias,
-                            e.cls_token.view(-1), e.position_embeddings.view(-1, cfg.hidden_size), cfg.patch_size,
-                            grads=(arena.grad(proj.weight), arena.grad(proj.bias), _flat(arena.grad(e.cls_token)),
-                                   _flat2(arena.grad(e.position_embeddings), cfg.hidden_size)))
+                            arena.f32_group(special).view(-1), e.position_embeddings.view(-1, cfg.hidden_size), cfg.patch_size,
+                            grads=(arena.grad(proj.weight), arena.grad(proj.bias), _flat(arena.grad_group(special)),
+                                   _flat2(arena.grad(e.position_embeddings), cfg.hidden_size)), ns=self.n_special)
         for i, layer in enumerate(self.encoder.layer):
             if i:
                 x = ops.backward_mark(x, ("enc_layer", i))      # data parallel: the gradients of layers >= i can be reduced from here on
@@ -330,6 +348,54 @@ class BertEmbeddings(nn.Module):
             raise ValueError("sequence longer than max_position_embeddings")
         x = ops.embedding(we, ids, we, pe, past_len=past_len, padding_idx=cfg.pad_token_id,
                           g_word=arena.grad(we), g_pos=arena.grad(pe))
+        x = _ln(arena, x, self.LayerNorm, cfg.layer_norm_eps)
+        drop = cfg.hidden_dropout_prob if self.training else 0.0
+        if drop > 0:
+            x = DropoutFn.apply(x, drop)
+        return x
+
+
+BERT_DEFAULTS = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                     hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, max_position_embeddings=512,
+                     type_vocab_size=2, initializer_range=0.02, layer_norm_eps=1e-12, pad_token_id=0, position_embedding_type="absolute",
+                     use_cache=True, is_decoder=False, add_cross_attention=False)
+ROBERTA_DEFAULTS = dict(BERT_DEFAULTS, vocab_size=50265, pad_token_id=1, bos_token_id=0, eos_token_id=2)
+
+
+class BertFullEmbeddings(BertEmbeddings):
+    """word + token-type + position embeddings -> LayerNorm -> dropout: hf BertEmbeddings (hf:models/bert/modeling_bert.py) and, with
+    ``roberta=True``, RobertaEmbeddings (hf:models/roberta/modeling_roberta.py:55-155): position ids = cumsum(ids != pad) * (ids != pad) + pad
+    and a position table whose pad row gets no gradient.  The reference never passes ``token_type_ids`` (ref:.../encoder_model.py:44-56,
+    decoder_model.py:42-47), so the type embedding is the constant row 0."""
+
+    def __init__(self, cfg, roberta=False):
+        super().__init__(cfg)
+        self.roberta = bool(roberta)
+        d, s = cfg.hidden_size, cfg.initializer_range
+        self.token_type_embeddings = _Holder()
+        self.token_type_embeddings.weight = nn.Parameter(torch.empty(cfg.type_vocab_size, d).normal_(0.0, s))
+        if self.roberta and cfg.pad_token_id is not None and 0 <= cfg.pad_token_id < cfg.max_position_embeddings:
+            with torch.no_grad():
+                self.position_embeddings.weight[cfg.pad_token_id].zero_()
+
+    def position_ids(self, ids, past_len=0):
+        """RoBERTa only (create_position_ids_from_input_ids); BERT positions are the column index + past_len (kernel default)"""
+        if not self.roberta:
+            return None
+        pad = self.cfg.pad_token_id
+        mask = ids.ne(pad).to(torch.int64)
+        return ((torch.cumsum(mask, dim=1) + past_len) * mask + pad).contiguous()
+
+    def forward(self, ids, arena, past_len=0):
+        cfg = self.cfg
+        we, pe, te = self.word_embeddings.weight, self.position_embeddings.weight, self.token_type_embeddings.weight
+        off = (cfg.pad_token_id + 1) if self.roberta else 0
+        if ids.shape[1] + past_len + off > cfg.max_position_embeddings:
+            raise ValueError("sequence longer than max_position_embeddings")
+        g_type = arena.grad(te)
+        x = ops.embedding_ex(we, ids.contiguous(), self.position_ids(ids, past_len), we, pe, te, past_len=past_len, padding_idx=cfg.pad_token_id,
+                             pos_offset=past_len + off, pos_pad=cfg.pad_token_id if self.roberta else -1,
+                             g_word=arena.grad(we), g_pos=arena.grad(pe), g_type=g_type.view(-1) if g_type is not None else None)
         x = _ln(arena, x, self.LayerNorm, cfg.layer_norm_eps)
         drop = cfg.hidden_dropout_prob if self.training else 0.0
         if drop > 0:

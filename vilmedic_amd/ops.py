@@ -306,6 +306,7 @@ GROUP_WGRAD = os.environ.get("VM_WGRAD_GROUP", "1") != "0"
 # 2 x 504 = 1008 -> 252); the 128 x 128-tile kernel 400 (512 resident workgroups, VM_WGRAD_P8=0)
 GROUP_TILES = int(os.environ.get("VM_WGRAD_GROUP_TILES", "400" if os.environ.get("VM_WGRAD_P8", "2") == "0" else "840"))
 _pg = {"items": [], "tiles": 0, "ptrs": set()}
+WGRAD_CHECK = os.environ.get("VM_WGRAD_CHECK", "") == "1"
 # first-touch tracking: a gradient buffer that no kernel has written since its arena zeroed the gradients may be STORED instead of accumulated
 # (vm_wgrad_problem.overwrite: the read half of 0.9 GB of fp32 read-modify-write per step).  ``touched``: buffers written since then;
 # ``shared``: buffers other kernels add into (the tied word embedding: vm_embedding_bwd) -- always accumulated; ``ranges``: arenas whose gradients
@@ -314,8 +315,21 @@ _touch = {"lo": [], "hi": [], "shared": [], "ranges": []}      # touched interva
 
 
 def _span(t):
+    """[lo, hi) byte interval a tensor's elements lie in (a column slice of a wider matrix spans its rows' strides, not numel)"""
     lo = t.data_ptr()
-    return lo, lo + t.numel() * t.element_size()
+    if t.dim() == 0 or t.numel() == 0:
+        return lo, lo + t.numel() * t.element_size()
+    last = sum((n - 1) * st for n, st in zip(t.shape, t.stride()))
+    return lo, lo + (last + 1) * t.element_size()
+
+
+def forget_range(lo, hi):
+    """an arena whose gradient buffer covered [lo, hi) is gone: nothing recorded about that memory may vouch for whatever the caching
+    allocator hands out there next (ParamArena registers this as its finalizer)"""
+    _touch["ranges"] = [r for r in _touch["ranges"] if r[1] <= lo or r[0] >= hi]
+    _touch["shared"] = [r for r in _touch["shared"] if r[1] <= lo or r[0] >= hi]
+    keep = [(a, b) for a, b in zip(_touch["lo"], _touch["hi"]) if b <= lo or a >= hi]
+    _touch["lo"], _touch["hi"] = [a for a, _ in keep], [b for _, b in keep]
 
 
 def grads_zeroed(gflat):
@@ -437,6 +451,11 @@ def flush_param_grads():
     _pg["items"], _pg["tiles"], _pg["ptrs"] = [], 0, set()
     arr = (_lib.WgradProblem * len(items))()
     tensors = []
+    if WGRAD_CHECK:             # VM_WGRAD_CHECK=1 (debug): a buffer about to be STORED into must still hold the zeros of zero_grad
+        for dY, X, dW, db, ld_dy, ld_x, alpha_dev, N, K, first in items:
+            if first and (float(dW[:N].abs().max()) != 0.0 or (db is not None and float(db[:N].abs().max()) != 0.0)):
+                raise RuntimeError("first-touch bookkeeping: an overwriting weight-gradient launch targets a buffer that is not zero "
+                                   f"(dW {tuple(dW.shape)} at {dW.data_ptr():#x}): some writer did not call ops.mark_touched")
     for q, (dY, X, dW, db, ld_dy, ld_x, alpha_dev, N, K, first) in zip(arr, items):
         q.dY, q.ld_dy, q.X, q.ld_x = dY.data_ptr(), ld_dy, X.data_ptr(), ld_x
         q.dW, q.ld_dw, q.db = dW.data_ptr(), dW.stride(0), (db.data_ptr() if db is not None else None)
@@ -446,6 +465,18 @@ def flush_param_grads():
         tensors += [t for t in (dY, X, alpha_dev) if t is not None]
     with on_side(*tensors):
         check(lib().vm_wgrad_grouped(arr, len(items), stream()), "vm_wgrad_grouped")
+
+
+def reset_host_state():
+    """forget everything queued on the host for launches that will never happen (an aborted graph capture: graph.GraphedTrainStep):
+    the weight-gradient and LayerNorm-reduce queues, the pending side-stream join, the masked-gradient hand-off table; the first-touch
+    records of every tracked arena are invalidated (nothing is known about the buffers until the next zero_grad)."""
+    _pg["items"], _pg["tiles"], _pg["ptrs"] = [], 0, set()
+    _lnq["items"], _lnq["ptrs"] = [], set()
+    _masked.clear()
+    _side["pending"], _side["callback_queued"], _side["defer"] = False, False, False
+    for lo, hi in _touch["ranges"]:
+        _touch_insert(lo, hi)                    # everything counts as touched: weight gradients accumulate until the arena is zeroed again
 
 
 def _ensure_end_of_backward_flush():
@@ -699,14 +730,14 @@ class AttentionFn(Fn):
     """q [B,Lq,*] k,v [B,Lk,*] are column slices (views) of projection outputs; heads are contiguous 64-wide blocks."""
 
     @staticmethod
-    def forward(ctx, q, k, v, key_mask, H, causal, dropout_p):
+    def forward(ctx, q, k, v, key_mask, H, causal, dropout_p, scale=None):
         B, Lq = q.shape[0], q.shape[1]
         Lk = k.shape[1]
         dh = q.shape[2] // H
         o = torch.empty(B, Lq, H * dh, dtype=BF16, device=q.device)
         stats = torch.empty(B, H, Lq, 2, dtype=torch.float32, device=q.device)
         seed = next_seed() if dropout_p > 0 else 0
-        scale = dh ** -0.5
+        scale = dh ** -0.5 if scale is None else scale
         check(lib().vm_attention_fwd(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), o.stride(1), ptr(stats),
                                      ptr(key_mask) if key_mask is not None else None, B, H, Lq, Lk, dh, scale, int(causal),
                                      dropout_p, seed, ptr(seed_dev(q.device)) if dropout_p > 0 else None, None, 0, stream()), "vm_attention_fwd")
@@ -731,7 +762,7 @@ class AttentionFn(Fn):
                                      ptr(d_o), d_o.stride(1), ptr(stats), ptr(key_mask) if key_mask is not None else None,
                                      ptr(dq), dq.stride(1), ptr(dk), dk.stride(1), ptr(dv), dv.stride(1),
                                      B, H, Lq, Lk, dh, scale, int(causal), dropout_p, seed, ptr(seed_dev(q.device)) if dropout_p > 0 else None, ptr(delta), stream()), "vm_attention_bwd")
-        return dq, dk, dv, None, None, None, None
+        return dq, dk, dv, None, None, None, None, None
 
 
 class PackedSelfAttentionFn(Fn):
@@ -875,11 +906,42 @@ def cross_kv_all(enc, w_all, b_all, n_layers, wgrad_buf=None, bgrad_buf=None, an
     return list(out[:n_layers]), list(out[n_layers:])
 
 
+HEAD_DIMS = (32, 64, 96, 128)          # head widths the attention kernels are instantiated for
+
+
+def padded_head_dim(dh):
+    """the kernel head width that carries heads of ``dh`` columns (dh itself when supported)"""
+    for w in HEAD_DIMS:
+        if dh <= w:
+            return w
+    raise ValueError(f"head_dim {dh} > {HEAD_DIMS[-1]} is outside the HIP attention kernels")
+
+
+def _attention_padded_heads(q, k, v, key_mask, H, causal, dropout_p):
+    """heads narrower than a kernel head width (BertGenerationConfig's default 16 heads on hidden_size 768 = 48 columns:
+    ref:config/RRG/baseline-HF.yml:26-30): every head is zero-padded to the next width -- QK^T and PV are unchanged by zero columns, the
+    softmax scale stays dh^-1/2 -- and the context is cut back.  torch pads / slices (autograd routes the gradients); not a tuned path."""
+    B, Lq, D = q.shape
+    dh = D // H
+    w = padded_head_dim(dh)
+
+    def pad(t):
+        return torch.nn.functional.pad(t.reshape(t.shape[0], t.shape[1], H, dh), (0, w - dh)).reshape(t.shape[0], t.shape[1], H * w)
+    o = AttentionFn.apply(pad(q), pad(k), pad(v), key_mask, H, causal, dropout_p, dh ** -0.5)
+    return o.view(B, Lq, H, w)[..., :dh].reshape(B, Lq, D)
+
+
 def self_attention(qkv, key_mask, H, causal, dropout_p=0.0):
+    D = qkv.shape[-1] // 3
+    if D // H not in HEAD_DIMS:
+        return _attention_padded_heads(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], key_mask, H, causal, dropout_p)
     return PackedSelfAttentionFn.apply(qkv, key_mask, H, causal, dropout_p)
 
 
 def cross_attention(q, kv, key_mask, H, dropout_p=0.0, dkv_out=None):
+    D = q.shape[-1]
+    if D // H not in HEAD_DIMS:
+        return _attention_padded_heads(q, kv[..., :D], kv[..., D:], key_mask, H, False, dropout_p)
     return PackedCrossAttentionFn.apply(q, kv, key_mask, H, dropout_p, dkv_out)
 
 
@@ -920,10 +982,91 @@ def embedding(anchor, ids, word, pos, *, past_len=0, padding_idx=None, g_word=No
     return EmbeddingFn.apply(anchor, ids, word, pos, past_len, padding_idx, g_word, g_pos)
 
 
+class EmbeddingExFn(Fn):
+    """BERT / RoBERTa embeddings: (word[ids] + type_row) + pos[pos_ids or t + past_len]  (vm_embedding_fwd_ex / _bwd_ex).
+    ``pos_ids``: int64 [B, L] or None; ``type_row``: the fp32 parameter whose row 0 is added (or None); ``pos_pad``: position row
+    that receives no gradient (RoBERTa's nn.Embedding(padding_idx), -1: none); ``pos_offset``: position of column t without pos_ids
+    and the "regular" position the backward sums in registers."""
+
+    @staticmethod
+    def forward(ctx, anchor, ids, pos_ids, word, pos, type_w, past_len, padding_idx, pos_offset, pos_pad, g_word, g_pos, g_type):
+        B, L = ids.shape
+        D = word.shape[1]
+        out = torch.empty(B, L, D, dtype=BF16, device=word.device)
+        check(lib().vm_embedding_fwd_ex(ptr(ids), ptr(pos_ids), ptr(word), ptr(pos), ptr(type_w), ptr(out), VM_BF16, B, L, D, past_len,
+                                        stream()), "vm_embedding_fwd_ex")
+        ctx.save_for_backward(ids, pos_ids)
+        ctx.meta = (padding_idx, pos_offset, pos_pad, g_word, g_pos, g_type, D)
+        if g_word is not None:
+            sp = _span(g_word)
+            if sp not in _touch["shared"]:
+                _touch["shared"].append(sp)                 # (as EmbeddingFn: the tied LM head's weight gradient accumulates into the same buffer)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        ids, pos_ids = ctx.saved_tensors
+        padding_idx, pos_offset, pos_pad, g_word, g_pos, g_type, D = ctx.meta
+        B, L = ids.shape
+        if g_word is not None:
+            d_out = d_out.contiguous()
+            mark_touched(g_word)
+            with on_side(d_out, ids, *([pos_ids] if pos_ids is not None else [])):
+                check(lib().vm_embedding_bwd_ex(ptr(ids), ptr(pos_ids), ptr(d_out), ptr(g_word), ptr(g_pos), ptr(g_type), B, L, D,
+                                                padding_idx if padding_idx is not None else -1, pos_offset, pos_pad, stream()),
+                      "vm_embedding_bwd_ex")
+        return (None,) * 13
+
+
+def embedding_ex(anchor, ids, pos_ids, word, pos, type_w, *, past_len=0, padding_idx=None, pos_offset=0, pos_pad=-1,
+                 g_word=None, g_pos=None, g_type=None):
+    return EmbeddingExFn.apply(anchor, ids, pos_ids, word, pos, type_w, past_len, padding_idx, pos_offset, pos_pad, g_word, g_pos, g_type)
+
+
+# ----------------------------------------------------------------------------- dense -> erf-GELU (LM-head transform of BERT / RoBERTa)
+class LinearGeluFn(Fn):
+    """y = gelu(x W^T + b); the pre-activation z is kept for the backward (dz = dy * gelu'(z): vm_gelu_bwd_bf16)."""
+
+    @staticmethod
+    def forward(ctx, x, w_sh, bias_f32, wgrad_buf, bgrad_buf, anchor):
+        x2 = _2d(x)
+        M, K = x2.shape
+        N = w_sh.shape[0]
+        z = torch.empty(M, N, dtype=BF16, device=x.device)
+        y = torch.empty(M, N, dtype=BF16, device=x.device)
+        gemm(x2, 0, w_sh, 0, y, M, N, K, bias=bias_f32, act=1, aux_out=z)
+        ctx.save_for_backward(x2, w_sh, z)
+        ctx.meta = (wgrad_buf, bgrad_buf, x.shape)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w_sh, z = ctx.saved_tensors
+        wgrad_buf, bgrad_buf, xshape = ctx.meta
+        dy2 = _2d(dy.contiguous())
+        M, N = dy2.shape
+        K = x2.shape[1]
+        dz = torch.empty_like(z)
+        check(lib().vm_gelu_bwd_bf16(ptr(dy2), ptr(z), ptr(dz), dz.numel(), stream()), "vm_gelu_bwd_bf16")
+        param_grads(dz, x2, wgrad_buf, bgrad_buf)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=BF16, device=dy.device)
+            gemm(dz, 0, w_sh, 1, dx, M, K, N)
+            dx = dx.view(xshape)
+        return dx, None, None, None, None, None
+
+
+def linear_gelu(x, w_sh, bias, *, wgrad_buf=None, bgrad_buf=None, anchor=None):
+    return LinearGeluFn.apply(x, w_sh, bias, wgrad_buf, bgrad_buf, anchor)
+
+
 # ----------------------------------------------------------------------------- ViT patch embedding (+cls +pos)
 class PatchEmbedFn(Fn):
+    """``cls``: fp32 [ns, D] special tokens in front of the patches (ViT: [CLS]; DeiT: [CLS], distillation), ``pos`` [(n + ns), D]."""
+
     @staticmethod
-    def forward(ctx, anchor, images, w_sh, bias, cls, pos, patch, g_w, g_b, g_cls, g_pos):
+    def forward(ctx, anchor, images, w_sh, bias, cls, pos, patch, g_w, g_b, g_cls, g_pos, ns=1):
         B, Cc, Hh, Ww = images.shape
         n = (Hh // patch) * (Ww // patch)
         D, Kd = w_sh.shape
@@ -931,26 +1074,26 @@ class PatchEmbedFn(Fn):
         check(lib().vm_im2col_patches(ptr(images), ptr(cols), B, Cc, Hh, Ww, patch, stream()), "vm_im2col_patches")
         pe = torch.empty(B * n, D, dtype=BF16, device=images.device)
         gemm(cols, 0, w_sh, 0, pe, B * n, D, Kd, bias=bias)
-        out = torch.empty(B, n + 1, D, dtype=BF16, device=images.device)
-        check(lib().vm_vit_assemble(ptr(pe), ptr(cls), ptr(pos), ptr(out), B, n, D, stream()), "vm_vit_assemble")
+        out = torch.empty(B, n + ns, D, dtype=BF16, device=images.device)
+        check(lib().vm_vit_assemble_ex(ptr(pe), ptr(cls), ptr(pos), ptr(out), B, n, ns, D, stream()), "vm_vit_assemble")
         ctx.save_for_backward(cols)
-        ctx.meta = (B, n, D, g_w, g_b, g_cls, g_pos)
+        ctx.meta = (B, n, D, g_w, g_b, g_cls, g_pos, ns)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         (cols,) = ctx.saved_tensors
-        B, n, D, g_w, g_b, g_cls, g_pos = ctx.meta
+        B, n, D, g_w, g_b, g_cls, g_pos, ns = ctx.meta
         if g_w is not None:
             d_out = d_out.contiguous()
             dpe = torch.empty(B * n, D, dtype=BF16, device=d_out.device)
-            check(lib().vm_vit_assemble_bwd(ptr(d_out), ptr(dpe), ptr(g_cls), ptr(g_pos), B, n, D, stream()), "vm_vit_assemble_bwd")
+            check(lib().vm_vit_assemble_bwd_ex(ptr(d_out), ptr(dpe), ptr(g_cls), ptr(g_pos), B, n, ns, D, stream()), "vm_vit_assemble_bwd")
             param_grads(dpe, cols, g_w.view(D, -1), g_b)
-        return (None,) * 11
+        return (None,) * 12
 
 
-def patch_embed(anchor, images, w_sh, bias, cls, pos, patch, grads=(None, None, None, None)):
-    return PatchEmbedFn.apply(anchor, images, w_sh, bias, cls, pos, patch, *grads)
+def patch_embed(anchor, images, w_sh, bias, cls, pos, patch, grads=(None, None, None, None), ns=1):
+    return PatchEmbedFn.apply(anchor, images, w_sh, bias, cls, pos, patch, *grads, ns)
 
 
 # ----------------------------------------------------------------------------- LM head + shifted CE (fused fwd/bwd)

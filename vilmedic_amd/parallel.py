@@ -79,6 +79,11 @@ def broadcast_(flat, dist, src=0):
     return flat
 
 
+def default_bf16_wire():
+    import os
+    return os.environ.get("VM_DDP_WIRE", "fp32").lower() == "bf16"
+
+
 class ArenaDDP:
     """Wraps a model whose parameters live in a ParamArena: broadcasts rank 0's parameters at construction and averages
     the flat gradient buffer across ranks.
@@ -93,14 +98,20 @@ class ArenaDDP:
     Every rank issues the same collectives in the same order (the marks fire in program order).
     ``finish()`` (no overlap) remains for callers that ran ``loss.backward()`` themselves."""
 
-    def __init__(self, model, dist, chunks=4, bf16_wire=True, wire=None, enc_buckets=4):
+    def __init__(self, model, dist, chunks=4, bf16_wire=None, wire=None, enc_buckets=4):
         from . import ops
         from .arena import arena_of
         self.dist = dist
         self.model = model
         self.arena = arena_of(model)
         self.chunks = chunks
-        self.bf16_wire = bf16_wire
+        # the wire format of the gradient all-reduce.  Default fp32: the averaged gradients equal the single-process gradients of the
+        # concatenated batch (SURVEY §8e's parity statement) -- the collective runs in place on the fp32 gradient arena, no cast passes.
+        # bf16 (``bf16_wire=True``, trainor.ddp_wire: bf16, VM_DDP_WIRE=bf16) halves the bytes over xGMI at one rounding per gradient
+        # (measured 1.7e-3 rel-L2 on the C2 model): an explicit opt-in, reported by bench.py as config.ddp_wire.
+        if bf16_wire is None:
+            bf16_wire = default_bf16_wire()
+        self.bf16_wire = bool(bf16_wire)
         self._ops = ops
         self.world = dist.get_world_size()
         broadcast_(self.arena.flat, dist)
