@@ -74,8 +74,8 @@ def test_proto_decoder_loss_logits_grads_vs_oracle(golden, tmp_path, mt):
         if stg[n].grad is None:
             continue
         got, ref = named[n].grad.float().cpu(), stg[n].grad
-        if ref.norm() == 0:
-            assert got.norm() == 0, n
+        if ref.norm() <= 1e-8 * max(1.0, ref.numel() ** 0.5):       # pad rows, and key biases (the softmax is invariant to them: rounding noise only)
+            assert got.norm() <= 1e-4, (n, got.norm())
             continue
         assert grads_close(got, ref, cos=0.998, rel=6e-2), (n, cosine(got, ref), rel_l2(got, ref))
     assert grads_close(enc_d.grad.float().cpu(), encg.grad)
