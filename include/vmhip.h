@@ -207,6 +207,23 @@ int vm_attention_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, con
                      int B, int H, int Lq, int Lk, int dh, float scale, int causal,
                      float dropout_p, uint64_t dropout_seed, const uint64_t* dropout_seed_dev, float* ws_delta /* fp32 [B,H,Lq] */, void* stream);
 
+/* ------------------------------------------------------------------ BatchNorm2d, channels-last, grouped statistics (csrc/batchnorm.hip)
+ * The CNN towers of ConVIRT / GLoRIA / MVQA (ref:vilmedic/models/selfsup/conVIRT.py:83-95: towers run in forward_batch_size micro-batches,
+ * so every BatchNorm sees micro-batch statistics; ref:vilmedic/models/mvqa/MVQA.py:41-43: DenseNet-169, ordinary statistics = one group).
+ * x, residual, y: [G * rows_per_group, C] (NHWC memory), bf16 or fp32 (``dtype``); C % 8 == 0, C <= 2048.
+ *   y = relu?( (x - mean_g) * rstd_g * gamma + beta + residual? )        per group g of rows_per_group consecutive rows
+ * training != 0: mean / rstd / var ([G, C] fp32; var = biased variance, for the caller's running-statistics update) are OUTPUTS;
+ * training == 0: mean / rstd are inputs (running statistics), var is not touched.  ws: vm_batchnorm_nhwc_ws(G, rows_per_group, C) bytes. */
+size_t vm_batchnorm_nhwc_ws(int G, int rows_per_group, int C);
+int vm_batchnorm_nhwc_fwd(const void* x, const void* residual /* or NULL */, void* y, const float* gamma /* or NULL */, const float* beta,
+                          float* mean, float* rstd, float* var, int G, int rows_per_group, int C, float eps, int dtype, int relu, int training,
+                          void* ws, size_t ws_bytes, void* stream);
+/* dy' = dy * [y > 0] when relu;  dx = gamma * rstd * (dy' - mean_g(dy') - xhat * mean_g(dy' * xhat))  (training; eval: gamma * rstd * dy');
+ * dres (NULL or same shape) = dy';  dgamma / dbeta (NULL or fp32 [C], ZEROED by the caller) += sums over all groups. */
+int vm_batchnorm_nhwc_bwd(const void* dy, const void* x, const void* residual, const float* gamma, const float* beta, const float* mean,
+                          const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta, int G, int rows_per_group, int C, int dtype,
+                          int relu, int training, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------ embeddings
  * hf:...bert_generation.py:394-426: out = word[ids] + pos[past_len + t]   (LayerNorm is a separate call) */
 int vm_embedding_fwd(const int64_t* ids, const float* word, const float* pos, void* out /* bf16 [B*L, D] */,

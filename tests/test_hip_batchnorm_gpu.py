@@ -1,0 +1,139 @@
+"""vm_batchnorm_nhwc_fwd / _bwd (csrc/batchnorm.hip) through blocks/vision/micro_bn.MicroBatchNorm2d on channels-last tensors, against the
+computation the reference performs: its towers run in ``forward_batch_size`` micro-batches (ref:vilmedic/models/selfsup/conVIRT.py:83-95), i.e.
+a stock ``nn.BatchNorm2d`` applied to each micro-batch in turn, followed by the block's residual add and ReLU.  Outputs, input /
+residual / affine gradients and the running statistics after the step.  fp32 tensors: 1e-4; bf16 tensors: one output rounding (2e-2).
+The stock module runs on the CPU in float64: on this stack the GPU's own NCHW BatchNorm backward is off by a few elements' worth for
+33 x 33 feature maps (dbeta err 2.6 - 7.9 against plain sums that the HIP kernel reproduces to 2e-5; tools/scratch history in DESIGN
+section 11), so it cannot serve as the checker."""
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def reference(x, res, w, b, rm, rv, g, relu, training, eps=1e-5, momentum=0.1):
+    """stock BatchNorm2d over consecutive micro-batches of g images (CPU, float64, NCHW), + residual, ReLU"""
+    bn = nn.BatchNorm2d(x.shape[1], eps=eps, momentum=momentum).double()
+    with torch.no_grad():
+        bn.weight.copy_(w), bn.bias.copy_(b), bn.running_mean.copy_(rm), bn.running_var.copy_(rv)
+    bn.train(training)
+    x = x.detach().cpu().double().contiguous().requires_grad_(True)
+    r = res.detach().cpu().double().contiguous().requires_grad_(True) if res is not None else None
+    chunks = [x] if (not training or g <= 0 or g >= x.shape[0]) else list(x.split(g))
+    y = torch.cat([bn(c) for c in chunks])
+    if r is not None:
+        y = y + r
+    if relu:
+        y = torch.relu(y)
+    return y, x, r, bn
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C,H,g,use_res,relu", [
+    (8, 64, 14, 4, False, True),          # two micro-batches, ReLU fused (ResNet conv1 / conv2 position)
+    (6, 256, 7, 4, True, True),           # one micro-batch + a trailing partial one, residual add + ReLU (end of a bottleneck)
+    (5, 104, 9, 0, False, False),         # ordinary statistics, C / 8 = 13 lanes per row (DenseNet widths are not powers of two)
+    (16, 2048, 7, 4, True, True),         # the widest ResNet-50 layer: one row per block sweep
+    (3, 32, 33, 2, False, True),          # long rows-per-thread loops, odd spatial size
+])
+def test_batchnorm_nhwc_training_vs_micro_batched_torch(dtype, B, C, H, g, use_res, relu):
+    from vilmedic_amd.blocks.vision.micro_bn import MicroBatchNorm2d, micro_batches
+    gen = torch.Generator(device="cpu").manual_seed(B * 1000 + C)
+    x = (torch.randn(B, C, H, H, generator=gen) * 1.5 + 0.3 * torch.randn(1, C, 1, 1, generator=gen)).to(dev())
+    res = torch.randn(B, C, H, H, generator=gen).to(dev()) if use_res else None
+    w, b = (1 + 0.2 * torch.randn(C, generator=gen)).to(dev()), (0.1 * torch.randn(C, generator=gen)).to(dev())
+    rm, rv = (0.1 * torch.randn(C, generator=gen)).to(dev()), (1 + 0.1 * torch.rand(C, generator=gen)).to(dev())
+    up = torch.randn(B, C, H, H, generator=gen).to(dev())
+    xq = x.to(dtype).contiguous(memory_format=torch.channels_last)
+    rq = res.to(dtype).contiguous(memory_format=torch.channels_last) if use_res else None
+    y_ref, x_ref, r_ref, bn_ref = reference(xq, rq, w, b, rm, rv, g, relu, True)
+    (y_ref * up.cpu().double()).sum().backward()
+    y_ref = y_ref.detach().float().to(dev())
+    bn = MicroBatchNorm2d(C).to(dev())
+    with torch.no_grad():
+        bn.weight.copy_(w), bn.bias.copy_(b), bn.running_mean.copy_(rm), bn.running_var.copy_(rv)
+    bn.train()
+    xh = xq.clone().requires_grad_(True)
+    rh = rq.clone().requires_grad_(True) if use_res else None
+    with micro_batches(g):
+        y = bn(xh, residual=rh, relu=relu)
+    assert y.dtype == dtype and y.is_contiguous(memory_format=torch.channels_last)
+    (y.float() * up).sum().backward()
+    torch.cuda.synchronize()
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    scale = y_ref.abs().max().item()
+    assert (y.float() - y_ref).abs().max().item() <= tol * max(1.0, scale), (y.float() - y_ref).abs().max().item()
+
+    def rel(a, b_):
+        a, b_ = a.detach().double().cpu(), b_.detach().double().cpu()
+        return ((a - b_).norm() / b_.norm().clamp_min(1e-12)).item()
+    gtol = 2e-4 if dtype == torch.float32 else 1.5e-2
+    assert rel(xh.grad, x_ref.grad) <= gtol, rel(xh.grad, x_ref.grad)
+    if use_res:
+        assert rel(rh.grad, r_ref.grad) <= gtol
+    assert rel(bn.weight.grad, bn_ref.weight.grad) <= gtol and rel(bn.bias.grad, bn_ref.bias.grad) <= gtol, \
+        (rel(bn.weight.grad, bn_ref.weight.grad), rel(bn.bias.grad, bn_ref.bias.grad))
+    stol = 1e-5 if dtype == torch.float32 else 1e-4
+    assert torch.allclose(bn.running_mean.cpu(), bn_ref.running_mean.float(), atol=stol, rtol=1e-4)
+    assert torch.allclose(bn.running_var.cpu(), bn_ref.running_var.float(), atol=stol, rtol=1e-4)
+    assert int(bn.num_batches_tracked) == int(bn_ref.num_batches_tracked)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batchnorm_nhwc_eval_mode_uses_running_statistics(dtype):
+    from vilmedic_amd.blocks.vision.micro_bn import MicroBatchNorm2d
+    B, C, H = 4, 96, 10
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(B, C, H, H, generator=gen).to(dev()).to(dtype).contiguous(memory_format=torch.channels_last)
+    res = torch.randn(B, C, H, H, generator=gen).to(dev()).to(dtype).contiguous(memory_format=torch.channels_last)
+    w, b = (1 + 0.2 * torch.randn(C, generator=gen)).to(dev()), (0.1 * torch.randn(C, generator=gen)).to(dev())
+    rm, rv = (0.3 * torch.randn(C, generator=gen)).to(dev()), (0.5 + torch.rand(C, generator=gen)).to(dev())
+    y_ref, x_ref, r_ref, bn_ref = reference(x, res, w, b, rm, rv, 0, True, False)
+    y_ref.sum().backward()
+    y_ref, xg_ref, wg_ref = y_ref.detach().float().to(dev()), x_ref.grad.float().to(dev()), bn_ref.weight.grad.float().to(dev())
+    bn = MicroBatchNorm2d(C).to(dev())
+    with torch.no_grad():
+        bn.weight.copy_(w), bn.bias.copy_(b), bn.running_mean.copy_(rm), bn.running_var.copy_(rv)
+    bn.eval()
+    xh, rh = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    y = bn(xh, residual=rh, relu=True)
+    y.float().sum().backward()
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert (y.float() - y_ref).abs().max().item() <= tol * max(1.0, y_ref.abs().max().item())
+    assert ((xh.grad.float() - xg_ref).norm() / xg_ref.norm()).item() <= (2e-4 if dtype == torch.float32 else 1.5e-2)
+    assert ((bn.weight.grad - wg_ref).norm() / wg_ref.norm()).item() <= (2e-4 if dtype == torch.float32 else 1.5e-2)
+    assert torch.equal(bn.running_mean, rm) and torch.equal(bn.running_var, rv)
+
+
+def test_resnet50_tower_channels_last_vs_the_cpu_tower():
+    """the whole ResNet-50 tower (blocks/vision/cnn.py, avgpool output) in training mode with micro-batches of 4 on a channels-last fp32
+    input -- every BatchNorm (+ add + ReLU) on the HIP kernel, convolutions on MIOpen -- against the SAME modules executed by torch on the
+    CPU (stock BatchNorm per micro-batch through the NCHW composition): features, the gradient of the first convolution, the running
+    statistics of the last BatchNorm"""
+    import copy
+    from vilmedic_amd.blocks.vision import cnn
+    from vilmedic_amd.blocks.vision.micro_bn import MicroBatchNorm2d, micro_batches
+    torch.manual_seed(0)
+    a = cnn.build("resnet50", "avgpool", False)
+    b = copy.deepcopy(a).to(dev())
+    assert sum(isinstance(m, MicroBatchNorm2d) for m in a.modules()) == 53
+    x = torch.randn(8, 3, 64, 64)
+    a.train(), b.train()
+    with micro_batches(4):
+        ya = a(x)
+        yb = b(x.to(dev()).contiguous(memory_format=torch.channels_last))
+    ya.square().sum().backward()
+    yb.square().sum().backward()
+    torch.cuda.synchronize()
+    yb, gb = yb.detach().cpu(), b[0].weight.grad.cpu()
+    ga = a[0].weight.grad
+    ey, eg = ((ya - yb).norm() / ya.norm()).item(), ((ga - gb).norm() / ga.norm()).item()
+    print(f"[parity] ResNet-50 tower, HIP BatchNorm on channels-last vs CPU: features rel {ey:.3e}, first-conv gradient rel {eg:.3e}", flush=True)
+    assert ey <= 2e-3 and eg <= 2e-2, (ey, eg)
+    la, lb = [m for m in a.modules() if isinstance(m, MicroBatchNorm2d)][-1], [m for m in b.modules() if isinstance(m, MicroBatchNorm2d)][-1]
+    assert torch.allclose(la.running_var, lb.running_var.cpu(), rtol=2e-3, atol=1e-5)

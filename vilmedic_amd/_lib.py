@@ -77,6 +77,9 @@ SIGNATURES = {
                               _I, _I, _I, _I, _I, _F, _I, _F, _U64, _P, _P, _P]),
     "vm_embedding_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "vm_embedding_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vm_batchnorm_nhwc_ws": (_SZ, [_I, _I, _I]),
+    "vm_batchnorm_nhwc_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _I, _I, _P, _SZ, _P]),
+    "vm_batchnorm_nhwc_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "vm_embedding_fwd_ex": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "vm_embedding_bwd_ex": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vm_gelu_bwd_bf16": (_I, [_P, _P, _P, _L, _P]),

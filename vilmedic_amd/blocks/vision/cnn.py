@@ -2,13 +2,17 @@
 YAMLs name (resnet18/34/50/101, densenet121/169) are declared here with torchvision's module / parameter names
 (``conv1, bn1, layer1.0.conv1 ...``, ``features.denseblock1.denselayer1.norm1 ...``) so reference checkpoints load;
 ``hfresnet`` is the HuggingFace-style ResNet (HF names, ResNetConfig kwargs).
-They run through MIOpen via PyTorch-ROCm (CNN stems are NOT hand-written kernels).
+Their convolutions run through MIOpen via PyTorch-ROCm (CNN stems are NOT hand-written kernels); every BatchNorm is a
+``micro_bn.MicroBatchNorm2d`` (same parameters and state-dict keys), which on channels-last activations runs the hand-written
+BatchNorm (+ residual add + ReLU) kernel of csrc/batchnorm.hip -- ``bn_act`` below is how the blocks hand it the add and the ReLU.
 ref: vilmedic/blocks/vision/visual_encoder.py:71-81 (eval(backbone)(pretrained=...) truncated at output_layer)."""
 from collections import OrderedDict
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from .micro_bn import bn_act, use_micro_batch_norm
 
 
 class BasicBlock(nn.Module):
@@ -25,9 +29,8 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        return self.relu(out + idt)
+        out = bn_act(self.bn1, self.conv1(x), self.relu)
+        return bn_act(self.bn2, self.conv2(out), self.relu, residual=idt)
 
 
 class Bottleneck(nn.Module):
@@ -46,10 +49,9 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        return self.relu(out + idt)
+        out = bn_act(self.bn1, self.conv1(x), self.relu)
+        out = bn_act(self.bn2, self.conv2(out), self.relu)
+        return bn_act(self.bn3, self.conv3(out), self.relu, residual=idt)
 
 
 class ResNet(nn.Module):
@@ -81,7 +83,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(bn_act(self.bn1, self.conv1(x), self.relu))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return self.fc(torch.flatten(self.avgpool(x), 1))
 
@@ -98,8 +100,8 @@ class _DenseLayer(nn.Module):
 
     def forward(self, feats):
         x = torch.cat(feats, 1) if isinstance(feats, (list, tuple)) else feats
-        x = self.conv1(self.relu1(self.norm1(x)))
-        return self.conv2(self.relu2(self.norm2(x)))
+        x = self.conv1(bn_act(self.norm1, x, self.relu1))
+        return self.conv2(bn_act(self.norm2, x, self.relu2))
 
 
 class _DenseBlock(nn.ModuleDict):
@@ -115,6 +117,13 @@ class _DenseBlock(nn.ModuleDict):
         return torch.cat(feats, 1)
 
 
+class _Transition(nn.Sequential):
+    """norm -> relu -> 1x1 conv -> 2x2 average pool (torchvision's _Transition: same child names); BatchNorm + ReLU as one kernel"""
+
+    def forward(self, x):
+        return self.pool(self.conv(bn_act(self.norm, x, self.relu)))
+
+
 class DenseNet(nn.Module):
     def __init__(self, growth=32, blocks=(6, 12, 24, 16), init_feat=64, bn_size=4, num_classes=1000):
         super().__init__()
@@ -126,7 +135,7 @@ class DenseNet(nn.Module):
             self.features.add_module(f"denseblock{i + 1}", _DenseBlock(n, nf, bn_size, growth))
             nf += n * growth
             if i != len(blocks) - 1:
-                self.features.add_module(f"transition{i + 1}", nn.Sequential(OrderedDict([
+                self.features.add_module(f"transition{i + 1}", _Transition(OrderedDict([
                     ("norm", nn.BatchNorm2d(nf)), ("relu", nn.ReLU(inplace=True)),
                     ("conv", nn.Conv2d(nf, nf // 2, 1, bias=False)), ("pool", nn.AvgPool2d(2, 2))])))
                 nf //= 2
@@ -163,6 +172,8 @@ class _HFConvLayer(nn.Module):
         self.activation = _ACT[activation]() if activation is not None else nn.Identity()
 
     def forward(self, x):
+        if isinstance(self.activation, (nn.ReLU, nn.Identity)):
+            return bn_act(self.normalization, self.convolution(x), self.activation if isinstance(self.activation, nn.ReLU) else None)
         return self.activation(self.normalization(self.convolution(x)))
 
 
@@ -194,6 +205,12 @@ class _HFResLayer(nn.Module):
         self.activation = _ACT[activation]()
 
     def forward(self, x):
+        last = self.layer[-1]
+        if isinstance(self.activation, nn.ReLU) and isinstance(last.activation, nn.Identity):       # relu(bn(conv(h)) + shortcut) in the BatchNorm kernel
+            h = x
+            for m in list(self.layer)[:-1]:
+                h = m(h)
+            return bn_act(last.normalization, last.convolution(h), self.activation, residual=self.shortcut(x))
         return self.activation(self.layer(x) + self.shortcut(x))
 
 
@@ -253,11 +270,15 @@ class HFResNetModel(nn.Module):
 
 
 def build(backbone, output_layer, pretrained, **kwargs):
+    return use_micro_batch_norm(_build(backbone, output_layer, pretrained, **kwargs))
+
+
+def _build(backbone, output_layer, pretrained, **kwargs):
     if "hfresnet" in backbone.lower():
         kwargs.pop("return_dict", None)
         return HFResNetModel(**kwargs)
     if "densenet" in backbone and output_layer == "avgpool":          # visual_encoder.py:48-53
-        sub = build(backbone, "features", pretrained, **kwargs)
+        sub = _build(backbone, "features", pretrained, **kwargs)
         sub.add_module("relu", nn.ReLU(inplace=True))
         sub.add_module("avgpool", nn.AdaptiveAvgPool2d((1, 1)))
         sub.add_module("flatten", nn.Flatten(1))

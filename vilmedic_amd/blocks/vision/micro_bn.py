@@ -1,20 +1,29 @@
-"""BatchNorm with MICRO-BATCH statistics at full batch.
+"""BatchNorm with MICRO-BATCH statistics at full batch, on a hand-written channels-last kernel.
 
 The reference's contrastive models run their towers in ``forward_batch_size`` micro-batches inside one autograd graph
 (ref: vilmedic/models/selfsup/conVIRT.py:83-95 with forward_batch_size 4 in config/SELFSUP/convirt-mimic.yml:22; GLoRIA.py:92-105), so in
 training mode every BatchNorm of the CNN normalises each micro-batch with ITS OWN statistics and updates the running statistics
 micro-batch by micro-batch.  Executing that literally costs ``batch / forward_batch_size`` passes over a ~160-kernel CNN (64 passes of
 4 images at the reference's ConVIRT setting: the step is launch-bound).  Here the CNN runs ONCE over the whole batch and only the
-normalisation is grouped: ``x.view(G, g, C, H, W)`` -> per-(group, channel) mean / biased variance -> normalise, which is what the
-G sequential passes compute; the running statistics receive the same G exponential-moving-average updates in closed form
+normalisation is grouped: per-(group, channel) mean / biased variance -> normalise, which is what the G sequential passes compute; the
+running statistics receive the same G exponential-moving-average updates in closed form
 (r_G = (1 - m)^G r_0 + m * sum_c (1 - m)^(G - 1 - c) s_c).  Convolutions, pooling and activations are per-sample, so nothing else
-changes.  A trailing partial micro-batch (batch % g) goes through the ordinary batch-norm path.
+changes.  A trailing partial micro-batch (batch % g) is one more group of its own.
+
+Round 5: on channels-last activations (what the MIOpen convolutions of the bf16 tower mode produce) the normalisation -- grouped or
+not -- runs on ``vm_batchnorm_nhwc_fwd / _bwd`` (csrc/batchnorm.hip): statistics pass + normalise pass, with the residual add and the ReLU
+that follow a BatchNorm in ResNet / DenseNet blocks inside the kernel (``forward(x, residual=..., relu=True)``, used by blocks/vision/cnn.py).
+As a composition of torch reductions / elementwise kernels on an fp32 copy of the activation the grouping was ~130 ms of a 205 ms ConVIRT
+step (profiles/r05_d_steady_kernel_stats_convirt.csv).  Tensors in the default NCHW layout keep the torch path below (plain torch
+BatchNorm when nothing is grouped): the layout decides, nothing falls back silently at a given layout.
 """
 import contextlib
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
+
+from ... import ops
+from ..._lib import VM_BF16, VM_F32, check, lib, ptr, stream
 
 _micro = {"size": 0}
 
@@ -30,8 +39,118 @@ def micro_batches(size):
         _micro["size"] = old
 
 
+_ws = {}
+
+
+def _workspace(nbytes, device):
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    w = _ws.get(key)
+    if w is None or w.numel() < nbytes:
+        w = _ws[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+    return w
+
+
+class _BatchNormNhwcFn(ops.Fn):
+    """one vm_batchnorm_nhwc_fwd / _bwd pair over ``G`` groups of ``x.shape[0] // G`` images (channels-last x, residual, y)"""
+
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, mean, rstd, G, relu, training, eps):
+        N, C, H, W = x.shape
+        R = (N // G) * H * W
+        y = torch.empty_like(x)
+        dt = VM_BF16 if x.dtype == torch.bfloat16 else VM_F32
+        var = None
+        if training:
+            mean = torch.empty(G, C, dtype=torch.float32, device=x.device)
+            rstd = torch.empty(G, C, dtype=torch.float32, device=x.device)
+            var = torch.empty(G, C, dtype=torch.float32, device=x.device)
+        nws = lib().vm_batchnorm_nhwc_ws(G, R, C)
+        ws = _workspace(nws, x.device)
+        check(lib().vm_batchnorm_nhwc_fwd(ptr(x), ptr(residual), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(var), G, R, C, eps, dt,
+                                          int(relu), int(training), ptr(ws), ws.numel(), stream()), "vm_batchnorm_nhwc_fwd")
+        ctx.save_for_backward(x, residual, gamma, beta, mean, rstd)
+        ctx.meta = (G, R, C, dt, relu, training)
+        if training:
+            ctx.mark_non_differentiable(mean, var)
+            return y, mean, var
+        return y, None, None
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        x, residual, gamma, beta, mean, rstd = ctx.saved_tensors
+        G, R, C, dt, relu, training = ctx.meta
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        dx = torch.empty_like(x)
+        want_res = residual is not None and ctx.needs_input_grad[1]
+        dres = torch.empty_like(x) if want_res else None
+        dgamma = torch.zeros(C, dtype=torch.float32, device=x.device) if gamma is not None else None
+        dbeta = torch.zeros(C, dtype=torch.float32, device=x.device) if beta is not None else None
+        ws = _workspace(lib().vm_batchnorm_nhwc_ws(G, R, C), x.device)
+        check(lib().vm_batchnorm_nhwc_bwd(ptr(dy), ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(dx), ptr(dres), ptr(dgamma),
+                                          ptr(dbeta), G, R, C, dt, int(relu), int(training), ptr(ws), ws.numel(), stream()), "vm_batchnorm_nhwc_bwd")
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
+
+
+def _nhwc_ok(x, C):
+    return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float32) and C % 8 == 0 and C <= 2048 and x.shape[0] > 0
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
 class MicroBatchNorm2d(nn.BatchNorm2d):
-    def forward(self, x):
+    """nn.BatchNorm2d (same parameters, buffers and state-dict keys) whose training statistics can be grouped per micro-batch and whose
+    channels-last path is the HIP kernel.  ``forward(x, residual=None, relu=False)`` computes ``relu?(bn(x) + residual?)``."""
+
+    def forward(self, x, residual=None, relu=False):
+        C = self.num_features
+        if _nhwc_ok(x, C) and self.affine and (residual is None or (residual.shape == x.shape and residual.dtype == x.dtype
+                                                                      and residual.is_contiguous(memory_format=torch.channels_last))):
+            return self._forward_hip(x, residual, relu)
+        y = self._forward_torch(x)
+        if residual is not None:
+            y = y + residual
+        return torch.relu(y) if relu else y
+
+    # ------------------------------------------------------------------ channels-last: csrc/batchnorm.hip
+    def _forward_hip(self, x, residual, relu):
+        g = _micro["size"]
+        B = x.shape[0]
+        use_batch_stats = self.training or not self.track_running_stats
+        if not use_batch_stats:
+            mean = self.running_mean.float().view(1, -1).contiguous()
+            rstd = torch.rsqrt(self.running_var.float() + self.eps).view(1, -1).contiguous()
+            return _BatchNormNhwcFn.apply(x, residual, self.weight, self.bias, mean, rstd, 1, relu, False, self.eps)[0]
+        grouped = self.training and 0 < g < B and self.track_running_stats
+        G = B // g if grouped else 1
+        main = G * g if grouped else B
+        parts = [(0, main, G)] + ([(main, B, 1)] if main < B else [])          # the trailing partial micro-batch is a group of its own
+        outs, stats = [], []
+        for lo, hi, Gp in parts:
+            xs = x if (lo == 0 and hi == B) else x[lo:hi]
+            rs = None if residual is None else (residual if (lo == 0 and hi == B) else residual[lo:hi])
+            y, mean, var = _BatchNormNhwcFn.apply(xs, rs, self.weight, self.bias, None, None, Gp, relu, True, self.eps)
+            outs.append(y)
+            stats.append((mean, var, (hi - lo) // Gp * x.shape[2] * x.shape[3]))
+        if self.training and self.track_running_stats:
+            self._update_running(stats)
+        return outs[0] if len(outs) == 1 else torch.cat(outs)
+
+    @torch.no_grad()
+    def _update_running(self, stats):
+        """the exponential moving averages after one update per group, in closed form"""
+        mom = self.momentum if self.momentum is not None else 0.1      # (momentum=None = cumulative average is not used by these models)
+        means = torch.cat([m for m, _, _ in stats])
+        uvars = torch.cat([v * (n / max(n - 1, 1)) for _, v, n in stats])         # running_var takes the unbiased estimate
+        Gt = means.shape[0]
+        w = mom * (1.0 - mom) ** torch.arange(Gt - 1, -1, -1, device=means.device, dtype=torch.float32)      # weight of group c
+        keep = (1.0 - mom) ** Gt
+        self.running_mean.mul_(keep).add_((w[:, None] * means).sum(0).to(self.running_mean.dtype))
+        self.running_var.mul_(keep).add_((w[:, None] * uvars).sum(0).to(self.running_var.dtype))
+        self.num_batches_tracked += Gt
+
+    # ------------------------------------------------------------------ NCHW (default layout): torch
+    def _forward_torch(self, x):
         g = _micro["size"]
         B = x.shape[0]
         if not self.training or g <= 0 or g >= B or not self.track_running_stats:
@@ -46,16 +165,8 @@ class MicroBatchNorm2d(nn.BatchNorm2d):
         if self.affine:
             y = y * self.weight.view(1, 1, C, 1, 1) + self.bias.view(1, 1, C, 1, 1)
         y = y.reshape(main.shape)
-        with torch.no_grad():
-            mom = self.momentum if self.momentum is not None else 0.1      # (momentum=None = cumulative average is not used by these models)
-            n = g * main[0, 0].numel()
-            w = mom * (1.0 - mom) ** torch.arange(G - 1, -1, -1, device=x.device, dtype=torch.float32)     # weight of micro-batch c
-            keep = (1.0 - mom) ** G
-            m_c = mean.view(G, C)
-            v_c = var.view(G, C) * (n / max(n - 1, 1))                     # running_var takes the unbiased estimate
-            self.running_mean.mul_(keep).add_((w[:, None] * m_c).sum(0).to(self.running_mean.dtype))
-            self.running_var.mul_(keep).add_((w[:, None] * v_c).sum(0).to(self.running_var.dtype))
-            self.num_batches_tracked += G
+        n = g * main[0, 0].numel()
+        self._update_running([(mean.view(G, C), var.view(G, C), n)])
         if rest.shape[0]:
             y = torch.cat([y, super().forward(rest)])
         return y
@@ -74,3 +185,14 @@ def use_micro_batch_norm(module):
         else:
             use_micro_batch_norm(child)
     return module
+
+
+def bn_act(bn, x, relu=None, residual=None):
+    """``relu(bn(x) + residual)`` -- inside ONE kernel when ``bn`` is a MicroBatchNorm2d on channels-last tensors and ``relu`` is a plain
+    nn.ReLU (or None); the module-by-module composition otherwise"""
+    if isinstance(bn, MicroBatchNorm2d) and (relu is None or isinstance(relu, nn.ReLU)):
+        return bn(x, residual=residual, relu=relu is not None)
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    return relu(y) if relu is not None else y

@@ -1,0 +1,412 @@
+// batchnorm.hip -- BatchNorm2d on channels-last (NHWC) activations with GROUPED batch statistics, forward and backward, with the
+// residual add and the ReLU that follow it in ResNet / DenseNet blocks fused in.  HBM-bound: 3 passes over the activation forward
+// (statistics; normalise), 5 backward (reductions; gradient) at 16 B (bf16) / 32 B (fp32) per lane.
+//
+// Why it exists (ref:vilmedic/models/selfsup/conVIRT.py:83-95, config/SELFSUP/convirt-mimic.yml:22): the reference runs its CNN tower in
+// ``forward_batch_size`` micro-batches, so every BatchNorm normalises each micro-batch with ITS OWN statistics.  The tower runs once over
+// the whole batch here and only the statistics are grouped (blocks/vision/micro_bn.py); as a composition of torch reductions and
+// elementwise kernels on an fp32 copy of the activation that grouping cost ~130 ms of a 205 ms ConVIRT step at B = 256
+// (profiles/r05_d_steady_kernel_stats_convirt.csv).  G = 1 is ordinary BatchNorm (DenseNet-169 of MVQA: 169 layers per step).
+//
+// Layout: x is [G * R, C] row-major (R = images per group * H * W rows of C channels), C % 8 == 0, C <= 2048.  A block of 256 threads
+// owns a contiguous row range of ONE group; thread t handles the 8 channels c8 = t % (C / 8) of rows rsub = t / (C / 8) (+ k * RPI).
+#include "common.h"
+
+namespace {
+
+template <typename T> struct Ld8;
+template <> struct Ld8<bf16_t> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float* f) { unpack8(*reinterpret_cast<const uint4*>(p), f); }
+    static __device__ __forceinline__ void store(bf16_t* p, const float* f) { *reinterpret_cast<uint4*>(p) = pack8(f); }
+};
+template <> struct Ld8<float> {
+    static __device__ __forceinline__ void load(const float* p, float* f) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float* f) {
+        *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    }
+};
+
+struct BnGeom { int G, R, C, CH8, RPI, S, rows_per_split; };
+
+__device__ __forceinline__ void split_range(const BnGeom& g, int si, int& r0, int& r1) {
+    r0 = si * g.rows_per_split;
+    r1 = min(g.R, r0 + g.rows_per_split);
+}
+
+// ---- forward statistics: per (group, split) partial (count, mean, M2) per channel.  Sums are taken relative to the first value a thread
+// sees (shifted sums), partials are merged with Chan's formula: no E[x^2] - mean^2 cancellation.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, float* __restrict__ pmean, float* __restrict__ pm2,
+                                                       float* __restrict__ pcnt, const BnGeom g) {
+    const int gi = blockIdx.x / g.S, si = blockIdx.x % g.S;
+    int r0, r1;
+    split_range(g, si, r0, r1);
+    const int t = threadIdx.x, c8 = t % g.CH8, rsub = t / g.CH8;
+    __shared__ float red[256 * 17];
+    float n = 0.f, k[8], s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { k[j] = 0.f; s[j] = 0.f; q[j] = 0.f; }
+    if (rsub < g.RPI) {
+        const T* base = x + ((int64_t)gi * g.R) * g.C + c8 * 8;
+        int r = r0 + rsub;
+        if (r < r1) {
+            Ld8<T>::load(base + (int64_t)r * g.C, k);           // the shift: this thread's first row
+            n = 1.f;
+            r += g.RPI;
+        }
+        for (; r + 3 * g.RPI < r1; r += 4 * g.RPI) {            // four rows in flight
+            float a[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Ld8<T>::load(base + (int64_t)(r + u * g.RPI) * g.C, a[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = a[u][j] - k[j]; s[j] += d; q[j] += d * d; }
+            n += 4.f;
+        }
+        for (; r < r1; r += g.RPI) {
+            float a[8];
+            Ld8<T>::load(base + (int64_t)r * g.C, a);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = a[j] - k[j]; s[j] += d; q[j] += d * d; }
+            n += 1.f;
+        }
+    }
+    // per-thread (n, mean, M2)
+    float* mine = red + t * 17;
+    mine[0] = n;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float inv = n > 0.f ? 1.f / n : 0.f;
+        mine[1 + j] = k[j] + s[j] * inv;
+        mine[9 + j] = q[j] - s[j] * s[j] * inv;
+    }
+    __syncthreads();
+    if (rsub == 0) {
+        float N = mine[0], m[8], M2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { m[j] = mine[1 + j]; M2[j] = mine[9 + j]; }
+        for (int o = 1; o < g.RPI; ++o) {
+            const float* p = red + (o * g.CH8 + c8) * 17;
+            const float nb = p[0];
+            if (nb <= 0.f) continue;
+            const float tot = N + nb, w = nb / tot;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = p[1 + j] - m[j];
+                m[j] += d * w;
+                M2[j] += p[9 + j] + d * d * N * w;
+            }
+            N = tot;
+        }
+        const int64_t o = ((int64_t)gi * g.S + si) * g.C + c8 * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { pmean[o + j] = m[j]; pm2[o + j] = M2[j]; }
+        if (c8 == 0) pcnt[gi * g.S + si] = N;
+    }
+}
+
+// merge the split partials -> mean, biased variance, rstd.  A block = 16 channels x 16 split lanes of one group: lane l merges the
+// splits l, l + 16, ... (Chan), the 16 lanes are merged through LDS (a single thread per (group, channel) walking up to 1024 dependent
+// merges measured in the tens of microseconds: longer than the streaming passes of the small late layers)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ pmean, const float* __restrict__ pm2, const float* __restrict__ pcnt,
+                                                          float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ var,
+                                                          const BnGeom g, float eps) {
+    const int chunks = (g.C + 15) / 16;
+    const int gi = blockIdx.x / chunks, c = (blockIdx.x % chunks) * 16 + (threadIdx.x & 15), l = threadIdx.x >> 4;
+    __shared__ float red[256 * 3];
+    float N = 0.f, m = 0.f, M2 = 0.f;
+    if (c < g.C)
+        for (int si = l; si < g.S; si += 16) {
+            const float nb = pcnt[gi * g.S + si];
+            if (nb <= 0.f) continue;
+            const int64_t o = ((int64_t)gi * g.S + si) * g.C + c;
+            const float tot = N + nb, w = nb / tot, d = pmean[o] - m;
+            m += d * w;
+            M2 += pm2[o] + d * d * N * w;
+            N = tot;
+        }
+    red[threadIdx.x * 3] = N; red[threadIdx.x * 3 + 1] = m; red[threadIdx.x * 3 + 2] = M2;
+    __syncthreads();
+    if (l == 0 && c < g.C) {
+        for (int o = 1; o < 16; ++o) {
+            const float* p = red + (o * 16 + (threadIdx.x & 15)) * 3;
+            const float nb = p[0];
+            if (nb <= 0.f) continue;
+            const float tot = N + nb, w = nb / tot, d = p[1] - m;
+            m += d * w;
+            M2 += p[2] + d * d * N * w;
+            N = tot;
+        }
+        const float v = M2 / N;
+        mean[gi * g.C + c] = m;
+        var[gi * g.C + c] = v;
+        rstd[gi * g.C + c] = rsqrtf(v + eps);
+    }
+}
+
+// y = relu?((x - mean) * rstd * gamma + beta + residual?)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd, const BnGeom g, int relu) {
+    const int gi = blockIdx.x / g.S, si = blockIdx.x % g.S;
+    int r0, r1;
+    split_range(g, si, r0, r1);
+    const int t = threadIdx.x, c8 = t % g.CH8, rsub = t / g.CH8;
+    if (rsub >= g.RPI) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c8 * 8 + j;
+        const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+        sc[j] = rstd[gi * g.C + c] * ga;
+        sh[j] = be - mean[gi * g.C + c] * sc[j];
+    }
+    const int64_t off = ((int64_t)gi * g.R) * g.C + c8 * 8;
+    for (int r = r0 + rsub; r < r1; r += 2 * g.RPI) {
+        float a[2][8], b[2][8];
+        const bool two = r + g.RPI < r1;
+        Ld8<T>::load(x + off + (int64_t)r * g.C, a[0]);
+        if (two) Ld8<T>::load(x + off + (int64_t)(r + g.RPI) * g.C, a[1]);
+        if (res) {
+            Ld8<T>::load(res + off + (int64_t)r * g.C, b[0]);
+            if (two) Ld8<T>::load(res + off + (int64_t)(r + g.RPI) * g.C, b[1]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = a[u][j] * sc[j] + sh[j];
+                if (res) v += b[u][j];
+                a[u][j] = relu ? fmaxf(v, 0.f) : v;
+            }
+            Ld8<T>::store(y + off + (int64_t)(r + u * g.RPI) * g.C, a[u]);
+        }
+    }
+}
+
+// ---- backward reductions: per (group, split) partial sums of dy' and dy' * xhat, dy' = dy * [output > 0] when the ReLU is fused
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ res,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           float* __restrict__ psum, float* __restrict__ psumx, const BnGeom g, int relu) {
+    const int gi = blockIdx.x / g.S, si = blockIdx.x % g.S;
+    int r0, r1;
+    split_range(g, si, r0, r1);
+    const int t = threadIdx.x, c8 = t % g.CH8, rsub = t / g.CH8;
+    __shared__ float red[256 * 16];
+    float s[8], sx[8], mu[8], rs[8], sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c8 * 8 + j;
+        s[j] = 0.f; sx[j] = 0.f;
+        mu[j] = mean[gi * g.C + c]; rs[j] = rstd[gi * g.C + c];
+        sc[j] = rs[j] * (gamma ? gamma[c] : 1.f);
+        sh[j] = (beta ? beta[c] : 0.f) - mu[j] * sc[j];
+    }
+    if (rsub < g.RPI) {
+        const int64_t off = ((int64_t)gi * g.R) * g.C + c8 * 8;
+        for (int r = r0 + rsub; r < r1; r += 2 * g.RPI) {
+            float d[2][8], a[2][8], b[2][8];
+            const bool two = r + g.RPI < r1;
+            Ld8<T>::load(dy + off + (int64_t)r * g.C, d[0]);
+            Ld8<T>::load(x + off + (int64_t)r * g.C, a[0]);
+            if (two) { Ld8<T>::load(dy + off + (int64_t)(r + g.RPI) * g.C, d[1]); Ld8<T>::load(x + off + (int64_t)(r + g.RPI) * g.C, a[1]); }
+            if (res && relu) {
+                Ld8<T>::load(res + off + (int64_t)r * g.C, b[0]);
+                if (two) Ld8<T>::load(res + off + (int64_t)(r + g.RPI) * g.C, b[1]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && !two) break;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = (a[u][j] - mu[j]) * rs[j];
+                    float gdy = d[u][j];
+                    if (relu) {                                  // the forward's own expression (same rounding): y = x * sc + sh (+ res)
+                        float v = a[u][j] * sc[j] + sh[j];
+                        if (res) v += b[u][j];
+                        if (!(v > 0.f)) gdy = 0.f;
+                    }
+                    s[j] += gdy; sx[j] += gdy * xh;
+                }
+            }
+        }
+    }
+    float* mine = red + t * 16;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { mine[j] = s[j]; mine[8 + j] = sx[j]; }
+    __syncthreads();
+    if (rsub == 0) {
+        for (int o = 1; o < g.RPI; ++o) {
+            const float* p = red + (o * g.CH8 + c8) * 16;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s[j] += p[j]; sx[j] += p[8 + j]; }
+        }
+        const int64_t o = ((int64_t)gi * g.S + si) * g.C + c8 * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { psum[o + j] = s[j]; psumx[o + j] = sx[j]; }
+    }
+}
+
+// sums over the splits (16 channels x 16 split lanes per block, as bn_finalize_kernel); dgamma / dbeta accumulate over the groups
+// (G-way atomics on [C] vectors the caller zeroed)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psumx,
+                                                              float* __restrict__ sdy, float* __restrict__ sdyx,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, const BnGeom g) {
+    const int chunks = (g.C + 15) / 16;
+    const int gi = blockIdx.x / chunks, c = (blockIdx.x % chunks) * 16 + (threadIdx.x & 15), l = threadIdx.x >> 4;
+    __shared__ float red[256 * 2];
+    float a = 0.f, b = 0.f;
+    if (c < g.C)
+        for (int si = l; si < g.S; si += 16) {
+            const int64_t o = ((int64_t)gi * g.S + si) * g.C + c;
+            a += psum[o]; b += psumx[o];
+        }
+    red[threadIdx.x * 2] = a; red[threadIdx.x * 2 + 1] = b;
+    __syncthreads();
+    if (l == 0 && c < g.C) {
+        for (int o = 1; o < 16; ++o) { a += red[(o * 16 + (threadIdx.x & 15)) * 2]; b += red[(o * 16 + (threadIdx.x & 15)) * 2 + 1]; }
+        sdy[gi * g.C + c] = a; sdyx[gi * g.C + c] = b;
+        if (dbeta) atomicAdd(dbeta + c, a);
+        if (dgamma) atomicAdd(dgamma + c, b);
+    }
+}
+
+// dx = gamma * rstd * (dy' - mean(dy') - xhat * mean(dy' * xhat));  dres = dy'
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ res,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ sdy, const float* __restrict__ sdyx,
+                                                           T* __restrict__ dx, T* __restrict__ dres, const BnGeom g, int relu, int training) {
+    const int gi = blockIdx.x / g.S, si = blockIdx.x % g.S;
+    int r0, r1;
+    split_range(g, si, r0, r1);
+    const int t = threadIdx.x, c8 = t % g.CH8, rsub = t / g.CH8;
+    if (rsub >= g.RPI) return;
+    float mu[8], rs[8], sc[8], sh[8], m1[8], m2[8];
+    const float invn = training ? 1.f / (float)g.R : 0.f;       // eval mode (running statistics are constants): dx = gamma * rstd * dy'
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c8 * 8 + j;
+        mu[j] = mean[gi * g.C + c]; rs[j] = rstd[gi * g.C + c];
+        sc[j] = rs[j] * (gamma ? gamma[c] : 1.f);
+        sh[j] = (beta ? beta[c] : 0.f) - mu[j] * sc[j];
+        m1[j] = sdy[gi * g.C + c] * invn; m2[j] = sdyx[gi * g.C + c] * invn;
+    }
+    const int64_t off = ((int64_t)gi * g.R) * g.C + c8 * 8;
+    for (int r = r0 + rsub; r < r1; r += 2 * g.RPI) {
+        float d[2][8], a[2][8], b[2][8];
+        const bool two = r + g.RPI < r1;
+        Ld8<T>::load(dy + off + (int64_t)r * g.C, d[0]);
+        Ld8<T>::load(x + off + (int64_t)r * g.C, a[0]);
+        if (two) { Ld8<T>::load(dy + off + (int64_t)(r + g.RPI) * g.C, d[1]); Ld8<T>::load(x + off + (int64_t)(r + g.RPI) * g.C, a[1]); }
+        if (res && relu) {
+            Ld8<T>::load(res + off + (int64_t)r * g.C, b[0]);
+            if (two) Ld8<T>::load(res + off + (int64_t)(r + g.RPI) * g.C, b[1]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (a[u][j] - mu[j]) * rs[j];
+                float gdy = d[u][j];
+                if (relu) {
+                    float v = a[u][j] * sc[j] + sh[j];
+                    if (res) v += b[u][j];
+                    if (!(v > 0.f)) gdy = 0.f;
+                }
+                d[u][j] = gdy;
+                o[j] = sc[j] * (gdy - m1[j] - xh * m2[j]);
+            }
+            Ld8<T>::store(dx + off + (int64_t)(r + u * g.RPI) * g.C, o);
+            if (dres) Ld8<T>::store(dres + off + (int64_t)(r + u * g.RPI) * g.C, d[u]);
+        }
+    }
+}
+
+BnGeom geometry(int G, int R, int C) {
+    BnGeom g;
+    g.G = G; g.R = R; g.C = C;
+    g.CH8 = C / 8;
+    g.RPI = 256 / g.CH8;
+    // splits per group: fill the chip (~4096 blocks in all: 16 resident blocks per CU hide the HBM latency of a streaming pass) while
+    // every split keeps >= 4 row sweeps of the block
+    int S = (4096 + G - 1) / G;
+    const int max_s = (R + 4 * g.RPI - 1) / (4 * g.RPI);
+    if (S > max_s) S = max_s;
+    if (S < 1) S = 1;
+    if (S > 1024) S = 1024;
+    g.rows_per_split = (R + S - 1) / S;
+    g.S = (R + g.rows_per_split - 1) / g.rows_per_split;
+    return g;
+}
+
+}  // namespace
+
+extern "C" size_t vm_batchnorm_nhwc_ws(int G, int rows_per_group, int C) {
+    if (G <= 0 || rows_per_group <= 0 || C <= 0 || (C % 8) || C > 2048) return 0;
+    const BnGeom g = geometry(G, rows_per_group, C);
+    return ((size_t)2 * G * g.S * C + (size_t)G * g.S + (size_t)2 * G * C) * sizeof(float);
+}
+
+extern "C" int vm_batchnorm_nhwc_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
+                                     float* var, int G, int rows_per_group, int C, float eps, int dtype, int relu, int training, void* ws,
+                                     size_t ws_bytes, void* stream) {
+    VM_REQUIRE(x && y && mean && rstd && G > 0 && rows_per_group > 0 && C > 0 && (C % 8) == 0 && C <= 2048 && (dtype == VM_BF16 || dtype == VM_F32),
+               "vm_batchnorm_nhwc_fwd: bad arguments (C %% 8 == 0, C <= 2048)");
+    hipStream_t s = (hipStream_t)stream;
+    const BnGeom g = geometry(G, rows_per_group, C);
+    const double bytes = (double)G * rows_per_group * C * (dtype == VM_BF16 ? 2 : 4);
+    VmProfScope prof(VM_FAM_LN, (training ? 3.0 : 2.0) * bytes, s);
+    if (training) {
+        VM_REQUIRE(var && ws && ws_bytes >= vm_batchnorm_nhwc_ws(G, rows_per_group, C), "vm_batchnorm_nhwc_fwd: workspace too small");
+        float* pmean = (float*)ws;
+        float* pm2 = pmean + (size_t)G * g.S * C;
+        float* pcnt = pm2 + (size_t)G * g.S * C;
+        if (dtype == VM_BF16) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(G * g.S), dim3(256), 0, s, (const bf16_t*)x, pmean, pm2, pcnt, g);
+        else hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(G * g.S), dim3(256), 0, s, (const float*)x, pmean, pm2, pcnt, g);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(G * ((C + 15) / 16)), dim3(256), 0, s, pmean, pm2, pcnt, mean, rstd, var, g, eps);
+    }
+    if (dtype == VM_BF16)
+        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(G * g.S), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, gamma, beta, mean, rstd, g, relu);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(G * g.S), dim3(256), 0, s, (const float*)x, (const float*)residual, (float*)y, gamma, beta, mean, rstd, g, relu);
+    return vm_check_launch("vm_batchnorm_nhwc_fwd");
+}
+
+extern "C" int vm_batchnorm_nhwc_bwd(const void* dy, const void* x, const void* residual, const float* gamma, const float* beta, const float* mean,
+                                     const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta, int G, int rows_per_group, int C,
+                                     int dtype, int relu, int training, void* ws, size_t ws_bytes, void* stream) {
+    VM_REQUIRE(dy && x && dx && mean && rstd && G > 0 && rows_per_group > 0 && C > 0 && (C % 8) == 0 && C <= 2048 && (dtype == VM_BF16 || dtype == VM_F32),
+               "vm_batchnorm_nhwc_bwd: bad arguments (C %% 8 == 0, C <= 2048)");
+    VM_REQUIRE(ws && ws_bytes >= vm_batchnorm_nhwc_ws(G, rows_per_group, C), "vm_batchnorm_nhwc_bwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const BnGeom g = geometry(G, rows_per_group, C);
+    const double bytes = (double)G * rows_per_group * C * (dtype == VM_BF16 ? 2 : 4);
+    VmProfScope prof(VM_FAM_LN, 5.0 * bytes, s);
+    float* psum = (float*)ws;
+    float* psumx = psum + (size_t)G * g.S * C;
+    float* sdy = psumx + (size_t)G * g.S * C + (size_t)G * g.S;
+    float* sdyx = sdy + (size_t)G * C;
+    if (dtype == VM_BF16)
+        hipLaunchKernelGGL(bn_bwd_stats_kernel<bf16_t>, dim3(G * g.S), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)residual, gamma, beta, mean, rstd, psum, psumx, g, relu);
+    else
+        hipLaunchKernelGGL(bn_bwd_stats_kernel<float>, dim3(G * g.S), dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)residual, gamma, beta, mean, rstd, psum, psumx, g, relu);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(G * ((C + 15) / 16)), dim3(256), 0, s, psum, psumx, sdy, sdyx, dgamma, dbeta, g);
+    if (dtype == VM_BF16)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(G * g.S), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)residual, gamma, beta, mean, rstd, sdy, sdyx, (bf16_t*)dx, (bf16_t*)dres, g, relu, training);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(G * g.S), dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)residual, gamma, beta, mean, rstd, sdy, sdyx, (float*)dx, (float*)dres, g, relu, training);
+    return vm_check_launch("vm_batchnorm_nhwc_bwd");
+}
