@@ -30,6 +30,10 @@ def get_network(backbone, output_layer, pretrained, **kwargs):
 
 
 CNN_AMP = os.environ.get("VM_CNN_AMP", "") == "bf16"
+# the CNN towers take their images channels-last (NHWC): MIOpen's convolutions then run their NHWC kernels and every BatchNorm (+ residual add
+# + ReLU) runs on the hand-written kernel of csrc/batchnorm.hip (blocks/vision/micro_bn.py) -- in fp32 by default, in bf16 under VM_CNN_AMP.
+# VM_CNN_LAYOUT=nchw restores the NCHW / torch-BatchNorm path (A/B switch)
+CNN_NHWC = os.environ.get("VM_CNN_LAYOUT", "nhwc").lower() != "nchw"
 
 class VisualEncoder(nn.Module):
     def __init__(self, backbone, permute, dropout_out=0.0, freeze=False, output_layer=None, pretrained=True,
@@ -98,9 +102,11 @@ class VisualEncoder(nn.Module):
             return self._dropout_out(out)
         # CNN backbones are torch modules on MIOpen.  VM_CNN_AMP=bf16: channels-last bf16 convolutions under autocast with
         # fp32 master weights and fp32 BatchNorm statistics -- the counterpart of the reference's use_amp (fp16 autocast) training mode
+        if images.dim() == 4 and (CNN_AMP or CNN_NHWC):
+            images = images.contiguous(memory_format=torch.channels_last)
         if CNN_AMP:
             with torch.autocast("cuda", dtype=torch.bfloat16):
-                out = self.model(images.contiguous(memory_format=torch.channels_last))
+                out = self.model(images)
             out = out.float()
         else:
             out = self.model(images)
