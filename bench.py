@@ -35,7 +35,24 @@ DEC_12L = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, in
                vocab_size=30522, max_position_embeddings=514, layer_norm_eps=1e-5, bos_token_id=0, pad_token_id=1,
                eos_token_id=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, initializer_range=0.02)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_PROFILE = "profiles/r04_pmc_gemm.txt"      # separate rocprofv3 --pmc passes of the dominant shapes (traffic is not measurable in-process)
+PMC_PROFILE = "profiles/r05_pmc_gemm.txt"      # separate rocprofv3 --pmc passes of the dominant shapes (traffic is not measurable in-process)
+PMC_FAMILY = "profiles/r05_pmc_gemm_family.json"   # FETCH_SIZE / WRITE_SIZE passes over a whole bench run, summed over the GEMM family (tools/pmc_family.py)
+
+
+def committed_traffic():
+    """HBM-side bytes of the GEMM family per step from the committed PMC passes (they cannot be collected in-process), with the digest of
+    the library they were measured on: ``current_build`` says whether that is the library this process loaded"""
+    try:
+        with open(os.path.join(ROOT, PMC_FAMILY)) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    from vilmedic_amd import build
+    fam = d.get("gemm_family", {})
+    return {"bytes_per_step": fam.get("traffic_MB_per_step", 0.0) * 1e6, "launches_per_step": fam.get("launches_per_step"),
+            "fetch_MB_per_step": fam.get("fetch_MB_per_step"), "write_MB_per_step": fam.get("write_MB_per_step"),
+            "profile": PMC_FAMILY, "profile_build_digest": (d.get("build_digest") or "")[:16],
+            "current_build": d.get("build_digest") == build._lib_digest()}
 
 
 def flops_per_pair_fwd(S=197, L=128, d=768, V=30522, layers=12):
@@ -61,15 +78,14 @@ def dominant_shape_roofline(dump_path):
         return None
     if n == 0:
         return None
-    # HBM-side bytes need rocprofv3 --pmc passes (tools/pmc_kernels.sh, not possible in-process): the value of the committed pass over this kernel
-    # and shape on the round-4 build -- FETCH_SIZE x 2 (gfx950 correction) 89.9 MB + WRITE_SIZE 55.5 MB
-    traffic = 145.4e6
+    # HBM-side bytes need rocprofv3 --pmc passes (tools/pmc_kernels.sh, not possible in-process): reported under a separate key that names the
+    # committed profile, never mixed with the figures measured in this run
     dur = ms / n * 1e-3
     algo = 2.0 * (M * K + N * K + M * N)
     return {"kernel": "gemm_fast_kernel<0,0,...> C[12608,2304] = A[12608,768] . B[2304,768]^T + bias (ViT QKV projection)",
             "bound": "mfma", "achieved": round(2.0 * M * N * K / dur / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(2.0 * M * N * K / dur / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "avg_launch_ms": round(dur * 1e3, 4),
-            "launches": int(n), "algorithmic_bytes": algo, "traffic": traffic, "traffic_profile": PMC_PROFILE,
+            "launches": int(n), "algorithmic_bytes": algo, "traffic": None, "traffic_from_committed_profile": PMC_PROFILE,
             "hbm_frac_of_8TBps_algorithmic": round(algo / dur / 8e12, 4)}
 
 
@@ -488,12 +504,14 @@ def main():
                                              "gemm_p8w_kernel (the grouped weight + bias gradient launches of vm_wgrad_grouped, 256 x 256 tiles)",
                     "achieved": round(ach, 1),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                    "traffic_note": "family of ~30 shapes, not measurable in-process; separate rocprofv3 --pmc passes on the round-4 build in " + PMC_PROFILE +
-                                    ": 12608x2304x768 forward FETCH_SIZE x2 89.9 MB + WRITE_SIZE 55.5 MB = 145.4 MB per launch at the fabric vs 81.0 MB "
-                                    "algorithmic (1.79x, as in rounds 2-3), its dgrad 116.4 MB (1.44x); a grouped weight-gradient launch of two encoder "
-                                    "layers on gemm_p8w_kernel 918.8 + 58.6 = 977 MB vs 677 MB algorithmic (1.44x)",
+                    "traffic_note": "HBM-side bytes cannot be collected in-process: traffic = (FETCH_SIZE x 2 + WRITE_SIZE) of every GEMM-family kernel of a "
+                                    "step / launches per step, from the committed rocprofv3 --pmc passes named in traffic_source (tools/pmc_family.py)",
                     "launches_per_step": gn // 2, "avg_launch_ms": round(gms / max(gn, 1), 4),
                     "family_ms_per_step": {k: round(v[0] / 2, 3) for k, v in fam.items()}}
+            ct = committed_traffic()
+            if ct is not None and ct["bytes_per_step"] > 0:
+                roof["traffic"] = round(ct["bytes_per_step"] / max(ct["launches_per_step"] or (gn // 2), 1))          # bytes per launch, like ``achieved``
+                roof["traffic_source"] = ct
             dump = os.environ.get("VM_PROF_DUMP") or os.path.join(tempfile.gettempdir(), f"vm_prof_{os.getpid()}.txt")
             L_.vm_prof_dump(dump.encode())
             roof["dominant_shape"] = dominant_shape_roofline(dump)

@@ -90,7 +90,7 @@ def run_task(task, args):
     dt = timed(train_step, steps, max(3, min(args.warmup, steps)) if task == "scst" else min(args.warmup, steps))      # (scst: 2 eager warm-ups + the capture)
     unit = "images/s" if task == "mvqa" else "pairs/s"
     print(json.dumps({"task": task, "metric": f"{task} training step", "value": round(B / dt, 1), "unit": unit, "ms_per_step": round(dt * 1e3, 2),
-                      "batch": B, "params": n_params, "steps": steps, **(mode if task == "scst" else {})}), flush=True)
+                      "batch": B, "params": n_params, "steps": steps, "cnn_tower": "bf16 autocast" if args.amp else "fp32", **(mode if task == "scst" else {})}), flush=True)
     if task == "mvqa":
         model.eval()
 
@@ -99,7 +99,7 @@ def run_task(task, args):
                 model(**batch)
         dt = timed(infer, args.steps, args.warmup)
         print(json.dumps({"task": task, "metric": "mvqa inference", "value": round(B / dt, 1), "unit": "images/s", "ms_per_step": round(dt * 1e3, 2),
-                          "batch": B}), flush=True)
+                          "batch": B, "cnn_tower": "bf16 autocast" if args.amp else "fp32"}), flush=True)
 
 
 def run_decode(args):
@@ -135,8 +135,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--only", default="convirt,gloria,mvqa,rrs,scst,decode")
     ap.add_argument("--dry", action="store_true")
+    ap.add_argument("--amp", type=int, default=0, help="1 = trainor.use_amp: the CNN towers run their convolutions in bf16 under autocast (default: fp32, "
+                                                       "the reference's default); both modes take channels-last images and the HIP BatchNorm")
     ap.add_argument("--scst-graph", type=int, default=0, help="scst: 1 = the update replayed from one captured HIP graph (RRG_SCST.graphed_step; measured 231 vs 200 ms: an extra encoder pass and the rollout padded to max_length), 0 = eager")
     args = ap.parse_args()
+    if args.amp:
+        from vilmedic_amd.blocks.vision import visual_encoder
+        visual_encoder.CNN_AMP = True
     for task in args.only.split(","):
         if task == "decode":
             run_decode(args)
