@@ -63,6 +63,18 @@ def flops_per_pair_fwd(S=197, L=128, d=768, V=30522, layers=12):
     return 2.0 * (vit + dec + head)
 
 
+def gemm_family_algorithmic_bytes(B=64, S=197, L=128, d=768, ff=3072, V=30528, layers=12):
+    """bytes a step's GEMM family must move at the least (bf16 operands and outputs once per product, fp32 weight gradients written once,
+    the epilogue operands -- residual, GELU pre-activation -- once): per linear of M rows, K inputs, N outputs the forward, dgrad and wgrad
+    products move 6 (MK + MN) + 8 NK bytes.  29.2 GB at the benched configuration."""
+    def lin(M, K, N, extra=0):
+        return 6 * (M * K + M * N) + 8 * N * K + extra
+    Me, Md = B * S, B * L
+    enc = layers * (lin(Me, d, 3 * d) + lin(Me, d, d, 2 * Me * d) + lin(Me, d, ff, 4 * Me * ff) + lin(Me, ff, d, 2 * Me * d))
+    dec = layers * (lin(Md, d, 3 * d) + 3 * lin(Md, d, d, 2 * Md * d) + lin(Md, d, ff, 4 * Md * ff) + lin(Md, ff, d, 2 * Md * d))
+    return enc + dec + lin(Me, d, 2 * d * layers) + lin(Md, d, V) + lin(B * (S - 1), d, d)
+
+
 def dominant_shape_roofline(dump_path):
     """the single largest forward GEMM shape (QKV projection of the ViT, 12608 x 2304 x 768, bias epilogue): achieved rate from
     this run's per-launch HIP events, HBM-side traffic per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2
@@ -512,6 +524,8 @@ def main():
             if ct is not None and ct["bytes_per_step"] > 0:
                 roof["traffic"] = round(ct["bytes_per_step"] / max(ct["launches_per_step"] or (gn // 2), 1))          # bytes per launch, like ``achieved``
                 roof["traffic_source"] = ct
+                roof["algorithmic_bytes"] = round(gemm_family_algorithmic_bytes(B=B, L=L) / max(ct["launches_per_step"] or (gn // 2), 1))
+                roof["traffic_over_algorithmic"] = round(roof["traffic"] / roof["algorithmic_bytes"], 3)
             dump = os.environ.get("VM_PROF_DUMP") or os.path.join(tempfile.gettempdir(), f"vm_prof_{os.getpid()}.txt")
             L_.vm_prof_dump(dump.encode())
             roof["dominant_shape"] = dominant_shape_roofline(dump)

@@ -179,5 +179,34 @@ def test_heads_of_48_columns_train_through_the_padded_path_vs_oracle():
               "bert.encoder.layer.0.attention.output.dense.weight"):
         got, ref = named[n].grad.float().cpu(), stg[n].grad
         assert grads_close(got, ref), (n, cosine(got, ref), rel_l2(got, ref))
-    with pytest.raises(NotImplementedError):
-        dec.generate(input_ids=torch.zeros((B, 1), dtype=torch.long, device=dev()), encoder_hidden_states=enc.to(dev()), max_length=8)
+
+
+def test_heads_of_48_columns_decode_on_padded_projections_vs_oracle():
+    """the cached decode step of the same head width: zero-padded projection weights (generation.DecodeState._build_padded_weights), greedy
+    and beam-4 token ids against the oracle's full-prefix recompute, bit-exact (fp32 step)"""
+    from oracle import torch_ref as O
+    from vilmedic_amd.blocks.huggingface.decoder.decoder_model import DecoderModel
+    cfg = dict(R.DEC_TINY, hidden_size=96, num_attention_heads=2, intermediate_size=192)
+    st = R.rand_state(R.decoder_shapes(cfg), 95, std=0.6, emb_std=0.2, qk_std=0.15, pos_std=0.6)
+    st["lm_head.bias"][cfg["eos_token_id"]] += 3.0
+    dec = DecoderModel(dict(proto=None, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **cfg)).to(dev()).eval()
+    full = dict(st)
+    full["lm_head.decoder.weight"], full["lm_head.decoder.bias"] = st["bert.embeddings.word_embeddings.weight"], st["lm_head.bias"]
+    dec.decoder.load_state_dict(full, strict=True)
+    B, S, T = 4, 9, 20
+    gen = torch.Generator().manual_seed(96)
+    enc = torch.randn(B, S, cfg["hidden_size"], generator=gen)
+    enc_mask = torch.ones(B, S, dtype=torch.bool)
+    enc_mask[3, 4:] = False
+    enc[~enc_mask] = 0.0
+    with torch.no_grad():
+        ref1 = O.greedy_decode(enc, enc_mask, st, cfg, 0, 2, 1, T)
+        ref4, sc4 = O.beam_decode(enc, enc_mask, st, cfg, 0, 2, 1, T, 4)
+        start = torch.zeros((B, 1), dtype=torch.long, device=dev())
+        kw = dict(encoder_hidden_states=enc.to(dev()), encoder_attention_mask=enc_mask.to(dev()), bos_token_id=0, eos_token_id=2, pad_token_id=1,
+                  max_length=T, return_dict_in_generate=True)
+        o1 = dec.generate(input_ids=start, **kw)
+        o4 = dec.generate(input_ids=start, num_beams=4, **kw)
+    assert torch.equal(o1.sequences.cpu(), ref1), (o1.sequences.tolist(), ref1.tolist())
+    assert torch.equal(o4.sequences.cpu(), ref4), (o4.sequences.tolist(), ref4.tolist())
+    torch.testing.assert_close(o4.sequences_scores.cpu(), sc4, rtol=1e-4, atol=1e-4)

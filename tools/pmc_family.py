@@ -37,7 +37,9 @@ def summarise(out, dst):
     per = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
     for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            k = per[r["Kernel_Name"].split("(")[0][:80]][r["Counter_Name"]]
+            kn = r["Kernel_Name"]
+            kn = kn[:kn.rfind("(")] if kn.endswith(")") else kn          # drop the argument list only ("(anonymous namespace)::" stays)
+            k = per[kn[:90]][r["Counter_Name"]]
             k[0] += float(r["Counter_Value"])
             k[1] += 1
     steps = STEPS + WARMUP

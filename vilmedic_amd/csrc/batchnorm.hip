@@ -110,38 +110,35 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
     }
 }
 
-// merge the split partials -> mean, biased variance, rstd.  A block = 16 channels x 16 split lanes of one group: lane l merges the
-// splits l, l + 16, ... (Chan), the 16 lanes are merged through LDS (a single thread per (group, channel) walking up to 1024 dependent
-// merges measured in the tens of microseconds: longer than the streaming passes of the small late layers)
+// merge the split partials -> mean, biased variance, rstd.  A block = (256 / LANES) channels x LANES split lanes of one group: lane l
+// merges the splits l, l + LANES, ... (Chan), the lanes are merged pairwise through LDS (a single thread per (group, channel) walking up
+// to 1024 dependent merges measured 30 us per layer on MVQA's DenseNet, G = 1: more than the streaming passes of its late layers)
+__device__ __forceinline__ void chan_merge(float& N, float& m, float& M2, float nb, float mb, float M2b) {
+    if (nb <= 0.f) return;
+    const float tot = N + nb, w = nb / tot, d = mb - m;
+    m += d * w;
+    M2 += M2b + d * d * N * w;
+    N = tot;
+}
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ pmean, const float* __restrict__ pm2, const float* __restrict__ pcnt,
                                                           float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ var,
-                                                          const BnGeom g, float eps) {
-    const int chunks = (g.C + 15) / 16;
-    const int gi = blockIdx.x / chunks, c = (blockIdx.x % chunks) * 16 + (threadIdx.x & 15), l = threadIdx.x >> 4;
+                                                          const BnGeom g, float eps, int lanes) {
+    const int cpb = 256 / lanes, chunks = (g.C + cpb - 1) / cpb;
+    const int gi = blockIdx.x / chunks, cl = threadIdx.x / lanes, l = threadIdx.x % lanes, c = (blockIdx.x % chunks) * cpb + cl;
     __shared__ float red[256 * 3];
     float N = 0.f, m = 0.f, M2 = 0.f;
     if (c < g.C)
-        for (int si = l; si < g.S; si += 16) {
-            const float nb = pcnt[gi * g.S + si];
-            if (nb <= 0.f) continue;
+        for (int si = l; si < g.S; si += lanes) {
             const int64_t o = ((int64_t)gi * g.S + si) * g.C + c;
-            const float tot = N + nb, w = nb / tot, d = pmean[o] - m;
-            m += d * w;
-            M2 += pm2[o] + d * d * N * w;
-            N = tot;
+            chan_merge(N, m, M2, pcnt[gi * g.S + si], pmean[o], pm2[o]);
         }
-    red[threadIdx.x * 3] = N; red[threadIdx.x * 3 + 1] = m; red[threadIdx.x * 3 + 2] = M2;
-    __syncthreads();
+    for (int st = lanes >> 1; st > 0; st >>= 1) {
+        red[threadIdx.x * 3] = N; red[threadIdx.x * 3 + 1] = m; red[threadIdx.x * 3 + 2] = M2;
+        __syncthreads();
+        if (l < st) { const float* p = red + (threadIdx.x + st) * 3; chan_merge(N, m, M2, p[0], p[1], p[2]); }
+        __syncthreads();
+    }
     if (l == 0 && c < g.C) {
-        for (int o = 1; o < 16; ++o) {
-            const float* p = red + (o * 16 + (threadIdx.x & 15)) * 3;
-            const float nb = p[0];
-            if (nb <= 0.f) continue;
-            const float tot = N + nb, w = nb / tot, d = p[1] - m;
-            m += d * w;
-            M2 += p[2] + d * d * N * w;
-            N = tot;
-        }
         const float v = M2 / N;
         mean[gi * g.C + c] = m;
         var[gi * g.C + c] = v;
@@ -256,24 +253,27 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__
     }
 }
 
-// sums over the splits (16 channels x 16 split lanes per block, as bn_finalize_kernel); dgamma / dbeta accumulate over the groups
-// (G-way atomics on [C] vectors the caller zeroed)
+// sums over the splits ((256 / LANES) channels x LANES split lanes per block, as bn_finalize_kernel); dgamma / dbeta accumulate over the
+// groups (G-way atomics on [C] vectors the caller zeroed)
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psumx,
                                                               float* __restrict__ sdy, float* __restrict__ sdyx,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, const BnGeom g) {
-    const int chunks = (g.C + 15) / 16;
-    const int gi = blockIdx.x / chunks, c = (blockIdx.x % chunks) * 16 + (threadIdx.x & 15), l = threadIdx.x >> 4;
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, const BnGeom g, int lanes) {
+    const int cpb = 256 / lanes, chunks = (g.C + cpb - 1) / cpb;
+    const int gi = blockIdx.x / chunks, cl = threadIdx.x / lanes, l = threadIdx.x % lanes, c = (blockIdx.x % chunks) * cpb + cl;
     __shared__ float red[256 * 2];
     float a = 0.f, b = 0.f;
     if (c < g.C)
-        for (int si = l; si < g.S; si += 16) {
+        for (int si = l; si < g.S; si += lanes) {
             const int64_t o = ((int64_t)gi * g.S + si) * g.C + c;
             a += psum[o]; b += psumx[o];
         }
-    red[threadIdx.x * 2] = a; red[threadIdx.x * 2 + 1] = b;
-    __syncthreads();
+    for (int st = lanes >> 1; st > 0; st >>= 1) {
+        red[threadIdx.x * 2] = a; red[threadIdx.x * 2 + 1] = b;
+        __syncthreads();
+        if (l < st) { a += red[(threadIdx.x + st) * 2]; b += red[(threadIdx.x + st) * 2 + 1]; }
+        __syncthreads();
+    }
     if (l == 0 && c < g.C) {
-        for (int o = 1; o < 16; ++o) { a += red[(o * 16 + (threadIdx.x & 15)) * 2]; b += red[(o * 16 + (threadIdx.x & 15)) * 2 + 1]; }
         sdy[gi * g.C + c] = a; sdyx[gi * g.C + c] = b;
         if (dbeta) atomicAdd(dbeta + c, a);
         if (dgamma) atomicAdd(dgamma + c, b);
@@ -335,6 +335,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
+// split lanes of the finalize kernels: enough that a lane walks at most ~16 partials
+static int finalize_lanes(int S) { return S > 512 ? 64 : (S > 128 ? 32 : 16); }
+
 BnGeom geometry(int G, int R, int C) {
     BnGeom g;
     g.G = G; g.R = R; g.C = C;
@@ -376,7 +379,10 @@ extern "C" int vm_batchnorm_nhwc_fwd(const void* x, const void* residual, void* 
         float* pcnt = pm2 + (size_t)G * g.S * C;
         if (dtype == VM_BF16) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(G * g.S), dim3(256), 0, s, (const bf16_t*)x, pmean, pm2, pcnt, g);
         else hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(G * g.S), dim3(256), 0, s, (const float*)x, pmean, pm2, pcnt, g);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(G * ((C + 15) / 16)), dim3(256), 0, s, pmean, pm2, pcnt, mean, rstd, var, g, eps);
+        {
+            const int lanes = finalize_lanes(g.S), cpb = 256 / lanes;
+            hipLaunchKernelGGL(bn_finalize_kernel, dim3(G * ((C + cpb - 1) / cpb)), dim3(256), 0, s, pmean, pm2, pcnt, mean, rstd, var, g, eps, lanes);
+        }
     }
     if (dtype == VM_BF16)
         hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(G * g.S), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, gamma, beta, mean, rstd, g, relu);
@@ -403,7 +409,10 @@ extern "C" int vm_batchnorm_nhwc_bwd(const void* dy, const void* x, const void* 
         hipLaunchKernelGGL(bn_bwd_stats_kernel<bf16_t>, dim3(G * g.S), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)residual, gamma, beta, mean, rstd, psum, psumx, g, relu);
     else
         hipLaunchKernelGGL(bn_bwd_stats_kernel<float>, dim3(G * g.S), dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)residual, gamma, beta, mean, rstd, psum, psumx, g, relu);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(G * ((C + 15) / 16)), dim3(256), 0, s, psum, psumx, sdy, sdyx, dgamma, dbeta, g);
+    {
+        const int lanes = finalize_lanes(g.S), cpb = 256 / lanes;
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(G * ((C + cpb - 1) / cpb)), dim3(256), 0, s, psum, psumx, sdy, sdyx, dgamma, dbeta, g, lanes);
+    }
     if (dtype == VM_BF16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(G * g.S), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)residual, gamma, beta, mean, rstd, sdy, sdyx, (bf16_t*)dx, (bf16_t*)dres, g, relu, training);
     else

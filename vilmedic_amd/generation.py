@@ -51,11 +51,11 @@ def _ln(x, aff, eps):
     return y
 
 
-def _attn(q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, dh, key_mask=None, kv_index=None, kv_index_ld=0):
+def _attn(q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, dh, key_mask=None, kv_index=None, kv_index_ld=0, scale=None):
     o = torch.empty(B * Lq, H * dh, dtype=BF16, device=q.device)
     stats = torch.empty(B * H * Lq * 2, dtype=torch.float32, device=q.device)
     check(lib().vm_attention_fwd(ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(o), H * dh, ptr(stats),
-                                 ptr(key_mask) if key_mask is not None else None, B, H, Lq, Lk, dh, dh ** -0.5, 0, 0.0, 0, None,
+                                 ptr(key_mask) if key_mask is not None else None, B, H, Lq, Lk, dh, scale or dh ** -0.5, 0, 0.0, 0, None,
                                  ptr(kv_index) if kv_index is not None else None, kv_index_ld, stream()), "vm_attention_fwd")
     return o
 
@@ -74,12 +74,12 @@ def _ln32(x, aff, eps):
     return y
 
 
-def _attn32(q, k, ldk, v, ldv, rows, H, Lk, dh, q_per_kv, key_mask=None, kv_index=None, kv_index_ld=0):
+def _attn32(q, k, ldk, v, ldv, rows, H, Lk, dh, q_per_kv, key_mask=None, kv_index=None, kv_index_ld=0, scale=None):
     o = torch.empty(rows, H * dh, dtype=F32, device=q.device)
     check(lib().vm_attention_decode_f32(ptr(q), q.stride(0), ptr(k), ldk, ptr(v), ldv, ptr(o), H * dh,
                                         ptr(key_mask) if key_mask is not None else None,
                                         ptr(kv_index) if kv_index is not None else None, kv_index_ld,
-                                        rows, H, Lk, dh, q_per_kv, dh ** -0.5, stream()), "vm_attention_decode_f32")
+                                        rows, H, Lk, dh, q_per_kv, scale or dh ** -0.5, stream()), "vm_attention_decode_f32")
     return o
 
 
@@ -102,16 +102,24 @@ class DecodeState:
         self.T = max_length
         self.D = cfg.hidden_size
         self.H = cfg.num_attention_heads
-        if self.D // self.H not in ops.HEAD_DIMS:
-            raise NotImplementedError(f"the cached decode step needs head_dim in {ops.HEAD_DIMS} (got {self.D // self.H}: such heads train through "
-                                      "the zero-padded path of ops._attention_padded_heads, which the KV-cache kernels do not have)")
+        # head widths the attention kernels do not have (BertGenerationConfig's default 16 heads on hidden_size 768 = 48 columns,
+        # ref:config/RRG/baseline-HF.yml): the step runs on zero-PADDED projection weights -- every head's Q / K / V rows and the matching
+        # columns of the output projections are spread to the next kernel width (``Da`` = heads x padded width), rebuilt from the
+        # parameters at every load_encoder().  Zero rows add nothing to QK^T, zero V columns give zero context columns that meet zero
+        # weight columns; the softmax scale stays dh^-1/2.
+        self.dh = self.D // self.H
+        self.dhp = ops.padded_head_dim(self.dh)
+        self.Da = self.H * self.dhp
+        self.padded = self.dhp != self.dh
+        self.scale = self.dh ** -0.5
         dev = enc.device
         self.S = enc.shape[1]
         self.layers = decoder.bert.encoder.layer
         # static buffers (their addresses are baked into the captured graphs)
         self.enc_mask = torch.ones(self.B, self.S, dtype=torch.uint8, device=dev) if enc_mask is not None else None
-        self.cross_kv = [torch.empty(self.B * self.S, 2 * self.D, dtype=self.act, device=dev) for _ in self.layers]
-        self.self_kv = [torch.empty(self.M * self.T, 2 * self.D, dtype=self.act, device=dev) for _ in self.layers]
+        self.cross_kv = [torch.empty(self.B * self.S, 2 * self.Da, dtype=self.act, device=dev) for _ in self.layers]
+        self.self_kv = [torch.empty(self.M * self.T, 2 * self.Da, dtype=self.act, device=dev) for _ in self.layers]
+        self.pw = None                    # per layer: the padded weights / biases of a padded-head step (built by load_encoder)
         self.index = torch.empty(self.M, self.T, dtype=torch.int32, device=dev)
         self.tok = torch.zeros(self.M, dtype=torch.long, device=dev)
         self.V = cfg.vocab_size
@@ -119,7 +127,8 @@ class DecodeState:
         # the step's activations (static: their addresses are baked into the captured graphs): pre-LN running sum, its LayerNorm (the
         # residual), the attention queries, the MLP hidden
         ff = max(l.intermediate.dense.weight.shape[0] for l in self.layers)
-        self.buf_s, self.buf_x, self.buf_q = (torch.empty(self.M, self.D, dtype=self.act, device=dev) for _ in range(3))
+        self.buf_s, self.buf_x = (torch.empty(self.M, self.D, dtype=self.act, device=dev) for _ in range(2))
+        self.buf_q = torch.empty(self.M, max(self.D, self.Da), dtype=self.act, device=dev)
         self.buf_h = torch.empty(self.M, ff, dtype=self.act, device=dev)
         self.buf_stat = torch.empty(2 * self.M, dtype=torch.float32, device=dev)
         self.graphs = {}
@@ -145,8 +154,17 @@ class DecodeState:
         enc2 = enc.view(self.B * self.S, enc.shape[2])
         if self.enc_mask is not None:
             self.enc_mask.copy_(to_key_mask(enc_mask))
-        for layer, kv in zip(self.layers, self.cross_kv):
+        if self.padded:
+            self._build_padded_weights()
+        for li, (layer, kv) in enumerate(zip(self.layers, self.cross_kv)):
             ca = layer.crossattention.self
+            if self.padded:
+                w, bias = self.pw[li]["ckv"]
+                if self.f32:
+                    _gemm32(enc2, w, bias, kv, self.B * self.S, 2 * self.Da, enc2.shape[1])
+                else:
+                    ops.gemm(enc2, 0, w, 0, kv, self.B * self.S, 2 * self.Da, enc2.shape[1], bias=bias)
+                continue
             if self.f32:
                 _gemm32(enc2, a.f32_group([ca.key.weight, ca.value.weight]), a.f32_group([ca.key.bias, ca.value.bias]), kv,
                         self.B * self.S, 2 * self.D, enc2.shape[1])
@@ -156,6 +174,34 @@ class DecodeState:
         dev = enc.device
         self.index.copy_(torch.arange(self.M, device=dev, dtype=torch.int32)[:, None] * self.T
                          + torch.arange(self.T, device=dev, dtype=torch.int32)[None, :])
+
+    @torch.no_grad()
+    def _build_padded_weights(self):
+        """zero-padded copies (step dtype; biases fp32) of the attention projections: rows / columns of head h at [h * dhp, h * dhp + dh)"""
+        H, dh, w, dt = self.H, self.dh, self.dhp, self.act
+
+        def rows(ws, bs):           # [n x D_out, K] stacked projections -> every head's rows spread to the padded width
+            W = torch.cat([p.detach().float().view(H, dh, -1) for p in ws], 0)                       # [n*H, dh, K]
+            Wp = torch.zeros(W.shape[0], w, W.shape[2], device=W.device)
+            Wp[:, :dh] = W
+            b = torch.cat([p.detach().float().view(H, dh) for p in bs], 0)
+            bp = torch.zeros(b.shape[0], w, device=b.device)
+            bp[:, :dh] = b
+            return Wp.view(-1, W.shape[2]).to(dt).contiguous(), bp.view(-1).contiguous()
+
+        def cols(p):                # [D, D_in] output projection -> its input columns spread likewise
+            W = p.detach().float().view(p.shape[0], H, dh)
+            Wp = torch.zeros(p.shape[0], H, w, device=W.device)
+            Wp[:, :, :dh] = W
+            return Wp.view(p.shape[0], -1).to(dt).contiguous()
+        self.pw = []
+        for layer in self.layers:
+            sa, ca = layer.attention.self, layer.crossattention.self
+            self.pw.append({"qkv": rows([sa.query.weight, sa.key.weight, sa.value.weight], [sa.query.bias, sa.key.bias, sa.value.bias]),
+                            "so": cols(layer.attention.output.dense.weight),
+                            "cq": rows([ca.query.weight], [ca.query.bias]),
+                            "ckv": rows([ca.key.weight, ca.value.weight], [ca.key.bias, ca.value.bias]),
+                            "co": cols(layer.crossattention.output.dense.weight)})
 
     def reorder(self, parent_rows, upto):
         """beam j continues old beam parent_rows[j]: its history 0..upto-1 is the parent's (index-table gather, no cache copy)"""
@@ -264,9 +310,35 @@ class DecodeState:
         check(fn(ptr(tokens.contiguous()), ptr(emb.word_embeddings.weight), ptr(pos), ptr(s), M, 1, D, t, stream()),
               "vm_embedding_fwd")
         ln = emb.LayerNorm                       # the LayerNorm that turns the running pre-LN sum ``s`` into the next sub-layer's input
+        Da, dhp, sc = self.Da, self.dhp, self.scale
         for li, layer in enumerate(self.layers):
             sa = layer.attention.self
             cache = self.self_kv[li]
+            if self.padded:                      # the same eight launches on the zero-padded projections (load_encoder built them)
+                pw = self.pw[li]
+                qp = q[:, :Da] if q.shape[1] == Da else q.as_strided((M, Da), (q.stride(0), 1))
+                self._dgl(s, ln, x, pw["qkv"][0], qp, M, 3 * Da, D, bias=pw["qkv"][1], c2=cache[t:], ldc2=T * 2 * Da, split_n=Da)
+                if self.f32:
+                    ctx = _attn32(qp, cache, 2 * Da, cache[:, Da:], 2 * Da, M, H, t + 1, dhp, 1, kv_index=self.index, kv_index_ld=T, scale=sc)
+                else:
+                    ctx = _attn(qp, qp.stride(0), cache, 2 * Da, cache[:, Da:], 2 * Da, M, H, 1, t + 1, dhp, kv_index=self.index, kv_index_ld=T, scale=sc)
+                blk = layer.attention.output
+                self._dg(ctx, pw["so"], s, M, D, Da, bias=blk.dense.bias, residual=x)
+                self._dgl(s, blk.LayerNorm, x, pw["cq"][0], qp, M, Da, D, bias=pw["cq"][1])
+                kv = self.cross_kv[li]
+                if self.f32:
+                    ctx = _attn32(qp, kv, 2 * Da, kv[:, Da:], 2 * Da, M, H, self.S, dhp, self.nb, key_mask=self.enc_mask, scale=sc)
+                else:
+                    ctx = _attn(qp, qp.stride(0), kv, 2 * Da, kv[:, Da:], 2 * Da, self.B, H, self.nb, self.S, dhp, key_mask=self.enc_mask, scale=sc)
+                blk = layer.crossattention.output
+                self._dg(ctx, pw["co"], s, M, D, Da, bias=blk.dense.bias, residual=x)
+                i, o = layer.intermediate.dense, layer.output.dense
+                F = i.weight.shape[0]
+                h = self.buf_h
+                self._dgl(s, blk.LayerNorm, x, self._w([i.weight]), h, M, F, D, bias=i.bias, act=1)
+                self._dg(h, self._w([o.weight]), s, M, D, F, bias=o.bias, residual=x)
+                ln = layer.output.LayerNorm
+                continue
             if getattr(sa, "fuse_q", False):     # Q|K|V in one launch: Q -> q, K|V of the new token -> cache row t
                 self._dgl(s, ln, x, self._w([sa.query.weight, sa.key.weight, sa.value.weight]), q, M, 3 * D, D,
                           bias=a.f32_group([sa.query.bias, sa.key.bias, sa.value.bias]), c2=cache[t:], ldc2=T * 2 * D, split_n=D)
@@ -299,8 +371,8 @@ class DecodeState:
         if self.f32:
             xl = _ln32(s, ln, cfg.layer_norm_eps)
             if hd is not None:
-                self._dg(xl, self._w([hd.weight]), q, M, D, D, bias=hd.bias, act=1)
-                xl = _ln32(q, hl, cfg.layer_norm_eps)
+                self._dg(xl, self._w([hd.weight]), x, M, D, D, bias=hd.bias, act=1)
+                xl = _ln32(x, hl, cfg.layer_norm_eps)
             V = self.V
             logits = torch.empty(M, (V + 3) // 4 * 4, dtype=F32, device=s.device)
             # (the decode GEMM's 64-row blocks: 128- / 256-row blocks measured 285 us for this product at 256 rows)
@@ -308,8 +380,8 @@ class DecodeState:
             return logits[:, :V]
         xl = _ln(s, ln, cfg.layer_norm_eps)
         if hd is not None:
-            self._dg(xl, self._w([hd.weight]), q, M, D, D, bias=hd.bias, act=1)
-            xl = _ln(q, hl, cfg.layer_norm_eps)
+            self._dg(xl, self._w([hd.weight]), x, M, D, D, bias=hd.bias, act=1)
+            xl = _ln(x, hl, cfg.layer_norm_eps)
         return ops.lm_logits_f32(xl, self.emb_sh, self.dec.lm_bias, self.V)
 
 
