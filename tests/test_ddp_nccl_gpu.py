@@ -165,7 +165,7 @@ def test_bf16_wire_error_on_the_c2_model(nccl):
 # VM_FORCE_DDP=1 makes a ONE-rank group take every collective path (vilmedic_amd/parallel.py: active / force_collectives), so the RCCL
 # calls of the training loop, of the contrastive-negatives all-gather and of the GLoRIA gather execute on the GPU box's communicator.
 # With one rank every collective is the identity, so the results must equal the run without a process group.
-def _tiny_trainor(tmp_path, tag, extra=(), yml="rrg-vit-synthetic.yml"):
+def _tiny_trainor(tmp_path, tag, extra=(), yml="rrg-vit-synthetic.yml", prepare=None):
     from vilmedic_amd.config import executor_view, get_config
     from vilmedic_amd.executors import Trainor
     os.makedirs(tmp_path / tag, exist_ok=True)
@@ -180,6 +180,8 @@ def _tiny_trainor(tmp_path, tag, extra=(), yml="rrg-vit-synthetic.yml"):
     t = executor_view(cfg, "trainor")
     t["validator_view"] = executor_view(cfg, "validator")
     tr = Trainor(t, seed=0)
+    if prepare is not None:
+        prepare(tr)
     losses, fwd = [], tr.model.forward
 
     def recording(**batch):
@@ -192,7 +194,8 @@ def _tiny_trainor(tmp_path, tag, extra=(), yml="rrg-vit-synthetic.yml"):
 
         def graphed(batch):
             loss = gi(batch)
-            losses.append(loss.detach().float().reshape(()).clone())
+            if loss is not None:                   # (None: this batch signature runs eagerly -- capture refused or failed)
+                losses.append(loss.detach().float().reshape(()).clone())
             return loss
         tr._graphed_iteration = graphed
     else:
@@ -220,6 +223,38 @@ def test_trainor_graph_step_replays_the_eager_iterations(tmp_path):
     assert dl <= 1e-5 and dp <= 1e-5
     assert s1[0] == s0[0]
     assert int(t1.optimizer.state_dict()["steps"]) == 12
+
+
+def test_trainor_graph_step_falls_back_to_eager_when_the_capture_fails(tmp_path):
+    """a forward that reads the device (legal eagerly, illegal while a stream is capturing) makes the capture of its batch signature fail:
+    the signature is marked eager, the host-side queues of the aborted capture are dropped (ops.reset_host_state), the optimizer's step count
+    is restored, and the run continues eagerly to the same parameters as a run that never tried; a graph cache of one signature evicts"""
+    extra = ["model.decoder.hidden_dropout_prob=0.0", "model.decoder.attention_probs_dropout_prob=0.0", "trainor.epochs=2"]
+
+    def spoil(tr):
+        fwd = tr.model.forward
+
+        def reading(**batch):
+            out = fwd(**batch)
+            if "loss" in out:
+                float(out["loss"].detach().float().sum())              # the host read
+            return out
+        tr.model.forward = reading
+    t0, l0, p0, s0 = _tiny_trainor(tmp_path, "eager_fb", extra)
+    t1, l1, p1, s1 = _tiny_trainor(tmp_path, "graph_fb", extra + ["trainor.graph_step=true"], prepare=spoil)
+    assert t1.graph_any and list(t1._graphs.values()) == [False]          # tried once, failed, stays eager
+    assert int(t1.optimizer.state_dict()["steps"]) == int(t0.optimizer.state_dict()["steps"]) == 12
+    dp = _rel(p1, p0)
+    print(f"[parity] Trainor.start() with graph_step whose capture fails: rel L2 of the final parameters vs the eager run {dp:.3e}; "
+          f"validation {s1[0]} vs {s0[0]}", flush=True)
+    assert dp <= 1e-5 and s1[0] == s0[0]
+    # LRU eviction: with room for ONE signature a second batch shape replaces the first (single process)
+    t2, _, _, _ = _tiny_trainor(tmp_path, "graph_lru", extra + ["trainor.graph_step=true", "trainor.graph_cache=1"])
+    assert t2.max_graphs == 1 and len(t2._graphs) == 1
+    key = next(iter(t2._graphs))
+    batch = {k: (v[:2] if isinstance(v, torch.Tensor) else v) for k, v in next(iter(t2.dl)).items()}       # another batch size = another signature
+    t2._graphed_iteration(batch)
+    assert len(t2._graphs) == 1 and next(iter(t2._graphs)) != key
 
 
 @pytest.mark.parametrize("wire", ["fp32", "bf16"])
