@@ -162,8 +162,12 @@ class BertLMHeadModel(_CausalLM):
 
 def text_config(model_type, kwargs):
     """HF config defaults of the two architectures + the values of a checkpoint's config.json"""
-    if model_type == "roberta":
-        return make_config(ROBERTA_DEFAULTS, kwargs)
-    if model_type == "bert":
-        return make_config(BERT_DEFAULTS, kwargs)
+    if model_type in ("roberta", "bert"):
+        cfg = make_config(ROBERTA_DEFAULTS if model_type == "roberta" else BERT_DEFAULTS, kwargs)
+        if (cfg.get("position_embedding_type") or "absolute") != "absolute":
+            raise NotImplementedError(f"position_embedding_type={cfg.position_embedding_type!r}: the HIP path implements absolute position embeddings "
+                                      "(what every checkpoint the reference's YAMLs name uses)")
+        if int(cfg.type_vocab_size) < 1:
+            raise ValueError("type_vocab_size must be >= 1 (token-type row 0 is added to every token)")
+        return cfg
     raise NotImplementedError(f"model_type {model_type!r}: the HIP path builds 'bert', 'roberta' and 'bert-generation' text models")
