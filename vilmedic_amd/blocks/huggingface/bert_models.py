@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from ... import ops
 from ...arena import arena_of
-from ...nn import (BERT_DEFAULTS, ROBERTA_DEFAULTS, Affine, BertFullEmbeddings, BertPooler, BertStack, _Holder, _linear, _ln,
+from ...nn import (BERT_DEFAULTS, ROBERTA_DEFAULTS, Affine, BertFullEmbeddings, BertPooler, BertStack, _Holder, _ln,
                    make_config, to_key_mask)
 from ... import nn as _nn
 from .decoder.bert_generation import ModelOutput, _rows
