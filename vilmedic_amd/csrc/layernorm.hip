@@ -60,6 +60,63 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
     }
 }
 
+// cols == 768 (every LayerNorm of the ViT-B / BERT-base stacks: 62 launches per C2 step): TWO consecutive rows per wave as ONE vector of
+// 192 16-byte chunks = exactly 3 per lane, all requested up front.  The one-row form leaves lanes 32..63 idle on its second chunk and has
+// each wave wait for a single row's latency with nothing else in flight: at 12608 rows that is 1.5 rounds of the chip's 8192 wave slots,
+// 9.6 - 10.2 us for 38.7 MB.  Chunk q of the pair lies in row q / 96; chunks l (row 0), l + 64 (row 0 for l < 32, else row 1), l + 128 (row 1).
+__global__ __launch_bounds__(256) void ln_fwd_pair768_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                             float* __restrict__ mean, float* __restrict__ rstd, int rows, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int npairs = (rows + 1) >> 1;
+    const bool lo = lane < 32;
+    // column chunk of each of the lane's three chunks (constant over the pairs): l, (l + 64) % 96, l + 32
+    const int cc[3] = {lane, lo ? lane + 64 : lane - 32, lane + 32};
+    float g[3][8], b[3][8];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float4 g0 = *reinterpret_cast<const float4*>(gamma + cc[k] * 8), g1 = *reinterpret_cast<const float4*>(gamma + cc[k] * 8 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(beta + cc[k] * 8), b1 = *reinterpret_cast<const float4*>(beta + cc[k] * 8 + 4);
+        g[k][0] = g0.x; g[k][1] = g0.y; g[k][2] = g0.z; g[k][3] = g0.w; g[k][4] = g1.x; g[k][5] = g1.y; g[k][6] = g1.z; g[k][7] = g1.w;
+        b[k][0] = b0.x; b[k][1] = b0.y; b[k][2] = b0.z; b[k][3] = b0.w; b[k][4] = b1.x; b[k][5] = b1.y; b[k][6] = b1.z; b[k][7] = b1.w;
+    }
+    for (int pr = blockIdx.x * 4 + (threadIdx.x >> 6); pr < npairs; pr += gridDim.x * 4) {
+        const int r0 = 2 * pr;
+        const bool two = r0 + 1 < rows;                         // (an odd row count: the last pair holds one row)
+        const bf16_t* xb = x + (int64_t)r0 * 768;
+        float v[3][8];
+        const bool ok1 = lo || two, ok2 = two;
+        unpack8(*reinterpret_cast<const uint4*>(xb + lane * 8), v[0]);
+        if (ok1) unpack8(*reinterpret_cast<const uint4*>(xb + (lane + 64) * 8), v[1]);
+        if (ok2) unpack8(*reinterpret_cast<const uint4*>(xb + (lane + 128) * 8), v[2]);
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { t0 += v[0][j]; t1 += ok1 ? v[1][j] : 0.f; t2 += ok2 ? v[2][j] : 0.f; }
+        const float mu0 = wave_sum(t0 + (lo ? t1 : 0.f)) * (1.f / 768.f);
+        const float mu1 = wave_sum((lo ? 0.f : t1) + t2) * (1.f / 768.f);
+        const float mk[3] = {mu0, lo ? mu0 : mu1, mu1};
+        float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d0 = v[0][j] - mk[0], d1 = ok1 ? v[1][j] - mk[1] : 0.f, d2 = ok2 ? v[2][j] - mk[2] : 0.f;
+            q0 += d0 * d0; q1 += d1 * d1; q2 += d2 * d2;
+        }
+        const float rs0 = rsqrtf(wave_sum(q0 + (lo ? q1 : 0.f)) * (1.f / 768.f) + eps);
+        const float rs1 = rsqrtf(wave_sum((lo ? 0.f : q1) + q2) * (1.f / 768.f) + eps);
+        if (lane == 0) { mean[r0] = mu0; rstd[r0] = rs0; if (two) { mean[r0 + 1] = mu1; rstd[r0 + 1] = rs1; } }
+        const float rk[3] = {rs0, lo ? rs0 : rs1, rs1};
+        bf16_t* yb = y + (int64_t)r0 * 768;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if ((k == 1 && !ok1) || (k == 2 && !ok2)) continue;
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (v[k][j] - mk[k]) * rk[k] * g[k][j] + b[k][j];
+            *reinterpret_cast<uint4*>(yb + (lane + 64 * k) * 8) = pack8(o);
+        }
+    }
+}
+
 // backward: dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  per-wave partial dgamma/dbeta
 // accumulated in registers over the wave's rows, then written to ws[wave][2][cols] and reduced by ln_bwd_reduce.
 // Residual-fork fusion (both optional): dy2 is a second incoming gradient of y (summed in fp32 before use: the LN
@@ -246,6 +303,10 @@ extern "C" int vm_layernorm_fwd(const void* x, const float* gamma, const float* 
     const int nch = (cols / 8 + 63) / 64;
     const int grid = ln_grid(rows, LN_FWD_CAP);
     const bf16_t* xp = (const bf16_t*)x; bf16_t* yp = (bf16_t*)y;
+    if (cols == 768 && rows >= 64) {          // two rows per wave, three full-width chunk loads per lane (above)
+        hipLaunchKernelGGL(ln_fwd_pair768_kernel, dim3(ln_grid((rows + 1) / 2, LN_FWD_CAP)), dim3(256), 0, s, xp, gamma, beta, yp, mean, rstd, rows, eps);
+        return vm_check_launch("vm_layernorm_fwd");
+    }
     switch (nch) {
         case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, dim3(grid), dim3(256), 0, s, xp, gamma, beta, yp, mean, rstd, rows, cols, eps); break;
         case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, dim3(grid), dim3(256), 0, s, xp, gamma, beta, yp, mean, rstd, rows, cols, eps); break;
