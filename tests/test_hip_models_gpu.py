@@ -220,7 +220,7 @@ def test_greedy_and_beam_decode_bit_exact_vs_golden(golden):
 def test_greedy_with_output_scores_and_bad_words_takes_the_library_argmax_loop(golden):
     """generation.sample's second loop (callers: ``output_scores=True``, a greedy call with ``bad_words_ids``): same ids as the one-kernel
     selection, one fp32 score tensor per emitted position whose arg-max is that token; a greedy call with a banned token never emits it;
-    sampling outside vm_select_tokens' domain raises instead of falling back to torch sampling"""
+    sampling outside vm_select_tokens' domain (top_k > 256, output_scores) is served by the torch.multinomial path (advisor, round 5)"""
     g, cfg, dec, st, enc, start, common = _g7_setup(golden)
     enc_d, mask_d = enc.to(dev()), g["enc_mask"].to(dev())
     ref = g["beams1_lp1.0"]["sequences"]
@@ -232,10 +232,30 @@ def test_greedy_with_output_scores_and_bad_words_takes_the_library_argmax_loop(g
     banned = int(ref[0, 1])
     ids = dec.generate(input_ids=start, encoder_hidden_states=enc_d, encoder_attention_mask=mask_d, bad_words_ids=[[banned]], **common).cpu()
     assert int(ids[0, 1]) != banned and not bool((ids[:, 1:] == banned).any())
-    with pytest.raises(NotImplementedError):
-        dec.generate(input_ids=start, encoder_hidden_states=enc_d, encoder_attention_mask=mask_d, do_sample=True, top_k=1000, **common)
-    with pytest.raises(NotImplementedError):
-        dec.generate(input_ids=start, encoder_hidden_states=enc_d, encoder_attention_mask=mask_d, do_sample=True, output_scores=True, **common)
+    # sampling outside vm_select_tokens' domain (ref:blocks/rl/SCST.py:142-157 passes the YAML's top_k and output_scores=True) runs the
+    # step-by-step path: HF's processors on the fp32 logits + torch.multinomial on the device
+    V = cfg["vocab_size"]
+    gen = torch.Generator(device=dev()).manual_seed(11)
+    out = dec.generate(input_ids=start, encoder_hidden_states=enc_d, encoder_attention_mask=mask_d, do_sample=True, top_k=min(1000, V), output_scores=True,
+                       bad_words_ids=[[1], [0]], return_dict_in_generate=True, generator=gen, **common)
+    seq = out.sequences.cpu()
+    assert seq.shape[0] == g["B"] and len(out.scores) == seq.shape[1] - 1
+    ended = torch.cumsum((seq[:, 1:] == 2).int(), 1) - (seq[:, 1:] == 2).int() > 0
+    assert not (((seq[:, 1:] == 0) | (seq[:, 1:] == 1)) & ~ended).any()                # banned tokens only as padding behind a row's eos
+    for t, sc in enumerate(out.scores):                                                  # every live token has a finite processed score
+        tok = seq[:, t + 1]
+        live = ~ended[:, t]
+        assert torch.isfinite(sc.cpu()[torch.arange(g["B"]), tok][live]).all()
+        assert bool((sc[:, [0, 1]] == -float("inf")).all())
+    # top_k = 1 sampling is the arg-max: the path's filter is exact
+    one = dec.generate(input_ids=start, encoder_hidden_states=enc_d, encoder_attention_mask=mask_d, do_sample=True, top_k=1, output_scores=True,
+                       return_dict_in_generate=True, generator=gen, **common)
+    assert torch.equal(one.sequences.cpu(), ref)
+    # greedy_rows on that path: the first rows are the arg-max of the raw logits
+    both = dec.generate(input_ids=torch.cat([start, start]), encoder_hidden_states=torch.cat([enc_d, enc_d]), encoder_attention_mask=torch.cat([mask_d, mask_d]),
+                        do_sample=True, greedy_rows=g["B"], top_k=min(1000, V), bad_words_ids=[[1], [0]], generator=gen, **common).cpu()
+    n = min(both.shape[1], ref.shape[1])
+    assert torch.equal(both[:g["B"], :n], ref[:, :n])
 
 
 def test_bf16_decode_step_stays_within_margin_of_fp32_oracle(golden):

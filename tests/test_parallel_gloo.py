@@ -1,5 +1,7 @@
-"""world_size-2 gloo tests (CPU) of the data-parallel host logic: chunked flat-gradient averaging equals the
-single-process gradient on the concatenated batch; all-gather-with-grad equals the single-process contrastive loss."""
+"""gloo tests (CPU) of the data-parallel host logic at world sizes 2 AND 8 (the node size BASELINE.json's metric is quoted on; no
+multi-GPU node was available to any round, so this is the only evidence at the target world size): chunked flat-gradient averaging equals
+the single-process gradient on the concatenated batch; all-gather-with-grad equals the single-process contrastive loss; two-phase backward,
+mark-started encoder buckets, gradient accumulation, the row-sharded contrastive loss, the GLoRIA gather and the validation merge."""
 import os
 
 import pytest
@@ -11,11 +13,15 @@ import torch.multiprocessing as mp
 def _worker(rank, world, port, fn, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)                       # 8 ranks on the build container's 8 cores
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ret[rank] = fn(rank, world)
     finally:
         dist.destroy_process_group()
+
+
+WORLDS = (2, 8)
 
 
 def _run(fn, world=2):
@@ -32,14 +38,14 @@ def _grad_avg(rank, world):
     torch.manual_seed(0)
     model = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.GELU(), torch.nn.Linear(32, 4))
     flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
-    if rank == 1:
-        flat += 1.0           # replicas start different: broadcast must fix it
+    if rank:
+        flat += float(rank)   # replicas start different: broadcast must fix it
     broadcast_(flat, dist)
     off = 0
     for p in model.parameters():
         p.data.copy_(flat[off:off + p.numel()].view_as(p)); off += p.numel()
     g = torch.Generator().manual_seed(5)
-    X, Y = torch.randn(8, 16, generator=g), torch.randn(8, 4, generator=g)
+    X, Y = torch.randn(4 * world, 16, generator=g), torch.randn(4 * world, 4, generator=g)
     xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
     torch.nn.functional.mse_loss(model(xs), ys).backward()
     gflat = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
@@ -56,19 +62,20 @@ def _grad_avg(rank, world):
     return out
 
 
-def test_flat_gradient_allreduce_equals_single_process_gradient():
-    r = _run(_grad_avg)
-    for rank in (0, 1):
+@pytest.mark.parametrize("world", WORLDS)
+def test_flat_gradient_allreduce_equals_single_process_gradient(world):
+    r = _run(_grad_avg, world)
+    for rank in range(world):
         torch.testing.assert_close(r[rank]["fp32"], r[rank]["ref"], rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(r[rank]["bf16"], r[rank]["ref"], rtol=2e-2, atol=2e-3)
-    torch.testing.assert_close(r[0]["fp32"], r[1]["fp32"])
+        torch.testing.assert_close(r[0]["fp32"], r[rank]["fp32"], rtol=0, atol=0)      # every replica holds the same averaged gradient
 
 
 def _contrastive(rank, world):
     from oracle import torch_ref as O
     from vilmedic_amd.parallel import all_gather_with_grad
     g = torch.Generator().manual_seed(9)
-    T, V = torch.randn(8, 32, generator=g), torch.randn(8, 32, generator=g)
+    T, V = torch.randn(4 * world, 32, generator=g), torch.randn(4 * world, 32, generator=g)
     t = T[rank * 4:(rank + 1) * 4].clone().requires_grad_(True)
     v = V[rank * 4:(rank + 1) * 4].clone().requires_grad_(True)
     tg, vg = all_gather_with_grad(t, dist), all_gather_with_grad(v, dist)
@@ -82,9 +89,10 @@ def _contrastive(rank, world):
                 rt=Tr.grad[rank * 4:(rank + 1) * 4], rv=Vr.grad[rank * 4:(rank + 1) * 4])
 
 
-def test_allgather_negatives_equals_single_process_contrastive_loss():
-    r = _run(_contrastive)
-    for rank in (0, 1):
+@pytest.mark.parametrize("world", WORLDS)
+def test_allgather_negatives_equals_single_process_contrastive_loss(world):
+    r = _run(_contrastive, world)
+    for rank in range(world):
         torch.testing.assert_close(r[rank]["loss"], r[rank]["lref"])
         torch.testing.assert_close(r[rank]["gt"], r[rank]["rt"], rtol=1e-4, atol=1e-6)
         torch.testing.assert_close(r[rank]["gv"], r[rank]["rv"], rtol=1e-4, atol=1e-6)
@@ -92,19 +100,23 @@ def test_allgather_negatives_equals_single_process_contrastive_loss():
 
 def _eval_merge(rank, world):
     from vilmedic_amd.parallel import gather_interleaved, mean_over_ranks
-    full = [f"sample {i}" for i in range(7)]
+    full = [f"sample {i}" for i in range(3 * world + 1)]         # ragged: rank 0 holds one sample more than the others
     mine = full[rank::world]                                     # create_data_loader's round-robin shard
     merged = gather_interleaved(mine, dist)
-    loss = mean_over_ranks([2.0, 5.0][rank], dist, weight=len(mine))
+    loss = mean_over_ranks(2.0 + 3.0 * rank, dist, weight=len(mine))
     return merged, loss
 
 
-def test_validation_outputs_and_losses_are_identical_on_every_rank():
+@pytest.mark.parametrize("world", WORLDS)
+def test_validation_outputs_and_losses_are_identical_on_every_rank(world):
     """every rank must see the same merged refs / hyps (dataset order) and the same sample-weighted loss, so that early stopping and
     checkpointing decide identically on all ranks"""
-    r = _run(_eval_merge)
-    assert r[0][0] == r[1][0] == [f"sample {i}" for i in range(7)]
-    assert r[0][1] == r[1][1] == pytest.approx((2.0 * 4 + 5.0 * 3) / 7)
+    r = _run(_eval_merge, world)
+    n = 3 * world + 1
+    want = sum((2.0 + 3.0 * k) * len(range(k, n, world)) for k in range(world)) / n
+    for rank in range(world):
+        assert r[rank][0] == [f"sample {i}" for i in range(n)]
+        assert r[rank][1] == r[0][1] == pytest.approx(want)
 
 
 class _FakeArena:
@@ -160,7 +172,7 @@ def _arena_ddp(rank, world):
     ddp = ArenaDDP(model, dist, chunks=4, bf16_wire=False)
     assert ddp.split_at == sum(p.numel() for p in model.dec.parameters()) and model.split_backward
     g = torch.Generator().manual_seed(11)
-    X, Y = torch.randn(8, 10, generator=g), torch.randn(8, 3, generator=g)
+    X, Y = torch.randn(4 * world, 10, generator=g), torch.randn(4 * world, 3, generator=g)
     loss = model(X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4])
     ddp.backward(loss)                               # decoder range reduced first, then the encoder range
     assert model._split is None
@@ -171,12 +183,13 @@ def _arena_ddp(rank, world):
             torch.cat([p.grad.reshape(-1) for p in ref.parameters()]))
 
 
-def test_arena_ddp_two_phase_backward_equals_single_process_gradient():
-    """ArenaDDP end to end on two gloo ranks: parameter broadcast, decoder / encoder split point, two-phase backward with the chunked
+@pytest.mark.parametrize("world", WORLDS)
+def test_arena_ddp_two_phase_backward_equals_single_process_gradient(world):
+    """ArenaDDP end to end on 2 / 8 gloo ranks: parameter broadcast, decoder / encoder split point, two-phase backward with the chunked
     all-reduce of each range, result = the gradient of the loss on the concatenated batch"""
-    r = _run(_arena_ddp)
-    torch.testing.assert_close(r[0][0], r[1][0], rtol=0, atol=0)                 # identical replicas after the broadcast
-    for rank in (0, 1):
+    r = _run(_arena_ddp, world)
+    for rank in range(world):
+        torch.testing.assert_close(r[0][0], r[rank][0], rtol=0, atol=0)          # identical replicas after the broadcast
         torch.testing.assert_close(r[rank][1], r[rank][2], rtol=1e-5, atol=1e-6)
 
 
@@ -216,7 +229,7 @@ def _arena_ddp_buckets(rank, world):
         ddp = ArenaDDP(model, dist, chunks=2, bf16_wire=False, enc_buckets=3)
         assert len(ddp._marks) == 2 and ops._bwd_mark["cb"] is not None
         g = torch.Generator().manual_seed(13)
-        X, Y = torch.randn(8, 10, generator=g), torch.randn(8, 3, generator=g)
+        X, Y = torch.randn(4 * world, 10, generator=g), torch.randn(4 * world, 3, generator=g)
         outs = []
         for step in range(2):                              # twice: the bucket state must reset between steps
             arena.gflat.zero_()
@@ -233,9 +246,10 @@ def _arena_ddp_buckets(rank, world):
         ops._bwd_mark["cb"] = None
 
 
-def test_arena_ddp_encoder_buckets_start_from_backward_marks():
-    r = _run(_arena_ddp_buckets)
-    for rank in (0, 1):
+@pytest.mark.parametrize("world", WORLDS)
+def test_arena_ddp_encoder_buckets_start_from_backward_marks(world):
+    r = _run(_arena_ddp_buckets, world)
+    for rank in range(world):
         outs, ref = r[rank]
         for fired, gflat in outs:
             assert fired == 2, fired
@@ -252,7 +266,7 @@ def _arena_ddp_grad_accu(rank, world):
     model.__dict__["_vm_arena_cache"] = _FakeArena(model)
     ddp = ArenaDDP(model, dist, chunks=2, bf16_wire=False)
     g = torch.Generator().manual_seed(12)
-    X, Y = torch.randn(16, 10, generator=g), torch.randn(16, 3, generator=g)
+    X, Y = torch.randn(8 * world, 10, generator=g), torch.randn(8 * world, 3, generator=g)
     xs, ys = X[rank * 8:(rank + 1) * 8], Y[rank * 8:(rank + 1) * 8]
     ddp.backward(model(xs[:4], ys[:4]), sync=False)
     enc_after_first = ddp.arena.gflat[ddp.split_at:].abs().sum().item()
@@ -272,9 +286,10 @@ def _arena_ddp_grad_accu(rank, world):
     return enc_after_first, ddp.arena.gflat.clone(), torch.cat([p.grad.reshape(-1) for p in ref.parameters()]), stray.grad is stray._vm_grad_view
 
 
-def test_arena_ddp_gradient_accumulation_trains_the_encoder_and_folds_stray_grads():
-    r = _run(_arena_ddp_grad_accu)
-    for rank in (0, 1):
+@pytest.mark.parametrize("world", WORLDS)
+def test_arena_ddp_gradient_accumulation_trains_the_encoder_and_folds_stray_grads(world):
+    r = _run(_arena_ddp_grad_accu, world)
+    for rank in range(world):
         assert r[rank][0] > 0, "encoder gradient missing after a non-stepping micro-batch"
         torch.testing.assert_close(r[rank][1], r[rank][2], rtol=1e-5, atol=1e-6)
         assert r[rank][3]
@@ -283,15 +298,16 @@ def test_arena_ddp_gradient_accumulation_trains_the_encoder_and_folds_stray_grad
 def _gloria_local_gather(rank, world):
     """GLoRIA's local loss over the GLOBAL batch: every rank holds 3 (image, caption) pairs, the local feature maps and
     word embeddings are all-gathered with gradient (the product's _maybe_gather, as GLoRIALoss.forward calls it), the loss is that of
-    the 6-pair batch and each rank's gradients are its slice of the single-process gradients (x world: ArenaDDP then averages parameter
+    the 3 x world-pair batch and each rank's gradients are its slice of the single-process gradients (x world: ArenaDDP then averages parameter
     gradients over ranks).  The loss itself is evaluated by the oracle here (the product's local loss is HIP-only)."""
     from oracle import torch_ref as O
     from vilmedic_amd.blocks.losses.selfsup import _maybe_gather
     g = torch.Generator().manual_seed(21)
-    B, b, D, T = 6, 3, 16, 5
+    b, D, T = 3, 16, 5
+    B = b * world
     img = torch.randn(B, D, 3, 3, generator=g)
     words = torch.randn(B, D, T, generator=g)
-    lens = [5, 3, 4, 2, 5, 4]
+    lens = [(5, 3, 4, 2, 5, 4)[i % 6] for i in range(B)]
     li = img[rank * b:(rank + 1) * b].clone().requires_grad_(True)
     lw = words[rank * b:(rank + 1) * b].clone().requires_grad_(True)
     (gi, gw), _, w = _maybe_gather(li, lw)
@@ -304,9 +320,10 @@ def _gloria_local_gather(rank, world):
     return (float(l0 + l1), float(r0 + r1), li.grad, world * fi.grad[rank * b:(rank + 1) * b], lw.grad, world * fw.grad[rank * b:(rank + 1) * b])
 
 
-def test_gloria_local_loss_contrasts_the_global_batch():
-    r = _run(_gloria_local_gather)
-    for rank in (0, 1):
+@pytest.mark.parametrize("world", WORLDS)
+def test_gloria_local_loss_contrasts_the_global_batch(world):
+    r = _run(_gloria_local_gather, world)
+    for rank in range(world):
         assert r[rank][0] == pytest.approx(r[rank][1], rel=1e-6)
         torch.testing.assert_close(r[rank][2], r[rank][3], rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(r[rank][4], r[rank][5], rtol=1e-5, atol=1e-6)
@@ -334,7 +351,7 @@ def _row_sharded_contrastive(rank, world):
         apply = staticmethod(_torch_similarity)
     selfsup._SimilarityLossFn = _Fn                    # the HIP kernels need a GPU; the host logic under test is everything around them
     g = torch.Generator().manual_seed(13)
-    T, V = torch.randn(8, 32, generator=g), torch.randn(8, 32, generator=g)
+    T, V = torch.randn(4 * world, 32, generator=g), torch.randn(4 * world, 32, generator=g)
     t = T[rank * 4:(rank + 1) * 4].clone().requires_grad_(True)
     v = V[rank * 4:(rank + 1) * 4].clone().requires_grad_(True)
     loss, loss_l, loss_v = selfsup.ConVIRTLoss(tau=0.1, lambda_=0.75)(t, v)
@@ -347,9 +364,10 @@ def _row_sharded_contrastive(rank, world):
                 loss=loss.detach(), local_mean=(0.75 * ref_v.detach()[sl] + 0.25 * ref_l.detach()[sl]).mean())
 
 
-def test_row_sharded_contrastive_losses_equal_the_global_batch():
-    r = _run(_row_sharded_contrastive)
-    for rank in (0, 1):
+@pytest.mark.parametrize("world", WORLDS)
+def test_row_sharded_contrastive_losses_equal_the_global_batch(world):
+    r = _run(_row_sharded_contrastive, world)
+    for rank in range(world):
         torch.testing.assert_close(r[rank]["ll"], r[rank]["rl"], rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(r[rank]["lv"], r[rank]["rv"], rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(r[rank]["loss"], r[rank]["local_mean"], rtol=1e-5, atol=1e-6)

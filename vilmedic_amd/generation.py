@@ -511,19 +511,29 @@ def sample(decoder, input_ids, enc, enc_mask, *, max_length, eos_token_id, pad_t
             cur += 1
             if cur % 8 == 0 and not bool(unf.any()):           # host sync only every 8 steps; trimmed exactly below
                 break
-    # The one selection kernel covers every call the reference makes (greedy; multinomial sampling with bad_words [[pad],[bos]] and an optional
-    # top_k: ref:blocks/rl/SCST.py:142-157).  What it does not return is the per-step score tensors: ``output_scores`` (and a greedy call
-    # with bad words) takes the loop below -- arg-max over the processed fp32 logits with the same library kernels (vm_argmax_f32), one
-    # launch more per step.  There is no torch-sampling twin of the kernel: sampling outside the kernel's domain raises.
-    if not fused and do_sample:
-        raise NotImplementedError("sampling runs in vm_select_tokens: at most 4 single-token bad words, top_k <= 256, no output_scores "
-                                  f"(got {len(bad)} bad words, top_k={top_k}, output_scores={output_scores})")
+    # The one selection kernel covers every call the reference's shipped configs make (greedy; multinomial sampling with bad_words [[pad],[bos]]
+    # and an optional top_k <= 256: ref:blocks/rl/SCST.py:142-157).  Outside its domain -- ``output_scores``, top_k > 256 (the YAML value is
+    # free), more than 4 bad words, a greedy call with bad words -- the loop below serves the same contract step by step: HF's logits
+    # processors on the fp32 logits (``_process``), then the library arg-max or ``torch.multinomial`` on the device (one launch more per step;
+    # ``greedy_rows`` keeps its meaning: the first rows take the arg-max of the RAW logits).
     unfinished = torch.ones(B, dtype=torch.bool, device=dev)
     while not fused and cur < max_length:
         logits = st.step(seq[:, cur - 1], cur - 1)
-        if bad or output_scores:
-            logits = _process(logits.clone(), bad, None)
-        nxt = argmax_f32(logits.contiguous())
+        if do_sample and greedy_rows:
+            g = int(greedy_rows)
+            nxt = torch.empty(B, dtype=torch.long, device=dev)
+            nxt[:g] = argmax_f32(logits[:g].contiguous())
+            proc = _process(logits[g:].clone(), bad, top_k)
+            nxt[g:] = torch.multinomial(torch.softmax(proc, dim=-1), 1, generator=generator).squeeze(1)
+            if output_scores:
+                logits = torch.cat([logits[:g], proc], dim=0)
+        else:
+            if do_sample or bad or output_scores:
+                logits = _process(logits.clone(), bad, top_k if do_sample else None)
+            if do_sample:
+                nxt = torch.multinomial(torch.softmax(logits, dim=-1), 1, generator=generator).squeeze(1)
+            else:
+                nxt = argmax_f32(logits.contiguous())
         if output_scores:
             scores.append(logits)
         nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad_token_id))
