@@ -124,6 +124,32 @@ def write_proto_dir(path, model_type, cfg, state, architectures=None):
     return path
 
 
+def write_ved_dir(path, enc_type, vit_cfg, dec_cfg, state):
+    """a ``VisionEncoderDecoderModel.save_pretrained`` directory (config.json with the two sub-configs + model.safetensors named
+    ``encoder.*`` / ``decoder.*`` / ``enc_to_dec_proj.*``) -- what ``RRG_HF(encoderdecoder=<dir>)`` loads (ref:models/rrg/RRG_HF.py:24-25)"""
+    import json
+    import os
+    from safetensors.torch import save_file
+    os.makedirs(path, exist_ok=True)
+    c = dict(model_type="vision-encoder-decoder", is_encoder_decoder=True, tie_word_embeddings=False,
+             architectures=["VisionEncoderDecoderModel"],
+             encoder=dict(vit_cfg, model_type=enc_type, hidden_act="gelu", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, qkv_bias=True),
+             decoder=dict(dec_cfg, model_type="bert-generation", hidden_act="gelu", is_decoder=True, add_cross_attention=True,
+                          hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, position_embedding_type="absolute"))
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(c, f, indent=1, sort_keys=True)
+    save_file({k: v.contiguous() for k, v in state.items()}, os.path.join(path, "model.safetensors"))
+    return path
+
+
+def vit_pooled_shapes(cfg, prefix=""):
+    """HF ViTModel(config) with its default pooler (what VisionEncoderDecoderModel / AutoModel hold)"""
+    s = vit_shapes(cfg)
+    d = cfg["hidden_size"]
+    s["pooler.dense.weight"], s["pooler.dense.bias"] = (d, d), (d,)
+    return {prefix + k: v for k, v in s.items()}
+
+
 def decoder_shapes(cfg, prefix=""):
     """BertGenerationDecoder with cross-attention; LM head tied to word embeddings
     (``lm_head.decoder.weight`` is an alias and is not generated)."""

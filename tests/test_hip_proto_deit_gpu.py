@@ -147,6 +147,48 @@ def test_deit_visual_encoder_and_rrg_hf_vs_golden(golden):
     assert close_bf16(out["logits"].float().cpu(), g["logits4"])
 
 
+def test_rrg_hf_from_local_checkpoint_directories_vs_golden(golden, tmp_path):
+    """RRG_HF(encoderdecoder=<dir>) and RRG_HF(vision=<dir>, decoder=<dir>) (ref:models/rrg/RRG_HF.py:24-25, 48-49, 86-87) on the checkpoint
+    directories fixture G25 was written from: loss and logits of the reference's own class (HF from_pretrained + RRG_HF.forward), and the
+    gradient of the loaded enc_to_dec_proj against the oracle"""
+    from oracle import torch_ref as O
+    from vilmedic_amd.models import RRG_HF
+    g = golden("g25_rrg_hf_pretrained")
+    a, b = g["ved"], g["strings"]
+    vst = R.rand_state(R.vit_pooled_shapes(a["vit_cfg"]), a["seed"])
+    dst = R.rand_state(R.decoder_shapes(a["dec_cfg"]), a["seed"] + 1)
+    gen = torch.Generator().manual_seed(a["seed"] + 2)
+    ved = {"encoder." + k: v for k, v in vst.items()}
+    ved.update({"decoder." + k: v for k, v in dst.items()})
+    ved["enc_to_dec_proj.weight"] = 0.1 * torch.randn(a["dec_cfg"]["hidden_size"], a["vit_cfg"]["hidden_size"], generator=gen)
+    ved["enc_to_dec_proj.bias"] = 0.02 * torch.randn(a["dec_cfg"]["hidden_size"], generator=gen)
+    assert R.state_checksum(ved) == a["checksum"]
+    m = RRG_HF(encoderdecoder=R.write_ved_dir(str(tmp_path / "ved"), "vit", a["vit_cfg"], a["dec_cfg"], ved)).to(dev())
+    images = R.make_images(a["B"], a["vit_cfg"]["image_size"], seed=a["seed"])
+    ids, am = R.make_reports(a["B"], a["L"], a["dec_cfg"]["vocab_size"], seed=a["seed"])
+    m.train()                                        # (the checkpoint's dropout probabilities are 0)
+    out = m(input_ids=ids.to(dev()), attention_mask=am.to(dev()), images=images.to(dev()))
+    assert abs(out["loss"].item() - a["loss"].item()) <= 2e-3 * max(1.0, abs(a["loss"].item())), (out["loss"].item(), a["loss"].item())
+    assert close_bf16(out["logits"].float().cpu(), a["logits"])
+    out["loss"].backward()
+    stg = {"model." + k: v.clone().requires_grad_(True) for k, v in ved.items()}
+    O.rrg_hf_forward(images, ids, am, stg, a["vit_cfg"], a["dec_cfg"])[0].backward()
+    got, ref = m.model.enc_to_dec_proj.weight.grad.float().cpu(), stg["model.enc_to_dec_proj.weight"].grad
+    assert grads_close(got, ref), (cosine(got, ref), rel_l2(got, ref))
+    # strings: AutoModel / AutoModelForCausalLM directories
+    vst2 = R.rand_state(R.vit_pooled_shapes(b["vit_cfg"]), b["seed"])
+    dst2 = R.rand_state(R.decoder_shapes(b["dec_cfg"]), b["seed"] + 1)
+    dv = R.write_proto_dir(str(tmp_path / "vit"), "vit", dict(b["vit_cfg"], hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0), vst2)
+    dd = R.write_proto_dir(str(tmp_path / "dec"), "bert-generation", dict(b["dec_cfg"], is_decoder=True, add_cross_attention=True,
+                                                                         hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0), dst2)
+    m2 = RRG_HF(vision=dv, decoder=dd).to(dev())
+    m2.eval()
+    with torch.no_grad():
+        out2 = m2(input_ids=ids.to(dev()), attention_mask=am.to(dev()), images=R.make_images(b["B"], b["vit_cfg"]["image_size"], seed=b["seed"]).to(dev()))
+    assert abs(out2["loss"].item() - b["loss"].item()) <= 2e-3 * max(1.0, abs(b["loss"].item()))
+    assert close_bf16(out2["logits"].float().cpu(), b["logits"])
+
+
 def test_heads_of_48_columns_train_through_the_padded_path_vs_oracle():
     """BertGenerationConfig's default 16 heads on hidden_size 768 (ref:config/RRG/baseline-HF.yml:26-30) are 48 columns wide: here 2 heads on
     hidden_size 96, self- and cross-attention, loss and gradients against the oracle"""

@@ -92,6 +92,52 @@ def test_rrg_hf_parameter_names_match_hf_vision_encoder_decoder():
         RRG_HF(encoderdecoder="some/pretrained-name")
 
 
+def test_rrg_hf_builds_from_local_checkpoint_directories(tmp_path):
+    """RRG_HF's pretrained arguments (ref:models/rrg/RRG_HF.py:24-25, 48-49, 86-87) on local directories: ``encoderdecoder=<dir>`` rebuilds
+    both towers from the nested config and loads every tensor (tied LM head included); ``vision`` / ``decoder`` strings go through the
+    AutoModel / AutoModelForCausalLM loaders; a name that is not on disk raises (the package never downloads)."""
+    import golden_recipes as R
+    from vilmedic_amd.models import RRG_HF
+    dcfg = R.DEC_TINY
+    vcfg = dict(R.VIT_TINY, hidden_size=64, intermediate_size=128, num_attention_heads=1)
+    vst = R.rand_state(R.vit_pooled_shapes(vcfg), 1)
+    dst = R.rand_state(R.decoder_shapes(dcfg), 2)
+    state = {"encoder." + k: v for k, v in vst.items()}
+    state.update({"decoder." + k: v for k, v in dst.items()})
+    state["enc_to_dec_proj.weight"] = torch.randn(dcfg["hidden_size"], vcfg["hidden_size"])
+    state["enc_to_dec_proj.bias"] = torch.randn(dcfg["hidden_size"])
+    d = R.write_ved_dir(str(tmp_path / "ved"), "vit", vcfg, dcfg, state)
+    m = RRG_HF(encoderdecoder=d)
+    sd = m.model.state_dict()
+    for k, v in state.items():
+        assert torch.equal(sd[k].float().cpu(), v), k
+    assert torch.equal(sd["decoder.lm_head.decoder.weight"].float().cpu(), dst["bert.embeddings.word_embeddings.weight"])
+    assert m.model._vm_missing_keys == [] and m.model._vm_unexpected_keys == []
+    assert m.model.decoder.config.is_decoder and m.model.decoder.config.add_cross_attention
+    assert m.model.config.decoder_start_token_id == dcfg["bos_token_id"] and m.model.config.pad_token_id == dcfg["pad_token_id"]
+    # DeiT encoder inside the container
+    dvst = R.rand_state(R.deit_shapes(R.DEIT_TINY), 3)
+    dstate = {"encoder." + k: v for k, v in dvst.items()}
+    dstate.update({"decoder." + k: v for k, v in dst.items()})
+    dd = R.write_ved_dir(str(tmp_path / "ved_deit"), "deit", R.DEIT_TINY, dcfg, dstate)
+    md = RRG_HF(encoderdecoder=dd)
+    assert md.model.encoder.n_special == 2 and "encoder.embeddings.distillation_token" in md.model.state_dict()
+    assert md.model._vm_missing_keys == ["encoder.pooler.dense.bias", "encoder.pooler.dense.weight"]      # fresh pooler, as HF does
+    # strings
+    vst2 = R.rand_state(R.vit_pooled_shapes(R.VIT_TINY), 4)
+    dv = R.write_proto_dir(str(tmp_path / "vit"), "vit", dict(R.VIT_TINY), vst2)
+    dc = R.write_proto_dir(str(tmp_path / "dec"), "bert-generation", dict(dcfg, is_decoder=True, add_cross_attention=True), dst)
+    m2 = RRG_HF(vision=dv, decoder=dc)
+    sd2 = m2.model.state_dict()
+    for k, v in vst2.items():
+        assert torch.equal(sd2["encoder." + k].float().cpu(), v), k
+    for k, v in dst.items():
+        assert torch.equal(sd2["decoder." + k].float().cpu(), v), k
+    assert not hasattr(m2.model, "enc_to_dec_proj")
+    with pytest.raises(NotImplementedError):
+        RRG_HF(vision="google/vit-not-on-disk", decoder=dc)
+
+
 def test_cnn_backbones_have_torchvision_names_and_shapes():
     from vilmedic_amd.blocks.vision import VisualEncoder
     enc = VisualEncoder(backbone="resnet18", permute="batch_first", output_layer="layer4", pretrained=False)

@@ -346,6 +346,43 @@ def test_g20_rrg_hf_forward_vs_the_reference_method(golden):
     torch.testing.assert_close(loss4, g["loss4"], rtol=1e-5, atol=1e-5)
 
 
+def _g25_states(g):
+    """(VisionEncoderDecoder state under ``model.``, checkpoint-directory writer) for both G25 cases, rebuilt from the recipe"""
+    a, b = g["ved"], g["strings"]
+    vst = R.rand_state(R.vit_pooled_shapes(a["vit_cfg"]), a["seed"])
+    dst = R.rand_state(R.decoder_shapes(a["dec_cfg"]), a["seed"] + 1)
+    gen = torch.Generator().manual_seed(a["seed"] + 2)
+    ved = {"encoder." + k: v for k, v in vst.items()}
+    ved.update({"decoder." + k: v for k, v in dst.items()})
+    ved["enc_to_dec_proj.weight"] = 0.1 * torch.randn(a["dec_cfg"]["hidden_size"], a["vit_cfg"]["hidden_size"], generator=gen)
+    ved["enc_to_dec_proj.bias"] = 0.02 * torch.randn(a["dec_cfg"]["hidden_size"], generator=gen)
+    assert R.state_checksum(ved) == a["checksum"]
+    vst2 = R.rand_state(R.vit_pooled_shapes(b["vit_cfg"]), b["seed"])
+    dst2 = R.rand_state(R.decoder_shapes(b["dec_cfg"]), b["seed"] + 1)
+    assert R.state_checksum(vst2) + R.state_checksum(dst2) == b["checksum"]
+    return ved, vst2, dst2
+
+
+def test_g25_rrg_hf_from_local_checkpoints_vs_the_reference_class(golden):
+    """G25: the reference's ``RRG_HF`` class built by HF's own ``from_pretrained`` calls -- ``encoderdecoder=<dir>`` (RRG_HF.py:24-25) and
+    ``vision`` / ``decoder`` given as strings (:48-49, :86-87) -- on checkpoint directories written from the recipe; oracle.rrg_hf_forward on
+    the same tensors must reproduce loss and logits."""
+    g = golden("g25_rrg_hf_pretrained")
+    ved, vst2, dst2 = _g25_states(g)
+    a, b = g["ved"], g["strings"]
+    ids, am = R.make_reports(a["B"], a["L"], a["dec_cfg"]["vocab_size"], seed=a["seed"])
+    with torch.no_grad():
+        loss, logits = O.rrg_hf_forward(R.make_images(a["B"], a["vit_cfg"]["image_size"], seed=a["seed"]), ids, am,
+                                        {"model." + k: v for k, v in ved.items()}, a["vit_cfg"], a["dec_cfg"])
+        st2 = {"model.encoder." + k: v for k, v in vst2.items()}
+        st2.update({"model.decoder." + k: v for k, v in dst2.items()})
+        loss2, logits2 = O.rrg_hf_forward(R.make_images(b["B"], b["vit_cfg"]["image_size"], seed=b["seed"]), ids, am, st2, b["vit_cfg"], b["dec_cfg"])
+    torch.testing.assert_close(logits, a["logits"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(loss, a["loss"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(logits2, b["logits"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(loss2, b["loss"], rtol=1e-5, atol=1e-5)
+
+
 def test_g21_gloria_forward_vs_the_reference_class(golden):
     """G21: the reference's own ``GLoRIA`` class (lifted by AST; its EncoderModel and GLoRIALoss, a stand-in CNN whose [6] is the hooked
     local feature map, a stand-in tokenizer vocabulary) -- towers in forward_batch_size chunks with training-mode BatchNorm, up-sampling

@@ -944,8 +944,81 @@ def gen_deit():
     save("g24_deit", res)
 
 
+# ------------------------------------------------------------------ G25: RRG_HF built from local checkpoints
+def gen_rrg_hf_pretrained():
+    """G25: the reference's ``RRG_HF`` class itself (``__init__`` + ``forward``, lifted by AST; HF's own ``from_pretrained`` does the loading)
+    on checkpoint directories written from the recipe:
+      (a) ``encoderdecoder=<dir>``  -> VisionEncoderDecoderModel.from_pretrained             models/rrg/RRG_HF.py:24-25
+          (ViT of width 64 with its pooler -> enc_to_dec_proj -> BertGenerationDecoder of width 128)
+      (b) ``vision=<dir>``, ``decoder=<dir>`` (strings) -> AutoModel.from_pretrained / AutoModelForCausalLM.from_pretrained(add_cross_attention=True)
+          :48-49, :86-87 (equal widths: the container then has no freshly initialised projection)."""
+    import ast
+    import tempfile
+    from importlib import import_module
+    from transformers import VisionEncoderDecoderModel, AutoModel, AutoModelForCausalLM
+    tree = ast.parse(open(REF + "models/rrg/RRG_HF.py").read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "RRG_HF"][0]
+
+    class DictConfig(dict):
+        pass
+    ns = {"torch": torch, "nn": torch.nn, "VisionEncoderDecoderModel": VisionEncoderDecoderModel, "AutoModel": AutoModel,
+          "AutoModelForCausalLM": AutoModelForCausalLM, "DictConfig": DictConfig, "import_module": import_module,
+          "evaluation": None, "evaluation_multi": None, "get_n_params": lambda m: 0}
+    exec(compile(ast.Module(body=[cls], type_ignores=[]), "RRG_HF.py", "exec"), ns)
+    Ref = ns["RRG_HF"]
+    tmp = tempfile.mkdtemp()
+    seed, B, L = 261, 3, 14
+    dcfg = R.DEC_TINY
+    out = {}
+    # ---- (a)
+    vcfg = dict(R.VIT_TINY, hidden_size=64, intermediate_size=128, num_attention_heads=1)
+    vst = R.rand_state(R.vit_pooled_shapes(vcfg), seed)
+    dst = R.rand_state(R.decoder_shapes(dcfg), seed + 1)
+    g = torch.Generator().manual_seed(seed + 2)
+    state = {"encoder." + k: v for k, v in vst.items()}
+    state.update({"decoder." + k: v for k, v in dst.items()})
+    state["enc_to_dec_proj.weight"] = 0.1 * torch.randn(dcfg["hidden_size"], vcfg["hidden_size"], generator=g)
+    state["enc_to_dec_proj.bias"] = 0.02 * torch.randn(dcfg["hidden_size"], generator=g)
+    d = R.write_ved_dir(os.path.join(tmp, "ved"), "vit", vcfg, dcfg, state)
+    m = Ref(encoderdecoder=d).eval()
+    assert type(m.model).__name__ == "VisionEncoderDecoderModel" and hasattr(m.model, "enc_to_dec_proj")
+    m.model.encoder.config._attn_implementation = "eager"
+    m.model.decoder.config._attn_implementation = "eager"
+    if not hasattr(m.model.decoder.config, "cross_attention_hidden_size"):
+        m.model.decoder.config.cross_attention_hidden_size = None      # PretrainedConfig default in the pinned 4.55.3; gone in 5.x
+    torch.testing.assert_close(m.model.enc_to_dec_proj.weight.detach(), state["enc_to_dec_proj.weight"])
+    torch.testing.assert_close(m.model.decoder.bert.encoder.layer[1].crossattention.self.key.weight.detach(), dst["bert.encoder.layer.1.crossattention.self.key.weight"])
+    images = R.make_images(B, vcfg["image_size"], seed=seed)
+    ids, am = R.make_reports(B, L, dcfg["vocab_size"], seed=seed)
+    with torch.no_grad():
+        o = m(ids, am, images)
+    out["ved"] = dict(vit_cfg=vcfg, dec_cfg=dcfg, seed=seed, B=B, L=L, checksum=R.state_checksum(state), loss=o["loss"].clone(), logits=o["logits"].clone())
+    # ---- (b)
+    vcfg2 = dict(R.VIT_TINY)
+    vst2 = R.rand_state(R.vit_pooled_shapes(vcfg2), seed + 10)
+    dst2 = R.rand_state(R.decoder_shapes(dcfg), seed + 11)
+    dv = R.write_proto_dir(os.path.join(tmp, "vit"), "vit", dict(vcfg2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, qkv_bias=True), vst2)
+    dd = R.write_proto_dir(os.path.join(tmp, "dec"), "bert-generation", dict(dcfg, is_decoder=True, add_cross_attention=True, hidden_dropout_prob=0.0,
+                                                                            attention_probs_dropout_prob=0.0), dst2)
+    m2 = Ref(vision=dv, decoder=dd).eval()
+    assert not hasattr(m2.model, "enc_to_dec_proj") and type(m2.model.decoder).__name__ == "BertGenerationDecoder"
+    m2.model.encoder.config._attn_implementation = "eager"
+    m2.model.decoder.config._attn_implementation = "eager"
+    if not hasattr(m2.model.decoder.config, "cross_attention_hidden_size"):
+        m2.model.decoder.config.cross_attention_hidden_size = None
+    torch.testing.assert_close(m2.model.decoder.bert.encoder.layer[1].crossattention.self.key.weight.detach(), dst2["bert.encoder.layer.1.crossattention.self.key.weight"])
+    torch.testing.assert_close(m2.model.encoder.embeddings.cls_token.detach(), vst2["embeddings.cls_token"])
+    images2 = R.make_images(B, vcfg2["image_size"], seed=seed + 10)
+    with torch.no_grad():
+        o2 = m2(ids, am, images2)
+    out["strings"] = dict(vit_cfg=vcfg2, dec_cfg=dcfg, seed=seed + 10, B=B, L=L, checksum=R.state_checksum(vst2) + R.state_checksum(dst2),
+                          loss=o2["loss"].clone(), logits=o2["logits"].clone())
+    print("G25 losses", float(o["loss"]), float(o2["loss"]))
+    save("g25_rrg_hf_pretrained", out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs", "vicreg", "bleu", "vit_multi", "schedulers", "model_compositions", "scst_sampling", "rrg_hf", "gloria_model", "ensemble_decode", "proto_towers", "deit"]
+    which = sys.argv[1:] or ["vit", "decoder", "rrg", "losses", "decode", "mvqa_text", "scst", "gloria_aggregate", "report_cleaning", "rrs", "vicreg", "bleu", "vit_multi", "schedulers", "model_compositions", "scst_sampling", "rrg_hf", "gloria_model", "ensemble_decode", "proto_towers", "deit", "rrg_hf_pretrained"]
     for w in which:
         globals()["gen_" + w]()

@@ -37,15 +37,23 @@ def resolve(proto):
                                   f"model.safetensors / pytorch_model.bin  [{type(e).__name__}]") from None
 
 
-def read_config(path):
-    with open(os.path.join(path, "config.json")) as f:
-        cfg = json.load(f)
+_VISION_DROP = ("encoder_stride", "pooler_act", "pooler_output_size", "attn_implementation")    # keys of ViT / DeiT configs the HIP encoder has no use for
+
+
+def clean_config(cfg):
+    """drop the bookkeeping keys of a (sub-)config dict read from config.json"""
+    cfg = dict(cfg)
     for k in ("architectures", "transformers_version", "dtype", "torch_dtype", "_name_or_path", "auto_map", "return_dict", "output_hidden_states",
               "output_attentions", "tie_word_embeddings", "classifier_dropout", "gradient_checkpointing", "_attn_implementation",
               "id2label", "label2id", "problem_type", "finetuning_task", "tokenizer_class", "task_specific_params", "chunk_size_feed_forward",
               "tie_encoder_decoder", "is_encoder_decoder", "pruned_heads", "torchscript", "cross_attention_hidden_size"):
         cfg.pop(k, None)
     return cfg
+
+
+def read_config(path):
+    with open(os.path.join(path, "config.json")) as f:
+        return clean_config(json.load(f))
 
 
 def read_state(path):
@@ -126,10 +134,17 @@ def auto_model(proto, add_pooling_layer=True):
 
 def auto_causal_lm(proto):
     """AutoModelForCausalLM.from_pretrained(proto, config=<is_decoder, add_cross_attention>) -> decoder module"""
+    path = resolve(proto)
+    model, prefix = _causal_lm_from_config(read_config(path))
+    load_into(model, read_state(path), prefix)
+    return model
+
+
+def _causal_lm_from_config(cfg):
+    """decoder module for a cleaned config dict (``model_type`` inside), cross-attention switched on -> (module, base-model prefix)"""
     from .bert_models import BertLMHeadModel, RobertaForCausalLM, text_config
     from .decoder.bert_generation import BertGenerationDecoder, decoder_config
-    path = resolve(proto)
-    cfg = read_config(path)
+    cfg = dict(cfg)
     mt = cfg.pop("model_type", None)
     if mt == "bert-generation":
         c = decoder_config(cfg)
@@ -141,5 +156,46 @@ def auto_causal_lm(proto):
         model = (RobertaForCausalLM if mt == "roberta" else BertLMHeadModel)(c)
         prefix = mt
     c.model_type = mt
-    load_into(model, read_state(path), prefix)
+    return model, prefix
+
+
+def _vision_from_config(cfg, vit_cls):
+    """ViTModel / DeiTModel (with HF's default pooler) for a cleaned config dict"""
+    from ...nn import VIT_DEFAULTS, make_config
+    cfg = dict(cfg)
+    mt = cfg.pop("model_type", None)
+    if mt not in ("vit", "deit"):
+        raise NotImplementedError(f"vision model_type {mt!r}: the HIP path builds 'vit' and 'deit' encoders")
+    for k in _VISION_DROP:
+        cfg.pop(k, None)
+    c = make_config(VIT_DEFAULTS, cfg)
+    c.model_type = mt
+    return vit_cls(c, distillation=(mt == "deit"))
+
+
+def auto_vision_model(proto, vit_cls):
+    """AutoModel.from_pretrained(proto) for the image tower of RRG_HF (ref:vilmedic/models/rrg/RRG_HF.py:48-49): a ViT / DeiT checkpoint
+    directory -> ``vit_cls`` (the encoder class with HF's pooler) loaded under HF's matching rules"""
+    path = resolve(proto)
+    cfg = read_config(path)
+    model = _vision_from_config(cfg, vit_cls)
+    load_into(model, read_state(path), cfg.get("model_type"))
+    return model
+
+
+def vision_encoder_decoder(proto, vit_cls, wrap):
+    """VisionEncoderDecoderModel.from_pretrained(proto) (ref:vilmedic/models/rrg/RRG_HF.py:24-25): config.json holds the two sub-configs,
+    the weights are named ``encoder.*`` / ``decoder.*`` / ``enc_to_dec_proj.*``; ``wrap(encoder, decoder)`` builds the container"""
+    path = resolve(proto)
+    with open(os.path.join(path, "config.json")) as f:
+        raw = json.load(f)
+    if raw.get("model_type") != "vision-encoder-decoder":
+        raise NotImplementedError(f"{path}: model_type {raw.get('model_type')!r} is not a VisionEncoderDecoderModel checkpoint")
+    encoder = _vision_from_config(clean_config(raw["encoder"]), vit_cls)
+    decoder, _ = _causal_lm_from_config(clean_config(raw["decoder"]))
+    model = wrap(encoder, decoder)
+    load_into(model, read_state(path), "\0no-base-prefix")
+    for k in ("decoder_start_token_id", "pad_token_id", "eos_token_id"):
+        if raw.get(k) is not None:
+            model.config[k] = raw[k]
     return model

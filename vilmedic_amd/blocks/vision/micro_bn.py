@@ -15,9 +15,11 @@ not -- runs on ``vm_batchnorm_nhwc_fwd / _bwd`` (csrc/batchnorm.hip): statistics
 that follow a BatchNorm in ResNet / DenseNet blocks inside the kernel (``forward(x, residual=..., relu=True)``, used by blocks/vision/cnn.py).
 As a composition of torch reductions / elementwise kernels on an fp32 copy of the activation the grouping was ~130 ms of a 205 ms ConVIRT
 step (profiles/r05_d_steady_kernel_stats_convirt.csv).  Tensors in the default NCHW layout keep the torch path below (plain torch
-BatchNorm when nothing is grouped): the layout decides, nothing falls back silently at a given layout.
+BatchNorm when nothing is grouped).  A channels-last input the kernel declines -- channel count not a multiple of 8 or above 2048, no affine
+parameters, a residual of another dtype / layout -- takes the torch path too, and says so once per module (``log.warning``).
 """
 import contextlib
+import logging
 
 import torch
 import torch.nn as nn
@@ -25,6 +27,7 @@ import torch.nn as nn
 from ... import ops
 from ..._lib import VM_BF16, VM_F32, check, lib, ptr, stream
 
+log = logging.getLogger(__name__)
 _micro = {"size": 0}
 
 
@@ -107,6 +110,12 @@ class MicroBatchNorm2d(nn.BatchNorm2d):
         if _nhwc_ok(x, C) and self.affine and (residual is None or (residual.shape == x.shape and residual.dtype == x.dtype
                                                                       and residual.is_contiguous(memory_format=torch.channels_last))):
             return self._forward_hip(x, residual, relu)
+        if x.is_cuda and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous() \
+                and not getattr(self, "_vm_declined", False):
+            self._vm_declined = True
+            log.warning("MicroBatchNorm2d(%d): channels-last input declined by the HIP kernel (C %% 8 = %d, C <= 2048: %s, affine: %s, residual "
+                        "matches: %s) -- this layer runs the torch path", C, C % 8, C <= 2048, self.affine,
+                        residual is None or (residual.shape == x.shape and residual.dtype == x.dtype))
         y = self._forward_torch(x)
         if residual is not None:
             y = y + residual
@@ -138,11 +147,18 @@ class MicroBatchNorm2d(nn.BatchNorm2d):
 
     @torch.no_grad()
     def _update_running(self, stats):
-        """the exponential moving averages after one update per group, in closed form"""
-        mom = self.momentum if self.momentum is not None else 0.1      # (momentum=None = cumulative average is not used by these models)
+        """the exponential moving averages after one update per group, in closed form; ``momentum=None`` is nn.BatchNorm2d's cumulative
+        average (factor 1 / num_batches_tracked per update): after Gt more updates r = (n0 r0 + sum_c s_c) / (n0 + Gt)"""
         means = torch.cat([m for m, _, _ in stats])
         uvars = torch.cat([v * (n / max(n - 1, 1)) for _, v, n in stats])         # running_var takes the unbiased estimate
         Gt = means.shape[0]
+        if self.momentum is None:
+            n0 = self.num_batches_tracked.to(torch.float32)
+            self.running_mean.mul_(n0).add_(means.sum(0).to(self.running_mean.dtype)).div_(n0 + Gt)
+            self.running_var.mul_(n0).add_(uvars.sum(0).to(self.running_var.dtype)).div_(n0 + Gt)
+            self.num_batches_tracked += Gt
+            return
+        mom = self.momentum
         w = mom * (1.0 - mom) ** torch.arange(Gt - 1, -1, -1, device=means.device, dtype=torch.float32)      # weight of group c
         keep = (1.0 - mom) ** Gt
         self.running_mean.mul_(keep).add_((w[:, None] * means).sum(0).to(self.running_mean.dtype))

@@ -253,11 +253,11 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__
     }
 }
 
-// sums over the splits ((256 / LANES) channels x LANES split lanes per block, as bn_finalize_kernel); dgamma / dbeta accumulate over the
-// groups (G-way atomics on [C] vectors the caller zeroed)
+// sums over the splits ((256 / LANES) channels x LANES split lanes per block, as bn_finalize_kernel) -> per-group sdy / sdyx.  dgamma / dbeta
+// (the sums over the groups) are added up in group order by the first blocks of bn_bwd_apply_kernel: no atomics, bitwise reproducible
+// (ConVIRT / GLoRIA run G = batch / 4 = 64 groups; G-way float atomics made their BatchNorm weight gradients order-dependent)
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psumx,
-                                                              float* __restrict__ sdy, float* __restrict__ sdyx,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, const BnGeom g, int lanes) {
+                                                              float* __restrict__ sdy, float* __restrict__ sdyx, const BnGeom g, int lanes) {
     const int cpb = 256 / lanes, chunks = (g.C + cpb - 1) / cpb;
     const int gi = blockIdx.x / chunks, cl = threadIdx.x / lanes, l = threadIdx.x % lanes, c = (blockIdx.x % chunks) * cpb + cl;
     __shared__ float red[256 * 2];
@@ -273,11 +273,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
         if (l < st) { a += red[(threadIdx.x + st) * 2]; b += red[(threadIdx.x + st) * 2 + 1]; }
         __syncthreads();
     }
-    if (l == 0 && c < g.C) {
-        sdy[gi * g.C + c] = a; sdyx[gi * g.C + c] = b;
-        if (dbeta) atomicAdd(dbeta + c, a);
-        if (dgamma) atomicAdd(dgamma + c, b);
-    }
+    if (l == 0 && c < g.C) { sdy[gi * g.C + c] = a; sdyx[gi * g.C + c] = b; }
 }
 
 // dx = gamma * rstd * (dy' - mean(dy') - xhat * mean(dy' * xhat));  dres = dy'
@@ -286,11 +282,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ sdy, const float* __restrict__ sdyx,
-                                                           T* __restrict__ dx, T* __restrict__ dres, const BnGeom g, int relu, int training) {
+                                                           T* __restrict__ dx, T* __restrict__ dres, const BnGeom g, int relu, int training,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int G) {
     const int gi = blockIdx.x / g.S, si = blockIdx.x % g.S;
     int r0, r1;
     split_range(g, si, r0, r1);
     const int t = threadIdx.x, c8 = t % g.CH8, rsub = t / g.CH8;
+    if (dgamma || dbeta) {   // dgamma / dbeta += sum over the groups, in group order; one owner thread per channel (grid-stride: tiny launches have < C / 256 blocks)
+        for (int c = blockIdx.x * 256 + t; c < g.C; c += (int)gridDim.x * 256) {
+            float a = 0.f, b = 0.f;
+            for (int k = 0; k < G; ++k) { a += sdy[k * g.C + c]; b += sdyx[k * g.C + c]; }
+            if (dbeta) dbeta[c] += a;
+            if (dgamma) dgamma[c] += b;
+        }
+    }
     if (rsub >= g.RPI) return;
     float mu[8], rs[8], sc[8], sh[8], m1[8], m2[8];
     const float invn = training ? 1.f / (float)g.R : 0.f;       // eval mode (running statistics are constants): dx = gamma * rstd * dy'
@@ -411,11 +416,11 @@ extern "C" int vm_batchnorm_nhwc_bwd(const void* dy, const void* x, const void* 
         hipLaunchKernelGGL(bn_bwd_stats_kernel<float>, dim3(G * g.S), dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)residual, gamma, beta, mean, rstd, psum, psumx, g, relu);
     {
         const int lanes = finalize_lanes(g.S), cpb = 256 / lanes;
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(G * ((C + cpb - 1) / cpb)), dim3(256), 0, s, psum, psumx, sdy, sdyx, dgamma, dbeta, g, lanes);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(G * ((C + cpb - 1) / cpb)), dim3(256), 0, s, psum, psumx, sdy, sdyx, g, lanes);
     }
     if (dtype == VM_BF16)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(G * g.S), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)residual, gamma, beta, mean, rstd, sdy, sdyx, (bf16_t*)dx, (bf16_t*)dres, g, relu, training);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(G * g.S), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)residual, gamma, beta, mean, rstd, sdy, sdyx, (bf16_t*)dx, (bf16_t*)dres, g, relu, training, dgamma, dbeta, G);
     else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(G * g.S), dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)residual, gamma, beta, mean, rstd, sdy, sdyx, (float*)dx, (float*)dres, g, relu, training);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(G * g.S), dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)residual, gamma, beta, mean, rstd, sdy, sdyx, (float*)dx, (float*)dres, g, relu, training, dgamma, dbeta, G);
     return vm_check_launch("vm_batchnorm_nhwc_bwd");
 }

@@ -313,7 +313,7 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
         //  410-436 us against 397 us on the 160-row kernel, profiles/r04_g_shape_table.txt vs r03_b_kernel_shape_breakdown.txt)
         const bool p8_auto = force < 0 && a_layout == 0 && b_layout == 0 && split == 1 && N >= 16384 && M >= 4096 && (M % 256) == 0 && K <= 1024 &&
                              (int64_t)((M + 255) / 256) * ((N + 255) / 256) >= 12 * 256;
-        if (((force == 8 || force == 9) && a_layout == 0) || p8_auto) {       // 8: four barrier pairs per K-tile, 9 / auto: two
+        if (((force == 8 || force == 9 || force == 10) && a_layout == 0) || p8_auto) {       // 8: four barrier pairs per K-tile, 9 / auto: two
             int mf = vm_env().gemm_p8_mf;
             if (mf < 5 || mf > 8) {      // rounds of the 256 CUs x rows per tile, ties to the larger tile
                 int64_t best = -1;
@@ -328,7 +328,7 @@ extern "C" int vm_gemm_bf16(const void* A, int64_t lda, int a_layout, const void
             a.tiles_n = (N + 255) / 256;
             a.group_w = a.tiles_n >= 12 ? 4 : a.tiles_n;
             if (vm_env().gemm_groupw > 0) a.group_w = vm_env().gemm_groupw;
-            int rc = vm_gemm_p8_dispatch(a, a_layout, b_layout, mf, force == 8 ? 4 : 2, a.tiles_m * a.tiles_n * split, s);
+            int rc = vm_gemm_p8_dispatch(a, a_layout, b_layout, mf, force == 8 ? 4 : 2, (force == 10 || p8_auto) ? 1 : 0, a.tiles_m * a.tiles_n * split, s);
             if (rc == VM_OK && split > 1) rc = vm_gemm_splitk_reduce(a, split, s);
             return rc;
         }

@@ -30,7 +30,7 @@ int vm_gemm_fast_dispatch(const GemmArgs& a, int a_layout, int b_layout, int nbl
 // two GEMMs of different operand layouts in one launch of 128 x 128 tiles (a0: row-major A x k-major B, a1: k-major A x k-major B)
 int vm_gemm_pair_launch(const GemmArgs& a0, const GemmArgs& a1, hipStream_t s);
 // wide-tile path (gemm_p8.hip): (32 mf) x 256 tiles, 8 waves, one workgroup per CU; row-major A
-int vm_gemm_p8_dispatch(const GemmArgs& a, int a_layout, int b_layout, int mf, int phases, int total, hipStream_t s);
+int vm_gemm_p8_dispatch(const GemmArgs& a, int a_layout, int b_layout, int mf, int phases, int epi, int total, hipStream_t s);
 // grouped weight gradients on 256 x 256 tiles (gemm_p8w.hip): dW[M, N] (+)= alpha * A^T B over `ktiles` 64-row steps, A = dY [rows, M] (lda),
 // B = X [rows, N] (ldb), C = dW fp32 (ldc); tile_start[i] = first tile of problem i, tile_start[P8W_MAX_GROUP] = all tiles
 #define P8W_MAX_GROUP 16

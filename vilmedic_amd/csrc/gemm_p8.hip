@@ -18,6 +18,7 @@
 // Reference call sites: hf:models/bert_generation/modeling_bert_generation.py:104-106 (Q|K|V), :264-291 (MLP), :590-598 (LM head),
 // hf:models/vit/modeling_vit.py:241-252 via ref:vilmedic/blocks/huggingface/decoder/decoder_model.py:39-49, ref:vilmedic/blocks/vision/visual_encoder.py:57,181.
 #include <type_traits>
+#include <utility>
 #include "common.h"
 #include "gemm_args.h"
 
@@ -47,10 +48,15 @@ __device__ __forceinline__ int p8_xcd_remap(int orig, int nwg) {
 // raw barrier (no fence, no vmcnt drain: LDS-DMA and global stores stay in flight across it), opaque to both the IR and the machine scheduler
 #define P8_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } while (0)
 
+template <class F, int... Is>
+__device__ __forceinline__ void p8_static_for_impl(F& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void p8_static_for(F&& f) { p8_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 constexpr int P8_BN = 256;
 constexpr int P8_EPI_BYTES = 32 * P8_BN * 4;      // one 16-row fragment row of both wave groups, fp32
 
-template <int LA, int LB, int MF, int NPH>
+template <int LA, int LB, int MF, int NPH, int EPI, int OPS>
 __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MFA = (MF + 1) / 2, MFB = MF / 2;      // A fragments of the two register sub-tiles
@@ -87,6 +93,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmArgs p) {
 
     int work = (int)blockIdx.x;                           // persistent: block b walks tiles b, b + grid, ... (same XCD every round)
     bool staged = false;                                  // PERSIST: the prologue DMA of this tile was issued before the previous epilogue
+    int young = 0;                                        // EPI 1: store instructions of the previous epilogue issued behind that DMA (-1: unknown)
     // DMA state of the tile being staged (set by tile_setup)
     uint32_t offA[2][2], offB[2][2];                      // [half][instruction] byte offsets from the SGPR bases
     const bf16_t* pA = nullptr; const bf16_t* pB = nullptr;   // SGPR bases of the next K-tile to request
@@ -164,8 +171,13 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmArgs p) {
         const int nk = kt_end - kt_begin;
         if (nk <= 0) { work += (int)gridDim.x; continue; }
 
-        if (!staged) { tile_setup(m0, n0, kt_begin); prologue(nk); }
-        if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!staged) { tile_setup(m0, n0, kt_begin); prologue(nk); young = 0; }
+        // A(0), B(0) landed; B(1) (4 requests) and -- EPI 1 -- the previous tile's stores (issued behind this tile's prologue DMA, counted exactly on
+        // whole tiles) may stay in flight: the memory counter retires in order, so "at most 4 + young outstanding" means the older DMA is done
+        if (nk > 1 && young == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (EPI == 1 && nk > 1 && young == 2 * MF) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + 2 * MF) : "memory");
+        else if (EPI == 1 && nk > 1 && young == 4 * MF) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + 4 * MF) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         P8_BARRIER();
 
         float4_t acc[4][MF];
@@ -321,6 +333,187 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmArgs p) {
             }
         };
 
+        if constexpr (EPI == 1) {
+        // ---- wave-private epilogue [r6].  Every wave stages ITS OWN 16 x 64 fragment row (4 KB of the 32-KB region) as fp32 and reads it back as
+        // whole 128-B output rows: no workgroup barrier anywhere in the epilogue (the staged form above needs 2 MF of them and moves one fragment
+        // row of all eight waves per step), MF fully unrolled passes of [4 ds_write_b128, 4 ds_read_b128, the element-wise chain on 16 values per
+        // lane, 2 (4 with the z side output) 16-B stores per lane = 8 rows x 128 B per instruction].  The next tile's prologue DMA goes out FIRST
+        // (the ring is idle); the stores are younger than it and are left in flight across the tile boundary (see the wait at the loop head).
+        // Per-element operands (gelu'(z) input or residual) arrive in two halves: the first is waited for before the DMA is issued, the second is
+        // requested behind the DMA and waited for with a counted vmcnt that leaves the first half's stores in flight.
+        // The arithmetic and its order are those of the staged epilogue: bit-identical results.
+            const vm_gemm_epilogue& e = p.e;
+            float alpha = e.alpha_dev ? e.alpha * (*e.alpha_dev) : e.alpha;
+            int lane_e = lane;                                 // opaque copy: nothing derived from it is hoisted above (and kept live through) the main loop
+            asm volatile("" : "+v"(lane_e));
+            const int c_e = lane_e & 15, g_e = lane_e >> 4, q8 = lane_e & 7, r8 = lane_e >> 3;
+            float* cs = reinterpret_cast<float*>(smem + 2 * SLOT) + wave * 1024;      // [16 rows][64 fp32], 16-B chunk ^= row
+            const int gn = n0 + wn * 64 + q8 * 8;
+            const bool col_ok = gn < p.N;
+            const int nvalid = min(8, p.N - gn);
+            const bool vec = nvalid == 8;
+            const int gn_safe = col_ok ? gn : 0;
+            const int mw = m0 + wm * WR;
+            const bool whole = m0 + BM <= p.M && n0 + P8_BN <= p.N;
+            const bf16_t* zsrc = p.slabs ? nullptr : reinterpret_cast<const bf16_t*>(e.mul_gelu_z);
+            const bf16_t* rsrc = p.slabs ? nullptr : reinterpret_cast<const bf16_t*>(e.residual);
+            const bf16_t* osrc = zsrc ? zsrc : rsrc;           // ONE pre-loaded operand (a launch with both reads the residual in place)
+            const int64_t ldo = zsrc ? p.ldc : e.ldr;
+            const bool aux = e.aux_out != nullptr && !p.slabs;
+            auto ldg16 = [](const void* src, uint4_t& dst) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory"); };
+            constexpr int HP = (MF + 1) / 2;                   // passes per operand half
+            constexpr int NO = OPS ? HP : 1;
+            uint4_t bq[2] = {(uint4_t){0u, 0u, 0u, 0u}, (uint4_t){0u, 0u, 0u, 0u}};
+            uint4_t oq[NO][2];                                  // ONE register set: the second half is loaded into it once the first is consumed
+#pragma unroll
+            for (int pp = 0; pp < NO; ++pp)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) oq[pp][it] = (uint4_t){0u, 0u, 0u, 0u};
+            auto issue_ops = [&](auto h_c) {
+                constexpr int H = decltype(h_c)::value;
+                if constexpr (OPS != 0) {
+#pragma unroll
+                    for (int pp = 0; pp < HP; ++pp) {
+                        if (H * HP + pp >= MF) continue;
+#pragma unroll
+                        for (int it = 0; it < 2; ++it) {
+                            const int gm = min(mw + (H * HP + pp) * 16 + it * 8 + r8, p.M - 1);
+                            ldg16(osrc + (int64_t)gm * ldo + gn_safe, oq[pp][it]);
+                        }
+                    }
+                }
+            };
+            const bool bias_on = e.bias != nullptr && !p.slabs;
+            if (bias_on) { ldg16(e.bias + gn_safe, bq[0]); ldg16(e.bias + (vec ? gn + 4 : gn_safe), bq[1]); }
+            issue_ops(std::integral_constant<int, 0>{});
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(bq[0]), "+v"(bq[1]));
+            if constexpr (OPS != 0) {
+#pragma unroll
+                for (int pp = 0; pp < HP; ++pp) asm volatile("" : "+v"(oq[pp][0]), "+v"(oq[pp][1]));
+            }
+            stage_next();
+            float bias8[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { bias8[r] = __uint_as_float(bq[0][r]); bias8[4 + r] = vec ? __uint_as_float(bq[1][r]) : 0.f; }
+            if (bias_on && !vec) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) bias8[r] = 0.f;
+                if (col_ok) for (int r = 0; r < nvalid; ++r) bias8[r] = e.bias[gn + r];
+            }
+            const DropKey dkey = drop_key(eff_seed(e.dropout_seed, e.dropout_seed_dev));
+            auto pass = [&](const int I, const float4_t (&t)[4], const uint4_t (&oqi)[2]) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int chunk = (j * 4 + g_e) ^ c_e;
+                    *reinterpret_cast<float4*>(cs + c_e * 64 + chunk * 4) = make_float4(t[j][0] * alpha, t[j][1] * alpha, t[j][2] * alpha, t[j][3] * alpha);
+                }
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int r = it * 8 + r8;
+                    const int gm = mw + I * 16 + r;
+                    float v[8];
+                    {
+                        const float4 lo = *reinterpret_cast<const float4*>(cs + r * 64 + (((2 * q8) ^ r) << 2));
+                        const float4 hi = *reinterpret_cast<const float4*>(cs + r * 64 + (((2 * q8 + 1) ^ r) << 2));
+                        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+                    }
+                    if (gm >= p.M || !col_ok) continue;
+                    if (p.dbg == 3) { if (v[0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = v[0]; continue; }      // timing experiment: everything but the stores
+                    const int64_t off = (int64_t)gm * p.ldc + gn;
+                    if (p.slabs) {
+                        float* sp = p.slabs + (int64_t)split * p.M * p.ldc + off;
+                        if (vec) {
+                            *reinterpret_cast<float4*>(sp) = make_float4(v[0], v[1], v[2], v[3]);
+                            *reinterpret_cast<float4*>(sp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                        } else for (int r2 = 0; r2 < nvalid; ++r2) sp[r2] = v[r2];
+                        continue;
+                    }
+#pragma unroll
+                    for (int r2 = 0; r2 < 8; ++r2) v[r2] += bias8[r2];
+                    if (aux) {
+                        bf16_t* z = reinterpret_cast<bf16_t*>(e.aux_out) + off;
+                        if (vec) p8_st16(z, pack8(v));
+                        else for (int r2 = 0; r2 < nvalid; ++r2) z[r2] = f32_to_bf16(v[r2]);
+                    }
+                    if (e.act == 1) {
+#pragma unroll
+                        for (int r2 = 0; r2 < 8; ++r2) v[r2] = gelu_f(v[r2]);
+                    }
+                    const uint4 oqv = make_uint4(oqi[it][0], oqi[it][1], oqi[it][2], oqi[it][3]);
+                    if (zsrc) {
+                        float zf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                        if (vec) unpack8(oqv, zf);
+                        else for (int r2 = 0; r2 < nvalid; ++r2) zf[r2] = bf16_to_f32(zsrc[off + r2]);
+#pragma unroll
+                        for (int r2 = 0; r2 < 8; ++r2) v[r2] *= gelu_grad_f(zf[r2]);
+                    }
+                    if (e.dropout_p > 0.f) {
+                        bool keep[8];
+                        dropout_keep_n<8>(dkey, (uint64_t)gm * (uint64_t)p.N + (uint64_t)gn, p.drop_thresh, keep);
+#pragma unroll
+                        for (int r2 = 0; r2 < 8; ++r2) v[r2] = keep[r2] ? v[r2] * p.drop_scale : 0.f;
+                    }
+                    if (rsrc) {
+                        float rf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                        if (vec && !zsrc) unpack8(oqv, rf);
+                        else if (vec) unpack8(*reinterpret_cast<const uint4*>(rsrc + (int64_t)gm * e.ldr + gn), rf);
+                        else for (int r2 = 0; r2 < nvalid; ++r2) rf[r2] = bf16_to_f32(rsrc[(int64_t)gm * e.ldr + gn + r2]);
+#pragma unroll
+                        for (int r2 = 0; r2 < 8; ++r2) v[r2] += rf[r2];
+                    }
+                    if (e.out_dtype == VM_BF16) {
+                        bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + off;
+                        if (vec) p8_st16(cp, pack8(v));
+                        else for (int r2 = 0; r2 < nvalid; ++r2) cp[r2] = f32_to_bf16(v[r2]);
+                    } else {
+                        float* cp = reinterpret_cast<float*>(p.C) + off;
+                        if (e.accumulate) {
+                            if (vec) {
+                                const float4 o0 = *reinterpret_cast<float4*>(cp), o1 = *reinterpret_cast<float4*>(cp + 4);
+                                *reinterpret_cast<float4*>(cp) = make_float4(o0.x + v[0], o0.y + v[1], o0.z + v[2], o0.w + v[3]);
+                                *reinterpret_cast<float4*>(cp + 4) = make_float4(o1.x + v[4], o1.y + v[5], o1.z + v[6], o1.w + v[7]);
+                            } else for (int r2 = 0; r2 < nvalid; ++r2) cp[r2] += v[r2];
+                        } else if (vec) {
+                            *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                            *reinterpret_cast<float4*>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                        } else for (int r2 = 0; r2 < nvalid; ++r2) cp[r2] = v[r2];
+                    }
+                }
+            };
+            const bool counted = whole && e.out_dtype == VM_BF16 && !p.slabs && p.dbg == 0;      // every store of the passes is issued by every wave: exact counts
+            if (p.dbg == 1) { young = -1; work = next; continue; }      // timing experiment: no epilogue passes at all
+            // ONE copy of the element-wise code: the passes are a runtime loop, the accumulator row and the operand pair of pass i are picked by a
+            // wave-uniform branch chain.  (Fully unrolled -- MF x 2 copies of every epilogue variant, ~60 KB of code walked by eight free-running
+            // waves -- the passes measured 20 us per tile against 2.6 us with the stores compiled out: instruction-cache misses, not stores.)
+#pragma unroll 1
+            for (int i = 0; i < MF; ++i) {
+                if constexpr (OPS != 0 && MF > HP) {
+                    if (i == HP) {                                   // second operand half into the same registers (one exposed round trip per tile; two
+                        issue_ops(std::integral_constant<int, 1>{}); // register sets next to the 128 accumulators spill)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int pp = 0; pp < HP; ++pp) asm volatile("" : "+v"(oq[pp][0]), "+v"(oq[pp][1]));
+                    }
+                }
+                float4_t t[4];
+                uint4_t o2[2] = {(uint4_t){0u, 0u, 0u, 0u}, (uint4_t){0u, 0u, 0u, 0u}};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = acc[j][0];
+                p8_static_for<MF>([&](auto i_c) {
+                    constexpr int I = decltype(i_c)::value;
+                    if (I > 0 && i == I) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) t[j] = acc[j][I];
+                    }
+                    if constexpr (OPS != 0) {
+                        if (i == I) { o2[0] = oq[I % HP][0]; o2[1] = oq[I % HP][1]; }
+                    }
+                });
+                pass(i, t, o2);
+            }
+            young = counted ? (aux ? 4 * MF : 2 * MF) : -1;
+        } else {
         // ---- epilogue: MF chunks of 32 rows (fragment row i of both groups) through the fp32 stage.
         // gfx950 has ONE counter for loads and stores: any wait for a load issued inside the chunk loop also waits for every older store, i.e.
         // a store round trip per chunk (measured: 8 us per tile).  So everything the loop consumes from HBM -- the bias, and ALL of this
@@ -476,39 +669,45 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmArgs p) {
             }
             }   // operand groups
         }
+        }   // EPI
         work = next;
     }
 }
 
-template <int LA, int LB, int MF, int NPH>
+template <int LA, int LB, int MF, int NPH, int EPI, int OPS>
 int launch_p8(const GemmArgs& a, int total, hipStream_t s) {
     constexpr int LDS = 2 * (2 * MF * 16 * 128 + 2 * 128 * 128) + P8_EPI_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_kernel<LA, LB, MF, NPH>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_kernel<LA, LB, MF, NPH, EPI, OPS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     const int grid = total < 256 ? total : 256;          // one workgroup per CU walks its tiles (block b: tiles b, b + 256, ...)
-    hipLaunchKernelGGL((gemm_p8_kernel<LA, LB, MF, NPH>), dim3(grid), dim3(512), LDS, s, a);
+    hipLaunchKernelGGL((gemm_p8_kernel<LA, LB, MF, NPH, EPI, OPS>), dim3(grid), dim3(512), LDS, s, a);
     return vm_check_launch("vm_gemm_bf16(p8)");
 }
 
-template <int LA, int LB, int NPH>
+template <int LA, int LB, int NPH, int EPI, int OPS>
 int launch_p8_mf(const GemmArgs& a, int mf, int total, hipStream_t s) {
     switch (mf) {
-        case 5: return launch_p8<LA, LB, 5, NPH>(a, total, s);
-        case 6: return launch_p8<LA, LB, 6, NPH>(a, total, s);
-        case 7: return launch_p8<LA, LB, 7, NPH>(a, total, s);
-        default: return launch_p8<LA, LB, 8, NPH>(a, total, s);
+        case 5: return launch_p8<LA, LB, 5, NPH, EPI, OPS>(a, total, s);
+        case 6: return launch_p8<LA, LB, 6, NPH, EPI, OPS>(a, total, s);
+        case 7: return launch_p8<LA, LB, 7, NPH, EPI, OPS>(a, total, s);
+        default: return launch_p8<LA, LB, 8, NPH, EPI, OPS>(a, total, s);
     }
 }
 
 }  // namespace
 
 // tile = (32 mf) x 256, mf in 5..8; phases = 2 or 4 barrier pairs per K-tile
-int vm_gemm_p8_dispatch(const GemmArgs& a, int a_layout, int b_layout, int mf, int phases, int total, hipStream_t s) {
-    if (a_layout == 0 && b_layout == 0) return phases == 4 ? launch_p8_mf<0, 0, 4>(a, mf, total, s) : launch_p8_mf<0, 0, 2>(a, mf, total, s);
-    if (a_layout == 0 && b_layout == 1) return phases == 4 ? launch_p8_mf<0, 1, 4>(a, mf, total, s) : launch_p8_mf<0, 1, 2>(a, mf, total, s);
+int vm_gemm_p8_dispatch(const GemmArgs& a, int a_layout, int b_layout, int mf, int phases, int epi, int total, hipStream_t s) {
+    if (epi == 1) {              // wave-private epilogue (two barrier pairs per K-tile only); OPS: a per-element operand (gelu'(z) input or residual) is pre-loaded
+        const bool ops = !a.slabs && (a.e.mul_gelu_z || a.e.residual);
+        if (a_layout == 0 && b_layout == 0) return ops ? launch_p8_mf<0, 0, 2, 1, 1>(a, mf, total, s) : launch_p8_mf<0, 0, 2, 1, 0>(a, mf, total, s);
+        if (a_layout == 0 && b_layout == 1) return ops ? launch_p8_mf<0, 1, 2, 1, 1>(a, mf, total, s) : launch_p8_mf<0, 1, 2, 1, 0>(a, mf, total, s);
+    }
+    if (a_layout == 0 && b_layout == 0) return phases == 4 ? launch_p8_mf<0, 0, 4, 0, 1>(a, mf, total, s) : launch_p8_mf<0, 0, 2, 0, 1>(a, mf, total, s);
+    if (a_layout == 0 && b_layout == 1) return phases == 4 ? launch_p8_mf<0, 1, 4, 0, 1>(a, mf, total, s) : launch_p8_mf<0, 1, 2, 0, 1>(a, mf, total, s);
     vm_set_error("vm_gemm_bf16(p8): layout (a=%d, b=%d) has no wide-tile kernel", a_layout, b_layout);
     return VM_EUNSUPPORTED;
 }

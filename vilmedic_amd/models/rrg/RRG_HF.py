@@ -7,7 +7,9 @@ pooler the HF class creates by default, ``model.decoder.bert.*`` / ``lm_head.*``
 hidden sizes differ, :137-140), returning ``vars(decoder_outputs)``.  Built on the HIP path: vilmedic_amd.nn.ViTModel +
 BertGenerationDecoder.  Class lookup by HF mapping name is restricted to the architectures of the hot path
 (``vit`` / ``deit`` encoders -- both shipped RRG_HF YAMLs name ``deit``, ref:config/RRG/baseline-HF.yml:22 -- and the
-``bert-generation`` decoder); pretrained names (strings) need a download and raise."""
+``bert-generation`` decoder).  Pretrained arguments -- ``encoderdecoder=<name>`` (RRG_HF.py:24-25), ``vision`` / ``decoder`` given as strings
+(:48-49, :86-87) -- load from a local checkpoint directory (or a hub name already in the local HF cache) through
+``blocks/huggingface/pretrained.py``; a name that is not on disk raises (the package never downloads)."""
 import torch
 import torch.nn as nn
 
@@ -44,25 +46,41 @@ class RRG_HF(nn.Module):
         super().__init__()
         assert (encoderdecoder is None) ^ (decoder is None or vision is None), \
             "Either proto should be provided, or both decoder and vision should be provided."
-        if encoderdecoder is not None or isinstance(vision, str) or isinstance(decoder, str):
-            raise NotImplementedError("RRG_HF: pretrained HF checkpoints cannot be fetched (no network); give `vision` and "
-                                      "`decoder` as config dicts (proto_model / proto_config / proto_config_args)")
-        vision, decoder = dict(vision), dict(decoder)
-        assert "proto_model" in vision and "proto_config" in vision
-        pm, pc = vision.pop("proto_model"), vision.pop("proto_config")
-        if pm != pc or pm not in ("vit", "deit"):
-            raise NotImplementedError("RRG_HF on the HIP path supports vision proto_model / proto_config 'vit' and 'deit'")
-        enc_args = dict(vision.pop("proto_config_args", None) or {})
-        encoder = _ViTWithPooler(make_config(VIT_DEFAULTS, enc_args), distillation=(pm == "deit"))
-        assert "proto_model" in decoder and "proto_config" in decoder
-        if decoder.pop("proto_model") != "bert-generation" or decoder.pop("proto_config") != "bert-generation":
-            raise NotImplementedError("RRG_HF on the HIP path supports decoder proto_model / proto_config 'bert-generation'")
-        dec_args = dict(decoder.pop("proto_config_args", None) or {})
-        if dl:                                                       # RRG_HF.py:73-79
-            tok = dl.dataset.seq.tokenizer
-            dec_args.update(vocab_size=tok.vocab_size, unk_token_id=tok.unk_token_id, bos_token_id=tok.cls_token_id,
-                            eos_token_id=tok.sep_token_id, pad_token_id=tok.pad_token_id)
-        self.model = _VisionEncoderDecoder(encoder, BertGenerationDecoder(decoder_config(dec_args)))
+        from ...blocks.huggingface import pretrained
+        if encoderdecoder is not None:                               # RRG_HF.py:24-25: VisionEncoderDecoderModel.from_pretrained
+            self.model = pretrained.vision_encoder_decoder(str(encoderdecoder), _ViTWithPooler, _VisionEncoderDecoder)
+            cfg = self.model.config
+            if cfg.decoder_start_token_id is None:
+                cfg.decoder_start_token_id = self.model.decoder.config.bos_token_id
+            if cfg.pad_token_id is None:
+                cfg.pad_token_id = self.model.decoder.config.pad_token_id
+            assert self.model.decoder.config.is_decoder and self.model.decoder.config.add_cross_attention
+            self.eval_func = evaluation
+            return
+        if isinstance(vision, str):                                  # RRG_HF.py:48-49: AutoModel.from_pretrained(vision)
+            encoder = pretrained.auto_vision_model(vision, _ViTWithPooler)
+        else:
+            vision = dict(vision)
+            assert "proto_model" in vision and "proto_config" in vision
+            pm, pc = vision.pop("proto_model"), vision.pop("proto_config")
+            if pm != pc or pm not in ("vit", "deit"):
+                raise NotImplementedError("RRG_HF on the HIP path supports vision proto_model / proto_config 'vit' and 'deit'")
+            enc_args = dict(vision.pop("proto_config_args", None) or {})
+            encoder = _ViTWithPooler(make_config(VIT_DEFAULTS, enc_args), distillation=(pm == "deit"))
+        if isinstance(decoder, str):                                 # RRG_HF.py:86-87: AutoModelForCausalLM.from_pretrained(decoder, add_cross_attention=True)
+            dec = pretrained.auto_causal_lm(decoder)
+        else:
+            decoder = dict(decoder)
+            assert "proto_model" in decoder and "proto_config" in decoder
+            if decoder.pop("proto_model") != "bert-generation" or decoder.pop("proto_config") != "bert-generation":
+                raise NotImplementedError("RRG_HF on the HIP path supports decoder proto_model / proto_config 'bert-generation'")
+            dec_args = dict(decoder.pop("proto_config_args", None) or {})
+            if dl:                                                   # RRG_HF.py:73-79
+                tok = dl.dataset.seq.tokenizer
+                dec_args.update(vocab_size=tok.vocab_size, unk_token_id=tok.unk_token_id, bos_token_id=tok.cls_token_id,
+                                eos_token_id=tok.sep_token_id, pad_token_id=tok.pad_token_id)
+            dec = BertGenerationDecoder(decoder_config(dec_args))
+        self.model = _VisionEncoderDecoder(encoder, dec)
         if dl:                                                       # RRG_HF.py:96-100
             tok = dl.dataset.seq.tokenizer
             self.model.config.decoder_start_token_id = tok.cls_token_id
