@@ -305,7 +305,24 @@ GROUP_WGRAD = os.environ.get("VM_WGRAD_GROUP", "1") != "0"
 # launch) wants ONE full round of the 256 CUs: the linears of two transformer layers (encoder 2 x 432 = 864 -> 216 tiles of 256 x 256, decoder
 # 2 x 504 = 1008 -> 252); the 128 x 128-tile kernel 400 (512 resident workgroups, VM_WGRAD_P8=0)
 GROUP_TILES = int(os.environ.get("VM_WGRAD_GROUP_TILES", "400" if os.environ.get("VM_WGRAD_P8", "2") == "0" else "840"))
-_pg = {"items": [], "tiles": 0, "ptrs": set()}
+# [r6] flush policy of the wide-tile kernel.  It is ONE persistent workgroup per CU (160 KB of LDS, all 512 registers of a SIMD lane) walking the
+# launch's 256 x 256 tiles: a launch costs ceil(tiles / 256) rounds whatever the tiles belong to -- and while it runs, no main-stream workgroup can
+# share a CU with it.  Three rules, measured on one box (profiles/r06_d_wgrad_flush_policy.txt; ms per step / GEMM family alone):
+#   threshold  flush the first time the queue holds >= 840 tiles of 128 x 128 (rounds 4-5): launches of 216-243 tiles (84-95 % of a round), the LM
+#              head alone (360 = two rounds at 70 %), the patch embedding's 9 tiles alone (164 us at 4 % of the chip)          23.79 / 17.43
+#   fill       flush BEFORE the problem that would open a new round once the queue fills its rounds to >= 0.9, never mix contraction lengths:
+#              252-tile launches, LM head + last decoder layer 486 / 512; best kernels, but a full round leaves the activation-gradient chain
+#              on the main stream no CU at all while it runs                                                                      23.75 / 16.95
+#   hybrid     the threshold rule, except that a launch is not cut while it fills its rounds to < 0.8 (the LM head takes the last layer's FC
+#              gradients along: 432 / 512), and a flush of < 16 tiles goes to the split-K GEMM instead (patch embedding)          23.63 / 17.31
+# The step is CU-time-bound either way; "hybrid" (default) keeps ~40 CUs free for the main stream in most launches.  VM_WGRAD_FLUSH picks the rule.
+WGRAD_FLUSH_MODE = os.environ.get("VM_WGRAD_FLUSH", "hybrid") if os.environ.get("VM_WGRAD_P8", "2") != "0" else "threshold"
+WGRAD_FLUSH_FILL = WGRAD_FLUSH_MODE == "fill"
+WGRAD_FLUSH_HYBRID = WGRAD_FLUSH_MODE == "hybrid"      # the threshold rule, but a launch is not cut while it fills its rounds to < 0.8 (the LM head alone)
+WGRAD_FILL = float(os.environ.get("VM_WGRAD_FILL", "0.9"))
+WGRAD_MAX_PROBLEMS = 16                          # P8W_MAX_GROUP of csrc/gemm_args.h: more problems would split the launch
+WGRAD_TRACE = os.environ.get("VM_WGRAD_TRACE", "") == "1"
+_pg = {"items": [], "tiles": 0, "ptrs": set(), "t256": 0}
 WGRAD_CHECK = os.environ.get("VM_WGRAD_CHECK", "") == "1"
 # first-touch tracking: a gradient buffer that no kernel has written since its arena zeroed the gradients may be STORED instead of accumulated
 # (vm_wgrad_problem.overwrite: the read half of 0.9 GB of fp32 read-modify-write per step).  ``touched``: buffers written since then;
@@ -404,6 +421,15 @@ def param_grads(dY, X, dW, db=None, *, ld_dy=None, ld_x=None, alpha_dev=None, co
         if dW.data_ptr() in _pg["ptrs"]:            # the same parameter twice in one backward graph: never in one launch (two owners of a tile)
             flush_param_grads()
         K = X.shape[1]
+        t256 = ((N + 255) // 256) * ((K + 255) // 256)
+        if WGRAD_FLUSH_FILL and _pg["items"]:
+            have = _pg["t256"]
+            rounds = (have + 255) // 256
+            # (a problem of another contraction length -- the decoder's 8192 rows / the encoder's 12608 -- never joins the queue: a workgroup's
+            #  tiles are dealt round-robin, and a launch that mixes 128- and 197-K-tile outputs runs as long as its longest pairing)
+            if (len(_pg["items"]) >= WGRAD_MAX_PROBLEMS or dY.shape[0] != _pg["items"][0][0].shape[0]
+                    or (have + t256 > 256 * rounds and have >= WGRAD_FILL * 256 * rounds)):
+                flush_param_grads()                 # the queue fills its rounds: the new problem starts the next launch
         fw = _first_touch(dW)
         fb = _first_touch(db) if db is not None else True
         if not (fw and fb):                         # one flag for both outputs of a problem; accumulating into a clean buffer is always right
@@ -411,7 +437,9 @@ def param_grads(dY, X, dW, db=None, *, ld_dy=None, ld_x=None, alpha_dev=None, co
         _pg["items"].append((dY, X, dW, db, ld_dy, ld_x, alpha_dev, N, K, fw))
         _pg["ptrs"].add(dW.data_ptr())
         _pg["tiles"] += ((N + 127) // 128) * ((K + 127) // 128)
-        if _pg["tiles"] >= GROUP_TILES:
+        _pg["t256"] += t256
+        if not WGRAD_FLUSH_FILL and _pg["tiles"] >= GROUP_TILES and not (
+                WGRAD_FLUSH_HYBRID and _pg["t256"] < 0.8 * 256 * ((_pg["t256"] + 255) // 256) and len(_pg["items"]) < WGRAD_MAX_PROBLEMS):
             flush_param_grads()
         else:
             _ensure_end_of_backward_flush()
@@ -448,7 +476,21 @@ def flush_param_grads():
     items = _pg["items"]
     if not items:
         return
-    _pg["items"], _pg["tiles"], _pg["ptrs"] = [], 0, set()
+    if WGRAD_TRACE:
+        import sys
+        print(f"[wgrad flush] {len(items)} problems, {_pg['t256']} tiles of 256 x 256 ({_pg['t256'] / (256 * max(1, (_pg['t256'] + 255) // 256)):.2f} of "
+              f"{max(1, (_pg['t256'] + 255) // 256)} round(s)): " + " ".join(f"{it[7]}x{it[8]}/{it[0].shape[0]}" for it in items), file=sys.stderr)
+    lonely = (WGRAD_FLUSH_FILL or WGRAD_FLUSH_HYBRID) and _pg["t256"] < 16
+    _pg["items"], _pg["tiles"], _pg["ptrs"], _pg["t256"] = [], 0, set(), 0
+    if lonely:
+        # [r6] a flush that holds a handful of tiles (the ViT patch embedding's 768 x 768 gradient over 12544 rows, alone behind the last encoder
+        # layer: 9 tiles) would walk its whole contraction with 4 % of the chip -- 164 us on the grouped kernel; the split-K GEMM + column sum take ~30
+        for dY, X, dW, db, ld_dy, ld_x, alpha_dev, N, K, first in items:
+            with on_side(*(t for t in (dY, X, alpha_dev) if t is not None)):
+                wgrad(dY, X, dW[:N] if dW.shape[0] != N else dW, ld_dy=ld_dy, ld_x=ld_x, alpha_dev=alpha_dev, n_out=N)
+                if db is not None:
+                    colsum(dY, db, rows=dY.shape[0], cols=N, scale_dev=alpha_dev)
+        return
     arr = (_lib.WgradProblem * len(items))()
     tensors = []
     if WGRAD_CHECK:             # VM_WGRAD_CHECK=1 (debug): a buffer about to be STORED into must still hold the zeros of zero_grad
@@ -471,7 +513,7 @@ def reset_host_state():
     """forget everything queued on the host for launches that will never happen (an aborted graph capture: graph.GraphedTrainStep):
     the weight-gradient and LayerNorm-reduce queues, the pending side-stream join, the masked-gradient hand-off table; the first-touch
     records of every tracked arena are invalidated (nothing is known about the buffers until the next zero_grad)."""
-    _pg["items"], _pg["tiles"], _pg["ptrs"] = [], 0, set()
+    _pg["items"], _pg["tiles"], _pg["ptrs"], _pg["t256"] = [], 0, set(), 0
     _lnq["items"], _lnq["ptrs"] = [], set()
     _masked.clear()
     _side["pending"], _side["callback_queued"], _side["defer"] = False, False, False
