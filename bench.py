@@ -35,8 +35,8 @@ DEC_12L = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, in
                vocab_size=30522, max_position_embeddings=514, layer_norm_eps=1e-5, bos_token_id=0, pad_token_id=1,
                eos_token_id=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, initializer_range=0.02)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_PROFILE = "profiles/r05_pmc_gemm.txt"      # separate rocprofv3 --pmc passes of the dominant shapes (traffic is not measurable in-process)
-PMC_FAMILY = "profiles/r05_pmc_gemm_family.json"   # FETCH_SIZE / WRITE_SIZE passes over a whole bench run, summed over the GEMM family (tools/pmc_family.py)
+PMC_PROFILE = "profiles/r06_pmc_gemm.txt"      # separate rocprofv3 --pmc passes of the dominant shapes (traffic is not measurable in-process)
+PMC_FAMILY = "profiles/r06_pmc_gemm_family.json"   # FETCH_SIZE / WRITE_SIZE passes over a whole bench run, summed over the GEMM family (tools/pmc_family.py)
 
 
 def committed_traffic():
