@@ -6,7 +6,7 @@
 // library: it is a measurement, not a product path.
 //
 // Candidate: 512 threads = 8 waves; wave w owns columns [96 w, 96 w + 96) of all 64 rows (4 A fragments x 6 B fragments = 96 accumulator
-// registers); 32-wide K-tiles through a 2-slot LDS-DMA ring (A 4 KB + B 48 KB per slot = 104 KB: one workgroup per CU); D^T accumulators
+// registers); 32-wide K-tiles through a 3-slot LDS-DMA ring with counted waits (A 4 KB + B 48 KB per slot = 156 KB: one workgroup per CU; the 2-slot form measured 43 / 52 us); D^T accumulators
 // (lane -> row c, 4 consecutive columns); epilogue: + bias + residual, rounded to bf16 (what the two-kernel path stores between its kernels),
 // row mean and variance in two passes over the registers (lane-group sums by permlane swaps, the 8 waves' partials through LDS), then the
 // pre-LN rows and the normalised rows staged through the idle ring as bf16 and stored in whole 1536-B rows.
@@ -48,7 +48,8 @@ __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_dst) {
 #define A_BYTES (RM * RK * 2)
 #define B_BYTES (RN * RK * 2)
 #define SLOT (A_BYTES + B_BYTES)
-#define LDS_BYTES (2 * SLOT)      // 106496 B >= 98304 (one staged bf16 output [64][768]) + 4096 (the waves' row partials) behind it
+#define NSLOT 3
+#define LDS_BYTES (NSLOT * SLOT)  // 159744 B (one workgroup per CU) >= 98304 (one staged bf16 output [64][768]) + 4096 (the waves' row partials) behind it
 
 // tile [rows][32 k] = 64 B per row; one DMA instruction = 16 rows x 64 B; 16-B chunk ^= (row >> 2) & 3 (gemm_fast.hip's 32-wide layout)
 __device__ __forceinline__ const bf16_t* stage_src(const bf16_t* base, int64_t ld, int row0, int nrows, int q, int lane) {
@@ -86,12 +87,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_rowres_kernel(const bf16_t* __
     for (int j = 0; j < 6; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    // 3-slot ring, two K-tiles in flight: "tile t landed" == at most this wave's pieces of tile t + 1 are outstanding (7 for waves 0-3, 6 for the others)
     stage(0);
+    if (nk > 1) stage(1);
     for (int t = 0; t < nk; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                      // K-tile t landed for every wave; slot (t + 1) & 1 is drained
-        if (t + 1 < nk) stage((t + 1) & 1);
-        const char* sa = smem + (t & 1) * SLOT;
+        if (t + 1 < nk) { if (wave < 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // K-tile t landed for every wave; slot (t + 2) % 3 (read in iteration t - 1) is drained
+        if (t + 2 < nk) stage((t + 2) % NSLOT);
+        const char* sa = smem + (t % NSLOT) * SLOT;
         const char* sb = sa + A_BYTES;
         bf16x8_t fa[4], fb[6];
 #pragma unroll
