@@ -223,6 +223,23 @@ int vm_batchnorm_nhwc_fwd(const void* x, const void* residual /* or NULL */, voi
 int vm_batchnorm_nhwc_bwd(const void* dy, const void* x, const void* residual, const float* gamma, const float* beta, const float* mean,
                           const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta, int G, int rows_per_group, int C, int dtype,
                           int relu, int training, void* ws, size_t ws_bytes, void* stream);
+/* The same passes with explicit strides, for a DenseNet block that keeps ONE channels-last feature buffer instead of re-concatenating it layer by
+ * layer (torchvision's torch.cat in _DenseLayer.forward, reached from ref:vilmedic/blocks/vision/cnn.py:62-66 via ref:vilmedic/models/mvqa/MVQA.py:41-43):
+ *   _stats   per-group mean / rstd / biased var of the C channels of x (rows ldx elements apart) -> mean / rstd / var[g * ldm + c]; the rows are also
+ *            written to copy_dst (rows ld_copy apart) when given; num_batches_tracked (NULL or a device int64) += G;
+ *   _apply   the normalisation pass of vm_batchnorm_nhwc_fwd over the first C channels of rows ldx apart (y and residual stay dense [rows, C]); with
+ *            running_mean / running_var (fp32 [C]) the moving averages take one update per group in group order, running_var from the unbiased
+ *            estimate: r = f * s_g + (1 - f) * r, f = momentum, or 1 / (updates so far) when momentum < 0 (nn.BatchNorm2d(momentum=None));
+ *   _bwd_ex  vm_batchnorm_nhwc_bwd with x rows ldx apart, dx rows lddx apart and, with accumulate != 0, dx += (the block's gradient buffer). */
+int vm_batchnorm_nhwc_stats(const void* x, int64_t ldx, void* copy_dst /* or NULL */, int64_t ld_copy, float* mean, float* rstd, float* var, int ldm,
+                            int64_t* num_batches_tracked /* or NULL */, int G, int rows_per_group, int C, float eps, int dtype, void* ws,
+                            size_t ws_bytes, void* stream);
+int vm_batchnorm_nhwc_apply(const void* x, int64_t ldx, const void* residual, void* y, const float* gamma, const float* beta, const float* mean,
+                            const float* rstd, const float* var, int ldm, float* running_mean /* or NULL */, float* running_var,
+                            const int64_t* num_batches_tracked, float momentum, int G, int rows_per_group, int C, int dtype, int relu, void* stream);
+int vm_batchnorm_nhwc_bwd_ex(const void* dy, const void* x, int64_t ldx, const void* residual, const float* gamma, const float* beta, const float* mean,
+                             const float* rstd, int ldm, void* dx, int64_t lddx, int accumulate, void* dres, float* dgamma, float* dbeta, int G,
+                             int rows_per_group, int C, int dtype, int relu, int training, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ embeddings
  * hf:...bert_generation.py:394-426: out = word[ids] + pos[past_len + t]   (LayerNorm is a separate call) */

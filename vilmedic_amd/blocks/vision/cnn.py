@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .micro_bn import bn_act, use_micro_batch_norm
+from .micro_bn import bn_act, dense_block_forward, dense_block_ok, use_micro_batch_norm
 
 
 class BasicBlock(nn.Module):
@@ -111,11 +111,15 @@ class _DenseBlock(nn.ModuleDict):
             self.add_module(f"denselayer{i + 1}", _DenseLayer(inp + i * growth, growth, bn_size))
 
     def forward(self, x):
-        # running concatenation [r6]: every layer consumes ONE tensor (the block's features so far) and the next one is cat(that, its 32 new
+        # [r6] one feature buffer for the block (blocks/vision/micro_bn.py: each layer's norm1 reads the first c channels of it, the backward pass
+        # accumulates onto one gradient buffer): MVQA's DenseNet-169 step ran 82 torch.cat copies of the growing tensor and as many gradient adds
+        layers = list(self.values())
+        if dense_block_ok(layers, x):
+            return dense_block_forward(layers, x)
+        # fallback, running concatenation: every layer consumes ONE tensor (the block's features so far) and the next one is cat(that, its 32 new
         # channels) -- the same bytes copied per layer as torchvision's cat(list) form, the same values, but in the backward pass each running
-        # tensor has exactly two consumers (its layer and the next cat): one gradient add per layer instead of one per (layer, earlier
-        # feature) pair.  MVQA's DenseNet-169 step: 1234 `add` launches of 32-channel slices (10.3 ms, launch-bound) -> 82.
-        for _, layer in self.items():
+        # tensor has exactly two consumers (its layer and the next cat): one gradient add per layer instead of one per (layer, earlier feature) pair
+        for layer in layers:
             x = torch.cat([x, layer(x)], 1)
         return x
 

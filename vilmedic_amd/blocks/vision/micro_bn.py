@@ -57,20 +57,25 @@ class _BatchNormNhwcFn(ops.Fn):
     """one vm_batchnorm_nhwc_fwd / _bwd pair over ``G`` groups of ``x.shape[0] // G`` images (channels-last x, residual, y)"""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, mean, rstd, G, relu, training, eps):
+    def forward(ctx, x, residual, gamma, beta, mean, rstd, G, relu, training, eps, running=None):
         N, C, H, W = x.shape
         R = (N // G) * H * W
         y = torch.empty_like(x)
         dt = VM_BF16 if x.dtype == torch.bfloat16 else VM_F32
         var = None
+        rm = rv = nbt = None
+        mom = 0.0
         if training:
             mean = torch.empty(G, C, dtype=torch.float32, device=x.device)
             rstd = torch.empty(G, C, dtype=torch.float32, device=x.device)
             var = torch.empty(G, C, dtype=torch.float32, device=x.device)
-        nws = lib().vm_batchnorm_nhwc_ws(G, R, C)
-        ws = _workspace(nws, x.device)
-        check(lib().vm_batchnorm_nhwc_fwd(ptr(x), ptr(residual), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(var), G, R, C, eps, dt,
-                                          int(relu), int(training), ptr(ws), ws.numel(), stream()), "vm_batchnorm_nhwc_fwd")
+            if running is not None:             # the moving averages are updated by the normalisation kernel (one update per group, in group order)
+                rm, rv, nbt, mom = running
+            ws = _workspace(lib().vm_batchnorm_nhwc_ws(G, R, C), x.device)
+            check(lib().vm_batchnorm_nhwc_stats(ptr(x), C, None, 0, ptr(mean), ptr(rstd), ptr(var), C, ptr(nbt), G, R, C, eps, dt, ptr(ws), ws.numel(),
+                                                stream()), "vm_batchnorm_nhwc_stats")
+        check(lib().vm_batchnorm_nhwc_apply(ptr(x), C, ptr(residual), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(var), C, ptr(rm), ptr(rv),
+                                            ptr(nbt), mom, G, R, C, dt, int(relu), stream()), "vm_batchnorm_nhwc_apply")
         ctx.save_for_backward(x, residual, gamma, beta, mean, rstd)
         ctx.meta = (G, R, C, dt, relu, training)
         if training:
@@ -93,7 +98,7 @@ class _BatchNormNhwcFn(ops.Fn):
         ws = _workspace(lib().vm_batchnorm_nhwc_ws(G, R, C), x.device)
         check(lib().vm_batchnorm_nhwc_bwd(ptr(dy), ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(dx), ptr(dres), ptr(dgamma),
                                           ptr(dbeta), G, R, C, dt, int(relu), int(training), ptr(ws), ws.numel(), stream()), "vm_batchnorm_nhwc_bwd")
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 def _nhwc_ok(x, C):
@@ -134,16 +139,27 @@ class MicroBatchNorm2d(nn.BatchNorm2d):
         G = B // g if grouped else 1
         main = G * g if grouped else B
         parts = [(0, main, G)] + ([(main, B, 1)] if main < B else [])          # the trailing partial micro-batch is a group of its own
+        running = self._running_args(x.device)
         outs, stats = [], []
         for lo, hi, Gp in parts:
             xs = x if (lo == 0 and hi == B) else x[lo:hi]
             rs = None if residual is None else (residual if (lo == 0 and hi == B) else residual[lo:hi])
-            y, mean, var = _BatchNormNhwcFn.apply(xs, rs, self.weight, self.bias, None, None, Gp, relu, True, self.eps)
+            y, mean, var = _BatchNormNhwcFn.apply(xs, rs, self.weight, self.bias, None, None, Gp, relu, True, self.eps, running)
             outs.append(y)
             stats.append((mean, var, (hi - lo) // Gp * x.shape[2] * x.shape[3]))
-        if self.training and self.track_running_stats:
+        if self.training and self.track_running_stats and running is None:
             self._update_running(stats)
         return outs[0] if len(outs) == 1 else torch.cat(outs)
+
+    def _running_args(self, device):
+        """(running_mean, running_var, num_batches_tracked, momentum or -1 for the cumulative average) when the kernel can update them in place"""
+        if not (self.training and self.track_running_stats):
+            return None
+        rm, rv, nbt = self.running_mean, self.running_var, self.num_batches_tracked
+        if not (rm.dtype == rv.dtype == torch.float32 and nbt.dtype == torch.int64 and rm.device == rv.device == nbt.device == device
+                and rm.is_contiguous() and rv.is_contiguous()):
+            return None
+        return rm, rv, nbt, (-1.0 if self.momentum is None else float(self.momentum))
 
     @torch.no_grad()
     def _update_running(self, stats):
@@ -186,6 +202,134 @@ class MicroBatchNorm2d(nn.BatchNorm2d):
         if rest.shape[0]:
             y = torch.cat([y, super().forward(rest)])
         return y
+
+
+# ----------------------------------------------------------------------------- DenseNet block on ONE feature buffer
+class _DenseState:
+    """what the layers of one dense-block call share: the channels-last feature buffer [N, Ctot, H, W], the batch statistics of its channels
+    ([G, Ctot]; a channel's statistics are the same for every norm1 that reads it, so each layer computes them for its NEW channels only) and, during
+    the backward pass, the gradient buffer every norm1 accumulates into"""
+    __slots__ = ("buf", "mean", "rstd", "var", "G", "R", "Ctot", "dt", "grad", "eps")
+
+
+class _DenseNormFn(ops.Fn):
+    """append ``new`` (the block input or the previous layer's growth channels) to the buffer at channel ``lo`` and return relu(norm1(buffer[:, :hi]))"""
+
+    @staticmethod
+    def forward(ctx, new, gamma, beta, st, bn, lo, hi):
+        buf = st.buf
+        new = new.contiguous(memory_format=torch.channels_last)
+        N, _, H, W = buf.shape
+        h = torch.empty((N, hi, H, W), dtype=buf.dtype, device=buf.device, memory_format=torch.channels_last)
+        esz = buf.element_size()
+        training = bn.training
+        if training:
+            rm, rv, nbt, mom = bn._running_args(buf.device)
+            ws = _workspace(lib().vm_batchnorm_nhwc_ws(st.G, st.R, hi - lo), buf.device)
+            check(lib().vm_batchnorm_nhwc_stats(ptr(new), hi - lo, buf.data_ptr() + lo * esz, st.Ctot, st.mean.data_ptr() + 4 * lo, st.rstd.data_ptr() + 4 * lo,
+                                                st.var.data_ptr() + 4 * lo, st.Ctot, ptr(nbt), st.G, st.R, hi - lo, st.eps, st.dt, ptr(ws), ws.numel(), stream()),
+                  "vm_batchnorm_nhwc_stats")
+            mean, rstd, ldm, G, R = st.mean, st.rstd, st.Ctot, st.G, st.R
+            check(lib().vm_batchnorm_nhwc_apply(ptr(buf), st.Ctot, None, ptr(h), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(st.var), ldm, ptr(rm), ptr(rv),
+                                                ptr(nbt), mom, G, R, hi, st.dt, 1, stream()), "vm_batchnorm_nhwc_apply")
+        else:
+            buf[:, lo:hi].copy_(new)
+            mean = bn.running_mean.float().view(1, -1).contiguous()
+            rstd = torch.rsqrt(bn.running_var.float() + bn.eps).view(1, -1).contiguous()
+            ldm, G, R = hi, 1, st.G * st.R
+            check(lib().vm_batchnorm_nhwc_apply(ptr(buf), st.Ctot, None, ptr(h), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), None, ldm, None, None, None, 0.0,
+                                                G, R, hi, st.dt, 1, stream()), "vm_batchnorm_nhwc_apply")
+        ctx.st, ctx.stat, ctx.meta = st, (mean, rstd, gamma, beta), (ldm, G, R, lo, hi, training)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        st = ctx.st
+        mean, rstd, gamma, beta = ctx.stat
+        ldm, G, R, lo, hi, training = ctx.meta
+        grad = st.grad
+        if grad is None:
+            raise RuntimeError("dense block backward: the gradient buffer of the block is missing (the block output's gradient has not arrived)")
+        dh = dh.contiguous(memory_format=torch.channels_last)
+        if dh.dtype != grad.dtype:
+            dh = dh.to(grad.dtype)
+        dgamma = torch.zeros(hi, dtype=torch.float32, device=grad.device)
+        dbeta = torch.zeros(hi, dtype=torch.float32, device=grad.device)
+        ws = _workspace(lib().vm_batchnorm_nhwc_ws(G, R, hi), grad.device)
+        check(lib().vm_batchnorm_nhwc_bwd_ex(ptr(dh), ptr(st.buf), st.Ctot, None, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ldm, ptr(grad), st.Ctot, 1, None,
+                                             ptr(dgamma), ptr(dbeta), G, R, hi, st.dt, 1, int(training), ptr(ws), ws.numel(), stream()), "vm_batchnorm_nhwc_bwd")
+        dnew = grad[:, lo:hi].contiguous(memory_format=torch.channels_last) if ctx.needs_input_grad[0] else None
+        if lo == 0:
+            st.grad = None                      # the first layer's backward is the block's last
+        return dnew, dgamma, dbeta, None, None, None, None
+
+
+class _DenseCloseFn(ops.Fn):
+    """append the last layer's channels: the buffer IS the block's output.  Backward: its gradient becomes the block's gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, new, st, lo):
+        st.buf[:, lo:].copy_(new)
+        ctx.st, ctx.lo = st, lo
+        return st.buf
+
+    @staticmethod
+    def backward(ctx, dout):
+        st = ctx.st
+        if dout.dtype != st.buf.dtype:
+            dout = dout.to(st.buf.dtype)
+        st.grad = dout.clone(memory_format=torch.channels_last)        # owned: the layers accumulate into it in place
+        return st.grad[:, ctx.lo:].contiguous(memory_format=torch.channels_last), None, None
+
+
+def dense_block_ok(layers, x):
+    """can this block run on one feature buffer?  channels-last device tensor, every norm1 a MicroBatchNorm2d the kernel takes, one eps / mode for all"""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float32) and x.is_contiguous(memory_format=torch.channels_last)
+            and not x.is_contiguous() and x.shape[0] > 0 and layers):
+        return False
+    c, first = x.shape[1], layers[0].norm1
+    g, B = _micro["size"], x.shape[0]
+    if first.training and first.track_running_stats and 0 < g < B and B % g:
+        return False
+    for layer in layers:
+        bn = layer.norm1
+        if not (isinstance(bn, MicroBatchNorm2d) and bn.affine and bn.track_running_stats and bn.num_features == c and c % 8 == 0 and c <= 2048
+                and bn.eps == first.eps and bn.training == first.training and (not bn.training or bn._running_args(x.device) is not None)
+                and isinstance(layer.relu1, nn.ReLU)):
+            return False
+        c += layer.conv2.out_channels
+    return c % 8 == 0 and c <= 2048
+
+
+def dense_block_forward(layers, x):
+    """torchvision's _DenseBlock.forward (every layer reads the concatenation of the block input and all earlier layers' outputs) without the
+    concatenations: the features live in one [N, Ctot, H, W] channels-last buffer, layer l normalises its first c_l channels in place of a
+    torch.cat, and in the backward pass every norm1 adds its input gradient onto the same gradient buffer (no per-layer gradient adds)"""
+    first = layers[0].norm1
+    N, c0, H, W = x.shape
+    st = _DenseState()
+    st.Ctot = c0 + sum(layer.conv2.out_channels for layer in layers)
+    st.buf = torch.empty((N, st.Ctot, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    g = _micro["size"]
+    st.G = N // g if (first.training and 0 < g < N) else 1
+    st.R = (N // st.G) * H * W
+    st.dt = VM_BF16 if x.dtype == torch.bfloat16 else VM_F32
+    st.eps, st.grad = first.eps, None
+    if first.training:
+        st.mean = torch.empty(st.G, st.Ctot, dtype=torch.float32, device=x.device)
+        st.rstd = torch.empty_like(st.mean)
+        st.var = torch.empty_like(st.mean)
+    else:
+        st.mean = st.rstd = st.var = None
+    new, lo = x, 0
+    for layer in layers:
+        hi = lo + new.shape[1]
+        h = _DenseNormFn.apply(new, layer.norm1.weight, layer.norm1.bias, st, layer.norm1, lo, hi)
+        new = layer.conv2(bn_act(layer.norm2, layer.conv1(h), layer.relu2))
+        if new.dtype != x.dtype:
+            new = new.to(x.dtype)
+        lo = hi
+    return _DenseCloseFn.apply(new, st, lo)
 
 
 def use_micro_batch_norm(module):

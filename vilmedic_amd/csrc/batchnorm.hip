@@ -30,7 +30,13 @@ template <> struct Ld8<float> {
     }
 };
 
-struct BnGeom { int G, R, C, CH8, RPI, S, rows_per_split; };
+struct BnGeom {
+    int G, R, C, CH8, RPI, S, rows_per_split;
+    int64_t ldx;      // row stride of x in elements (>= C: x may be the first C channels of a wider channels-last buffer)
+    int64_t ldd;      // row stride of dx (backward)
+    int ldm;          // group stride of mean / rstd / var (>= C: the statistics may live in a wider per-buffer array)
+    int acc;          // backward: dx += instead of dx =
+};
 
 __device__ __forceinline__ void split_range(const BnGeom& g, int si, int& r0, int& r1) {
     r0 = si * g.rows_per_split;
@@ -41,8 +47,10 @@ __device__ __forceinline__ void split_range(const BnGeom& g, int si, int& r0, in
 // sees (shifted sums), partials are merged with Chan's formula: no E[x^2] - mean^2 cancellation.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, float* __restrict__ pmean, float* __restrict__ pm2,
-                                                       float* __restrict__ pcnt, const BnGeom g) {
+                                                       float* __restrict__ pcnt, const BnGeom g, T* __restrict__ copy_dst, int64_t ldc,
+                                                       int64_t* __restrict__ nbt) {
     const int gi = blockIdx.x / g.S, si = blockIdx.x % g.S;
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += g.G;      // num_batches_tracked: one update per group (bn_apply_kernel reads it afterwards)
     int r0, r1;
     split_range(g, si, r0, r1);
     const int t = threadIdx.x, c8 = t % g.CH8, rsub = t / g.CH8;
@@ -51,17 +59,23 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) { k[j] = 0.f; s[j] = 0.f; q[j] = 0.f; }
     if (rsub < g.RPI) {
-        const T* base = x + ((int64_t)gi * g.R) * g.C + c8 * 8;
+        const T* base = x + ((int64_t)gi * g.R) * g.ldx + c8 * 8;
+        T* cbase = copy_dst ? copy_dst + ((int64_t)gi * g.R) * ldc + c8 * 8 : nullptr;      // the rows are also copied (a dense block's feature buffer)
         int r = r0 + rsub;
         if (r < r1) {
-            Ld8<T>::load(base + (int64_t)r * g.C, k);           // the shift: this thread's first row
+            Ld8<T>::load(base + (int64_t)r * g.ldx, k);         // the shift: this thread's first row
+            if (cbase) Ld8<T>::store(cbase + (int64_t)r * ldc, k);
             n = 1.f;
             r += g.RPI;
         }
         for (; r + 3 * g.RPI < r1; r += 4 * g.RPI) {            // four rows in flight
             float a[4][8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) Ld8<T>::load(base + (int64_t)(r + u * g.RPI) * g.C, a[u]);
+            for (int u = 0; u < 4; ++u) Ld8<T>::load(base + (int64_t)(r + u * g.RPI) * g.ldx, a[u]);
+            if (cbase) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) Ld8<T>::store(cbase + (int64_t)(r + u * g.RPI) * ldc, a[u]);
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -70,7 +84,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
         }
         for (; r < r1; r += g.RPI) {
             float a[8];
-            Ld8<T>::load(base + (int64_t)r * g.C, a);
+            Ld8<T>::load(base + (int64_t)r * g.ldx, a);
+            if (cbase) Ld8<T>::store(cbase + (int64_t)r * ldc, a);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float d = a[j] - k[j]; s[j] += d; q[j] += d * d; }
             n += 1.f;
@@ -140,9 +155,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
     if (l == 0 && c < g.C) {
         const float v = M2 / N;
-        mean[gi * g.C + c] = m;
-        var[gi * g.C + c] = v;
-        rstd[gi * g.C + c] = rsqrtf(v + eps);
+        mean[gi * g.ldm + c] = m;
+        var[gi * g.ldm + c] = v;
+        rstd[gi * g.ldm + c] = rsqrtf(v + eps);
     }
 }
 
@@ -150,26 +165,43 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const float* __restrict__ mean, const float* __restrict__ rstd, const BnGeom g, int relu) {
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd, const BnGeom g, int relu,
+                                                       const float* __restrict__ var, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                       const int64_t* __restrict__ nbt, float momentum) {
     const int gi = blockIdx.x / g.S, si = blockIdx.x % g.S;
     int r0, r1;
     split_range(g, si, r0, r1);
     const int t = threadIdx.x, c8 = t % g.CH8, rsub = t / g.CH8;
+    if (rmean) {        // running statistics: one update per group, in group order (nn.BatchNorm2d run micro-batch by micro-batch); one owner thread per channel
+        const float unb = g.R > 1 ? (float)g.R / (float)(g.R - 1) : 1.f;      // running_var takes the unbiased estimate
+        for (int c = blockIdx.x * 256 + t; c < g.C; c += (int)gridDim.x * 256) {
+            float rm = rmean[c], rv = rvar[c];
+            float n = nbt ? (float)(nbt[0] - g.G) : 0.f;                      // momentum < 0: cumulative average, factor 1 / num_batches_tracked
+            for (int k = 0; k < g.G; ++k) {
+                n += 1.f;
+                const float f = momentum >= 0.f ? momentum : 1.f / n;
+                rm = f * mean[k * g.ldm + c] + (1.f - f) * rm;
+                rv = f * (var[k * g.ldm + c] * unb) + (1.f - f) * rv;
+            }
+            rmean[c] = rm; rvar[c] = rv;
+        }
+    }
     if (rsub >= g.RPI) return;
     float sc[8], sh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = c8 * 8 + j;
         const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-        sc[j] = rstd[gi * g.C + c] * ga;
-        sh[j] = be - mean[gi * g.C + c] * sc[j];
+        sc[j] = rstd[gi * g.ldm + c] * ga;
+        sh[j] = be - mean[gi * g.ldm + c] * sc[j];
     }
     const int64_t off = ((int64_t)gi * g.R) * g.C + c8 * 8;
+    const T* xb = x + ((int64_t)gi * g.R) * g.ldx + c8 * 8;
     for (int r = r0 + rsub; r < r1; r += 2 * g.RPI) {
         float a[2][8], b[2][8];
         const bool two = r + g.RPI < r1;
-        Ld8<T>::load(x + off + (int64_t)r * g.C, a[0]);
-        if (two) Ld8<T>::load(x + off + (int64_t)(r + g.RPI) * g.C, a[1]);
+        Ld8<T>::load(xb + (int64_t)r * g.ldx, a[0]);
+        if (two) Ld8<T>::load(xb + (int64_t)(r + g.RPI) * g.ldx, a[1]);
         if (res) {
             Ld8<T>::load(res + off + (int64_t)r * g.C, b[0]);
             if (two) Ld8<T>::load(res + off + (int64_t)(r + g.RPI) * g.C, b[1]);
@@ -204,18 +236,19 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__
     for (int j = 0; j < 8; ++j) {
         const int c = c8 * 8 + j;
         s[j] = 0.f; sx[j] = 0.f;
-        mu[j] = mean[gi * g.C + c]; rs[j] = rstd[gi * g.C + c];
+        mu[j] = mean[gi * g.ldm + c]; rs[j] = rstd[gi * g.ldm + c];
         sc[j] = rs[j] * (gamma ? gamma[c] : 1.f);
         sh[j] = (beta ? beta[c] : 0.f) - mu[j] * sc[j];
     }
     if (rsub < g.RPI) {
         const int64_t off = ((int64_t)gi * g.R) * g.C + c8 * 8;
+        const T* xb = x + ((int64_t)gi * g.R) * g.ldx + c8 * 8;
         for (int r = r0 + rsub; r < r1; r += 2 * g.RPI) {
             float d[2][8], a[2][8], b[2][8];
             const bool two = r + g.RPI < r1;
             Ld8<T>::load(dy + off + (int64_t)r * g.C, d[0]);
-            Ld8<T>::load(x + off + (int64_t)r * g.C, a[0]);
-            if (two) { Ld8<T>::load(dy + off + (int64_t)(r + g.RPI) * g.C, d[1]); Ld8<T>::load(x + off + (int64_t)(r + g.RPI) * g.C, a[1]); }
+            Ld8<T>::load(xb + (int64_t)r * g.ldx, a[0]);
+            if (two) { Ld8<T>::load(dy + off + (int64_t)(r + g.RPI) * g.C, d[1]); Ld8<T>::load(xb + (int64_t)(r + g.RPI) * g.ldx, a[1]); }
             if (res && relu) {
                 Ld8<T>::load(res + off + (int64_t)r * g.C, b[0]);
                 if (two) Ld8<T>::load(res + off + (int64_t)(r + g.RPI) * g.C, b[1]);
@@ -302,18 +335,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = c8 * 8 + j;
-        mu[j] = mean[gi * g.C + c]; rs[j] = rstd[gi * g.C + c];
+        mu[j] = mean[gi * g.ldm + c]; rs[j] = rstd[gi * g.ldm + c];
         sc[j] = rs[j] * (gamma ? gamma[c] : 1.f);
         sh[j] = (beta ? beta[c] : 0.f) - mu[j] * sc[j];
         m1[j] = sdy[gi * g.C + c] * invn; m2[j] = sdyx[gi * g.C + c] * invn;
     }
     const int64_t off = ((int64_t)gi * g.R) * g.C + c8 * 8;
+    const T* xb = x + ((int64_t)gi * g.R) * g.ldx + c8 * 8;
+    T* dxb = dx + ((int64_t)gi * g.R) * g.ldd + c8 * 8;
     for (int r = r0 + rsub; r < r1; r += 2 * g.RPI) {
-        float d[2][8], a[2][8], b[2][8];
+        float d[2][8], a[2][8], b[2][8], e[2][8];
         const bool two = r + g.RPI < r1;
         Ld8<T>::load(dy + off + (int64_t)r * g.C, d[0]);
-        Ld8<T>::load(x + off + (int64_t)r * g.C, a[0]);
-        if (two) { Ld8<T>::load(dy + off + (int64_t)(r + g.RPI) * g.C, d[1]); Ld8<T>::load(x + off + (int64_t)(r + g.RPI) * g.C, a[1]); }
+        Ld8<T>::load(xb + (int64_t)r * g.ldx, a[0]);
+        if (two) { Ld8<T>::load(dy + off + (int64_t)(r + g.RPI) * g.C, d[1]); Ld8<T>::load(xb + (int64_t)(r + g.RPI) * g.ldx, a[1]); }
+        if (g.acc) {                                             // dx already holds the gradient of the buffer's other consumers
+            Ld8<T>::load(dxb + (int64_t)r * g.ldd, e[0]);
+            if (two) Ld8<T>::load(dxb + (int64_t)(r + g.RPI) * g.ldd, e[1]);
+        }
         if (res && relu) {
             Ld8<T>::load(res + off + (int64_t)r * g.C, b[0]);
             if (two) Ld8<T>::load(res + off + (int64_t)(r + g.RPI) * g.C, b[1]);
@@ -333,8 +372,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                 }
                 d[u][j] = gdy;
                 o[j] = sc[j] * (gdy - m1[j] - xh * m2[j]);
+                if (g.acc) o[j] += e[u][j];
             }
-            Ld8<T>::store(dx + off + (int64_t)(r + u * g.RPI) * g.C, o);
+            Ld8<T>::store(dxb + (int64_t)(r + u * g.RPI) * g.ldd, o);
             if (dres) Ld8<T>::store(dres + off + (int64_t)(r + u * g.RPI) * g.C, d[u]);
         }
     }
@@ -346,6 +386,7 @@ static int finalize_lanes(int S) { return S > 512 ? 64 : (S > 128 ? 32 : 16); }
 BnGeom geometry(int G, int R, int C) {
     BnGeom g;
     g.G = G; g.R = R; g.C = C;
+    g.ldx = C; g.ldd = C; g.ldm = C; g.acc = 0;
     g.CH8 = C / 8;
     g.RPI = 256 / g.CH8;
     // splits per group: fill the chip (~4096 blocks in all: 16 resident blocks per CU hide the HBM latency of a streaming pass) while
@@ -368,44 +409,83 @@ extern "C" size_t vm_batchnorm_nhwc_ws(int G, int rows_per_group, int C) {
     return ((size_t)2 * G * g.S * C + (size_t)G * g.S + (size_t)2 * G * C) * sizeof(float);
 }
 
+// ---- forward in two calls, so that a DenseNet block can keep ONE feature buffer: the statistics of a channel do not change from layer to layer (every
+// norm1 of a block normalises the same values with its own gamma / beta), so each layer computes them for its 32 NEW channels only (copying those
+// rows into the buffer on the way) and normalises the first C channels of the wide buffer with the statistics array of the whole block.
+extern "C" int vm_batchnorm_nhwc_stats(const void* x, int64_t ldx, void* copy_dst, int64_t ld_copy, float* mean, float* rstd, float* var, int ldm,
+                                       int64_t* num_batches_tracked, int G, int rows_per_group, int C, float eps, int dtype, void* ws, size_t ws_bytes,
+                                       void* stream) {
+    VM_REQUIRE(x && mean && rstd && var && G > 0 && rows_per_group > 0 && C > 0 && (C % 8) == 0 && C <= 2048 && (dtype == VM_BF16 || dtype == VM_F32) &&
+               ldx >= C && (ldx % 8) == 0 && ldm >= C && (!copy_dst || (ld_copy >= C && (ld_copy % 8) == 0)),
+               "vm_batchnorm_nhwc_stats: bad arguments (C %% 8 == 0, C <= 2048, strides >= C and multiples of 8)");
+    VM_REQUIRE(ws && ws_bytes >= vm_batchnorm_nhwc_ws(G, rows_per_group, C), "vm_batchnorm_nhwc_stats: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    BnGeom g = geometry(G, rows_per_group, C);
+    g.ldx = ldx; g.ldm = ldm;
+    const double bytes = (double)G * rows_per_group * C * (dtype == VM_BF16 ? 2 : 4);
+    VmProfScope prof(VM_FAM_LN, (copy_dst ? 2.0 : 1.0) * bytes, s);
+    float* pmean = (float*)ws;
+    float* pm2 = pmean + (size_t)G * g.S * C;
+    float* pcnt = pm2 + (size_t)G * g.S * C;
+    if (dtype == VM_BF16) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(G * g.S), dim3(256), 0, s, (const bf16_t*)x, pmean, pm2, pcnt, g, (bf16_t*)copy_dst, ld_copy, num_batches_tracked);
+    else hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(G * g.S), dim3(256), 0, s, (const float*)x, pmean, pm2, pcnt, g, (float*)copy_dst, ld_copy, num_batches_tracked);
+    const int lanes = finalize_lanes(g.S), cpb = 256 / lanes;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(G * ((C + cpb - 1) / cpb)), dim3(256), 0, s, pmean, pm2, pcnt, mean, rstd, var, g, eps, lanes);
+    return vm_check_launch("vm_batchnorm_nhwc_stats");
+}
+
+// y = relu?((x - mean) * rstd * gamma + beta + residual?) over the first C channels of rows ldx apart; with running_mean / running_var the exponential
+// (momentum >= 0) or cumulative (momentum < 0, needs num_batches_tracked as left by vm_batchnorm_nhwc_stats) moving averages take one update per group
+extern "C" int vm_batchnorm_nhwc_apply(const void* x, int64_t ldx, const void* residual, void* y, const float* gamma, const float* beta,
+                                       const float* mean, const float* rstd, const float* var, int ldm, float* running_mean, float* running_var,
+                                       const int64_t* num_batches_tracked, float momentum, int G, int rows_per_group, int C, int dtype, int relu,
+                                       void* stream) {
+    VM_REQUIRE(x && y && mean && rstd && G > 0 && rows_per_group > 0 && C > 0 && (C % 8) == 0 && C <= 2048 && (dtype == VM_BF16 || dtype == VM_F32) &&
+               ldx >= C && (ldx % 8) == 0 && ldm >= C, "vm_batchnorm_nhwc_apply: bad arguments (C %% 8 == 0, C <= 2048, strides >= C)");
+    VM_REQUIRE(!running_mean || (running_var && var && (momentum >= 0.f || num_batches_tracked)),
+               "vm_batchnorm_nhwc_apply: the running update needs running_var, var and (cumulative average) num_batches_tracked");
+    hipStream_t s = (hipStream_t)stream;
+    BnGeom g = geometry(G, rows_per_group, C);
+    g.ldx = ldx; g.ldm = ldm;
+    const double bytes = (double)G * rows_per_group * C * (dtype == VM_BF16 ? 2 : 4);
+    VmProfScope prof(VM_FAM_LN, (residual ? 3.0 : 2.0) * bytes, s);
+    if (dtype == VM_BF16)
+        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(G * g.S), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, gamma, beta, mean, rstd, g, relu,
+                           var, running_mean, running_var, num_batches_tracked, momentum);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(G * g.S), dim3(256), 0, s, (const float*)x, (const float*)residual, (float*)y, gamma, beta, mean, rstd, g, relu,
+                           var, running_mean, running_var, num_batches_tracked, momentum);
+    return vm_check_launch("vm_batchnorm_nhwc_apply");
+}
+
 extern "C" int vm_batchnorm_nhwc_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
                                      float* var, int G, int rows_per_group, int C, float eps, int dtype, int relu, int training, void* ws,
                                      size_t ws_bytes, void* stream) {
     VM_REQUIRE(x && y && mean && rstd && G > 0 && rows_per_group > 0 && C > 0 && (C % 8) == 0 && C <= 2048 && (dtype == VM_BF16 || dtype == VM_F32),
                "vm_batchnorm_nhwc_fwd: bad arguments (C %% 8 == 0, C <= 2048)");
-    hipStream_t s = (hipStream_t)stream;
-    const BnGeom g = geometry(G, rows_per_group, C);
-    const double bytes = (double)G * rows_per_group * C * (dtype == VM_BF16 ? 2 : 4);
-    VmProfScope prof(VM_FAM_LN, (training ? 3.0 : 2.0) * bytes, s);
     if (training) {
         VM_REQUIRE(var && ws && ws_bytes >= vm_batchnorm_nhwc_ws(G, rows_per_group, C), "vm_batchnorm_nhwc_fwd: workspace too small");
-        float* pmean = (float*)ws;
-        float* pm2 = pmean + (size_t)G * g.S * C;
-        float* pcnt = pm2 + (size_t)G * g.S * C;
-        if (dtype == VM_BF16) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(G * g.S), dim3(256), 0, s, (const bf16_t*)x, pmean, pm2, pcnt, g);
-        else hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(G * g.S), dim3(256), 0, s, (const float*)x, pmean, pm2, pcnt, g);
-        {
-            const int lanes = finalize_lanes(g.S), cpb = 256 / lanes;
-            hipLaunchKernelGGL(bn_finalize_kernel, dim3(G * ((C + cpb - 1) / cpb)), dim3(256), 0, s, pmean, pm2, pcnt, mean, rstd, var, g, eps, lanes);
-        }
+        const int rc = vm_batchnorm_nhwc_stats(x, C, nullptr, 0, mean, rstd, var, C, nullptr, G, rows_per_group, C, eps, dtype, ws, ws_bytes, stream);
+        if (rc != VM_OK) return rc;
     }
-    if (dtype == VM_BF16)
-        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(G * g.S), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, gamma, beta, mean, rstd, g, relu);
-    else
-        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(G * g.S), dim3(256), 0, s, (const float*)x, (const float*)residual, (float*)y, gamma, beta, mean, rstd, g, relu);
-    return vm_check_launch("vm_batchnorm_nhwc_fwd");
+    return vm_batchnorm_nhwc_apply(x, C, residual, y, gamma, beta, mean, rstd, var, C, nullptr, nullptr, nullptr, 0.f, G, rows_per_group, C, dtype, relu, stream);
 }
 
-extern "C" int vm_batchnorm_nhwc_bwd(const void* dy, const void* x, const void* residual, const float* gamma, const float* beta, const float* mean,
-                                     const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta, int G, int rows_per_group, int C,
-                                     int dtype, int relu, int training, void* ws, size_t ws_bytes, void* stream) {
-    VM_REQUIRE(dy && x && dx && mean && rstd && G > 0 && rows_per_group > 0 && C > 0 && (C % 8) == 0 && C <= 2048 && (dtype == VM_BF16 || dtype == VM_F32),
-               "vm_batchnorm_nhwc_bwd: bad arguments (C %% 8 == 0, C <= 2048)");
+// x: first C channels of rows ldx apart; dx: rows lddx apart, `accumulate` adds into it (the gradient buffer of a DenseNet block: every layer's
+// BatchNorm gradient lands on the channels it read, no separate add); mean / rstd: group stride ldm
+extern "C" int vm_batchnorm_nhwc_bwd_ex(const void* dy, const void* x, int64_t ldx, const void* residual, const float* gamma, const float* beta,
+                                        const float* mean, const float* rstd, int ldm, void* dx, int64_t lddx, int accumulate, void* dres, float* dgamma,
+                                        float* dbeta, int G, int rows_per_group, int C, int dtype, int relu, int training, void* ws, size_t ws_bytes,
+                                        void* stream) {
+    VM_REQUIRE(dy && x && dx && mean && rstd && G > 0 && rows_per_group > 0 && C > 0 && (C % 8) == 0 && C <= 2048 && (dtype == VM_BF16 || dtype == VM_F32) &&
+               ldx >= C && (ldx % 8) == 0 && lddx >= C && (lddx % 8) == 0 && ldm >= C,
+               "vm_batchnorm_nhwc_bwd: bad arguments (C %% 8 == 0, C <= 2048, strides >= C and multiples of 8)");
     VM_REQUIRE(ws && ws_bytes >= vm_batchnorm_nhwc_ws(G, rows_per_group, C), "vm_batchnorm_nhwc_bwd: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    const BnGeom g = geometry(G, rows_per_group, C);
+    BnGeom g = geometry(G, rows_per_group, C);
+    g.ldx = ldx; g.ldd = lddx; g.ldm = ldm; g.acc = accumulate ? 1 : 0;
     const double bytes = (double)G * rows_per_group * C * (dtype == VM_BF16 ? 2 : 4);
-    VmProfScope prof(VM_FAM_LN, 5.0 * bytes, s);
+    VmProfScope prof(VM_FAM_LN, (5.0 + (accumulate ? 1.0 : 0.0) + (dres ? 1.0 : 0.0)) * bytes, s);
     float* psum = (float*)ws;
     float* psumx = psum + (size_t)G * g.S * C;
     float* sdy = psumx + (size_t)G * g.S * C + (size_t)G * g.S;
@@ -423,4 +503,11 @@ extern "C" int vm_batchnorm_nhwc_bwd(const void* dy, const void* x, const void* 
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(G * g.S), dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)residual, gamma, beta, mean, rstd, sdy, sdyx, (float*)dx, (float*)dres, g, relu, training, dgamma, dbeta, G);
     return vm_check_launch("vm_batchnorm_nhwc_bwd");
+}
+
+extern "C" int vm_batchnorm_nhwc_bwd(const void* dy, const void* x, const void* residual, const float* gamma, const float* beta, const float* mean,
+                                     const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta, int G, int rows_per_group, int C,
+                                     int dtype, int relu, int training, void* ws, size_t ws_bytes, void* stream) {
+    return vm_batchnorm_nhwc_bwd_ex(dy, x, C, residual, gamma, beta, mean, rstd, C, dx, C, 0, dres, dgamma, dbeta, G, rows_per_group, C, dtype, relu,
+                                    training, ws, ws_bytes, stream);
 }
