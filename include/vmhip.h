@@ -230,13 +230,15 @@ int vm_batchnorm_nhwc_bwd(const void* dy, const void* x, const void* residual, c
  *   _apply   the normalisation pass of vm_batchnorm_nhwc_fwd over the first C channels of rows ldx apart (y and residual stay dense [rows, C]); with
  *            running_mean / running_var (fp32 [C]) the moving averages take one update per group in group order, running_var from the unbiased
  *            estimate: r = f * s_g + (1 - f) * r, f = momentum, or 1 / (updates so far) when momentum < 0 (nn.BatchNorm2d(momentum=None));
+ *            rstd == NULL: rsqrt(var + eps) in the kernel (inference from running_mean / running_var without a host-side rsqrt);
  *   _bwd_ex  vm_batchnorm_nhwc_bwd with x rows ldx apart, dx rows lddx apart and, with accumulate != 0, dx += (the block's gradient buffer). */
 int vm_batchnorm_nhwc_stats(const void* x, int64_t ldx, void* copy_dst /* or NULL */, int64_t ld_copy, float* mean, float* rstd, float* var, int ldm,
                             int64_t* num_batches_tracked /* or NULL */, int G, int rows_per_group, int C, float eps, int dtype, void* ws,
                             size_t ws_bytes, void* stream);
 int vm_batchnorm_nhwc_apply(const void* x, int64_t ldx, const void* residual, void* y, const float* gamma, const float* beta, const float* mean,
                             const float* rstd, const float* var, int ldm, float* running_mean /* or NULL */, float* running_var,
-                            const int64_t* num_batches_tracked, float momentum, int G, int rows_per_group, int C, int dtype, int relu, void* stream);
+                            const int64_t* num_batches_tracked, float momentum, float eps, int G, int rows_per_group, int C, int dtype, int relu,
+                            void* stream);
 int vm_batchnorm_nhwc_bwd_ex(const void* dy, const void* x, int64_t ldx, const void* residual, const float* gamma, const float* beta, const float* mean,
                              const float* rstd, int ldm, void* dx, int64_t lddx, int accumulate, void* dres, float* dgamma, float* dbeta, int G,
                              int rows_per_group, int C, int dtype, int relu, int training, void* ws, size_t ws_bytes, void* stream);

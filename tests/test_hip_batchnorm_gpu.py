@@ -240,4 +240,14 @@ def test_dense_block_on_one_feature_buffer_vs_concatenation(dtype, g, training, 
             assert torch.equal(s1, s2), n1
         else:
             assert torch.allclose(s1, s2, atol=1e-5 if dtype == torch.float32 else 2e-3, rtol=1e-4), n1
+    if not training:            # inference without a graph: rsqrt(running_var + eps) is taken inside the kernel
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+            yn = a(x)
+            xs = x[:, :64].contiguous(memory_format=torch.channels_last)
+            bn0 = a.denselayer1.norm1
+            y1, y2 = bn0(xs, relu=True), None
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+            y2 = bn0(xs.clone().requires_grad_(True), relu=True)
+        assert rel(yn, ya) <= (1e-6 if dtype == torch.float32 else 1e-2), rel(yn, ya)
+        assert rel(y1, y2) <= (1e-6 if dtype == torch.float32 else 1e-2), rel(y1, y2)
     print(f"[parity] dense block buffer vs cat ({dtype}, g={g}, training={training}): out {rel(ya, yb):.2e} dx {rel(xa.grad, xb.grad):.2e} params {worst:.2e}")

@@ -81,7 +81,7 @@ SIGNATURES = {
     "vm_batchnorm_nhwc_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _I, _I, _P, _SZ, _P]),
     "vm_batchnorm_nhwc_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "vm_batchnorm_nhwc_stats": (_I, [_P, _L, _P, _L, _P, _P, _P, _I, _P, _I, _I, _I, _F, _I, _P, _SZ, _P]),
-    "vm_batchnorm_nhwc_apply": (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
+    "vm_batchnorm_nhwc_apply": (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _F, _F, _I, _I, _I, _I, _I, _P]),
     "vm_batchnorm_nhwc_bwd_ex": (_I, [_P, _P, _L, _P, _P, _P, _P, _P, _I, _P, _L, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "vm_embedding_fwd_ex": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "vm_embedding_bwd_ex": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

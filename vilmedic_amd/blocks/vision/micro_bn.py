@@ -53,16 +53,42 @@ def _workspace(nbytes, device):
     return w
 
 
+def _plain_running(bn):
+    rm, rv = bn.running_mean, bn.running_var
+    return rm is not None and rm.dtype == rv.dtype == torch.float32 and rm.is_cuda and rm.is_contiguous() and rv.is_contiguous()
+
+
+def _grad_target(p):
+    """the fp32 accumulation buffer a kernel may add this parameter's gradient onto directly: its ParamArena gradient view while that IS ``p.grad``
+    (arena.py; what autograd's AccumulateGrad would add into with one more launch per parameter) -- else None: the gradient is returned to autograd"""
+    if p is None:
+        return None
+    g, v = p.grad, getattr(p, "_vm_grad_view", None)
+    if v is None or g is None or g.data_ptr() != v.data_ptr() or g.dtype != torch.float32 or not g.is_contiguous() or not g.is_cuda:
+        return None
+    return g
+
+
+def _affine_grads(gamma, beta, C, device):
+    """-> (dgamma buffer, dbeta buffer, what backward returns for the two): the arena views (returns None, None) or fresh zeroed vectors"""
+    tg, tb = _grad_target(gamma), _grad_target(beta)
+    if gamma is not None and beta is not None and tg is not None and tb is not None:
+        return tg, tb, None, None
+    dgamma = torch.zeros(C, dtype=torch.float32, device=device) if gamma is not None else None
+    dbeta = torch.zeros(C, dtype=torch.float32, device=device) if beta is not None else None
+    return dgamma, dbeta, dgamma, dbeta
+
+
 class _BatchNormNhwcFn(ops.Fn):
     """one vm_batchnorm_nhwc_fwd / _bwd pair over ``G`` groups of ``x.shape[0] // G`` images (channels-last x, residual, y)"""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, mean, rstd, G, relu, training, eps, running=None):
+    def forward(ctx, x, residual, gamma, beta, mean, rstd, G, relu, training, eps, running=None, eval_var=None):
         N, C, H, W = x.shape
         R = (N // G) * H * W
         y = torch.empty_like(x)
         dt = VM_BF16 if x.dtype == torch.bfloat16 else VM_F32
-        var = None
+        var = eval_var                          # inference without a graph: rstd is None, the kernel takes rsqrt(running_var + eps) itself
         rm = rv = nbt = None
         mom = 0.0
         if training:
@@ -75,7 +101,7 @@ class _BatchNormNhwcFn(ops.Fn):
             check(lib().vm_batchnorm_nhwc_stats(ptr(x), C, None, 0, ptr(mean), ptr(rstd), ptr(var), C, ptr(nbt), G, R, C, eps, dt, ptr(ws), ws.numel(),
                                                 stream()), "vm_batchnorm_nhwc_stats")
         check(lib().vm_batchnorm_nhwc_apply(ptr(x), C, ptr(residual), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(var), C, ptr(rm), ptr(rv),
-                                            ptr(nbt), mom, G, R, C, dt, int(relu), stream()), "vm_batchnorm_nhwc_apply")
+                                            ptr(nbt), mom, eps, G, R, C, dt, int(relu), stream()), "vm_batchnorm_nhwc_apply")
         ctx.save_for_backward(x, residual, gamma, beta, mean, rstd)
         ctx.meta = (G, R, C, dt, relu, training)
         if training:
@@ -93,12 +119,11 @@ class _BatchNormNhwcFn(ops.Fn):
         dx = torch.empty_like(x)
         want_res = residual is not None and ctx.needs_input_grad[1]
         dres = torch.empty_like(x) if want_res else None
-        dgamma = torch.zeros(C, dtype=torch.float32, device=x.device) if gamma is not None else None
-        dbeta = torch.zeros(C, dtype=torch.float32, device=x.device) if beta is not None else None
+        dgamma, dbeta, ret_g, ret_b = _affine_grads(gamma, beta, C, x.device)
         ws = _workspace(lib().vm_batchnorm_nhwc_ws(G, R, C), x.device)
         check(lib().vm_batchnorm_nhwc_bwd(ptr(dy), ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(dx), ptr(dres), ptr(dgamma),
                                           ptr(dbeta), G, R, C, dt, int(relu), int(training), ptr(ws), ws.numel(), stream()), "vm_batchnorm_nhwc_bwd")
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dres, ret_g, ret_b, None, None, None, None, None, None, None, None
 
 
 def _nhwc_ok(x, C):
@@ -132,6 +157,8 @@ class MicroBatchNorm2d(nn.BatchNorm2d):
         B = x.shape[0]
         use_batch_stats = self.training or not self.track_running_stats
         if not use_batch_stats:
+            if _plain_running(self) and not torch.is_grad_enabled():
+                return _BatchNormNhwcFn.apply(x, residual, self.weight, self.bias, self.running_mean, None, 1, relu, False, self.eps, None, self.running_var)[0]
             mean = self.running_mean.float().view(1, -1).contiguous()
             rstd = torch.rsqrt(self.running_var.float() + self.eps).view(1, -1).contiguous()
             return _BatchNormNhwcFn.apply(x, residual, self.weight, self.bias, mean, rstd, 1, relu, False, self.eps)[0]
@@ -231,14 +258,18 @@ class _DenseNormFn(ops.Fn):
                   "vm_batchnorm_nhwc_stats")
             mean, rstd, ldm, G, R = st.mean, st.rstd, st.Ctot, st.G, st.R
             check(lib().vm_batchnorm_nhwc_apply(ptr(buf), st.Ctot, None, ptr(h), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(st.var), ldm, ptr(rm), ptr(rv),
-                                                ptr(nbt), mom, G, R, hi, st.dt, 1, stream()), "vm_batchnorm_nhwc_apply")
+                                                ptr(nbt), mom, st.eps, G, R, hi, st.dt, 1, stream()), "vm_batchnorm_nhwc_apply")
         else:
             buf[:, lo:hi].copy_(new)
-            mean = bn.running_mean.float().view(1, -1).contiguous()
-            rstd = torch.rsqrt(bn.running_var.float() + bn.eps).view(1, -1).contiguous()
+            if _plain_running(bn) and not any(ctx.needs_input_grad[:3]):
+                mean, rstd, var = bn.running_mean, None, bn.running_var        # rsqrt(running_var + eps) in the kernel
+            else:
+                mean = bn.running_mean.float().view(1, -1).contiguous()
+                rstd = torch.rsqrt(bn.running_var.float() + bn.eps).view(1, -1).contiguous()
+                var = None
             ldm, G, R = hi, 1, st.G * st.R
-            check(lib().vm_batchnorm_nhwc_apply(ptr(buf), st.Ctot, None, ptr(h), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), None, ldm, None, None, None, 0.0,
-                                                G, R, hi, st.dt, 1, stream()), "vm_batchnorm_nhwc_apply")
+            check(lib().vm_batchnorm_nhwc_apply(ptr(buf), st.Ctot, None, ptr(h), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(var), ldm, None, None, None, 0.0,
+                                                bn.eps, G, R, hi, st.dt, 1, stream()), "vm_batchnorm_nhwc_apply")
         ctx.st, ctx.stat, ctx.meta = st, (mean, rstd, gamma, beta), (ldm, G, R, lo, hi, training)
         return h
 
@@ -253,15 +284,14 @@ class _DenseNormFn(ops.Fn):
         dh = dh.contiguous(memory_format=torch.channels_last)
         if dh.dtype != grad.dtype:
             dh = dh.to(grad.dtype)
-        dgamma = torch.zeros(hi, dtype=torch.float32, device=grad.device)
-        dbeta = torch.zeros(hi, dtype=torch.float32, device=grad.device)
+        dgamma, dbeta, ret_g, ret_b = _affine_grads(gamma, beta, hi, grad.device)
         ws = _workspace(lib().vm_batchnorm_nhwc_ws(G, R, hi), grad.device)
         check(lib().vm_batchnorm_nhwc_bwd_ex(ptr(dh), ptr(st.buf), st.Ctot, None, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ldm, ptr(grad), st.Ctot, 1, None,
                                              ptr(dgamma), ptr(dbeta), G, R, hi, st.dt, 1, int(training), ptr(ws), ws.numel(), stream()), "vm_batchnorm_nhwc_bwd")
         dnew = grad[:, lo:hi].contiguous(memory_format=torch.channels_last) if ctx.needs_input_grad[0] else None
         if lo == 0:
             st.grad = None                      # the first layer's backward is the block's last
-        return dnew, dgamma, dbeta, None, None, None, None
+        return dnew, ret_g, ret_b, None, None, None, None
 
 
 class _DenseCloseFn(ops.Fn):

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd, const BnGeom g, int relu,
                                                        const float* __restrict__ var, float* __restrict__ rmean, float* __restrict__ rvar,
-                                                       const int64_t* __restrict__ nbt, float momentum) {
+                                                       const int64_t* __restrict__ nbt, float momentum, float eps) {
     const int gi = blockIdx.x / g.S, si = blockIdx.x % g.S;
     int r0, r1;
     split_range(g, si, r0, r1);
@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     for (int j = 0; j < 8; ++j) {
         const int c = c8 * 8 + j;
         const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-        sc[j] = rstd[gi * g.ldm + c] * ga;
+        const float rs = rstd ? rstd[gi * g.ldm + c] : rsqrtf(var[gi * g.ldm + c] + eps);      // (inference: mean / var are the running statistics)
+        sc[j] = rs * ga;
         sh[j] = be - mean[gi * g.ldm + c] * sc[j];
     }
     const int64_t off = ((int64_t)gi * g.R) * g.C + c8 * 8;
@@ -435,12 +436,13 @@ extern "C" int vm_batchnorm_nhwc_stats(const void* x, int64_t ldx, void* copy_ds
 }
 
 // y = relu?((x - mean) * rstd * gamma + beta + residual?) over the first C channels of rows ldx apart; with running_mean / running_var the exponential
-// (momentum >= 0) or cumulative (momentum < 0, needs num_batches_tracked as left by vm_batchnorm_nhwc_stats) moving averages take one update per group
+// (momentum >= 0) or cumulative (momentum < 0, needs num_batches_tracked as left by vm_batchnorm_nhwc_stats) moving averages take one update per group;
+// rstd == NULL: rsqrt(var + eps) is taken in the kernel (inference straight from running_mean / running_var)
 extern "C" int vm_batchnorm_nhwc_apply(const void* x, int64_t ldx, const void* residual, void* y, const float* gamma, const float* beta,
                                        const float* mean, const float* rstd, const float* var, int ldm, float* running_mean, float* running_var,
-                                       const int64_t* num_batches_tracked, float momentum, int G, int rows_per_group, int C, int dtype, int relu,
-                                       void* stream) {
-    VM_REQUIRE(x && y && mean && rstd && G > 0 && rows_per_group > 0 && C > 0 && (C % 8) == 0 && C <= 2048 && (dtype == VM_BF16 || dtype == VM_F32) &&
+                                       const int64_t* num_batches_tracked, float momentum, float eps, int G, int rows_per_group, int C, int dtype,
+                                       int relu, void* stream) {
+    VM_REQUIRE(x && y && mean && (rstd || var) && G > 0 && rows_per_group > 0 && C > 0 && (C % 8) == 0 && C <= 2048 && (dtype == VM_BF16 || dtype == VM_F32) &&
                ldx >= C && (ldx % 8) == 0 && ldm >= C, "vm_batchnorm_nhwc_apply: bad arguments (C %% 8 == 0, C <= 2048, strides >= C)");
     VM_REQUIRE(!running_mean || (running_var && var && (momentum >= 0.f || num_batches_tracked)),
                "vm_batchnorm_nhwc_apply: the running update needs running_var, var and (cumulative average) num_batches_tracked");
@@ -451,10 +453,10 @@ extern "C" int vm_batchnorm_nhwc_apply(const void* x, int64_t ldx, const void* r
     VmProfScope prof(VM_FAM_LN, (residual ? 3.0 : 2.0) * bytes, s);
     if (dtype == VM_BF16)
         hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(G * g.S), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, gamma, beta, mean, rstd, g, relu,
-                           var, running_mean, running_var, num_batches_tracked, momentum);
+                           var, running_mean, running_var, num_batches_tracked, momentum, eps);
     else
         hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(G * g.S), dim3(256), 0, s, (const float*)x, (const float*)residual, (float*)y, gamma, beta, mean, rstd, g, relu,
-                           var, running_mean, running_var, num_batches_tracked, momentum);
+                           var, running_mean, running_var, num_batches_tracked, momentum, eps);
     return vm_check_launch("vm_batchnorm_nhwc_apply");
 }
 
@@ -468,7 +470,7 @@ extern "C" int vm_batchnorm_nhwc_fwd(const void* x, const void* residual, void* 
         const int rc = vm_batchnorm_nhwc_stats(x, C, nullptr, 0, mean, rstd, var, C, nullptr, G, rows_per_group, C, eps, dtype, ws, ws_bytes, stream);
         if (rc != VM_OK) return rc;
     }
-    return vm_batchnorm_nhwc_apply(x, C, residual, y, gamma, beta, mean, rstd, var, C, nullptr, nullptr, nullptr, 0.f, G, rows_per_group, C, dtype, relu, stream);
+    return vm_batchnorm_nhwc_apply(x, C, residual, y, gamma, beta, mean, rstd, var, C, nullptr, nullptr, nullptr, 0.f, eps, G, rows_per_group, C, dtype, relu, stream);
 }
 
 // x: first C channels of rows ldx apart; dx: rows lddx apart, `accumulate` adds into it (the gradient buffer of a DenseNet block: every layer's
