@@ -135,7 +135,10 @@ class DecodeState:
         # BERT / RoBERTa decoders (blocks/huggingface/bert_models.py): the token-type row rides in a derived position table, and HF's
         # generate() numbers the positions 0, 1, 2, ... for them too -- it builds ``position_ids`` from the attention mask because their
         # forward accepts that argument (hf:generation/utils.py _prepare_position_ids_for_generation), which overrides RoBERTa's
-        # pad-offset numbering of the training forward.  Reproduced as is: the reference decodes through that call.
+        # pad-offset numbering of the training forward.  Reproduced as is: the reference decodes through that call.  Verified against
+        # RobertaForCausalLM.generate / BertLMHeadModel.generate of the installed transformers (5.15): fixture G23, greedy and beam-4 token ids
+        # bit-equal (tests/test_oracle_golden.py::test_g23_proto_decoder_loss_grads_and_decode_ids and its GPU twin); the pinned 4.55.3 is not
+        # installable here (no network), so a 4.55.3 build whose RoBERTa generate() kept the pad-offset numbering would decode differently.
         self.pos_table = None
         if hasattr(decoder.bert.embeddings, "token_type_embeddings"):
             self.pos_table = torch.empty_like(decoder.bert.embeddings.position_embeddings.weight)
