@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 tag=$1; task=$2; shift 2
 out=/tmp/prof_${tag}_${task}
 rm -rf $out; mkdir -p $out $R/gpurun_out
-(cd $R && env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d $out -o p -- python tools/bench_secondary.py --only $task --steps 6 --warmup 3 > $R/gpurun_out/${tag}_${task}.log 2>&1)
+(cd $R && env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d $out -o p -- python tools/bench_secondary.py --only $task --steps 6 --warmup 3 ${BENCH_ARGS:-} > $R/gpurun_out/${tag}_${task}.log 2>&1)
 f=$(find $out -name "*kernel_stats.csv" | head -1)
 if [ -n "$f" ]; then cp "$f" $R/gpurun_out/${tag}_kernel_stats_${task}.csv; else echo "no kernel_stats.csv under $out" >&2; find $out | head >&2; fi
 t=$(find $out -name "*kernel_trace.csv" | head -1)

@@ -10,6 +10,7 @@
 //
 // Layout: x is [G * R, C] row-major (R = images per group * H * W rows of C channels), C % 8 == 0, C <= 2048.  A block of 256 threads
 // owns a contiguous row range of ONE group; thread t handles the 8 channels c8 = t % (C / 8) of rows rsub = t / (C / 8) (+ k * RPI).
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -29,6 +30,23 @@ template <> struct Ld8<float> {
         *reinterpret_cast<float4*>(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
     }
 };
+
+// 8 consecutive channels of one row AS LOADED (16 B of bf16 / 32 B of fp32): the streaming loops request U rows before they unpack the first, so a
+// bf16 thread keeps as many bytes in flight as an fp32 one without holding U x 8 floats (round 6: bf16 passes 3.7 -> see profiles/r06_g_bn_bench.txt)
+template <typename T> struct Row8;
+template <> struct Row8<bf16_t> {
+    uint4 v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void unpack(float* f) const { unpack8(v, f); }
+    __device__ __forceinline__ void store(bf16_t* p) const { *reinterpret_cast<uint4*>(p) = v; }
+};
+template <> struct Row8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+    __device__ __forceinline__ void unpack(float* f) const { f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w; }
+    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = a; *reinterpret_cast<float4*>(p + 4) = b; }
+};
+template <typename T> constexpr int bn_rows_in_flight() { return sizeof(T) == 2 ? 4 : 2; }
 
 struct BnGeom {
     int G, R, C, CH8, RPI, S, rows_per_split;
@@ -68,19 +86,23 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
             n = 1.f;
             r += g.RPI;
         }
-        for (; r + 3 * g.RPI < r1; r += 4 * g.RPI) {            // four rows in flight
-            float a[4][8];
+        constexpr int U = 2 * bn_rows_in_flight<T>();           // eight (bf16) / four (fp32) rows in flight
+        for (; r + (U - 1) * g.RPI < r1; r += U * g.RPI) {
+            Row8<T> a[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) Ld8<T>::load(base + (int64_t)(r + u * g.RPI) * g.ldx, a[u]);
+            for (int u = 0; u < U; ++u) a[u].load(base + (int64_t)(r + u * g.RPI) * g.ldx);
             if (cbase) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) Ld8<T>::store(cbase + (int64_t)(r + u * g.RPI) * ldc, a[u]);
+                for (int u = 0; u < U; ++u) a[u].store(cbase + (int64_t)(r + u * g.RPI) * ldc);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < U; ++u) {
+                float f[8];
+                a[u].unpack(f);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const float d = a[u][j] - k[j]; s[j] += d; q[j] += d * d; }
-            n += 4.f;
+                for (int j = 0; j < 8; ++j) { const float d = f[j] - k[j]; s[j] += d; q[j] += d * d; }
+            }
+            n += (float)U;
         }
         for (; r < r1; r += g.RPI) {
             float a[8];
@@ -198,25 +220,31 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     }
     const int64_t off = ((int64_t)gi * g.R) * g.C + c8 * 8;
     const T* xb = x + ((int64_t)gi * g.R) * g.ldx + c8 * 8;
-    for (int r = r0 + rsub; r < r1; r += 2 * g.RPI) {
-        float a[2][8], b[2][8];
-        const bool two = r + g.RPI < r1;
-        Ld8<T>::load(xb + (int64_t)r * g.ldx, a[0]);
-        if (two) Ld8<T>::load(xb + (int64_t)(r + g.RPI) * g.ldx, a[1]);
-        if (res) {
-            Ld8<T>::load(res + off + (int64_t)r * g.C, b[0]);
-            if (two) Ld8<T>::load(res + off + (int64_t)(r + g.RPI) * g.C, b[1]);
+    constexpr int U = bn_rows_in_flight<T>();
+    for (int r = r0 + rsub; r < r1; r += U * g.RPI) {
+        Row8<T> a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ru = r + u * g.RPI;
+            if (ru < r1) {
+                a[u].load(xb + (int64_t)ru * g.ldx);
+                if (res) b[u].load(res + off + (int64_t)ru * g.C);
+            }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (u == 1 && !two) break;
+        for (int u = 0; u < U; ++u) {
+            const int ru = r + u * g.RPI;
+            if (ru >= r1) break;
+            float f[8], rb[8];
+            a[u].unpack(f);
+            if (res) b[u].unpack(rb);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float v = a[u][j] * sc[j] + sh[j];
-                if (res) v += b[u][j];
-                a[u][j] = relu ? fmaxf(v, 0.f) : v;
+                float v = f[j] * sc[j] + sh[j];
+                if (res) v += rb[j];
+                f[j] = relu ? fmaxf(v, 0.f) : v;
             }
-            Ld8<T>::store(y + off + (int64_t)(r + u * g.RPI) * g.C, a[u]);
+            Ld8<T>::store(y + off + (int64_t)ru * g.C, f);
         }
     }
 }
@@ -244,26 +272,31 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__
     if (rsub < g.RPI) {
         const int64_t off = ((int64_t)gi * g.R) * g.C + c8 * 8;
         const T* xb = x + ((int64_t)gi * g.R) * g.ldx + c8 * 8;
-        for (int r = r0 + rsub; r < r1; r += 2 * g.RPI) {
-            float d[2][8], a[2][8], b[2][8];
-            const bool two = r + g.RPI < r1;
-            Ld8<T>::load(dy + off + (int64_t)r * g.C, d[0]);
-            Ld8<T>::load(xb + (int64_t)r * g.ldx, a[0]);
-            if (two) { Ld8<T>::load(dy + off + (int64_t)(r + g.RPI) * g.C, d[1]); Ld8<T>::load(xb + (int64_t)(r + g.RPI) * g.ldx, a[1]); }
-            if (res && relu) {
-                Ld8<T>::load(res + off + (int64_t)r * g.C, b[0]);
-                if (two) Ld8<T>::load(res + off + (int64_t)(r + g.RPI) * g.C, b[1]);
+        constexpr int U = bn_rows_in_flight<T>();
+        for (int r = r0 + rsub; r < r1; r += U * g.RPI) {
+            Row8<T> d[U], a[U], b[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ru = r + u * g.RPI;
+                if (ru < r1) {
+                    d[u].load(dy + off + (int64_t)ru * g.C);
+                    a[u].load(xb + (int64_t)ru * g.ldx);
+                    if (res && relu) b[u].load(res + off + (int64_t)ru * g.C);
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (u == 1 && !two) break;
+            for (int u = 0; u < U; ++u) {
+                if (r + u * g.RPI >= r1) break;
+                float df[8], af[8], bf[8];
+                d[u].unpack(df); a[u].unpack(af);
+                if (res && relu) b[u].unpack(bf);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float xh = (a[u][j] - mu[j]) * rs[j];
-                    float gdy = d[u][j];
+                    const float xh = (af[j] - mu[j]) * rs[j];
+                    float gdy = df[j];
                     if (relu) {                                  // the forward's own expression (same rounding): y = x * sc + sh (+ res)
-                        float v = a[u][j] * sc[j] + sh[j];
-                        if (res) v += b[u][j];
+                        float v = af[j] * sc[j] + sh[j];
+                        if (res) v += bf[j];
                         if (!(v > 0.f)) gdy = 0.f;
                     }
                     s[j] += gdy; sx[j] += gdy * xh;
@@ -331,52 +364,56 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         }
     }
     if (rsub >= g.RPI) return;
-    float mu[8], rs[8], sc[8], sh[8], m1[8], m2[8];
+    float mu[8], sc[8], sh[8], c1[8], c2[8];                     // dx = sc * dy' - c1 - c2 * (x - mean): c1 = sc * mean(dy'), c2 = sc * rstd * mean(dy' * xhat) * rstd
     const float invn = training ? 1.f / (float)g.R : 0.f;       // eval mode (running statistics are constants): dx = gamma * rstd * dy'
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = c8 * 8 + j;
-        mu[j] = mean[gi * g.ldm + c]; rs[j] = rstd[gi * g.ldm + c];
-        sc[j] = rs[j] * (gamma ? gamma[c] : 1.f);
+        const float rs = rstd[gi * g.ldm + c];
+        mu[j] = mean[gi * g.ldm + c];
+        sc[j] = rs * (gamma ? gamma[c] : 1.f);
         sh[j] = (beta ? beta[c] : 0.f) - mu[j] * sc[j];
-        m1[j] = sdy[gi * g.C + c] * invn; m2[j] = sdyx[gi * g.C + c] * invn;
+        c1[j] = sc[j] * (sdy[gi * g.C + c] * invn);
+        c2[j] = sc[j] * (sdyx[gi * g.C + c] * invn) * rs;
     }
     const int64_t off = ((int64_t)gi * g.R) * g.C + c8 * 8;
     const T* xb = x + ((int64_t)gi * g.R) * g.ldx + c8 * 8;
     T* dxb = dx + ((int64_t)gi * g.R) * g.ldd + c8 * 8;
-    for (int r = r0 + rsub; r < r1; r += 2 * g.RPI) {
-        float d[2][8], a[2][8], b[2][8], e[2][8];
-        const bool two = r + g.RPI < r1;
-        Ld8<T>::load(dy + off + (int64_t)r * g.C, d[0]);
-        Ld8<T>::load(xb + (int64_t)r * g.ldx, a[0]);
-        if (two) { Ld8<T>::load(dy + off + (int64_t)(r + g.RPI) * g.C, d[1]); Ld8<T>::load(xb + (int64_t)(r + g.RPI) * g.ldx, a[1]); }
-        if (g.acc) {                                             // dx already holds the gradient of the buffer's other consumers
-            Ld8<T>::load(dxb + (int64_t)r * g.ldd, e[0]);
-            if (two) Ld8<T>::load(dxb + (int64_t)(r + g.RPI) * g.ldd, e[1]);
-        }
-        if (res && relu) {
-            Ld8<T>::load(res + off + (int64_t)r * g.C, b[0]);
-            if (two) Ld8<T>::load(res + off + (int64_t)(r + g.RPI) * g.C, b[1]);
+    constexpr int U = bn_rows_in_flight<T>();
+    for (int r = r0 + rsub; r < r1; r += U * g.RPI) {
+        Row8<T> d[U], a[U], b[U], e[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ru = r + u * g.RPI;
+            if (ru < r1) {
+                d[u].load(dy + off + (int64_t)ru * g.C);
+                a[u].load(xb + (int64_t)ru * g.ldx);
+                if (g.acc) e[u].load(dxb + (int64_t)ru * g.ldd);      // dx already holds the gradient of the buffer's other consumers
+                if (res && relu) b[u].load(res + off + (int64_t)ru * g.C);
+            }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (u == 1 && !two) break;
-            float o[8];
+        for (int u = 0; u < U; ++u) {
+            const int ru = r + u * g.RPI;
+            if (ru >= r1) break;
+            float df[8], af[8], bf[8], ef[8], o[8];
+            d[u].unpack(df); a[u].unpack(af);
+            if (g.acc) e[u].unpack(ef);
+            if (res && relu) b[u].unpack(bf);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float xh = (a[u][j] - mu[j]) * rs[j];
-                float gdy = d[u][j];
+                float gdy = df[j];
                 if (relu) {
-                    float v = a[u][j] * sc[j] + sh[j];
-                    if (res) v += b[u][j];
+                    float v = af[j] * sc[j] + sh[j];
+                    if (res) v += bf[j];
                     if (!(v > 0.f)) gdy = 0.f;
                 }
-                d[u][j] = gdy;
-                o[j] = sc[j] * (gdy - m1[j] - xh * m2[j]);
-                if (g.acc) o[j] += e[u][j];
+                df[j] = gdy;
+                o[j] = sc[j] * gdy - c1[j] - c2[j] * (af[j] - mu[j]);
+                if (g.acc) o[j] += ef[j];
             }
-            Ld8<T>::store(dxb + (int64_t)(r + u * g.RPI) * g.ldd, o);
-            if (dres) Ld8<T>::store(dres + off + (int64_t)(r + u * g.RPI) * g.C, d[u]);
+            Ld8<T>::store(dxb + (int64_t)ru * g.ldd, o);
+            if (dres) Ld8<T>::store(dres + off + (int64_t)ru * g.C, df);
         }
     }
 }
@@ -390,9 +427,12 @@ BnGeom geometry(int G, int R, int C) {
     g.ldx = C; g.ldd = C; g.ldm = C; g.acc = 0;
     g.CH8 = C / 8;
     g.RPI = 256 / g.CH8;
-    // splits per group: fill the chip (~4096 blocks in all: 16 resident blocks per CU hide the HBM latency of a streaming pass) while
-    // every split keeps >= 4 row sweeps of the block
-    int S = (4096 + G - 1) / G;
+    // splits per group.  Round 6 (tools/bn_bench.py, profiles/r06_g_bn_bench.txt): ~512 blocks in all (two per CU, each streaming many rows) instead of
+    // ~4096 -- the large layers are indifferent (+-3 %), the 14 x 14 and 7 x 7 layers that make up 128 of DenseNet-169's 169 BatchNorms gain 15-40 %
+    // (a block's start-up -- its per-channel constants, the reduction tail, the partials the finalize kernel has to merge -- was most of their time);
+    // every split keeps >= 4 row sweeps of the block.  VM_BN_BLOCKS overrides (diagnostic).
+    static const int blocks = [] { const char* e = getenv("VM_BN_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+    int S = (blocks + G - 1) / G;
     const int max_s = (R + 4 * g.RPI - 1) / (4 * g.RPI);
     if (S > max_s) S = max_s;
     if (S < 1) S = 1;
