@@ -525,3 +525,27 @@ def test_deit_parameter_names():
     names = set(m.state_dict())
     assert {"model.encoder." + k for k in R.deit_shapes(R.DEIT_TINY)} <= names
     assert "model.encoder.pooler.dense.weight" in names and "model.encoder.embeddings.distillation_token" in names
+
+
+def test_dense_block_takes_the_concatenation_path_off_the_gpu_and_equals_torchvision_form():
+    """blocks/vision/cnn._DenseBlock: the single-feature-buffer path (micro_bn.dense_block_forward) is for channels-last DEVICE tensors only -- a CPU tensor,
+    an NCHW tensor, or a block whose norm1 is not a MicroBatchNorm2d runs the running torch.cat form, which equals torchvision's cat(list-of-features) form;
+    the eligibility test itself never touches the library"""
+    import torch.nn as nn
+    from vilmedic_amd.blocks.vision import cnn, micro_bn
+    torch.manual_seed(0)
+    blk = cnn._DenseBlock(3, 16, 2, 8)
+    x = torch.randn(2, 16, 5, 5)
+    layers = list(blk.values())
+    assert not micro_bn.dense_block_ok(layers, x)                                            # stock BatchNorm2d, CPU
+    micro_bn.use_micro_batch_norm(blk)
+    assert not micro_bn.dense_block_ok(layers, x)                                            # CPU tensor
+    assert not micro_bn.dense_block_ok(layers, x.contiguous(memory_format=torch.channels_last))
+    assert micro_bn._grad_target(layers[0].norm1.weight) is None and micro_bn._grad_target(None) is None
+    assert layers[0].norm1._running_args(x.device) is None or layers[0].norm1.running_mean.device.type == "cpu"
+    blk.eval()
+    feats = [x]
+    for layer in layers:                                                                     # torchvision: every layer reads cat(all earlier features)
+        feats.append(layer(torch.cat(feats, 1)))
+    assert torch.allclose(blk(x), torch.cat(feats, 1), atol=1e-6)
+    assert isinstance(layers[0].relu1, nn.ReLU)
