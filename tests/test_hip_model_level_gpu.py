@@ -332,3 +332,31 @@ def test_rrg_scst_graphed_step_equals_the_eager_step():
     assert modes[:2] == ["eager (graph warm-up)"] * 2 and modes[2:] == ["hip-graph replay"] * 3
     assert all(abs(x) > 1e-4 for x in l1), "fixture: the reward difference must not vanish"
     assert err <= 2e-3 and perr <= 2e-3
+
+
+def test_hfpoolformer_visual_encoder_on_the_gpu_vs_the_cpu_module():
+    """``VisualEncoder(backbone='hfpoolformer')`` (ref:vilmedic/blocks/vision/visual_encoder.py:67-69,192-208): the tower on the GPU (MIOpen convolutions,
+    channels-last input) against the SAME modules on the CPU -- which tests/test_host_cpu.py pins against transformers' PoolFormerModel --: the
+    ``batch_first`` features, the input gradient, and ``encode`` (bf16 features + the all-zero-feature mask of visual_encoder.py:138-140)"""
+    import copy
+    from vilmedic_amd.blocks.vision import VisualEncoder
+    torch.manual_seed(11)
+    kw = dict(depths=[1, 2, 1, 1], hidden_sizes=[16, 32, 48, 64], mlp_ratio=2.0, layer_scale_init_value=0.5, initializer_range=0.2)
+    enc = VisualEncoder(backbone="hfpoolformer", permute="batch_first", dropout_out=0.0, **kw)
+    cpu = copy.deepcopy(enc.model).eval()
+    enc = enc.to(dev()).eval()
+    x = torch.randn(3, 3, 96, 96)
+    a, b = x.clone().requires_grad_(True), x.to(dev()).requires_grad_(True)
+    fm = cpu(a)
+    want = fm.view(*fm.shape[:2], -1).permute(0, 2, 1)
+    got = enc(b)
+    assert got.shape == want.shape == (3, 9, 64)
+    e = _rel(got.float().cpu(), want)
+    want.square().mean().backward(); got.float().square().mean().backward()
+    eg = _rel(b.grad.cpu(), a.grad)
+    print(f"[parity] hfpoolformer tower GPU vs CPU: features rel {e:.2e}, input gradient rel {eg:.2e}")
+    assert e <= 2e-3 and eg <= 5e-3, (e, eg)
+    with torch.no_grad():
+        feats, mask = enc.encode(x)
+    assert feats.dtype == BF and feats.shape == (3, 9, 64) and mask.shape == (3, 9) and bool(mask.all())
+    assert _rel(feats.float().cpu(), want.detach()) <= 1e-2

@@ -24,8 +24,11 @@ def get_network(backbone, output_layer, pretrained, **kwargs):
     if "deit" in backbone.lower():                # visual_encoder.py:59-61: DeiTModel(DeiTConfig(**kwargs), add_pooling_layer=False)
         kwargs = {k: v for k, v in kwargs.items() if k not in ("attn_implementation", "return_dict")}
         return ViTModel(make_config(VIT_DEFAULTS, kwargs), distillation=True)
-    if "hfpoolformer" in backbone.lower() or "3d" in backbone.lower():
-        raise NotImplementedError(f"backbone {backbone!r} is outside the MI355X hot path (SURVEY §8a)")
+    if "hfpoolformer" in backbone.lower():        # visual_encoder.py:67-69: HFPoolFormerModel(PoolFormerConfig(**kwargs))
+        from .poolformer import HFPoolFormerModel
+        return HFPoolFormerModel(**kwargs)
+    if "3d" in backbone.lower():                  # MONAI's 3-D DenseNets (visual_encoder.py:8-13): MONAI is not installed here, nothing to pin an implementation on
+        raise NotImplementedError(f"backbone {backbone!r} (MONAI 3-D DenseNet) is outside the MI355X hot path (SURVEY §8a)")
     return _cnn.build(backbone, output_layer, pretrained, **kwargs)
 
 
