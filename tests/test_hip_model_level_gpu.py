@@ -360,3 +360,32 @@ def test_hfpoolformer_visual_encoder_on_the_gpu_vs_the_cpu_module():
         feats, mask = enc.encode(x)
     assert feats.dtype == BF and feats.shape == (3, 9, 64) and mask.shape == (3, 9) and bool(mask.all())
     assert _rel(feats.float().cpu(), want.detach()) <= 1e-2
+
+
+def test_3d_densenet_visual_encoder_volume_and_per_slice_encoding():
+    """``VisualEncoder(backbone='_3d_densenet121', ...)`` (ref:vilmedic/blocks/vision/visual_encoder.py:71,144-157): a 5-D volume through the restated
+    N-d DenseNet (Conv3d / BatchNorm3d on MIOpen) against the same modules on the CPU; ``encode`` of the full volume (features cut, batch_first) and of
+    slices (``slice_encode``, the ``class_layers`` vector per slice stacked along dim 1) with the all-zero-feature mask"""
+    import copy
+    from vilmedic_amd.blocks.vision import VisualEncoder
+    torch.manual_seed(4)
+    kw = dict(spatial_dims=3, in_channels=1, out_channels=16, block_config=(2, 2), init_features=8, growth_rate=4)
+    enc = VisualEncoder(backbone="_3d_densenet121", permute="batch_first", dropout_out=0.0, output_layer="features", **kw)
+    cpu = copy.deepcopy(enc.model).eval()
+    enc = enc.to(dev()).eval()
+    vol = torch.randn(2, 1, 32, 32, 32)
+    fm = cpu(vol)
+    want = fm.view(*fm.shape[:2], -1).permute(0, 2, 1)
+    with torch.no_grad():
+        feats, mask = enc.encode(vol)
+    assert feats.shape == want.shape == (2, 64, 16) and mask.shape == (2, 64)
+    e = _rel(feats.float().cpu(), want.detach())
+    print(f"[parity] 3-D DenseNet tower GPU vs CPU (bf16 features): rel {e:.2e}")
+    assert e <= 1e-2, e
+    sl = VisualEncoder(backbone="_3d_densenet121", permute="batch_first", dropout_out=0.0, output_layer="class_layers", slice_encode=True, slice_dim=2,
+                       **dict(kw, spatial_dims=2)).to(dev()).eval()
+    with torch.no_grad():
+        f2, m2 = sl.encode(vol[:, :, :5])
+    assert f2.shape == (2, 5, 16) and m2.shape == (2, 5)
+    with pytest.raises(Exception, match="slice_dim"):
+        VisualEncoder(backbone="_3d_densenet121", permute="batch_first", output_layer="class_layers", slice_encode=True, **kw)

@@ -577,3 +577,28 @@ def test_hfpoolformer_backbone_matches_transformers_poolformer(extra):
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
     got.square().mean().backward(); want.square().mean().backward()
     torch.testing.assert_close(a.grad, b.grad, rtol=1e-4, atol=1e-7)
+
+
+def test_nd_densenet_equals_the_torchvision_named_densenet_in_two_dimensions_and_runs_volumes():
+    """``backbone: _3d_densenet121`` (ref:vilmedic/blocks/vision/visual_encoder.py:8-13,71: MONAI's N-d DenseNet; MONAI is not installed, parity with it is
+    UNPINNED): with spatial_dims=2 the restated network computes what the torchvision-named DenseNet-121 of blocks/vision/cnn.py computes (same weights under
+    the key mapping ``denselayerK.layers.X`` <-> ``denselayerK.X``, ``class_layers.out`` <-> ``classifier``); in 3-D the ``features`` cut returns a volume
+    feature map and the constructor checks of the reference hold"""
+    from vilmedic_amd.blocks.vision import cnn, densenet3d
+    torch.manual_seed(2)
+    nd = densenet3d.build("_3d_densenet121", None, False, spatial_dims=2, in_channels=3, out_channels=10).eval()
+    tv = cnn._FACTORY["densenet121"]()
+    tv.classifier = torch.nn.Linear(tv.classifier.in_features, 10)
+    tv.eval()
+    sd = {k.replace(".layers.", ".").replace("class_layers.out.", "classifier."): v for k, v in nd.state_dict().items()}
+    assert set(sd) == set(tv.state_dict())
+    tv.load_state_dict(sd, strict=True)
+    x = torch.randn(2, 3, 64, 64)
+    torch.testing.assert_close(nd(x), tv(x), rtol=1e-5, atol=1e-6)
+    vol = densenet3d.build("_3d_densenet121", "features", False, spatial_dims=3, in_channels=1, out_channels=2, block_config=(2, 2), init_features=8, growth_rate=4)
+    out = vol.eval()(torch.randn(1, 1, 32, 32, 32))
+    assert out.shape == (1, 16, 4, 4, 4), out.shape        # 8 -> 16 -> (transition) 8 -> 16 channels; 32 / 2 / 2 / 2 voxels
+    names = list(densenet3d.DenseNetND(3, 1, 2, block_config=(1, 1), init_features=8, growth_rate=4).state_dict())
+    assert "features.denseblock1.denselayer1.layers.conv2.weight" in names and "features.transition1.conv.weight" in names and "class_layers.out.bias" in names
+    with pytest.raises(ValueError):
+        densenet3d.build("_3d_densenet999", None, False, spatial_dims=3, in_channels=1, out_channels=2)

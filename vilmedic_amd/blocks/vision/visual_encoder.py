@@ -27,8 +27,9 @@ def get_network(backbone, output_layer, pretrained, **kwargs):
     if "hfpoolformer" in backbone.lower():        # visual_encoder.py:67-69: HFPoolFormerModel(PoolFormerConfig(**kwargs))
         from .poolformer import HFPoolFormerModel
         return HFPoolFormerModel(**kwargs)
-    if "3d" in backbone.lower():                  # MONAI's 3-D DenseNets (visual_encoder.py:8-13): MONAI is not installed here, nothing to pin an implementation on
-        raise NotImplementedError(f"backbone {backbone!r} (MONAI 3-D DenseNet) is outside the MI355X hot path (SURVEY §8a)")
+    if "3d" in backbone.lower():                  # MONAI's N-d DenseNets (visual_encoder.py:8-13,71): restated, parity unpinned (blocks/vision/densenet3d.py)
+        from .densenet3d import build as _build3d
+        return _build3d(backbone, output_layer, pretrained, **kwargs)
     return _cnn.build(backbone, output_layer, pretrained, **kwargs)
 
 
@@ -52,6 +53,10 @@ class VisualEncoder(nn.Module):
         self.is3D = "3d" in backbone
         self.slice_encode = slice_encode
         self.slice_dim = slice_dim
+        if self.slice_encode and self.output_layer == "features":
+            raise Exception("If encoding per slices, output of forward pass should be a vector. Try avgpool or features as output_layer parameter.")
+        if self.slice_encode and self.slice_dim is None:
+            raise Exception("slice_encode is True but slice_dim is None, please specify slice_dim")
         if visual_projection:
             vp = dict(visual_projection)
             self.visual_projection = Affine(vp["out_features"], vp["in_features"], std=(1.0 / vp["in_features"]) ** 0.5)
@@ -70,8 +75,12 @@ class VisualEncoder(nn.Module):
             features = self(images)
             return self._mask_and_project(features)
         assert images.dim() == 5, "wrong images shape"
-        if self.is3D:
-            raise NotImplementedError("3-D backbones are outside the MI355X hot path")
+        if self.is3D:                              # visual_encoder.py:144-157: per-slice encoding (stacked vectors) or the full volume
+            if self.slice_encode:
+                features = torch.stack([self(images.narrow(self.slice_dim, i, 1).squeeze(self.slice_dim)) for i in range(images.size(self.slice_dim))], dim=1)
+            else:
+                features = self(images)
+            return self._mask_and_project(features)
         B, N = images.shape[:2]
         features = self(images.reshape(B * N, *images.shape[2:]))
         if features.dim() <= 2:
