@@ -36,6 +36,11 @@ def main():
     if len(sys.argv) < 2:
         raise SystemExit(__doc__)
     config, seed = prepare(get_config(sys.argv[1], sys.argv[2:]))
+    # ref:bin/utils.py:158 (get_seed, called by the reference's bin/train.py): cudnn.benchmark on -- on ROCm MIOpen's search over its convolution solvers
+    # per shape.  The first steps of a CNN-tower run pay for it (minutes on a box without MIOpen's kernel cache); the steady step gains 8-27 %
+    # (profiles/r06_h_cudnn_benchmark.txt: MVQA 122.2 -> 113.0 ms fp32, 73.5 -> 64.7 ms bf16 towers).  VM_CUDNN_BENCHMARK=0 keeps the immediate-mode choice.
+    import torch
+    torch.backends.cudnn.benchmark = os.environ.get("VM_CUDNN_BENCHMARK", "1") != "0"
     rank0 = int(os.environ.get("RANK", "0")) == 0
     logger = get_logger(path=os.path.join(config["ckpt_dir"], "{}.log".format(seed)) if rank0 else None)
     if rank0:

@@ -138,7 +138,12 @@ def main():
     ap.add_argument("--amp", type=int, default=0, help="1 = trainor.use_amp: the CNN towers run their convolutions in bf16 under autocast (default: fp32, "
                                                        "the reference's default); both modes take channels-last images and the HIP BatchNorm")
     ap.add_argument("--scst-graph", type=int, default=0, help="scst: 1 = the update replayed from one captured HIP graph (RRG_SCST.graphed_step; measured 231 vs 200 ms: an extra encoder pass and the rollout padded to max_length), 0 = eager")
+    ap.add_argument("--cudnn-benchmark", type=int, default=-1, help="1 / 0: force torch.backends.cudnn.benchmark (MIOpen's exhaustive find per convolution shape) "
+                                                                     "on / off for an A/B; default: leave what the package set")
     args = ap.parse_args()
+    if args.cudnn_benchmark >= 0:
+        import torch
+        torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
     if args.amp:
         from vilmedic_amd.blocks.vision import visual_encoder
         visual_encoder.CNN_AMP = True
