@@ -63,7 +63,9 @@ def timed(fn, steps, warmup):
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
+    t1 = time.perf_counter()                          # the host has ENQUEUED every step (unless something in a step waits for the device)
     torch.cuda.synchronize()
+    timed.host_ms = (t1 - t0) / steps * 1e3
     return (time.perf_counter() - t0) / steps
 
 
@@ -90,7 +92,7 @@ def run_task(task, args):
     dt = timed(train_step, steps, max(3, min(args.warmup, steps)) if task == "scst" else min(args.warmup, steps))      # (scst: 2 eager warm-ups + the capture)
     unit = "images/s" if task == "mvqa" else "pairs/s"
     print(json.dumps({"task": task, "metric": f"{task} training step", "value": round(B / dt, 1), "unit": unit, "ms_per_step": round(dt * 1e3, 2),
-                      "batch": B, "params": n_params, "steps": steps, "cnn_tower": "bf16 autocast" if args.amp else "fp32", **(mode if task == "scst" else {})}), flush=True)
+                      "host_enqueue_ms_per_step": round(timed.host_ms, 2), "batch": B, "params": n_params, "steps": steps, "cnn_tower": "bf16 autocast" if args.amp else "fp32", **(mode if task == "scst" else {})}), flush=True)
     if task == "mvqa":
         model.eval()
 
@@ -99,7 +101,7 @@ def run_task(task, args):
                 model(**batch)
         dt = timed(infer, args.steps, args.warmup)
         print(json.dumps({"task": task, "metric": "mvqa inference", "value": round(B / dt, 1), "unit": "images/s", "ms_per_step": round(dt * 1e3, 2),
-                          "batch": B, "cnn_tower": "bf16 autocast" if args.amp else "fp32"}), flush=True)
+                          "host_enqueue_ms_per_step": round(timed.host_ms, 2), "batch": B, "cnn_tower": "bf16 autocast" if args.amp else "fp32"}), flush=True)
 
 
 def run_decode(args):
